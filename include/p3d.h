@@ -1,0 +1,135 @@
+/*
+ * p3d.h -- C ABI of libp3d_hip.so: the MI355X (gfx950) implementation of the POCS hot path of
+ * fwrnke/pseudo-3D-interpolation.
+ *
+ * The reference has no FFI layer; its boundary for this path is the Python callable
+ *     POCS_algorithm(x, mask, auxiliary_data, transform, itransform, transform_kind, niter, thresh_op,
+ *                    thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, verbose, version,
+ *                    results_dict, path_results)         pseudo_3D_interpolation/functions/POCS.py:371-391
+ * called once per (iline, xline) slice by xr.apply_ufunc(..., vectorize=True)
+ *                                                        pseudo_3D_interpolation/cube_POCS_interpolation_3D.py:314-340
+ * The entry points below are what a ctypes binding of that callable needs (INTEGRATION.md shows
+ * the stub): plain pointers and sizes, no Python / torch types.
+ *
+ * Conventions
+ *   - every function returns P3D_OK (0) or a negative error code; p3d_last_error() gives the text
+ *     (thread-local);
+ *   - a "slice" is one (nil x nxl) array, C-contiguous, xline fastest; a cube is [nslices][nil][nxl]
+ *     (the slice-major layout written by cube_binning_3D.py:1313-1351);
+ *   - *_dev functions take DEVICE pointers (hipMalloc / p3d_malloc / torch data_ptr), the
+ *     un-suffixed ones take HOST pointers and stage through buffers owned by the plan;
+ *   - a plan is bound to one device and one internal stream and is not re-entrant; different plans
+ *     may be used from different host threads / processes;
+ *   - all calls are synchronous: when they return, outputs are complete.
+ */
+#ifndef P3D_H
+#define P3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_ABI_VERSION 1
+
+#define P3D_OK 0
+#define P3D_ERR_INVALID (-1)     /* bad argument */
+#define P3D_ERR_UNSUPPORTED (-2) /* shape / option not covered by the HIP kernels */
+#define P3D_ERR_HIP (-3)         /* a HIP runtime call failed (no GPU, out of memory, ...) */
+
+/* element type of the observed cube `x` and of the result (np.iscomplexobj(x), POCS.py:511, 653-656) */
+#define P3D_C64 0 /* complex64: frequency-domain cube (dim 'freq_twt') */
+#define P3D_F32 1 /* float32 : time-domain cube (dim 'twt'); result is np.real() of the iterate */
+
+/* thresh_op (POCS.py:91-102 -> threshold_operator.py:9-112) */
+#define P3D_OP_HARD 0
+#define P3D_OP_SOFT 1
+#define P3D_OP_GARROTE 2
+
+/* version (POCS.py:564-575).  FAST is accepted and runs REGULAR: in the reference the momentum
+ * term of 'fast' is identically zero (POCS.py:549-550, 566-571, 629). */
+#define P3D_VER_REGULAR 0
+#define P3D_VER_FAST 1
+#define P3D_VER_ADAPTIVE 2
+
+/* p3d_pocs_params.flags */
+#define P3D_FLAG_PROFILE 1 /* bracket every kernel launch with HIP events; read with p3d_last_profile() */
+
+typedef struct p3d_plan p3d_plan;
+
+typedef struct p3d_pocs_params {
+    int32_t niter;     /* number of iterations (POCS.py:560) */
+    int32_t thresh_op; /* P3D_OP_* */
+    int32_t version;   /* P3D_VER_* */
+    int32_t flags;     /* P3D_FLAG_* */
+    double eps;        /* early exit: iiter > 2 and cost < eps (POCS.py:631); 0 disables */
+    double alpha;      /* re-insertion weight (POCS.py:616-619) */
+} p3d_pocs_params;
+
+/* number of doubles per slice written by p3d_pocs_stats*: everything get_threshold_decay
+ * (POCS.py:169-368) needs from X0 = fft2(x):
+ *   [0] Re, [1] Im of the lexicographic max of X0 (numpy's complex .max(), POCS.py:288)
+ *   [2] max |X0|, [3] min |X0|   (POCS.py:261-262)
+ *   [4] sum |X0|^2               (POCS.py:299)
+ *   [5] reserved (0)                                                                       */
+#define P3D_STATS_PER_SLICE 6
+
+int p3d_abi_version(void);
+const char* p3d_last_error(void);
+int p3d_device_count(int* n);
+
+/* 1 when the HIP kernels cover an (nil, nxl) slice shape, else 0 */
+int p3d_shape_supported(int nil, int nxl);
+
+int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices);
+int p3d_plan_destroy(p3d_plan* plan);
+
+/* device-memory helpers so that a pure-ctypes caller needs no other GPU runtime */
+int p3d_malloc(p3d_plan* plan, void** dptr, size_t bytes);
+int p3d_free(p3d_plan* plan, void* dptr);
+int p3d_memcpy_h2d(p3d_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
+int p3d_memcpy_d2h(p3d_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
+
+/* Batched 2-D FFT of complex64 slices, numpy.fft.fft2 / ifft2 conventions (unnormalised forward,
+ * 1/(nil*nxl) inverse).  Replaces the callables injected at cube_POCS_interpolation_3D.py:255-257;
+ * exported as a test hook.  in == out is allowed. */
+int p3d_fft2_c64_dev(p3d_plan* plan, const void* in_dev, void* out_dev, int nslices, int inverse);
+int p3d_fft2_c64(p3d_plan* plan, const void* in_host, void* out_host, int nslices, int inverse);
+
+/* Per-slice statistics of X0 = fft2(x) for the threshold schedule (replaces the device-independent
+ * part of get_threshold_decay, POCS.py:535-546).  stats_host: [nslices][P3D_STATS_PER_SLICE]. */
+int p3d_pocs_stats_dev(p3d_plan* plan, const void* x_dev, int dtype, int nslices, double* stats_host);
+int p3d_pocs_stats(p3d_plan* plan, const void* x_host, int dtype, int nslices, double* stats_host);
+
+/* The POCS loop (POCS.py:549-632) for a batch of slices sharing one trace mask.
+ *   x        [nslices][nil][nxl] observed data, zeros at missing traces, dtype as given
+ *   mask     [nil][nxl] float32, 1 = observed trace, 0 = missing (cube_POCS_interpolation_3D.py:242-244)
+ *   tau      HOST, [nslices][niter][2] doubles: Re, Im of the threshold used at each iteration
+ *            (decay[k], or sqrt(decay[k]) for sqrt_decay; POCS.py:595).  A slice whose first tau is
+ *            NaN in both parts AND whose `active` entry is 0 is not processed.
+ *   active   HOST, [nslices] uint8 or NULL: 0 marks an all-zero slice, which the reference returns
+ *            untouched with niterations = 0 (POCS.py:515-521)
+ *   out      [nslices][nil][nxl], same dtype as x
+ *   niter_done  HOST [nslices] int32: iterations executed per slice (POCS.py:634)
+ *   sums     HOST [(niter+1)][nslices] doubles or NULL: sums[0][s] = sum|x_s|, sums[k+1][s] =
+ *            sum|x_k| after iteration k (0 where not executed); cost_k = ((S_k+1 - S_k)/S_k+1)^2
+ *            (POCS.py:622)
+ *   elapsed_ms  device time of the whole call measured with HIP events on the plan's stream, or NULL */
+int p3d_pocs_run_dev(p3d_plan* plan, const void* x_dev, int dtype, const float* mask_dev, const double* tau,
+                     const uint8_t* active, const p3d_pocs_params* params, void* out_dev, int nslices,
+                     int32_t* niter_done, double* sums, double* elapsed_ms);
+int p3d_pocs_run(p3d_plan* plan, const void* x_host, int dtype, const float* mask_host, const double* tau,
+                 const uint8_t* active, const p3d_pocs_params* params, void* out_host, int nslices,
+                 int32_t* niter_done, double* sums, double* elapsed_ms);
+
+/* After a run with P3D_FLAG_PROFILE: average duration (ms) and launch count of the spectrum
+ * (column) pass and of the space (row) pass kernels of the iteration loop. */
+int p3d_last_profile(p3d_plan* plan, double* colpass_ms, int* colpass_launches, double* rowpass_ms,
+                     int* rowpass_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3D_H */

@@ -1,0 +1,239 @@
+"""ctypes binding of include/p3d.h (libp3d_hip.so).  No fallback: if the library is missing or no
+GPU is visible, every compute entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp3d_hip.so")
+
+P3D_OK = 0
+P3D_ERR_INVALID, P3D_ERR_UNSUPPORTED, P3D_ERR_HIP = -1, -2, -3
+P3D_C64, P3D_F32 = 0, 1
+P3D_OP = {"hard": 0, "soft": 1, "garrote": 2, "garotte": 2}
+P3D_VER = {"regular": 0, "fast": 1, "adaptive": 2}
+P3D_FLAG_PROFILE = 1
+STATS_PER_SLICE = 6
+
+
+class P3DError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libp3d_hip error {code}: {msg}")
+        self.code = code
+
+
+class UnsupportedError(P3DError, NotImplementedError):
+    pass
+
+
+class PocsParams(C.Structure):
+    _fields_ = [("niter", C.c_int32), ("thresh_op", C.c_int32), ("version", C.c_int32), ("flags", C.c_int32),
+                ("eps", C.c_double), ("alpha", C.c_double)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/p3d.h
+PROTOTYPES = {
+    "p3d_abi_version": (C.c_int, []),
+    "p3d_last_error": (C.c_char_p, []),
+    "p3d_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "p3d_shape_supported": (C.c_int, [C.c_int, C.c_int]),
+    "p3d_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "p3d_plan_destroy": (C.c_int, [C.c_void_p]),
+    "p3d_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "p3d_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "p3d_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "p3d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "p3d_fft2_c64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "p3d_fft2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_pocs_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_pocs_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_double)]),
+    "p3d_pocs_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_double)]),
+    "p3d_last_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int)]),
+}
+
+
+def lib():
+    """Load libp3d_hip.so once.  Raises ``ImportError`` if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != P3D_OK:
+        msg = lib().p3d_last_error().decode("utf-8", "replace")
+        raise (UnsupportedError if code == P3D_ERR_UNSUPPORTED else P3DError)(code, msg)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().p3d_device_count(C.byref(n)))
+    return n.value
+
+
+def shape_supported(nil, nxl):
+    return bool(lib().p3d_shape_supported(int(nil), int(nxl)))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer owned through a plan (for callers that keep cubes resident in HBM)."""
+
+    def __init__(self, plan, nbytes):
+        self.plan, self.nbytes = plan, int(nbytes)
+        p = C.c_void_p()
+        check(lib().p3d_malloc(plan.handle, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib().p3d_memcpy_h2d(self.plan.handle, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().p3d_memcpy_d2h(self.plan.handle, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib().p3d_free(self.plan.handle, self.ptr))
+            self.ptr = None
+
+
+class Plan:
+    """p3d_plan wrapper: one device, one (nil, nxl) slice shape, up to ``max_slices`` per call."""
+
+    def __init__(self, nil, nxl, max_slices, device=0):
+        self.nil, self.nxl, self.max_slices, self.device = int(nil), int(nxl), int(max_slices), int(device)
+        h = C.c_void_p()
+        check(lib().p3d_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.max_slices))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().p3d_plan_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _cube(self, x):
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[None]
+        if x.ndim != 3 or x.shape[1:] != (self.nil, self.nxl):
+            raise ValueError(f"expected (nslices, {self.nil}, {self.nxl}), got {x.shape}")
+        if x.shape[0] > self.max_slices:
+            raise ValueError(f"{x.shape[0]} slices > max_slices {self.max_slices}")
+        if np.iscomplexobj(x):
+            return np.ascontiguousarray(x, dtype=np.complex64), P3D_C64
+        return np.ascontiguousarray(x, dtype=np.float32), P3D_F32
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # ---- transforms ------------------------------------------------------------------------
+    def fft2(self, x, inverse=False):
+        x = np.asarray(x)
+        squeeze = x.ndim == 2
+        xc, _ = self._cube(x.astype(np.complex64, copy=False))
+        out = np.empty_like(xc)
+        check(lib().p3d_fft2_c64(self.handle, _ptr(xc), _ptr(out), xc.shape[0], int(bool(inverse))))
+        return out[0] if squeeze else out
+
+    # ---- POCS ------------------------------------------------------------------------------
+    def stats(self, x):
+        xc, dt = self._cube(x)
+        st = np.empty((xc.shape[0], STATS_PER_SLICE), np.float64)
+        check(lib().p3d_pocs_stats(self.handle, _ptr(xc), dt, xc.shape[0], _ptr(st)))
+        return st
+
+    def stats_dev(self, x_ptr, dtype, nslices):
+        st = np.empty((nslices, STATS_PER_SLICE), np.float64)
+        check(lib().p3d_pocs_stats_dev(self.handle, x_ptr, dtype, nslices, _ptr(st)))
+        return st
+
+    @staticmethod
+    def _params(niter, thresh_op, version, eps, alpha, profile):
+        if thresh_op not in P3D_OP:
+            raise UnsupportedError(P3D_ERR_UNSUPPORTED, f"thresh_op {thresh_op!r} is not implemented by the HIP kernels")
+        return PocsParams(int(niter), P3D_OP[thresh_op], P3D_VER[version], P3D_FLAG_PROFILE if profile else 0,
+                          float(eps), float(alpha))
+
+    @staticmethod
+    def _tau(tau, nslices, niter):
+        tau = np.asarray(tau)
+        t = np.empty((nslices, niter, 2), np.float64)
+        t[..., 0] = np.broadcast_to(tau.real, (nslices, niter))
+        t[..., 1] = np.broadcast_to(tau.imag, (nslices, niter)) if np.iscomplexobj(tau) else 0.0
+        return t
+
+    def run(self, x, mask, tau, niter, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None,
+            profile=False):
+        """Host arrays in, host arrays out.  Returns (out, niter_done, sums, elapsed_ms)."""
+        xc, dt = self._cube(x)
+        n = xc.shape[0]
+        m = np.ascontiguousarray(mask, dtype=np.float32)
+        if m.shape != (self.nil, self.nxl):
+            raise ValueError(f"mask shape {m.shape} != {(self.nil, self.nxl)}")
+        t = self._tau(tau, n, niter)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = self._params(niter, thresh_op, version, eps, alpha, profile)
+        out = np.empty_like(xc)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_pocs_run(self.handle, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act),
+                                 C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return out, done, sums, ms.value
+
+    def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, nslices, thresh_op="hard", version="regular",
+                eps=0.0, alpha=1.0, active=None, profile=False, want_sums=True):
+        """Device pointers in/out (cube stays resident in HBM).  Returns (niter_done, sums, elapsed_ms)."""
+        t = self._tau(tau, nslices, niter)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = self._params(niter, thresh_op, version, eps, alpha, profile)
+        done = np.zeros(nslices, np.int32)
+        sums = np.zeros((niter + 1, nslices), np.float64) if want_sums else None
+        ms = C.c_double(0.0)
+        check(lib().p3d_pocs_run_dev(self.handle, x_ptr, dtype, mask_ptr, _ptr(t), None if act is None else _ptr(act),
+                                     C.byref(prm), out_ptr, nslices, _ptr(done), None if sums is None else _ptr(sums),
+                                     C.byref(ms)))
+        return done, sums, ms.value
+
+    def last_profile(self):
+        cm, rm, cn, rn = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        check(lib().p3d_last_profile(self.handle, C.byref(cm), C.byref(cn), C.byref(rm), C.byref(rn)))
+        return {"colpass_ms": cm.value, "colpass_launches": cn.value, "rowpass_ms": rm.value,
+                "rowpass_launches": rn.value}

@@ -1,0 +1,528 @@
+// p3d_api.hip -- C ABI (include/p3d.h) over the HIP kernels: plan management, schedule statistics,
+// the POCS iteration driver, staging for host-pointer callers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "p3d.h"
+#include "p3d_kernels.hpp"
+
+namespace p3d {
+#define P3D_DECL(n) const LineOps* get_line_ops_##n();
+P3D_DECL(2) P3D_DECL(4) P3D_DECL(8) P3D_DECL(16) P3D_DECL(32) P3D_DECL(64) P3D_DECL(128) P3D_DECL(256)
+P3D_DECL(512) P3D_DECL(1024) P3D_DECL(2048) P3D_DECL(4096)
+#undef P3D_DECL
+
+static const LineOps* find_ops(int n)
+{
+    switch (n) {
+        case 2: return get_line_ops_2();
+        case 4: return get_line_ops_4();
+        case 8: return get_line_ops_8();
+        case 16: return get_line_ops_16();
+        case 32: return get_line_ops_32();
+        case 64: return get_line_ops_64();
+        case 128: return get_line_ops_128();
+        case 256: return get_line_ops_256();
+        case 512: return get_line_ops_512();
+        case 1024: return get_line_ops_1024();
+        case 2048: return get_line_ops_2048();
+        case 4096: return get_line_ops_4096();
+        default: return nullptr;
+    }
+}
+}  // namespace p3d
+
+using namespace p3d;
+
+// ---- convergence bookkeeping (POCS.py:622, 631) ------------------------------------------------
+static __global__ void conv_kernel(const double* sums, int* done, int nslices, int iter, double eps)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices || done[s] != 0) return;
+    const double cur = sums[(size_t)(iter + 1) * nslices + s];
+    const double prev = sums[(size_t)iter * nslices + s];
+    const double d = cur - prev;
+    const double cost = (d * d) / (cur * cur);
+    if (iter > 2 && cost < eps) done[s] = iter + 1;
+}
+
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(P3D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct p3d_plan {
+    int device = 0;
+    int nil = 0, nxl = 0, max_slices = 0;
+    hipStream_t stream = nullptr;
+    const LineOps* ops_col = nullptr;  // length nil (transform along iline = down the columns)
+    const LineOps* ops_row = nullptr;  // length nxl (transform along xline = along the rows)
+    c32 *tw_col_f = nullptr, *tw_col_i = nullptr, *tw_row_f = nullptr, *tw_row_i = nullptr;
+    c32* work = nullptr;
+    double* sums = nullptr;
+    size_t sums_cap = 0;
+    c32* tau = nullptr;
+    size_t tau_cap = 0;
+    int* done = nullptr;
+    float* partials = nullptr;
+    int tiles = 0;
+    // staging for host-pointer entry points
+    void* st_x = nullptr;
+    void* st_out = nullptr;
+    float* st_mask = nullptr;
+    size_t st_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> prof_events;
+    double prof_col_ms = 0, prof_row_ms = 0;
+    int prof_col_n = 0, prof_row_n = 0;
+
+    size_t slice_elems() const { return (size_t)nil * nxl; }
+};
+
+static int upload_table(p3d_plan* p, const LineOps* ops, int dir, c32** dst)
+{
+    std::vector<c32> host(ops->n, c32{0.f, 0.f});
+    ops->twiddles(dir, host.data());
+    HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * ops->n));
+    HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * ops->n, hipMemcpyHostToDevice));
+    return P3D_OK;
+}
+
+extern "C" {
+
+int p3d_abi_version(void) { return P3D_ABI_VERSION; }
+
+const char* p3d_last_error(void) { return g_err.c_str(); }
+
+int p3d_device_count(int* n)
+{
+    if (!n) return fail(P3D_ERR_INVALID, "n is NULL");
+    *n = 0;
+    HIP_TRY(hipGetDeviceCount(n));
+    return P3D_OK;
+}
+
+int p3d_shape_supported(int nil, int nxl) { return (find_ops(nil) != nullptr && find_ops(nxl) != nullptr) ? 1 : 0; }
+
+int p3d_plan_destroy(p3d_plan* p)
+{
+    if (!p) return P3D_OK;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    void* bufs[] = {p->tw_col_f, p->tw_col_i, p->tw_row_f, p->tw_row_i, p->work, p->sums, p->tau,
+                    p->done,     p->partials, p->st_x,     p->st_out,   p->st_mask};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    for (hipEvent_t e : p->prof_events) hipEventDestroy(e);
+    if (p->ev0) hipEventDestroy(p->ev0);
+    if (p->ev1) hipEventDestroy(p->ev1);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+    return P3D_OK;
+}
+
+int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices)
+{
+    if (!out) return fail(P3D_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (nil < 1 || nxl < 1 || max_slices < 1) return fail(P3D_ERR_INVALID, "nil, nxl and max_slices must be positive");
+    if (max_slices > 65535) return fail(P3D_ERR_INVALID, "max_slices > 65535: split the cube into batches");
+    const LineOps* oc = find_ops(nil);
+    const LineOps* orow = find_ops(nxl);
+    if (!oc || !orow)
+        return fail(P3D_ERR_UNSUPPORTED, "slice shape %d x %d: HIP kernels cover power-of-two extents 2..4096", nil, nxl);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(P3D_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    p3d_plan* p = new p3d_plan;
+    p->device = device;
+    p->nil = nil;
+    p->nxl = nxl;
+    p->max_slices = max_slices;
+    p->ops_col = oc;
+    p->ops_row = orow;
+    p->tiles = (nxl + oc->col_tile - 1) / oc->col_tile;
+    int rc = P3D_OK;
+    auto bail = [&](int code) {
+        std::string keep = g_err;
+        p3d_plan_destroy(p);
+        g_err = keep;
+        return code;
+    };
+#define TRY_OR_BAIL(expr)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            fail(P3D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                         \
+            return bail(P3D_ERR_HIP);                                                                 \
+        }                                                                                             \
+    } while (0)
+    TRY_OR_BAIL(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    TRY_OR_BAIL(hipEventCreate(&p->ev0));
+    TRY_OR_BAIL(hipEventCreate(&p->ev1));
+    if ((rc = upload_table(p, oc, FWD, &p->tw_col_f)) != P3D_OK) return bail(rc);
+    if ((rc = upload_table(p, oc, INV, &p->tw_col_i)) != P3D_OK) return bail(rc);
+    if ((rc = upload_table(p, orow, FWD, &p->tw_row_f)) != P3D_OK) return bail(rc);
+    if ((rc = upload_table(p, orow, INV, &p->tw_row_i)) != P3D_OK) return bail(rc);
+    TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * p->slice_elems() * max_slices));
+    TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
+    TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
+#undef TRY_OR_BAIL
+    *out = p;
+    return P3D_OK;
+}
+
+int p3d_malloc(p3d_plan* p, void** dptr, size_t bytes)
+{
+    if (!p || !dptr) return fail(P3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMalloc(dptr, bytes));
+    return P3D_OK;
+}
+
+int p3d_free(p3d_plan* p, void* dptr)
+{
+    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipFree(dptr));
+    return P3D_OK;
+}
+
+int p3d_memcpy_h2d(p3d_plan* p, void* dst, const void* src, size_t bytes)
+{
+    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return P3D_OK;
+}
+
+int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
+{
+    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+}  // extern "C"
+
+// ---- internal helpers ---------------------------------------------------------------------------
+static int check_batch(p3d_plan* p, int nslices)
+{
+    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    if (nslices < 1 || nslices > p->max_slices)
+        return fail(P3D_ERR_INVALID, "nslices = %d outside 1..max_slices (%d)", nslices, p->max_slices);
+    return P3D_OK;
+}
+
+static RowArgs row_args(p3d_plan* p, int nslices)
+{
+    RowArgs r{};
+    r.tw_fwd = p->tw_row_f;
+    r.tw_inv = p->tw_row_i;
+    r.n1 = p->nil;
+    r.nslices = nslices;
+    r.alpha = 1.0f;
+    r.scale = (float)(1.0 / ((double)p->nil * (double)p->nxl));
+    return r;
+}
+
+static ColArgs col_args(p3d_plan* p, int nslices)
+{
+    ColArgs c{};
+    c.tw_fwd = p->tw_col_f;
+    c.tw_inv = p->tw_col_i;
+    c.n2 = p->nxl;
+    c.nslices = nslices;
+    return c;
+}
+
+static int ensure_staging(p3d_plan* p, size_t bytes_per_cube)
+{
+    if (p->st_cap >= bytes_per_cube && p->st_x) return P3D_OK;
+    if (p->st_x) hipFree(p->st_x);
+    if (p->st_out) hipFree(p->st_out);
+    p->st_x = p->st_out = nullptr;
+    p->st_cap = 0;
+    HIP_TRY(hipMalloc(&p->st_x, bytes_per_cube));
+    HIP_TRY(hipMalloc(&p->st_out, bytes_per_cube));
+    if (!p->st_mask) HIP_TRY(hipMalloc((void**)&p->st_mask, sizeof(float) * p->slice_elems()));
+    p->st_cap = bytes_per_cube;
+    return P3D_OK;
+}
+
+extern "C" {
+
+int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!in || !out) return fail(P3D_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!inverse) {
+        RowArgs r = row_args(p, nslices);
+        r.x = in;
+        r.work = (c32*)out;
+        r.dtype = P3D_C64;
+        HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+        ColArgs c = col_args(p, nslices);
+        c.in = (const c32*)out;
+        c.out = (c32*)out;
+        HIP_TRY(p->ops_col->col(COL_FWD, c, p->stream));
+    } else {
+        ColArgs c = col_args(p, nslices);
+        c.in = (const c32*)in;
+        c.out = (c32*)out;
+        HIP_TRY(p->ops_col->col(COL_INV, c, p->stream));
+        RowArgs r = row_args(p, nslices);
+        r.work = (c32*)out;
+        r.out = out;
+        r.dtype = P3D_C64;
+        HIP_TRY(p->ops_row->row(ROW_LAST, r, p->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return P3D_OK;
+}
+
+int p3d_fft2_c64(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!in || !out) return fail(P3D_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t bytes = sizeof(c32) * p->slice_elems() * nslices;
+    if ((rc = ensure_staging(p, sizeof(c32) * p->slice_elems() * p->max_slices))) return rc;
+    HIP_TRY(hipMemcpy(p->st_x, in, bytes, hipMemcpyHostToDevice));
+    if ((rc = p3d_fft2_c64_dev(p, p->st_x, p->st_out, nslices, inverse))) return rc;
+    HIP_TRY(hipMemcpy(out, p->st_out, bytes, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, double* stats)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!x || !stats) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    HIP_TRY(hipSetDevice(p->device));
+    RowArgs r = row_args(p, nslices);
+    r.x = x;
+    r.work = p->work;
+    r.dtype = dtype;
+    HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+    ColArgs c = col_args(p, nslices);
+    c.in = p->work;
+    c.partials = p->partials;
+    HIP_TRY(p->ops_col->col(COL_STATS, c, p->stream));
+    std::vector<float> part((size_t)STATS_PARTIAL * p->tiles * nslices);
+    HIP_TRY(hipMemcpyAsync(part.data(), p->partials, sizeof(float) * part.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int s = 0; s < nslices; ++s) {
+        double lr = -INFINITY, li = -INFINITY, mx = 0.0, mn = INFINITY, sq = 0.0;
+        for (int t = 0; t < p->tiles; ++t) {
+            const float* q = &part[((size_t)s * p->tiles + t) * STATS_PARTIAL];
+            if (q[0] > lr || (q[0] == lr && q[1] > li)) { lr = q[0]; li = q[1]; }
+            if (q[2] > mx) mx = q[2];
+            if (q[3] < mn) mn = q[3];
+            sq += q[4];
+        }
+        double* o = stats + (size_t)s * P3D_STATS_PER_SLICE;
+        o[0] = lr; o[1] = li; o[2] = mx; o[3] = mn; o[4] = sq; o[5] = 0.0;
+    }
+    return P3D_OK;
+}
+
+int p3d_pocs_stats(p3d_plan* p, const void* x, int dtype, int nslices, double* stats)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!x || !stats) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    HIP_TRY(hipSetDevice(p->device));
+    if ((rc = ensure_staging(p, sizeof(c32) * p->slice_elems() * p->max_slices))) return rc;
+    const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
+    HIP_TRY(hipMemcpy(p->st_x, x, esz * p->slice_elems() * nslices, hipMemcpyHostToDevice));
+    return p3d_pocs_stats_dev(p, p->st_x, dtype, nslices, stats);
+}
+
+int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, const double* tau, const uint8_t* active,
+                     const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
+                     double* elapsed_ms)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!x || !mask || !tau || !prm || !out) return fail(P3D_ERR_INVALID, "NULL argument");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    if (prm->niter < 1) return fail(P3D_ERR_INVALID, "niter must be >= 1");
+    if (prm->thresh_op < P3D_OP_HARD || prm->thresh_op > P3D_OP_GARROTE)
+        return fail(P3D_ERR_UNSUPPORTED, "thresh_op %d is not implemented by the HIP kernels", prm->thresh_op);
+    if (prm->version < P3D_VER_REGULAR || prm->version > P3D_VER_ADAPTIVE)
+        return fail(P3D_ERR_INVALID, "unknown version %d", prm->version);
+    HIP_TRY(hipSetDevice(p->device));
+
+    const int niter = prm->niter;
+    const bool profile = (prm->flags & P3D_FLAG_PROFILE) != 0;
+    const bool early = prm->eps > 0.0;
+    const bool adaptive = prm->version == P3D_VER_ADAPTIVE;
+
+    // device-side schedule, state and cost accumulators
+    const size_t ntau = (size_t)nslices * niter;
+    if (p->tau_cap < ntau) {
+        if (p->tau) hipFree(p->tau);
+        p->tau = nullptr;
+        p->tau_cap = 0;
+        HIP_TRY(hipMalloc((void**)&p->tau, sizeof(c32) * ntau));
+        p->tau_cap = ntau;
+    }
+    const size_t nsum = (size_t)(niter + 1) * nslices;
+    if (p->sums_cap < nsum) {
+        if (p->sums) hipFree(p->sums);
+        p->sums = nullptr;
+        p->sums_cap = 0;
+        HIP_TRY(hipMalloc((void**)&p->sums, sizeof(double) * nsum));
+        p->sums_cap = nsum;
+    }
+    std::vector<c32> tau_f(ntau);
+    for (size_t i = 0; i < ntau; ++i) tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+    std::vector<int> done_h(nslices, 0);
+    if (active)
+        for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;
+    HIP_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
+
+    size_t nev = 0;
+    if (profile) {
+        const size_t need = 2 * (size_t)niter + 2;
+        while (p->prof_events.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            p->prof_events.push_back(e);
+        }
+    }
+    auto stamp = [&]() -> hipError_t {
+        if (!profile) return hipSuccess;
+        return hipEventRecord(p->prof_events[nev++], p->stream);
+    };
+
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+
+    RowArgs r = row_args(p, nslices);
+    r.x = x;
+    r.mask = mask;
+    r.work = p->work;
+    r.out = out;
+    r.sums = p->sums;
+    r.done = p->done;
+    r.dtype = dtype;
+    r.adaptive = adaptive ? 1 : 0;
+    r.write_out = early ? 1 : 0;
+    r.alpha = (float)prm->alpha;
+    r.sum_row = 0;
+    HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+
+    ColArgs c = col_args(p, nslices);
+    c.in = p->work;
+    c.out = p->work;
+    c.tau = p->tau;
+    c.done = p->done;
+    c.niter = niter;
+    c.op = prm->thresh_op;
+
+    HIP_TRY(stamp());
+    for (int k = 0; k < niter; ++k) {
+        c.iter = k;
+        HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
+        HIP_TRY(stamp());
+        r.sum_row = k + 1;
+        HIP_TRY(p->ops_row->row(k + 1 < niter ? ROW_MID : ROW_LAST, r, p->stream));
+        HIP_TRY(stamp());
+        if (early) conv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+
+    HIP_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
+    if (sums) HIP_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+
+    if (niter_done)
+        for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
+    if (elapsed_ms) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        *elapsed_ms = ms;
+    }
+    if (profile) {
+        p->prof_col_ms = p->prof_row_ms = 0;
+        p->prof_col_n = p->prof_row_n = 0;
+        for (int k = 0; k < niter; ++k) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, p->prof_events[2 * k], p->prof_events[2 * k + 1]));
+            HIP_TRY(hipEventElapsedTime(&b, p->prof_events[2 * k + 1], p->prof_events[2 * k + 2]));
+            p->prof_col_ms += a;
+            p->prof_col_n += 1;
+            if (k + 1 < niter) {  // the last space pass is ROW_LAST (no forward transform): not averaged in
+                p->prof_row_ms += b;
+                p->prof_row_n += 1;
+            }
+        }
+    }
+    return P3D_OK;
+}
+
+int p3d_pocs_run(p3d_plan* p, const void* x, int dtype, const float* mask, const double* tau, const uint8_t* active,
+                 const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
+                 double* elapsed_ms)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!x || !mask || !out) return fail(P3D_ERR_INVALID, "NULL argument");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    HIP_TRY(hipSetDevice(p->device));
+    if ((rc = ensure_staging(p, sizeof(c32) * p->slice_elems() * p->max_slices))) return rc;
+    const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
+    const size_t bytes = esz * p->slice_elems() * nslices;
+    HIP_TRY(hipMemcpy(p->st_x, x, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->st_mask, mask, sizeof(float) * p->slice_elems(), hipMemcpyHostToDevice));
+    if ((rc = p3d_pocs_run_dev(p, p->st_x, dtype, p->st_mask, tau, active, prm, p->st_out, nslices, niter_done, sums,
+                               elapsed_ms)))
+        return rc;
+    HIP_TRY(hipMemcpy(out, p->st_out, bytes, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+int p3d_last_profile(p3d_plan* p, double* col_ms, int* col_n, double* row_ms, int* row_n)
+{
+    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    if (col_ms) *col_ms = p->prof_col_n ? p->prof_col_ms / p->prof_col_n : 0.0;
+    if (col_n) *col_n = p->prof_col_n;
+    if (row_ms) *row_ms = p->prof_row_n ? p->prof_row_ms / p->prof_row_n : 0.0;
+    if (row_n) *row_n = p->prof_row_n;
+    return P3D_OK;
+}
+
+}  // extern "C"

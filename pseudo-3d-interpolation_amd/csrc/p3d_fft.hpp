@@ -1,0 +1,285 @@
+// p3d_fft.hpp -- in-register radix butterflies and the LDS Stockham line-FFT engine (gfx950).
+//
+// Replaces, on the device, what the reference gets from numpy.fft.fft2 / ifft2 (pocketfft) at
+// pseudo_3D_interpolation/cube_POCS_interpolation_3D.py:255-257, called from
+// pseudo_3D_interpolation/functions/POCS.py:535, 592, 613.
+//
+// One "line" (a row or a column of an (iline, xline) slice) of N = 2^m points is transformed by
+// TPL = N/PPT threads, each holding PPT = min(16, N) points in registers.  Canonical register
+// layout, valid before the first and after the last pass of every transform:
+//
+//        register q of thread tl  <->  element  tl + TPL*q            (q = 0..PPT-1)
+//
+// so global loads/stores of a contiguous line are coalesced over tl, and two transforms can be
+// chained through registers (forward -> threshold -> inverse, or inverse -> re-insertion ->
+// forward) without touching LDS in between.  A pass of radix R (Ns = product of the radices
+// before it) follows the Stockham autosort recipe
+//        v[t]  = in[j + t*N/R] * w^(t*(j mod Ns)),  w = exp(-+2*pi*i/(Ns*R))
+//        out[(j div Ns)*Ns*R + (j mod Ns) + k*Ns] = DFT_R(v)[k]
+// and exchanges data through LDS only between passes.  Forward transforms use the radix
+// sequence 16,16,..,rem and inverse transforms the reversed sequence rem,..,16,16: the last
+// forward pass and the first inverse pass then touch the same elements per thread.
+#pragma once
+
+#if defined(__HIPCC__)
+#define P3D_HD __host__ __device__ __forceinline__
+#define P3D_D __device__ __forceinline__
+#else
+#define P3D_HD inline
+#define P3D_D inline
+#endif
+
+namespace p3d {
+
+struct __attribute__((aligned(8))) c32 {
+    float x, y;
+};
+
+P3D_HD c32 operator+(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+P3D_HD c32 operator-(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+P3D_HD c32 operator*(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+P3D_HD c32 operator*(c32 a, float s) { return {a.x * s, a.y * s}; }
+
+constexpr int FWD = -1;  // exp(-i...)  (numpy fft2)
+constexpr int INV = +1;  // exp(+i...)  (numpy ifft2, unnormalised here; 1/N applied by the caller)
+
+// multiply by DIR*i
+template <int DIR>
+P3D_HD c32 mul_i(c32 a)
+{
+    return DIR < 0 ? c32{a.y, -a.x} : c32{-a.y, a.x};
+}
+
+// ---- natural-order radix-2 / radix-4 -------------------------------------------------------
+P3D_HD void dft2(c32& a, c32& b)
+{
+    c32 s = a + b;
+    b = a - b;
+    a = s;
+}
+
+template <int DIR>
+P3D_HD void dft4(c32& v0, c32& v1, c32& v2, c32& v3)
+{
+    c32 s0 = v0 + v2, d0 = v0 - v2;
+    c32 s1 = v1 + v3, d1 = mul_i<DIR>(v1 - v3);
+    v0 = s0 + s1;
+    v2 = s0 - s1;
+    v1 = d0 + d1;
+    v3 = d0 - d1;
+}
+
+// ---- in-place radix-R DFT; result k ends up at position digit_rev<R>(k) --------------------
+template <int R>
+constexpr int digit_rev(int k)
+{
+    return R == 16 ? (k >> 2) + 4 * (k & 3) : R == 8 ? (k >> 2) + 2 * (k & 3) : k;
+}
+
+template <int R, int DIR>
+struct Dft;
+
+template <int DIR>
+struct Dft<1, DIR> {
+    static P3D_HD void run(c32*) {}
+};
+template <int DIR>
+struct Dft<2, DIR> {
+    static P3D_HD void run(c32* a) { dft2(a[0], a[1]); }
+};
+template <int DIR>
+struct Dft<4, DIR> {
+    static P3D_HD void run(c32* a) { dft4<DIR>(a[0], a[1], a[2], a[3]); }
+};
+template <int DIR>
+struct Dft<8, DIR> {
+    static P3D_HD void run(c32* a)
+    {
+        constexpr float H = 0.70710678118654752440f;
+        dft4<DIR>(a[0], a[2], a[4], a[6]);
+        dft4<DIR>(a[1], a[3], a[5], a[7]);
+        a[3] = a[3] * c32{H, DIR * H};   // W8^1
+        a[5] = mul_i<DIR>(a[5]);         // W8^2
+        a[7] = a[7] * c32{-H, DIR * H};  // W8^3
+        dft2(a[0], a[1]);
+        dft2(a[2], a[3]);
+        dft2(a[4], a[5]);
+        dft2(a[6], a[7]);
+    }
+};
+template <int DIR>
+struct Dft<16, DIR> {
+    static P3D_HD void run(c32* a)
+    {
+        constexpr float H = 0.70710678118654752440f;
+        constexpr float C = 0.92387953251128675613f;  // cos(pi/8)
+        constexpr float S = 0.38268343236508977173f;  // sin(pi/8)
+        dft4<DIR>(a[0], a[4], a[8], a[12]);
+        dft4<DIR>(a[1], a[5], a[9], a[13]);
+        dft4<DIR>(a[2], a[6], a[10], a[14]);
+        dft4<DIR>(a[3], a[7], a[11], a[15]);
+        // a[t1 + 4*k2] *= W16^(t1*k2)
+        a[5] = a[5] * c32{C, DIR * S};     // 1
+        a[9] = a[9] * c32{H, DIR * H};     // 2
+        a[13] = a[13] * c32{S, DIR * C};   // 3
+        a[6] = a[6] * c32{H, DIR * H};     // 2
+        a[10] = mul_i<DIR>(a[10]);         // 4
+        a[14] = a[14] * c32{-H, DIR * H};  // 6
+        a[7] = a[7] * c32{S, DIR * C};     // 3
+        a[11] = a[11] * c32{-H, DIR * H};  // 6
+        a[15] = a[15] * c32{-C, -DIR * S}; // 9
+        dft4<DIR>(a[0], a[1], a[2], a[3]);
+        dft4<DIR>(a[4], a[5], a[6], a[7]);
+        dft4<DIR>(a[8], a[9], a[10], a[11]);
+        dft4<DIR>(a[12], a[13], a[14], a[15]);
+    }
+};
+
+// ---- compile-time plan of a length-N line ----------------------------------------------------
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+
+template <int N>
+struct Plan {
+    static_assert(N >= 2 && (N & (N - 1)) == 0, "power-of-two line length expected");
+    static constexpr int LOG2 = ilog2(N);
+    static constexpr int PPT = N >= 16 ? 16 : N;   // points per thread
+    static constexpr int TPL = N / PPT;             // threads per line
+    static constexpr int NFULL = LOG2 <= 4 ? 0 : LOG2 / 4;
+    static constexpr int REM = LOG2 <= 4 ? N : (1 << (LOG2 % 4));
+    static constexpr int NPASS = LOG2 <= 4 ? 1 : NFULL + (REM > 1 ? 1 : 0);
+
+    // radix of pass p for direction DIR
+    static constexpr int radix(int dir, int p)
+    {
+        if (LOG2 <= 4) return N;
+        int pf = dir == FWD ? p : NPASS - 1 - p;  // position in the forward ordering
+        return pf < NFULL ? 16 : REM;
+    }
+    // product of the radices before pass p
+    static constexpr int ns(int dir, int p)
+    {
+        int r = 1;
+        for (int q = 0; q < p; ++q) r *= radix(dir, q);
+        return r;
+    }
+    // offset of pass p's twiddles inside the per-direction table ((R-1)*Ns entries per pass, p >= 1)
+    static constexpr int tw_off(int dir, int p)
+    {
+        int o = 0;
+        for (int q = 1; q < p; ++q) o += (radix(dir, q) - 1) * ns(dir, q);
+        return o;
+    }
+    static constexpr int tw_len(int dir) { return tw_off(dir, NPASS); }
+};
+
+// Host side: fill the per-direction twiddle table (layout: for every pass p >= 1, (R-1) rows of
+// Ns entries, row t-1 holding exp(dir*2*pi*i*t*jm/(Ns*R)) for jm = 0..Ns-1, i.e. exactly the
+// order in which neighbouring threads read it).  Evaluated in double, stored as float.
+template <int N>
+inline void build_twiddles(int dir, c32* out)
+{
+    using PL = Plan<N>;
+    for (int p = 1; p < PL::NPASS; ++p) {
+        const int R = PL::radix(dir, p), NS = PL::ns(dir, p), off = PL::tw_off(dir, p);
+        for (int t = 1; t < R; ++t)
+            for (int jm = 0; jm < NS; ++jm) {
+                const double ang = dir * 6.283185307179586476925286766559 * double(t) * double(jm) / (double(NS) * R);
+                out[off + (t - 1) * NS + jm] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
+            }
+    }
+}
+
+// ---- LDS views ---------------------------------------------------------------------------------
+// Row view: one line is contiguous; one padding slot after every 16 points keeps the strided
+// Stockham scatter (stride R*8 B) off a single bank.
+struct LdsRow {
+    c32* base;
+    static constexpr int stride(int n) { return n + (n >> 4); }
+    P3D_HD c32& at(int pos) const { return base[pos + (pos >> 4)]; }
+};
+// Column-tile view: T lines interleaved, element-major ([pos][column]); the T columns of a wave
+// are adjacent so every access pattern of the engine is conflict-free without padding.
+template <int T>
+struct LdsCol {
+    c32* base;  // already offset by the column of this thread
+    P3D_HD c32& at(int pos) const { return base[pos * T]; }
+};
+
+// One pass, all in registers: twiddle, radix-R DFTs, re-order to "output k of butterfly s at
+// register s + NB*k".
+template <int N, int DIR, int P>
+P3D_HD void pass_compute(c32 (&v)[Plan<N>::PPT], const c32* __restrict__ tab, int tl)
+{
+    using PL = Plan<N>;
+    constexpr int R = PL::radix(DIR, P);
+    constexpr int NS = PL::ns(DIR, P);
+    constexpr int NB = PL::PPT / R;
+    constexpr int OFF = PL::tw_off(DIR, P);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        c32 a[R];
+        const int jm = (tl + s * PL::TPL) & (NS - 1);
+        a[0] = v[s];
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+            if constexpr (P == 0) {
+                a[t] = v[s + NB * t];
+            } else {
+                a[t] = v[s + NB * t] * tab[OFF + (t - 1) * NS + jm];
+            }
+        }
+        Dft<R, DIR>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[s + NB * k] = a[digit_rev<R>(k)];
+    }
+}
+
+template <int N, int DIR, int P, class LDS>
+P3D_HD void pass_scatter(const c32 (&v)[Plan<N>::PPT], LDS lds, int tl)
+{
+    using PL = Plan<N>;
+    constexpr int R = PL::radix(DIR, P);
+    constexpr int NS = PL::ns(DIR, P);
+    constexpr int NB = PL::PPT / R;
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        const int jb = tl + s * PL::TPL;
+        const int j0 = (jb & ~(NS - 1)) * R + (jb & (NS - 1));
+#pragma unroll
+        for (int k = 0; k < R; ++k) lds.at(j0 + k * NS) = v[s + NB * k];
+    }
+}
+
+template <int N, class LDS>
+P3D_HD void canonical_gather(c32 (&v)[Plan<N>::PPT], LDS lds, int tl)
+{
+#pragma unroll
+    for (int q = 0; q < Plan<N>::PPT; ++q) v[q] = lds.at(tl + Plan<N>::TPL * q);
+}
+
+#if defined(__HIPCC__)
+template <int N, int DIR, int P, class LDS>
+struct PassLoop {
+    static P3D_D void run(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tab, int tl)
+    {
+        if constexpr (P > 0) canonical_gather<N>(v, lds, tl);
+        pass_compute<N, DIR, P>(v, tab, tl);
+        if constexpr (P + 1 < Plan<N>::NPASS) {
+            __syncthreads();  // every thread is done reading the previous contents
+            pass_scatter<N, DIR, P>(v, lds, tl);
+            __syncthreads();
+            PassLoop<N, DIR, P + 1, LDS>::run(v, lds, tab, tl);
+        }
+    }
+};
+
+// Transform one line held in canonical register layout; result is canonical again.
+// Every thread of the workgroup must call this (it contains workgroup barriers).
+template <int N, int DIR, class LDS>
+P3D_D void line_fft(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tab, int tl)
+{
+    PassLoop<N, DIR, 0, LDS>::run(v, lds, tab, tl);
+}
+#endif  // __HIPCC__
+
+}  // namespace p3d

@@ -1,0 +1,18 @@
+// p3d_inst.hip -- compiled once per supported line length (-DP3D_N=<power of two>); exports the
+// launchers of that length to the API layer (p3d_api.hip) through one LineOps record.
+#include "p3d_kernels.hpp"
+
+#ifndef P3D_N
+#error "compile with -DP3D_N=<line length>"
+#endif
+#define P3D_CAT2(a, b) a##b
+#define P3D_CAT(a, b) P3D_CAT2(a, b)
+
+namespace p3d {
+const LineOps* P3D_CAT(get_line_ops_, P3D_N)()
+{
+    static const LineOps ops = {P3D_N, col_tile<P3D_N>(), &launch_row<P3D_N>, &launch_col<P3D_N>,
+                                &build_twiddles<P3D_N>};
+    return &ops;
+}
+}  // namespace p3d

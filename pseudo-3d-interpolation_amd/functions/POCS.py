@@ -1,0 +1,370 @@
+"""
+POCS interpolation on MI355X -- host-side mirror of ``pseudo_3D_interpolation/functions/POCS.py``.
+
+Same public names and keyword arguments as the reference module
+(``POCS_algorithm`` POCS.py:371-391, ``POCS`` / ``FPOCS`` / ``APOCS`` POCS.py:659-661,
+``get_threshold_decay`` POCS.py:169-177) so existing callers -- in particular
+``xr.apply_ufunc(POCS, ...)`` of the step-13 driver (cube_POCS_interpolation_3D.py:314-340) --
+keep working, plus :func:`pocs_cube`, which hands a whole batch of slices to the GPU at once.
+
+What runs where
+---------------
+* GPU (libp3d_hip.so, hand-written HIP): the forward transform of the observed slice and its
+  statistics, and the whole iteration loop (forward FFT2, thresholding, inverse FFT2, re-insertion
+  of the observed traces, cost sums, early exit).
+* Host (this file, a few scalars per slice): argument checks and the threshold schedule
+  tau_k, k = 1..niter, evaluated with NumPy in complex128 exactly like POCS.py:251-368 so that the
+  reference's NumPy conventions (lexicographic complex max, complex log/exp) carry over.
+
+There is no CPU fallback for the loop: without the library or without a GPU these functions raise.
+"""
+import time
+from functools import partial
+
+import numpy as np
+
+from .. import _ffi
+
+TRANSFORMS = ('FFT', 'WAVELET', 'SHEARLET', 'CURVELET', 'DCT')
+_HIP_TRANSFORMS = ('FFT',)
+_THRESH_OPS = ('soft', 'hard', 'garrote', 'garotte', 'soft-percentile', 'hard-percentile',
+               'garrote-percentile', 'garotte-percentile')
+
+
+# =================================================================================================
+#                                      threshold schedule (host)
+# =================================================================================================
+def _tail_number(name, default=1.0, strict=False):
+    """Number after the last '-' of a model name ('exponential-2' -> 2.0)."""
+    if '-' not in name:
+        return default
+    tail = name.split('-')[-1]
+    if strict:  # POCS.py:352 lets a malformed suffix raise
+        return float(tail)
+    try:  # POCS.py:266-270 falls back to 1
+        return float(tail)
+    except Exception:  # noqa
+        return default
+
+
+def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, sumsq, size):
+    """tau[..., k] for k = 1..niter from the statistics of X0 = transform(x).
+
+    ``peak`` is the (lexicographic) complex maximum of X0, ``abs_max`` / ``abs_min`` the extrema of
+    |X0|, ``sumsq`` = sum |X0|^2, ``size`` = X0.size.  All of them may carry leading batch axes
+    (one entry per slice); the schedule is broadcast along a new last axis.  Follows
+    POCS.py:251-274 (inverse proportional), :277-333 (end points), :336-354 (linear, exponential).
+    """
+    steps = np.arange(1, niter + 1)
+
+    if all(s in thresh_model for s in ['inverse', 'proportional']):
+        q = _tail_number(thresh_model)
+        nq = niter ** q
+        hi = np.asarray(abs_max)[..., None]
+        lo = np.asarray(abs_min)[..., None]
+        a = (nq * (hi - lo)) / (nq - 1)
+        b = (nq * lo - hi) / (nq - 1)
+        return a / (steps ** q) + b
+
+    if kind == 'values':
+        peak = np.asarray(peak)[..., None]
+        if isinstance(p_min, str) and p_min == 'adaptive':
+            tau_min = 0.01 * np.sqrt(np.asarray(sumsq)[..., None] / size)
+        else:
+            tau_min = p_min * peak
+        tau_max = p_max * peak
+    elif kind == 'factors':
+        tau_max, tau_min = p_max, p_min
+    else:
+        raise ValueError('Parameter `kind` only supports arguments "values" or "factors"')
+
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ramp = (steps - 1) / (niter - 1)
+        if thresh_model == 'linear':
+            return tau_max - (tau_max - tau_min) * ramp
+        if 'exponential' in thresh_model:
+            q = _tail_number(thresh_model, strict=True)
+            return tau_max * np.exp(np.log(tau_min / tau_max) * ramp ** q)
+    raise NotImplementedError(f'{thresh_model} is not implemented for FFT transform!')
+
+
+def _data_driven(x_fwd, niter, p_max, p_min):
+    """'data-driven' model (POCS.py:356-362): thresholds picked from the sorted coefficients."""
+    steps = np.arange(1, niter + 1)
+    peak = x_fwd.max()
+    if isinstance(p_min, str) and p_min == 'adaptive':
+        tau_min = 0.01 * np.sqrt(np.linalg.norm(x_fwd, axis=None) ** 2 / x_fwd.size)
+    else:
+        tau_min = p_min * peak
+    tau_max = p_max * peak
+    tau = np.zeros((steps.size,), dtype=x_fwd.dtype)
+    chosen = np.sort(x_fwd[(x_fwd > tau_min) & (x_fwd < tau_max)])[::-1]
+    tau[0] = chosen[0]
+    tau[1:] = chosen[np.ceil((steps[1:] - 1) * (chosen.size - 1) / (niter - 1)).astype('int')]
+    return tau
+
+
+def get_threshold_decay(
+    thresh_model,
+    niter: int,
+    transform_kind: str = None,
+    p_max: float = 0.99,
+    p_min: float = 1e-3,
+    x_fwd=None,
+    kind: str = 'values',
+):
+    """
+    Iteration-based decay of the threshold (same signature as the reference, POCS.py:169-177).
+
+    ``x_fwd`` is the forward-transformed input as a NumPy array; only the single-scale transforms
+    (`FFT`, `DCT`, `CURVELET`) are covered.  Returns ``tau`` with ``niter`` entries: complex when the
+    'values' kind scales by the (complex) maximum of ``x_fwd``, real otherwise.
+    """
+    if transform_kind is None:
+        pass
+    elif transform_kind.upper() not in TRANSFORMS and (kind == 'values' or thresh_model == 'data-driven'):
+        raise ValueError(f'Unsupported transform. Please select one of: {TRANSFORMS}')
+    else:
+        transform_kind = transform_kind.upper()
+    if transform_kind in ('WAVELET', 'SHEARLET'):
+        raise NotImplementedError(f'{transform_kind} schedules are not available in the HIP build yet')
+
+    if x_fwd is None and (kind == 'values' or thresh_model == 'data-driven'):
+        raise ValueError('`x_fwd` must be specified for thresh_model="data-driven" or kind="values"!')
+
+    inverse_prop = all(s in thresh_model for s in ['inverse', 'proportional'])
+    if kind == 'values' and transform_kind is None and not inverse_prop:
+        raise ValueError('`transform_kind` must be specified for thresh_model="data-driven" or kind="values"!')
+    if thresh_model == 'data-driven' and not inverse_prop:
+        if kind != 'values':
+            raise NotImplementedError('data-driven thresholds need kind="values"')
+        return _data_driven(np.asarray(x_fwd), niter, p_max, p_min)
+
+    peak = abs_max = abs_min = sumsq = size = None
+    if x_fwd is not None:
+        x_fwd = np.asarray(x_fwd)
+        if inverse_prop:
+            mag = np.abs(x_fwd)
+            abs_max, abs_min = mag.max(), mag.min()
+        elif kind == 'values':
+            peak = x_fwd.max()  # complex -> lexicographic, keeps the imaginary part (POCS.py:288)
+            if isinstance(p_min, str) and p_min == 'adaptive':
+                sumsq, size = np.linalg.norm(x_fwd, axis=None) ** 2, x_fwd.size
+    return _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, sumsq, size)
+
+
+def _schedule_from_stats(stats, size, thresh_model, niter, p_max, p_min, kind):
+    """Batch form used by the GPU path: ``stats`` is (nslices, 6) from ``p3d_pocs_stats``."""
+    peak = stats[:, 0] + 1j * stats[:, 1]
+    tau = _schedule(thresh_model, niter, p_max, p_min, kind, peak, stats[:, 2], stats[:, 3], stats[:, 4], size)
+    return np.broadcast_to(tau, (stats.shape[0], niter))
+
+
+# =================================================================================================
+#                                      batched GPU entry point
+# =================================================================================================
+_plans = {}
+
+
+def _get_plan(nil, nxl, nslices, device):
+    key = (nil, nxl, device)
+    plan = _plans.get(key)
+    if plan is None or plan.max_slices < nslices:
+        if plan is not None:
+            plan.close()
+        plan = _ffi.Plan(nil, nxl, max(nslices, 1), device)
+        _plans[key] = plan
+    return plan
+
+
+def release_plans():
+    """Free the cached GPU plans (work buffers) of this process."""
+    for plan in _plans.values():
+        plan.close()
+    _plans.clear()
+
+
+def _check_common(mask, transform_kind, thresh_op):
+    if np.max(mask) > 1:
+        raise ValueError(f'mask should be quasi-boolean (0 or 1) but has maximum of {np.max(mask)}')
+    if transform_kind is None or transform_kind.upper() not in TRANSFORMS:
+        raise ValueError(f'Unsupported transform. Please select one of: {TRANSFORMS}')
+    kind = transform_kind.upper()
+    if kind not in _HIP_TRANSFORMS:
+        raise NotImplementedError(
+            f'{kind} transform is not implemented by the HIP kernels yet (available: {_HIP_TRANSFORMS})')
+    if thresh_op not in _THRESH_OPS:
+        raise ValueError(f'Unknown threshold operator {thresh_op!r}. Please select one of: {_THRESH_OPS}')
+    if thresh_op.endswith('-percentile'):
+        raise NotImplementedError(f'thresh_op={thresh_op!r} is not implemented by the HIP kernels yet')
+    return kind
+
+
+def pocs_cube(
+    cube,
+    mask,
+    transform_kind='FFT',
+    niter=50,
+    thresh_op='hard',
+    thresh_model='exponential',
+    eps=1e-9,
+    alpha=1.0,
+    p_max=0.99,
+    p_min=1e-5,
+    sqrt_decay=False,
+    decay_kind='values',
+    version='regular',
+    results=None,
+    device=0,
+    batch_slices=None,
+    **ignored,
+):
+    """
+    Interpolate every ``(iline, xline)`` slice of ``cube`` (shape ``(nslices, nil, nxl)``, slice-major
+    like the netCDF cubes of the workflow) with the POCS iteration of ``POCS_algorithm`` -- all slices
+    of a batch advance together on the GPU.
+
+    Parameters are those of :func:`POCS_algorithm`; ``mask`` (``(nil, nxl)``) is shared by all slices
+    (cube_POCS_interpolation_3D.py:242-244).  ``results`` (list, optional) receives one dict per
+    slice with ``niterations``, ``runtime``, ``cost`` and ``costs``.  ``transform`` / ``itransform``
+    callables in ``**ignored`` are accepted for signature compatibility and not called: the transform
+    is selected by ``transform_kind``.
+
+    Returns an array with the shape and dtype of ``cube``.
+    """
+    cube = np.asarray(cube)
+    if cube.ndim != 3:
+        raise ValueError(f'cube must be (nslices, iline, xline), got shape {cube.shape}')
+    mask = np.asarray(mask)
+    if mask.shape != cube.shape[1:]:
+        raise ValueError(f'mask shape {mask.shape} does not match slice shape {cube.shape[1:]}')
+    kind = _check_common(mask, transform_kind, thresh_op)
+    if version not in _ffi.P3D_VER:
+        raise ValueError(f'Unknown POCS version {version!r}')
+    niter, eps, p_max, alpha = int(niter), float(eps), float(p_max), float(alpha)
+    if isinstance(p_min, str) and p_min != 'adaptive':
+        p_min = float(p_min)  # YAML 1.1 reads 1e-4 as a string
+
+    nslices, nil, nxl = cube.shape
+    out = np.empty_like(cube)
+    if nslices == 0:
+        return out
+    if niter < 1:  # the reference's loop body never runs and it then fails on `iiter`; be explicit
+        raise ValueError('niter must be >= 1')
+    step = int(batch_slices) if batch_slices else nslices
+    plan = _get_plan(nil, nxl, min(step, nslices), device)
+    maskf = np.ascontiguousarray(mask, dtype=np.float32)
+
+    for lo in range(0, nslices, step):
+        chunk = cube[lo:lo + step]
+        n = chunk.shape[0]
+        active = chunk.reshape(n, -1).any(axis=1)  # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+        t0 = time.perf_counter()
+        if thresh_model == 'data-driven':
+            X0 = plan.fft2(chunk.astype(np.complex64))
+            tau = np.zeros((n, niter), np.complex128)
+            for s in np.flatnonzero(active):
+                tau[s] = _data_driven(X0[s], niter, p_max, p_min)
+        else:
+            stats = plan.stats(chunk)
+            stats[~active] = 1.0  # keep NaNs of empty slices out of the (unused) schedule rows
+            tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
+        if sqrt_decay:
+            tau = np.sqrt(tau)  # POCS.py:595
+        res, done, sums, _ = plan.run(chunk, maskf, tau, niter, thresh_op=thresh_op, version=version, eps=eps,
+                                      alpha=alpha, active=active)
+        runtime = time.perf_counter() - t0
+        out[lo:lo + n] = res
+        if results is not None:
+            with np.errstate(invalid='ignore', divide='ignore'):
+                costs = ((sums[1:] - sums[:-1]) / sums[1:]) ** 2  # POCS.py:622
+            for s in range(n):
+                k = int(done[s])
+                results.append({
+                    'niterations': k,
+                    'runtime': round(runtime / n, 3) if k else 0,
+                    'cost': float(costs[k - 1, s]) if k else 0,
+                    'costs': [float(c) for c in costs[:k, s]] if k else [0],
+                })
+    return out
+
+
+# =================================================================================================
+#                                      per-slice contract
+# =================================================================================================
+def POCS_algorithm(
+    x,
+    mask,
+    auxiliary_data=None,
+    transform=None,
+    itransform=None,
+    transform_kind: str = None,
+    niter: int = 50,
+    thresh_op: str = 'hard',
+    thresh_model: str = 'exponential',
+    eps: float = 1e-9,
+    alpha: int = 1.0,
+    p_max: float = 0.99,
+    p_min: float = 1e-5,
+    sqrt_decay: str = False,
+    decay_kind: str = 'values',
+    verbose: bool = False,
+    version: str = 'regular',
+    results_dict: dict = None,
+    path_results: str = None,
+):
+    """
+    Interpolate sparse input grid using Point Onto Convex Sets (POCS) algorithm -- drop-in for the
+    reference's ``POCS_algorithm`` (POCS.py:371-656) with the loop executed by the HIP kernels.
+
+    Parameters, error behaviour (``ValueError`` for a non-boolean mask, missing transforms, unknown
+    transform kind, shearlet without Psi; POCS.py:488-503), side channels (``results_dict`` keys
+    ``niterations`` / ``runtime`` / ``cost``; one ``niter;runtime;cost_1;..`` line appended to
+    ``path_results``; POCS.py:644-651) and return value (complex in -> complex out, real in -> real
+    part; POCS.py:653-656) follow the reference.  Differences: ``transform`` / ``itransform`` must be
+    supplied but are not called (the transform is chosen by ``transform_kind``; only ``'FFT'`` is
+    implemented so far), and arithmetic is float32 on the GPU.
+    """
+    if np.max(mask) > 1:
+        raise ValueError(f'mask should be quasi-boolean (0 or 1) but has maximum of {np.max(mask)}')
+    if any(v is None for v in [transform, itransform]):
+        raise ValueError('Forward and inverse transform function have to be supplied')
+    if transform_kind is None or transform_kind.upper() not in TRANSFORMS:
+        raise ValueError(f'Unsupported transform. Please select one of: {TRANSFORMS}')
+    transform_kind = transform_kind.upper()
+    if transform_kind == 'SHEARLET' and auxiliary_data is None:
+        raise ValueError(f'{transform_kind} requires pre-computed shearlets in Fourier domain (Psi)')
+
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError(f'x must be a 2D slice, got shape {x.shape}')
+    results = []
+    out = pocs_cube(
+        x[None], mask, transform_kind=transform_kind, niter=niter, thresh_op=thresh_op,
+        thresh_model=thresh_model, eps=eps, alpha=alpha, p_max=p_max, p_min=p_min, sqrt_decay=sqrt_decay,
+        decay_kind=decay_kind, version=version, results=results,
+    )[0]
+    info = results[0]
+
+    if verbose:
+        print('\n' + '-' * 20)
+        print(f'# iterations:  {info["niterations"]:4d}')
+        print(f'cost function: {info["cost"]}')
+        print(f'runtime:       {info["runtime"]:.3f} s')
+        print('-' * 20)
+
+    if isinstance(results_dict, dict):
+        results_dict['niterations'] = info['niterations']
+        results_dict['runtime'] = info['runtime']
+        results_dict['cost'] = info['cost']
+
+    if path_results is not None:
+        with open(path_results, mode="a", newline='\n') as f:
+            f.write(';'.join([str(i) for i in [info['niterations'], info['runtime']] + info['costs']]) + '\n')
+
+    return out
+
+
+POCS = partial(POCS_algorithm, version='regular')
+FPOCS = partial(POCS_algorithm, version='fast')
+APOCS = partial(POCS_algorithm, version='adaptive')

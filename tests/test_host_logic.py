@@ -1,0 +1,134 @@
+"""CPU-only checks of the product's host side: threshold schedule vs the reference's golden vectors,
+error contract of POCS_algorithm, C-ABI surface of libp3d_hip.so, host emulation of the FFT engine."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+import pseudo_3d_interpolation_amd as pkg
+from pseudo_3d_interpolation_amd import _ffi
+from pseudo_3d_interpolation_amd.functions import POCS as P
+from pseudo_3d_interpolation_amd.functions import backends
+
+CSRC = os.path.join(ROOT, "pseudo-3d-interpolation_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    if not os.path.isfile(_ffi.LIB_PATH):
+        subprocess.run(["make", "-C", CSRC, "-j8"], check=True, capture_output=True)
+    return _ffi.LIB_PATH
+
+
+def test_package_layout():
+    assert pkg.__version__
+    assert os.path.basename(os.path.dirname(pkg.__file__)) == "pseudo-3d-interpolation_amd"
+    assert backends.hip_library_path == _ffi.LIB_PATH
+    for name in ("POCS_algorithm", "POCS", "FPOCS", "APOCS", "get_threshold_decay", "pocs_cube"):
+        assert hasattr(P, name)
+    assert P.POCS.keywords == {"version": "regular"}
+    assert P.FPOCS.keywords == {"version": "fast"}
+    assert P.APOCS.keywords == {"version": "adaptive"}
+
+
+def test_schedule_matches_reference_golden():
+    g = load_golden("decay.npz")
+    keys = sorted(k[:-5] for k in g.files if k.endswith("_meta"))
+    n = 0
+    for key in keys:
+        sname, model, kind, p_min, niter = [str(v) for v in g[key + "_meta"]]
+        p_min = "adaptive" if p_min == "adaptive" else float(p_min)
+        with np.errstate(all="ignore"):
+            tau = P.get_threshold_decay(model, int(niter), "FFT", 0.99, p_min, g["X0_" + sname], kind)
+        want = g[key + "_tau"]
+        assert np.asarray(tau).shape == want.shape, (key, model, kind)
+        assert np.asarray(tau).dtype == want.dtype, (key, model, kind)
+        assert np.array_equal(np.asarray(tau), want, equal_nan=True), (key, model, kind, p_min, niter)
+        n += 1
+    assert n > 100
+
+
+def test_batched_schedule_equals_scalar_schedule():
+    """The (nslices, 6) statistics form used by the GPU path must reproduce the per-slice function."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((5, 16, 8)) + 1j * rng.standard_normal((5, 16, 8))
+    stats = np.zeros((5, 6))
+    for s in range(5):
+        pk = X[s].max()
+        stats[s] = [pk.real, pk.imag, np.abs(X[s]).max(), np.abs(X[s]).min(), np.linalg.norm(X[s]) ** 2, 0]
+    for model in ("linear", "exponential", "exponential-2", "inverse_proportional-2"):
+        for kind in ("values", "factors"):
+            for p_min in (1e-3, "adaptive"):
+                if kind == "factors" and p_min == "adaptive":
+                    continue
+                got = P._schedule_from_stats(stats, X[0].size, model, 12, 0.99, p_min, kind)
+                for s in range(5):
+                    want = P.get_threshold_decay(model, 12, "FFT", 0.99, p_min, X[s], kind)
+                    assert np.allclose(got[s], want, rtol=1e-13, atol=0), (model, kind, p_min)
+
+
+def test_error_contract_matches_reference():
+    tab = {str(r[0]): (str(r[1]), str(r[2])) for r in load_golden("errors.npz")["table"]}
+    x = np.ones((8, 8), np.complex64)
+    m = np.ones((8, 8), np.uint8)
+    f, i = np.fft.fft2, np.fft.ifft2
+    with pytest.raises(ValueError) as e:
+        P.POCS_algorithm(x, m * 2, transform=f, itransform=i, transform_kind="FFT")
+    assert str(e.value) == tab["mask_gt_1"][1]
+    with pytest.raises(ValueError) as e:
+        P.POCS_algorithm(x, m, transform=None, itransform=None, transform_kind="FFT")
+    assert str(e.value) == tab["no_transform"][1]
+    with pytest.raises(ValueError) as e:
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="HAAR")
+    assert str(e.value) == tab["bad_kind"][1]
+    with pytest.raises(ValueError) as e:
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="SHEARLET")
+    assert str(e.value) == tab["shearlet_no_psi"][1]
+    # options the HIP build does not cover yet fail loudly instead of falling back to the CPU
+    with pytest.raises(NotImplementedError):
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET")
+    with pytest.raises(NotImplementedError):
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="FFT", thresh_op="hard-percentile")
+
+
+def test_product_never_imports_oracle():
+    pk = os.path.join(ROOT, "pseudo-3d-interpolation_amd")
+    for dirpath, _, files in os.walk(pk):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), fn
+                assert "pocs_oracle" not in txt, fn
+
+
+def test_cabi_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "p3d.h")).read()
+    declared = set(re.findall(r"\b(p3d_[a-z0-9_]+)\s*\(", header))
+    declared -= {"p3d_plan", "p3d_pocs_params"}
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/p3d.h but not exported"
+    assert declared == set(_ffi.PROTOTYPES), "ctypes prototype table out of sync with include/p3d.h"
+    assert lib.p3d_abi_version() == 1
+    # shape query needs no GPU
+    assert lib.p3d_shape_supported(1024, 1024) == 1
+    assert lib.p3d_shape_supported(64, 2048) == 1
+    assert lib.p3d_shape_supported(90, 50) in (0, 1)
+    assert ctypes.sizeof(_ffi.PocsParams) == 32
+
+
+def test_fft_engine_host_emulation(tmp_path):
+    """Drive the device FFT templates (butterflies, pass schedule, Stockham scatter, twiddle layout,
+    both LDS views) thread-by-thread on the CPU for every supported line length."""
+    exe = tmp_path / "fft_host"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", CSRC, os.path.join(ROOT, "tests", "csrc", "test_fft_host.cpp"),
+                    "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:]
+    assert "ALL OK" in res.stdout
