@@ -98,6 +98,12 @@ int p3d_memcpy_d2h(p3d_plan* plan, void* dst_host, const void* src_dev, size_t b
 int p3d_fft2_c64_dev(p3d_plan* plan, const void* in_dev, void* out_dev, int nslices, int inverse);
 int p3d_fft2_c64(p3d_plan* plan, const void* in_host, void* out_host, int nslices, int inverse);
 
+/* Thresholded spectrum of every slice: threshold(fft2(x), tau_s, kind) as the first half of one POCS
+ * iteration computes it (POCS.py:592-599 -> threshold_operator.py:9-112).  tau: HOST [nslices][2]
+ * doubles (Re, Im).  Test hook: lets a checker see the keep/zero decision of every coefficient. */
+int p3d_fft2_shrink_c64(p3d_plan* plan, const void* in_host, const double* tau, int thresh_op, void* out_host,
+                        int nslices);
+
 /* Per-slice statistics of X0 = fft2(x) for the threshold schedule (replaces the device-independent
  * part of get_threshold_decay, POCS.py:535-546).  stats_host: [nslices][P3D_STATS_PER_SLICE]. */
 int p3d_pocs_stats_dev(p3d_plan* plan, const void* x_dev, int dtype, int nslices, double* stats_host);
@@ -107,8 +113,7 @@ int p3d_pocs_stats(p3d_plan* plan, const void* x_host, int dtype, int nslices, d
  *   x        [nslices][nil][nxl] observed data, zeros at missing traces, dtype as given
  *   mask     [nil][nxl] float32, 1 = observed trace, 0 = missing (cube_POCS_interpolation_3D.py:242-244)
  *   tau      HOST, [nslices][niter][2] doubles: Re, Im of the threshold used at each iteration
- *            (decay[k], or sqrt(decay[k]) for sqrt_decay; POCS.py:595).  A slice whose first tau is
- *            NaN in both parts AND whose `active` entry is 0 is not processed.
+ *            (decay[k], or sqrt(decay[k]) for sqrt_decay; POCS.py:595)
  *   active   HOST, [nslices] uint8 or NULL: 0 marks an all-zero slice, which the reference returns
  *            untouched with niterations = 0 (POCS.py:515-521)
  *   out      [nslices][nil][nxl], same dtype as x

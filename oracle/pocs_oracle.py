@@ -261,6 +261,26 @@ def pocs_slice(
     return cur if complex_in else np.real(cur)
 
 
+def pocs_step(prev, x, mask, tau, thresh_op="hard", alpha=1.0, keep=None, fwd=np.fft.fft2, inv=np.fft.ifft2):
+    """ONE regular iteration (POCS.py:592-619) from the iterate ``prev``.
+
+    ``keep`` (bool array, hard threshold only) overrides the keep/zero decision per coefficient: tests
+    use it to replay the device's decisions for coefficients whose modulus is within float32 rounding
+    of tau, where no single-precision implementation (the reference's own complex64 path included)
+    can be expected to decide like a double-precision one.  Returns (x_new, spectrum before
+    thresholding, thresholded spectrum).
+    """
+    spec = fwd(prev)
+    if keep is None:
+        shr = apply_threshold(spec, tau, kind=thresh_op)
+    else:
+        shr = np.where(keep, spec, 0)
+    cur = inv(shr)
+    cur *= 1 - alpha * mask
+    cur += x * alpha
+    return cur, spec, shr
+
+
 def pocs_cube(cube, mask, infos=None, **params):
     """Apply :func:`pocs_slice` to every leading-axis slice of ``cube`` (the job the reference's
     ``xr.apply_ufunc(..., vectorize=True)`` does, cube_POCS_interpolation_3D.py:314-340); the

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "p3d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3d_fft2_c64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "p3d_fft2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "p3d_fft2_shrink_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_pocs_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_pocs_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -170,6 +171,19 @@ class Plan:
         xc, _ = self._cube(x.astype(np.complex64, copy=False))
         out = np.empty_like(xc)
         check(lib().p3d_fft2_c64(self.handle, _ptr(xc), _ptr(out), xc.shape[0], int(bool(inverse))))
+        return out[0] if squeeze else out
+
+    def fft2_shrink(self, x, tau, thresh_op="hard"):
+        """threshold(fft2(x), tau, kind) on the device; ``tau`` scalar or one value per slice."""
+        x = np.asarray(x)
+        squeeze = x.ndim == 2
+        xc, _ = self._cube(x.astype(np.complex64, copy=False))
+        n = xc.shape[0]
+        t = np.empty((n, 2), np.float64)
+        tau = np.broadcast_to(np.asarray(tau, dtype=np.complex128), (n,))
+        t[:, 0], t[:, 1] = tau.real, tau.imag
+        out = np.empty_like(xc)
+        check(lib().p3d_fft2_shrink_c64(self.handle, _ptr(xc), _ptr(t), P3D_OP[thresh_op], _ptr(out), n))
         return out[0] if squeeze else out
 
     # ---- POCS ------------------------------------------------------------------------------

@@ -321,6 +321,44 @@ int p3d_fft2_c64(p3d_plan* p, const void* in, void* out, int nslices, int invers
     return P3D_OK;
 }
 
+int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, void* out, int nslices)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!in || !out || !tau) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (op < P3D_OP_HARD || op > P3D_OP_GARROTE) return fail(P3D_ERR_UNSUPPORTED, "thresh_op %d is not implemented", op);
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t bytes = sizeof(c32) * p->slice_elems() * nslices;
+    if ((rc = ensure_staging(p, sizeof(c32) * p->slice_elems() * p->max_slices))) return rc;
+    if (p->tau_cap < (size_t)nslices) {
+        if (p->tau) hipFree(p->tau);
+        p->tau = nullptr;
+        p->tau_cap = 0;
+        HIP_TRY(hipMalloc((void**)&p->tau, sizeof(c32) * nslices));
+        p->tau_cap = nslices;
+    }
+    std::vector<c32> tau_f(nslices);
+    for (int s = 0; s < nslices; ++s) tau_f[s] = c32{(float)tau[2 * s], (float)tau[2 * s + 1]};
+    HIP_TRY(hipMemcpy(p->tau, tau_f.data(), sizeof(c32) * nslices, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->st_x, in, bytes, hipMemcpyHostToDevice));
+    RowArgs r = row_args(p, nslices);
+    r.x = p->st_x;
+    r.work = (c32*)p->st_out;
+    r.dtype = P3D_C64;
+    HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+    ColArgs c = col_args(p, nslices);
+    c.in = (const c32*)p->st_out;
+    c.out = (c32*)p->st_out;
+    c.tau = p->tau;
+    c.niter = 1;
+    c.iter = 0;
+    c.op = op;
+    HIP_TRY(p->ops_col->col(COL_FWD, c, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(out, p->st_out, bytes, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
 int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, double* stats)
 {
     int rc = check_batch(p, nslices);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL) void col_kernel(const ColArgs a)
 
     if (MODE != COL_INV) line_fft<N, FWD>(v, lds, tabF, tl);
 
-    if (MODE == COL_ITER) {
+    if (MODE == COL_ITER || (MODE == COL_FWD && a.tau != nullptr)) {
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = shrink(v[q], tau, a.op);

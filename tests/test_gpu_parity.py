@@ -150,16 +150,38 @@ def test_zero_slice_and_results_file(P, tmp_path):
 
 # ------------------------------------------------------------------------------------------------
 # oracle on seeded synthetic cubes (sizes the oracle finishes in seconds)
+#
+# The hard threshold is discontinuous: a coefficient whose modulus is within float32 rounding of tau
+# is kept by one implementation and zeroed by another.  Late in the schedule tau sits in the
+# incoherent floor of the spectrum where tens of thousands of coefficients crowd around it, and the
+# reference's OWN complex64 path (what NumPy >= 2 runs for complex64 cubes) then differs from its
+# complex128 path by up to ~1e-3 rel-L2 (1024x1024, 80 % missing, 10 iterations: 7.5e-4, see
+# DESIGN.md "Parity").  Parity is therefore established in three layers:
+#   A. end-to-end <= 1e-5 vs the double-fed oracle wherever the problem is well conditioned
+#      (continuous operators, or thresholds that stay above the floor);
+#   B. decision-level: ONE iteration, spectrum and result, against the oracle; every coefficient
+#      outside the float32 tie band must agree, the band may go either way (test_step_*);
+#   C. the fused multi-iteration loop is bit-identical to chaining single iterations (test_fused_*),
+#      so B carries over to whole runs;
+# plus end-to-end runs in the ill-conditioned regime held to the reference's own fp32 sensitivity.
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [
-    dict(nil=64, nxl=64, n=8, missing=0.5, niter=20, thresh_op="hard"),                       # BASELINE configs[0] shape
-    dict(nil=128, nxl=256, n=3, missing=0.7, niter=25, thresh_op="hard"),
+WELL_CONDITIONED = [
+    dict(nil=64, nxl=64, n=8, missing=0.5, niter=20, thresh_op="hard", p_min=0.02),          # BASELINE configs[0] shape
+    dict(nil=128, nxl=256, n=3, missing=0.7, niter=25, thresh_op="hard", p_min=0.05),
     dict(nil=256, nxl=128, n=3, missing=0.6, niter=15, thresh_op="soft"),
-    dict(nil=512, nxl=512, n=2, missing=0.7, niter=12, thresh_op="hard"),                     # configs[1] slice
+    dict(nil=512, nxl=512, n=2, missing=0.7, niter=12, thresh_op="soft"),                     # configs[1] slice
+    dict(nil=512, nxl=512, n=1, missing=0.7, niter=12, thresh_op="hard", p_min=0.05),
     dict(nil=64, nxl=1024, n=2, missing=0.8, niter=10, thresh_op="garrote"),
-    dict(nil=64, nxl=64, n=4, missing=0.5, niter=12, thresh_op="hard", version="adaptive", alpha=0.75, p_min="adaptive"),
-    dict(nil=32, nxl=64, n=4, missing=0.5, niter=12, thresh_op="hard", real=True),
-])
+    dict(nil=64, nxl=64, n=4, missing=0.5, niter=12, thresh_op="soft", version="adaptive", alpha=0.75, p_min="adaptive"),
+    dict(nil=64, nxl=64, n=4, missing=0.5, niter=12, thresh_op="hard", version="adaptive", alpha=0.75, p_min=0.02),
+    dict(nil=32, nxl=64, n=4, missing=0.5, niter=12, thresh_op="hard", real=True, p_min=0.02),
+    dict(nil=64, nxl=32, n=4, missing=0.5, niter=12, thresh_op="soft", real=True, thresh_model="linear"),
+    dict(nil=128, nxl=128, n=2, missing=0.5, niter=10, thresh_op="hard", alpha=0.8, p_min=0.02, sqrt_decay=True),
+    dict(nil=1024, nxl=1024, n=1, missing=0.8, niter=8, thresh_op="soft"),                    # headline slice size
+]
+
+
+@pytest.mark.parametrize("cfg", WELL_CONDITIONED)
 def test_cube_vs_oracle(P, orc, cfg):
     cfg = dict(cfg)
     nil, nxl, n, missing = cfg.pop("nil"), cfg.pop("nxl"), cfg.pop("n"), cfg.pop("missing")
@@ -174,13 +196,107 @@ def test_cube_vs_oracle(P, orc, cfg):
         assert rel_l2(got[s], want[s]) < TOL, (s, rel_l2(got[s], want[s]))
 
 
-def test_benchmark_slice_vs_oracle(P, orc):
-    """One 1024x1024 slice of the headline configuration (80 % missing, hard, exponential)."""
-    _, mask, obs = orc.synthetic_cube(1024, 1024, 1, 0.8)
-    params = dict(niter=10, thresh_op="hard", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
+ILL_CONDITIONED = [
+    dict(nil=64, nxl=64, n=8, missing=0.5, niter=20),        # BASELINE configs[0]: tau_min = 1e-3 * peak
+    dict(nil=512, nxl=512, n=2, missing=0.7, niter=12),      # configs[1] slice
+    dict(nil=1024, nxl=1024, n=1, missing=0.8, niter=10),    # configs[2] slice
+]
+
+
+@pytest.mark.parametrize("cfg", ILL_CONDITIONED)
+def test_cube_vs_oracle_threshold_in_the_floor(P, orc, cfg):
+    """Hard threshold driven into the spectral floor: compare with the double-fed oracle at the level
+    at which the reference's own float32 run agrees with it (never looser than 2e-3)."""
+    nil, nxl, n, missing, niter = cfg["nil"], cfg["nxl"], cfg["n"], cfg["missing"], cfg["niter"]
+    params = dict(niter=niter, thresh_op="hard", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
+    _, mask, obs = orc.synthetic_cube(nil, nxl, n, missing)
     got = P.pocs_cube(obs, mask, **params)
     want = orc.pocs_cube(obs.astype(np.complex128), mask, **params)
-    assert rel_l2(got[0], want[0]) < TOL
+    ref32 = orc.pocs_cube(obs, mask, **params)  # what the reference computes for complex64 cubes
+    for s in range(n):
+        spread = rel_l2(ref32[s], want[s])
+        err = rel_l2(got[s], want[s])
+        assert err < min(max(10 * spread, 2e-4), 2e-3), (s, err, spread)
+
+
+def _tie_band(spec, tau_re, scale=2e-6):
+    """Coefficients whose modulus float32 arithmetic cannot place relative to tau: the absolute error
+    of a float32 FFT coefficient is ~1e-7 * max|X| regardless of the coefficient's own size."""
+    return np.abs(np.abs(spec) - tau_re) <= scale * np.abs(spec).max()
+
+
+STEP_CASES = [
+    # (nil, nxl, missing, iterations of oracle run-in, p_min, thresh_op)
+    (64, 64, 0.5, 0, 1e-3, "hard"),
+    (64, 64, 0.5, 19, 1e-3, "hard"),       # last iteration of configs[0]: tau in the floor
+    (256, 512, 0.7, 10, 1e-3, "hard"),
+    (512, 512, 0.7, 11, 1e-3, "hard"),     # configs[1] slice, threshold in the floor
+    (1024, 1024, 0.8, 8, 1e-3, "hard"),    # configs[2] slice, 150k coefficients kept
+    (1024, 1024, 0.8, 9, 1e-3, "hard"),
+    (128, 64, 0.6, 5, 1e-3, "soft"),
+    (128, 64, 0.6, 5, 1e-3, "garrote"),
+    (1024, 1024, 0.8, 9, 1e-3, "soft"),
+]
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_step_decisions_and_result(ffi, orc, case):
+    """Layer B: one iteration from an iterate taken off the oracle's trajectory."""
+    nil, nxl, missing, warm, p_min, op = case
+    niter = max(warm + 1, 2)
+    _, mask, obs = orc.synthetic_cube(nil, nxl, 1, missing)
+    x = obs[0].astype(np.complex128)
+    tau = orc.threshold_schedule("exponential", niter, "FFT", 0.99, p_min, np.fft.fft2(x), "values")
+    prev = x
+    for k in range(warm):
+        prev, _, _ = orc.pocs_step(prev, x, mask, tau[k], op)
+    prev32 = prev.astype(np.complex64)          # the state the device starts from
+    prev = prev32.astype(np.complex128)
+    t = tau[warm]
+    with ffi.Plan(nil, nxl, 1) as plan:
+        shr_gpu = plan.fft2_shrink(prev32, t, op)
+        # a one-iteration run whose observed data ARE the iterate: re-insertion puts prev back at the
+        # observed traces, exactly what the oracle step below does with x = prev
+        out_gpu, done, sums, _ = plan.run(prev32[None], mask.astype(np.float32), np.array([[t]]), 1, thresh_op=op)
+    want, spec, shr = orc.pocs_step(prev, prev, mask, t, op)
+    peak = np.abs(spec).max()
+    if op == "hard":
+        band = _tie_band(spec, t.real)
+        assert band.mean() < 0.02, "tie band should be a sliver of the spectrum"
+        kept_gpu = shr_gpu != 0
+        kept_ref = shr != 0
+        # outside the band the decisions are identical ...
+        assert np.array_equal(kept_gpu[~band], kept_ref[~band]), int(np.count_nonzero(kept_gpu[~band] != kept_ref[~band]))
+        # ... and kept coefficients carry the transform's value
+        assert np.abs(shr_gpu - np.where(kept_gpu, spec, 0)).max() < 2e-6 * peak
+        want, _, _ = orc.pocs_step(prev, prev, mask, t, op, keep=kept_gpu)   # replay the device's ties
+    else:
+        assert np.abs(shr_gpu - shr).max() < 4e-6 * peak
+    assert rel_l2(out_gpu[0], want) < 2e-6, rel_l2(out_gpu[0], want)
+    assert abs(sums[1, 0] - np.abs(want).sum()) < 1e-5 * np.abs(want).sum()
+    assert abs(sums[0, 0] - np.abs(prev).sum()) < 1e-5 * np.abs(prev).sum()
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (256, 128), (1024, 1024)])
+def test_fused_loop_equals_chained_single_iterations(ffi, orc, shape):
+    """Layer C: K fused iterations (row pass = inverse transform + re-insertion + next forward
+    transform in one kernel) give the same BITS as K one-iteration runs fed with each other's output
+    (alpha = 1: the observed traces of every iterate are the observed data)."""
+    from pseudo_3d_interpolation_amd.functions.POCS import _schedule_from_stats
+
+    nil, nxl = shape
+    K = 6
+    _, mask, obs = orc.synthetic_cube(nil, nxl, 2, 0.7)
+    maskf = mask.astype(np.float32)
+    with ffi.Plan(nil, nxl, 2) as plan:
+        st = plan.stats(obs)
+        tau = _schedule_from_stats(st, nil * nxl, "exponential", K, 0.99, 1e-3, "values")
+        fused, _, sums_f, _ = plan.run(obs, maskf, tau, K)
+        cur = obs
+        for k in range(K):
+            cur, _, sums_c, _ = plan.run(cur, maskf, tau[:, k:k + 1], 1)
+            assert np.array_equal(sums_c[1], sums_f[k + 1])
+    assert np.array_equal(fused, cur)
 
 
 # ------------------------------------------------------------------------------------------------
