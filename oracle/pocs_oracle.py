@@ -264,17 +264,29 @@ def pocs_slice(
 def pocs_step(prev, x, mask, tau, thresh_op="hard", alpha=1.0, keep=None, fwd=np.fft.fft2, inv=np.fft.ifft2):
     """ONE regular iteration (POCS.py:592-619) from the iterate ``prev``.
 
-    ``keep`` (bool array, hard threshold only) overrides the keep/zero decision per coefficient: tests
-    use it to replay the device's decisions for coefficients whose modulus is within float32 rounding
-    of tau, where no single-precision implementation (the reference's own complex64 path included)
-    can be expected to decide like a double-precision one.  Returns (x_new, spectrum before
-    thresholding, thresholded spectrum).
+    ``keep`` (bool array) overrides the keep/zero decision per coefficient: kept coefficients get the
+    operator's (unclipped) gain, the others become 0.  Tests use it to replay the device's decisions
+    for coefficients whose modulus is within float32 rounding of Re(tau), where no single-precision
+    implementation (the reference's own complex64 path included) can be expected to decide like a
+    double-precision one.  With the reference's complex tau all three operators are discontinuous
+    there: hard jumps by |X|, soft and garrote by ~|Im tau|.
+    Returns (x_new, spectrum before thresholding, thresholded spectrum).
     """
     spec = fwd(prev)
     if keep is None:
         shr = apply_threshold(spec, tau, kind=thresh_op)
     else:
-        shr = np.where(keep, spec, 0)
+        mag = np.absolute(spec)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if thresh_op == "hard":
+                gain = 1.0
+            elif thresh_op == "soft":
+                gain = 1 - tau / mag
+            elif thresh_op in ("garrote", "garotte"):
+                gain = 1 - tau**2 / mag**2
+            else:
+                raise ValueError(thresh_op)
+            shr = np.where(keep, spec * gain, 0)
     cur = inv(shr)
     cur *= 1 - alpha * mask
     cur += x * alpha
