@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3d_hip.so")
+LIB_PATH = os.environ.get("P3D_LIB_PATH") or os.path.join(_HERE, "libp3d_hip.so")  # env override: experiments only
 
 P3D_OK = 0
 P3D_ERR_INVALID, P3D_ERR_UNSUPPORTED, P3D_ERR_HIP = -1, -2, -3

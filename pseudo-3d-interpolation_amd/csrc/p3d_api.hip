@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,6 +54,26 @@ static __global__ void conv_kernel(const double* sums, int* done, int nslices, i
 }
 
 
+// ---- packed trace mask ---------------------------------------------------------------------------
+// bits[row][tl] bit q = (mask[row][tl + tpl*q] == 1); *nonbinary is raised when an entry is neither 0 nor 1
+// (the reference accepts any mask with max <= 1, POCS.py:488; such masks take the float path).
+static __global__ void pack_mask_kernel(const float* mask, uint16_t* bits, int* nonbinary, int n1, int n2, int tpl, int ppt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1 * tpl) return;
+    const int row = i / tpl, tl = i - row * tpl;
+    unsigned w = 0;
+    bool odd = false;
+    for (int q = 0; q < ppt; ++q) {
+        const float m = mask[(size_t)row * n2 + tl + tpl * q];
+        if (m == 1.0f) w |= 1u << q;
+        else if (m != 0.0f) odd = true;
+    }
+    bits[i] = (uint16_t)w;
+    if (odd) atomicOr(nonbinary, 1);
+}
+
+
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...)
@@ -78,8 +99,10 @@ struct p3d_plan {
     hipStream_t stream = nullptr;
     const LineOps* ops_col = nullptr;  // length nil (transform along iline = down the columns)
     const LineOps* ops_row = nullptr;  // length nxl (transform along xline = along the rows)
-    c32 *tw_col_f = nullptr, *tw_col_i = nullptr, *tw_row_f = nullptr, *tw_row_i = nullptr;
-    c32* work = nullptr;
+    c32 *tw_col = nullptr, *tw_row = nullptr;  // padded twiddle tables of length nil / nxl
+    c32* work = nullptr;                        // column-blocked work buffer
+    uint16_t* bits = nullptr;                   // packed binary trace mask [nil][tpl(nxl)]
+    int* flag = nullptr;                        // device int: mask has entries other than 0 / 1
     double* sums = nullptr;
     size_t sums_cap = 0;
     c32* tau = nullptr;
@@ -100,12 +123,12 @@ struct p3d_plan {
     size_t slice_elems() const { return (size_t)nil * nxl; }
 };
 
-static int upload_table(p3d_plan* p, const LineOps* ops, int dir, c32** dst)
+static int upload_table(p3d_plan* p, const LineOps* ops, c32** dst)
 {
-    std::vector<c32> host(ops->n, c32{0.f, 0.f});
-    ops->twiddles(dir, host.data());
-    HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * ops->n));
-    HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * ops->n, hipMemcpyHostToDevice));
+    std::vector<c32> host(tw_slots(ops->n));
+    build_twiddles(ops->n, host.data());
+    HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * host.size()));
+    HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
     return P3D_OK;
 }
 
@@ -130,8 +153,8 @@ int p3d_plan_destroy(p3d_plan* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->tw_col_f, p->tw_col_i, p->tw_row_f, p->tw_row_i, p->work, p->sums, p->tau,
-                    p->done,     p->partials, p->st_x,     p->st_out,   p->st_mask};
+    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->sums, p->tau,
+                    p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (hipEvent_t e : p->prof_events) hipEventDestroy(e);
@@ -183,11 +206,11 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     TRY_OR_BAIL(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     TRY_OR_BAIL(hipEventCreate(&p->ev0));
     TRY_OR_BAIL(hipEventCreate(&p->ev1));
-    if ((rc = upload_table(p, oc, FWD, &p->tw_col_f)) != P3D_OK) return bail(rc);
-    if ((rc = upload_table(p, oc, INV, &p->tw_col_i)) != P3D_OK) return bail(rc);
-    if ((rc = upload_table(p, orow, FWD, &p->tw_row_f)) != P3D_OK) return bail(rc);
-    if ((rc = upload_table(p, orow, INV, &p->tw_row_i)) != P3D_OK) return bail(rc);
-    TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * p->slice_elems() * max_slices));
+    if ((rc = upload_table(p, oc, &p->tw_col)) != P3D_OK) return bail(rc);
+    if ((rc = upload_table(p, orow, &p->tw_row)) != P3D_OK) return bail(rc);
+    TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * wk_slice_stride(nil, nxl) * max_slices));
+    TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
+    TRY_OR_BAIL(hipMalloc((void**)&p->flag, sizeof(int)));
     TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
 #undef TRY_OR_BAIL
@@ -241,8 +264,7 @@ static int check_batch(p3d_plan* p, int nslices)
 static RowArgs row_args(p3d_plan* p, int nslices)
 {
     RowArgs r{};
-    r.tw_fwd = p->tw_row_f;
-    r.tw_inv = p->tw_row_i;
+    r.tw = p->tw_row;
     r.n1 = p->nil;
     r.nslices = nslices;
     r.alpha = 1.0f;
@@ -253,8 +275,7 @@ static RowArgs row_args(p3d_plan* p, int nslices)
 static ColArgs col_args(p3d_plan* p, int nslices)
 {
     ColArgs c{};
-    c.tw_fwd = p->tw_col_f;
-    c.tw_inv = p->tw_col_i;
+    c.tw = p->tw_col;
     c.n2 = p->nxl;
     c.nslices = nslices;
     return c;
@@ -285,22 +306,25 @@ int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int in
     if (!inverse) {
         RowArgs r = row_args(p, nslices);
         r.x = in;
-        r.work = (c32*)out;
+        r.work = p->work;
         r.dtype = P3D_C64;
         HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
         ColArgs c = col_args(p, nslices);
-        c.in = (const c32*)out;
+        c.in = p->work;
         c.out = (c32*)out;
+        c.out_std = 1;
         HIP_TRY(p->ops_col->col(COL_FWD, c, p->stream));
     } else {
         ColArgs c = col_args(p, nslices);
         c.in = (const c32*)in;
-        c.out = (c32*)out;
+        c.in_std = 1;
+        c.out = p->work;
         HIP_TRY(p->ops_col->col(COL_INV, c, p->stream));
         RowArgs r = row_args(p, nslices);
-        r.work = (c32*)out;
+        r.work = p->work;
         r.out = out;
         r.dtype = P3D_C64;
+        r.plain = 1;
         HIP_TRY(p->ops_row->row(ROW_LAST, r, p->stream));
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -343,12 +367,13 @@ int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, 
     HIP_TRY(hipMemcpy(p->st_x, in, bytes, hipMemcpyHostToDevice));
     RowArgs r = row_args(p, nslices);
     r.x = p->st_x;
-    r.work = (c32*)p->st_out;
+    r.work = p->work;
     r.dtype = P3D_C64;
     HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
     ColArgs c = col_args(p, nslices);
-    c.in = (const c32*)p->st_out;
+    c.in = p->work;
     c.out = (c32*)p->st_out;
+    c.out_std = 1;
     c.tau = p->tau;
     c.niter = 1;
     c.iter = 0;
@@ -468,9 +493,24 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
 
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
 
+    // packed trace mask: binary masks (the workflow's fold-derived mask, cube_POCS_interpolation_3D.py:242-244)
+    // travel as one 16-bit word per thread and row; anything else keeps the float weights
+    {
+        const int words = p->nil * p->ops_row->tpl;
+        HIP_TRY(hipMemsetAsync(p->flag, 0, sizeof(int), p->stream));
+        pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl,
+                                                                    p->ops_row->ppt);
+        HIP_TRY(hipGetLastError());
+    }
+    int nonbinary = 0;
+    HIP_TRY(hipMemcpyAsync(&nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (getenv("P3D_NO_MASK_BITS")) nonbinary = 1;  // experiments only
+
     RowArgs r = row_args(p, nslices);
     r.x = x;
-    r.mask = mask;
+    r.mask = nonbinary ? mask : nullptr;
+    r.bits = nonbinary ? nullptr : p->bits;
     r.work = p->work;
     r.out = out;
     r.sums = p->sums;

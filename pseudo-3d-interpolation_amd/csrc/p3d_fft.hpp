@@ -19,6 +19,11 @@
 // and exchanges data through LDS only between passes.  Forward transforms use the radix
 // sequence 16,16,..,rem and inverse transforms the reversed sequence rem,..,16,16: the last
 // forward pass and the first inverse pass then touch the same elements per thread.
+//
+// Twiddles: ONE table per line length, tw[k] = exp(-2*pi*i*k/N), k = 0..N-1, evaluated in double
+// and rounded once; every pass of both directions indexes it (the inverse conjugates).  In LDS it
+// is padded by one slot per 32 entries so that the power-of-two strides of the passes spread over
+// the banks.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -162,30 +167,19 @@ struct Plan {
         for (int q = 0; q < p; ++q) r *= radix(dir, q);
         return r;
     }
-    // offset of pass p's twiddles inside the per-direction table ((R-1)*Ns entries per pass, p >= 1)
-    static constexpr int tw_off(int dir, int p)
-    {
-        int o = 0;
-        for (int q = 1; q < p; ++q) o += (radix(dir, q) - 1) * ns(dir, q);
-        return o;
-    }
-    static constexpr int tw_len(int dir) { return tw_off(dir, NPASS); }
 };
 
-// Host side: fill the per-direction twiddle table (layout: for every pass p >= 1, (R-1) rows of
-// Ns entries, row t-1 holding exp(dir*2*pi*i*t*jm/(Ns*R)) for jm = 0..Ns-1, i.e. exactly the
-// order in which neighbouring threads read it).  Evaluated in double, stored as float.
-template <int N>
-inline void build_twiddles(int dir, c32* out)
+// ---- twiddle table ---------------------------------------------------------------------------
+constexpr int tw_slot(int k) { return k + (k >> 5); }       // padded position of entry k
+constexpr int tw_slots(int n) { return n + (n >> 5) + 1; }  // length of the padded table
+
+// Host side: tw[tw_slot(k)] = exp(-2*pi*i*k/n), double precision rounded once to float.
+inline void build_twiddles(int n, c32* out)
 {
-    using PL = Plan<N>;
-    for (int p = 1; p < PL::NPASS; ++p) {
-        const int R = PL::radix(dir, p), NS = PL::ns(dir, p), off = PL::tw_off(dir, p);
-        for (int t = 1; t < R; ++t)
-            for (int jm = 0; jm < NS; ++jm) {
-                const double ang = dir * 6.283185307179586476925286766559 * double(t) * double(jm) / (double(NS) * R);
-                out[off + (t - 1) * NS + jm] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
-            }
+    for (int i = 0; i < tw_slots(n); ++i) out[i] = c32{0.f, 0.f};
+    for (int k = 0; k < n; ++k) {
+        const double ang = -6.283185307179586476925286766559 * double(k) / double(n);
+        out[tw_slot(k)] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
     }
 }
 
@@ -197,24 +191,26 @@ struct LdsRow {
     static constexpr int stride(int n) { return n + (n >> 4); }
     P3D_HD c32& at(int pos) const { return base[pos + (pos >> 4)]; }
 };
-// Column-tile view: T lines interleaved, element-major ([pos][column]); the T columns of a wave
-// are adjacent so every access pattern of the engine is conflict-free without padding.
-template <int T>
-struct LdsCol {
-    c32* base;  // already offset by the column of this thread
-    P3D_HD c32& at(int pos) const { return base[pos * T]; }
+// Column-block view: W (<= 8) columns of one 64-byte column block interleaved, element-major
+// ([pos][W]) with the same padding; `base` already points at this thread's column.
+template <int W>
+struct LdsColW {
+    c32* base;
+    static constexpr int stride(int n) { return (n + (n >> 4)) * W; }  // elements per column block
+    P3D_HD c32& at(int pos) const { return base[(pos + (pos >> 4)) * W]; }
 };
+using LdsColBlk = LdsColW<8>;
 
 // One pass, all in registers: twiddle, radix-R DFTs, re-order to "output k of butterfly s at
 // register s + NB*k".
 template <int N, int DIR, int P>
-P3D_HD void pass_compute(c32 (&v)[Plan<N>::PPT], const c32* __restrict__ tab, int tl)
+P3D_HD void pass_compute(c32 (&v)[Plan<N>::PPT], const c32* __restrict__ tw, int tl)
 {
     using PL = Plan<N>;
     constexpr int R = PL::radix(DIR, P);
     constexpr int NS = PL::ns(DIR, P);
     constexpr int NB = PL::PPT / R;
-    constexpr int OFF = PL::tw_off(DIR, P);
+    constexpr int STEP = N / (NS * R);  // tw index of exp(-2*pi*i/(NS*R))
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         c32 a[R];
@@ -225,7 +221,9 @@ P3D_HD void pass_compute(c32 (&v)[Plan<N>::PPT], const c32* __restrict__ tab, in
             if constexpr (P == 0) {
                 a[t] = v[s + NB * t];
             } else {
-                a[t] = v[s + NB * t] * tab[OFF + (t - 1) * NS + jm];
+                c32 w = tw[tw_slot(t * STEP * jm)];
+                if (DIR > 0) w.y = -w.y;
+                a[t] = v[s + NB * t] * w;
             }
         }
         Dft<R, DIR>::run(a);
@@ -258,27 +256,42 @@ P3D_HD void canonical_gather(c32 (&v)[Plan<N>::PPT], LDS lds, int tl)
 }
 
 #if defined(__HIPCC__)
-template <int N, int DIR, int P, class LDS>
+// Exchange synchronisation.  WAVE = true: every line lives inside one wavefront (TPL <= 64), LDS
+// operations of one wave execute in program order, so only the compiler has to be kept from
+// reordering them; false: workgroup barrier.
+template <bool WAVE>
+P3D_D void exchange_sync()
+{
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int N, int DIR, int P, bool WAVE, class LDS>
 struct PassLoop {
-    static P3D_D void run(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tab, int tl)
+    static P3D_D void run(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tw, int tl)
     {
         if constexpr (P > 0) canonical_gather<N>(v, lds, tl);
-        pass_compute<N, DIR, P>(v, tab, tl);
+        pass_compute<N, DIR, P>(v, tw, tl);
         if constexpr (P + 1 < Plan<N>::NPASS) {
-            __syncthreads();  // every thread is done reading the previous contents
+            exchange_sync<WAVE>();  // everybody is done reading the previous contents
             pass_scatter<N, DIR, P>(v, lds, tl);
-            __syncthreads();
-            PassLoop<N, DIR, P + 1, LDS>::run(v, lds, tab, tl);
+            exchange_sync<WAVE>();
+            PassLoop<N, DIR, P + 1, WAVE, LDS>::run(v, lds, tw, tl);
         }
     }
 };
 
 // Transform one line held in canonical register layout; result is canonical again.
-// Every thread of the workgroup must call this (it contains workgroup barriers).
-template <int N, int DIR, class LDS>
-P3D_D void line_fft(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tab, int tl)
+// Every thread of the workgroup (WAVE = false) / wavefront (WAVE = true) must call this.
+template <int N, int DIR, bool WAVE, class LDS>
+P3D_D void line_fft(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tw, int tl)
 {
-    PassLoop<N, DIR, 0, LDS>::run(v, lds, tab, tl);
+    PassLoop<N, DIR, 0, WAVE, LDS>::run(v, lds, tw, tl);
 }
 #endif  // __HIPCC__
 

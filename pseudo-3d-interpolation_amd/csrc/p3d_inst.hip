@@ -11,8 +11,8 @@
 namespace p3d {
 const LineOps* P3D_CAT(get_line_ops_, P3D_N)()
 {
-    static const LineOps ops = {P3D_N, col_tile<P3D_N>(), &launch_row<P3D_N>, &launch_col<P3D_N>,
-                                &build_twiddles<P3D_N>};
+    static const LineOps ops = {P3D_N,           col_tile<P3D_N>(), Plan<P3D_N>::TPL, Plan<P3D_N>::PPT,
+                                &launch_row<P3D_N>, &launch_col<P3D_N>};
     return &ops;
 }
 }  // namespace p3d

@@ -5,16 +5,24 @@
 // is regrouped so that every slice is read and written exactly twice per iteration:
 //
 //   spectrum (column) pass  col_kernel<N1,T,COL_ITER>:
-//        load a tile of T columns of the row-transformed slice  -> forward column FFT
-//        -> threshold (threshold_operator.py:9-112)             -> inverse column FFT -> store
+//        load T columns of the row-transformed slice -> forward column FFT
+//        -> threshold (threshold_operator.py:9-112)  -> inverse column FFT -> store
 //   space (row) pass        row_kernel<N2,ROW_MID>:
 //        load rows -> inverse row FFT, 1/(N1*N2) -> re-insertion of the observed traces
 //        (POCS.py:616-619) -> sum|x| for the cost (POCS.py:622) -> [APOCS input mix, POCS.py:574-575]
 //        -> forward row FFT of the NEXT iteration -> store
 //
 // ROW_FIRST starts the chain (x_obs -> forward row FFT), ROW_LAST ends it (stores x instead of
-// transforming again).  The work buffer therefore always holds either "rows transformed" (after a
-// row pass) or "rows transformed, columns back in space" (after a column pass).
+// transforming again).
+//
+// Work-buffer layout ("column blocked"): the intermediate between the two passes is private to this
+// library, so it is stored as  W[slice][cb = col/8][row][col%8]  (complex64).  One column block
+// (8 columns = 64 bytes per row) of a slice is then ONE contiguous N1*64-byte run: the column pass
+// streams it with perfectly linear addresses and needs only N1*64 B of LDS per tile (2 workgroups
+// per CU at N1 = 1024, so loads of one tile overlap the transforms of another), while the row pass,
+// whose workgroups own adjacent rows, still touches 64-byte pieces that are neighbours in memory.
+// Measured on MI355X (tools/micro/membench.hip): 4.9-5.2 TB/s for the blocked column tiles vs 4.7
+// (16-column tiles, 1 WG/CU) and 3.0 TB/s (8-column tiles) on the row-major layout.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,39 +30,63 @@
 
 #include "p3d_fft.hpp"
 
+// build-time knobs for experiments (tools/build_variant.sh)
+#ifndef P3D_ROW_THREADS
+#define P3D_ROW_THREADS 256
+#endif
+#ifndef P3D_WAVES_PER_EU
+#define P3D_WAVES_PER_EU 4  // register budget of the column pass: 512/4 = 128 VGPRs -> 16 waves per CU
+#endif
+#ifndef P3D_XO_GROUP
+#define P3D_XO_GROUP 4   // observed samples fetched per step of the re-insertion loop (late mode)
+#endif
+#ifndef P3D_XO_EARLY
+#define P3D_XO_EARLY 0   // 1: prefetch all observed samples ahead of the inverse transform (32 VGPRs)
+#endif
+#ifndef P3D_ABL
+#define P3D_ABL 0        // ablations for timing only (results wrong): 1 no transforms, 2 no forward, 4 no work store
+#endif
+#ifndef P3D_ROW_WAVES_PER_EU
+#define P3D_ROW_WAVES_PER_EU (P3D_ROW_THREADS >= 512 ? 4 : 3)
+#endif
+
 namespace p3d {
 
 enum RowMode { ROW_FIRST = 0, ROW_MID = 1, ROW_LAST = 2 };
 enum ColMode { COL_ITER = 0, COL_STATS = 1, COL_FWD = 2, COL_INV = 3 };
 
-constexpr int ROW_THREADS = 256;
+constexpr int ROW_THREADS = P3D_ROW_THREADS;
 constexpr int STATS_PARTIAL = 8;  // floats per (slice, tile) written by COL_STATS
 
+// ---- column-blocked work layout ------------------------------------------------------------------
+__host__ __device__ inline size_t wk_slice_stride(int n1, int n2) { return (size_t)((n2 + 7) / 8) * 8 * n1; }
+__host__ __device__ inline size_t wk_off(int row, int col, int n1) { return ((size_t)(col >> 3) * n1 + row) * 8 + (col & 7); }
+
 struct RowArgs {
-    const void* x;      // observed cube (c64 or f32), [nslices][n1][N]           (FIRST, MID, LAST*)
-    const float* mask;  // [n1][N] or nullptr (LAST with nullptr = plain inverse transform)
-    c32* work;          // [nslices][n1][N]
-    void* out;          // result cube (c64 or f32)                                (MID if write_out, LAST)
-    const c32* tw_fwd;  // twiddle tables of length N (device)
-    const c32* tw_inv;
-    double* sums;       // row `sum_row` of [(niter+1)][nslices] receives sum|x| per slice, or nullptr
-    const int* done;    // per slice: 0 running, >0 finished at that iteration, <0 all-zero slice; or nullptr
+    const void* x;         // observed cube (c64 or f32), [nslices][n1][N]
+    const float* mask;     // [n1][N] float weights (generic path) or nullptr
+    const uint16_t* bits;  // [n1][TPL] packed binary mask: bit q of entry (row, tl) = mask[row][tl + TPL*q]
+    c32* work;             // column-blocked work buffer
+    void* out;             // result cube (c64 or f32), row-major         (MID if write_out, LAST)
+    const c32* tw;         // padded twiddle table of length N (device)
+    double* sums;          // row `sum_row` of [(niter+1)][nslices] receives sum|x| per slice, or nullptr
+    const int* done;       // per slice: 0 running, >0 finished at that iteration, <0 all-zero slice; or nullptr
     int n1;
     int nslices;
     int sum_row;
-    int dtype;          // 0 = c64, 1 = f32 (of x and out)
-    int adaptive;       // APOCS input mix
-    int write_out;      // MID: also store the iterate to `out` (needed only when eps > 0)
+    int dtype;             // 0 = c64, 1 = f32 (of x and out)
+    int adaptive;          // APOCS input mix
+    int write_out;         // MID: also store the iterate to `out` (needed only when eps > 0)
+    int plain;             // LAST: plain inverse transform (no re-insertion): fft2 hook
     float alpha;
-    float scale;        // 1/(n1*N)
+    float scale;           // 1/(n1*N)
 };
 
 struct ColArgs {
-    const c32* in;      // [nslices][N][n2]
+    const c32* in;
     c32* out;           // may alias `in`
-    const c32* tw_fwd;  // twiddle tables of length N (device)
-    const c32* tw_inv;
-    const c32* tau;     // [nslices][niter] (COL_ITER)
+    const c32* tw;      // padded twiddle table of length N (device)
+    const c32* tau;     // [nslices][niter] (COL_ITER, optional for COL_FWD)
     const int* done;
     float* partials;    // [nslices][tiles][STATS_PARTIAL] (COL_STATS)
     int n2;
@@ -62,9 +94,13 @@ struct ColArgs {
     int niter;
     int iter;
     int op;
+    int in_std;         // `in` is row-major [nslices][N][n2] instead of column-blocked
+    int out_std;        // same for `out`
 };
 
-__device__ __forceinline__ float wave_sum(float v)
+// per-thread partial sums are float (16 terms); across the wave they are combined in double so that the
+// cost, a difference of two nearly equal sums (POCS.py:622), keeps its leading digits
+__device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -99,17 +135,18 @@ __device__ __forceinline__ c32 shrink(c32 X, c32 tau, int op)
 // =================================================================================================
 // space (row) pass
 // =================================================================================================
-template <int N, int MODE>
-__global__ __launch_bounds__(ROW_THREADS) void row_kernel(const RowArgs a)
+// BITS: the trace mask is binary and comes as one packed 16-bit word per thread and row.
+template <int N, int MODE, bool BITS>
+__global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
     constexpr int LB = ROW_THREADS / TPL;  // lines per workgroup
     constexpr int LSTR = LdsRow::stride(N);
+    constexpr bool WAVE = TPL <= 64;       // a line never leaves its wavefront
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    c32* tabF = reinterpret_cast<c32*>(smem_raw);
-    c32* tabI = tabF + N;
-    c32* data = tabI + N;
+    c32* tw = reinterpret_cast<c32*>(smem_raw);
+    c32* data = tw + tw_slots(N);
 
     const int tid = threadIdx.x;
     const int line = tid / TPL;
@@ -137,39 +174,52 @@ __global__ __launch_bounds__(ROW_THREADS) void row_kernel(const RowArgs a)
         return;
     }
 
-    for (int i = tid; i < N; i += ROW_THREADS) {
-        if (MODE != ROW_LAST) tabF[i] = a.tw_fwd[i];
-        if (MODE != ROW_FIRST) tabI[i] = a.tw_inv[i];
-    }
+    for (int i = tid; i < tw_slots(N); i += ROW_THREADS) tw[i] = a.tw[i];
     __syncthreads();
 
     const LdsRow lds{data + line * LSTR};
-    const size_t off = ((size_t)slice * a.n1 + (valid ? row : 0)) * N;
-    const size_t moff = (size_t)(valid ? row : 0) * N;
+    const int vrow = valid ? row : 0;
+    // Addressing: wave-uniform 64-bit bases (scalar registers) + 32-bit per-lane element offsets, so the 16
+    // loads and 16 stores of a thread do not each pin a 64-bit address in VGPRs (one slice is < 2^31 elements).
+    const size_t sbase = (size_t)slice * a.n1 * N;                                  // row-major cubes (x, out)
+    const unsigned off = (unsigned)vrow * N + tl;                                   // + TPL*q
+    c32* const wslice = a.work + (size_t)slice * wk_slice_stride(a.n1, N);          // column-blocked work buffer
+    const unsigned wblk = (unsigned)a.n1 * 8;                                       // elements per column block
+    auto woff = [&](int q, int lane_in_line) -> unsigned {
+        const int e = lane_in_line + TPL * q;
+        return (unsigned)(e >> 3) * wblk + (unsigned)vrow * 8 + (e & 7);
+    };
     c32 v[PPT];
-    c32 xo[PPT];
 
-    // observed data (needed by every mode except a plain inverse transform)
-    const bool need_obs = (MODE == ROW_FIRST) || (a.mask != nullptr);
-    if (need_obs) {
+    // observed data (every mode except a plain inverse transform) and the mask word of this thread
+    const bool need_obs = (MODE == ROW_FIRST) || !a.plain;
+    unsigned mbits = 0;
+    if (BITS && need_obs) mbits = valid ? a.bits[(size_t)vrow * TPL + tl] : 0u;
+    auto obs_at = [&](int q) -> c32 {
+        if (!valid) return c32{0.f, 0.f};
+        if (a.dtype == 0) return (reinterpret_cast<const c32*>(a.x) + sbase)[off + TPL * q];
+        return c32{(reinterpret_cast<const float*>(a.x) + sbase)[off + TPL * q], 0.f};
+    };
+    auto mask_at = [&](int q) -> float {
+        if (BITS) return (float)((mbits >> q) & 1u);
+        return valid ? a.mask[off + TPL * q] : 0.f;
+    };
+
+    c32 xe[P3D_XO_EARLY ? PPT : 1];
+    if (P3D_XO_EARLY && MODE != ROW_FIRST && !a.plain) {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int e = tl + TPL * q;
-            if (!valid) xo[q] = c32{0.f, 0.f};
-            else if (a.dtype == 0) xo[q] = reinterpret_cast<const c32*>(a.x)[off + e];
-            else xo[q] = c32{reinterpret_cast<const float*>(a.x)[off + e], 0.f};
-        }
+        for (int q = 0; q < PPT; ++q) xe[q] = obs_at(q);
     }
 
     float acc = 0.f;
     if (MODE == ROW_FIRST) {
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const c32 x = xo[q];
+            const c32 x = obs_at(q);
             acc += sqrtf(x.x * x.x + x.y * x.y);
             if (a.adaptive) {
                 // x_old = x at the first iteration (POCS.py:549, 574-575)
-                const float m = valid ? a.mask[moff + tl + TPL * q] : 0.f;
+                const float m = mask_at(q);
                 const float w = 1.0f - a.alpha * m;
                 const c32 blend = x * a.alpha + x * w;
                 v[q] = blend + (x - x * m) * (1.0f - a.alpha);
@@ -179,47 +229,65 @@ __global__ __launch_bounds__(ROW_THREADS) void row_kernel(const RowArgs a)
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = valid ? a.work[off + tl + TPL * q] : c32{0.f, 0.f};
-        line_fft<N, INV>(v, lds, tabI, tl);
+        for (int q = 0; q < PPT; ++q) v[q] = valid ? wslice[woff(q, tl)] : c32{0.f, 0.f};
+        if (!(P3D_ABL & 1)) line_fft<N, INV, WAVE>(v, lds, tw, tl);
+        // The observed samples are fetched here, a few at a time, instead of being prefetched ahead of
+        // the inverse transform: holding 16 of them across the transform costs 32 VGPRs and the 16
+        // waves per CU this kernel is budgeted for (128 VGPRs) cover the latency instead.
+        constexpr int G = PPT < P3D_XO_GROUP ? PPT : P3D_XO_GROUP;
+        asm volatile("" : "+v"(mbits));  // keep the 16 mask weights from being expanded ahead of the transform
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int e = tl + TPL * q;
-            c32 xn = v[q] * a.scale;
-            float m = 0.f;
-            if (a.mask != nullptr) {
-                m = valid ? a.mask[moff + e] : 0.f;
-                const float w = 1.0f - a.alpha * m;       // POCS.py:616
-                xn = xn * w + xo[q] * a.alpha;            // POCS.py:619
+        for (int g = 0; g < PPT; g += G) {
+            c32 xo[G];
+            if (!a.plain) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) xo[i] = P3D_XO_EARLY ? xe[g + i] : obs_at(g + i);
             }
-            acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
-            if (MODE == ROW_LAST || a.write_out) {
-                if (valid) {
-                    if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[off + e] = xn;
-                    else reinterpret_cast<float*>(a.out)[off + e] = xn.x;  // np.real(), POCS.py:656
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int q = g + i;
+                c32 xn = v[q] * a.scale;
+                float m = 0.f;
+                if (!a.plain) {
+                    m = mask_at(q);
+                    const float w = 1.0f - a.alpha * m;       // POCS.py:616
+                    xn = xn * w + xo[i] * a.alpha;            // POCS.py:619
+                }
+                acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+                if (MODE == ROW_LAST || a.write_out) {
+                    if (valid) {
+                        if (a.dtype == 0) (reinterpret_cast<c32*>(a.out) + sbase)[off + TPL * q] = xn;
+                        else (reinterpret_cast<float*>(a.out) + sbase)[off + TPL * q] = xn.x;  // np.real(), POCS.py:656
+                    }
+                }
+                if (MODE == ROW_MID) {
+                    if (a.adaptive) {  // x_input of the next iteration (POCS.py:574-575)
+                        const float w = 1.0f - a.alpha * m;
+                        const c32 blend = xo[i] * a.alpha + xn * w;
+                        v[q] = blend + (xo[i] - xn * m) * (1.0f - a.alpha);
+                    } else {
+                        v[q] = xn;
+                    }
                 }
             }
-            if (MODE == ROW_MID) {
-                if (a.adaptive) {  // x_input of the next iteration (POCS.py:574-575)
-                    const float w = 1.0f - a.alpha * m;
-                    const c32 blend = xo[q] * a.alpha + xn * w;
-                    v[q] = blend + (xo[q] - xn * m) * (1.0f - a.alpha);
-                } else {
-                    v[q] = xn;
-                }
-            }
+            if (!P3D_XO_EARLY) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     if (a.sums != nullptr) {
-        const float ws = wave_sum(valid ? acc : 0.f);
-        if ((tid & 63) == 0) atomicAdd(&a.sums[(size_t)a.sum_row * a.nslices + slice], (double)ws);
+        const double ws = wave_sum(valid ? (double)acc : 0.0);
+        if ((tid & 63) == 0) atomicAdd(&a.sums[(size_t)a.sum_row * a.nslices + slice], ws);
     }
 
     if (MODE != ROW_LAST) {
-        line_fft<N, FWD>(v, lds, tabF, tl);
-        if (valid) {
+        if (!(P3D_ABL & 3)) line_fft<N, FWD, WAVE>(v, lds, tw, tl);
+        if (valid && !(P3D_ABL & 4)) {
+            // recompute the store offsets from a laundered copy of the lane index: otherwise the compiler keeps
+            // the 16 load offsets alive across both transforms (16 VGPRs the 128-register budget does not have)
+            int tls = tl;
+            asm volatile("" : "+v"(tls));
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) a.work[off + tl + TPL * q] = v[q];
+            for (int q = 0; q < PPT; ++q) wslice[woff(q, tls)] = v[q];
         }
     }
 }
@@ -232,39 +300,46 @@ __device__ __forceinline__ bool lex_greater(float ar, float ai, float br, float 
     return (ar > br) || (ar == br && ai > bi);
 }
 
+// T columns per workgroup; CW = min(T, 8) of them share a 64-byte column block.
 template <int N, int T, int MODE>
-__global__ __launch_bounds__(T* Plan<N>::TPL) void col_kernel(const ColArgs a)
+__global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3D_WAVES_PER_EU)) void col_kernel(const ColArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
     constexpr int THREADS = T * TPL;
+    constexpr int CW = T < 8 ? T : 8;
+    using LDS = LdsColW<CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    c32* tabF = reinterpret_cast<c32*>(smem_raw);
-    c32* tabI = tabF + N;
-    c32* data = tabI + N;
+    c32* tw = reinterpret_cast<c32*>(smem_raw);
+    c32* data = tw + tw_slots(N);
 
     const int tid = threadIdx.x;
-    const int tl = tid / T;
-    const int c = tid - tl * T;
+    const int c_lo = tid % CW;
+    const int tl = (tid / CW) % TPL;
+    const int cbl = tid / (CW * TPL);  // column block of this thread inside the tile
     const int slice = blockIdx.y;
-    const int col = blockIdx.x * T + c;
+    const int col = blockIdx.x * T + cbl * CW + c_lo;
     const bool valid = col < a.n2;
 
     if (a.done && a.done[slice] != 0) return;
 
-    for (int i = tid; i < N; i += THREADS) {
-        if (MODE != COL_INV) tabF[i] = a.tw_fwd[i];
-        if (MODE == COL_ITER || MODE == COL_INV) tabI[i] = a.tw_inv[i];
-    }
+    for (int i = tid; i < tw_slots(N); i += THREADS) tw[i] = a.tw[i];
     __syncthreads();
 
-    const LdsCol<T> lds{data + c};
-    const size_t base = (size_t)slice * N * a.n2 + (valid ? col : 0);
+    const LDS lds{data + cbl * LDS::stride(N) + c_lo};
+    const int vcol = valid ? col : 0;
+    // wave-uniform slice bases + 32-bit element offsets (see row_kernel)
+    const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
+    c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
+    const unsigned blk0 = ((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7);  // column-blocked: + row*8
+    auto eoff = [&](int std_layout, int r) -> unsigned {
+        return std_layout ? (unsigned)r * a.n2 + vcol : blk0 + (unsigned)r * 8;
+    };
     c32 v[PPT];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) v[q] = valid ? a.in[base + (size_t)(tl + TPL * q) * a.n2] : c32{0.f, 0.f};
+    for (int q = 0; q < PPT; ++q) v[q] = valid ? inb[eoff(a.in_std, tl + TPL * q)] : c32{0.f, 0.f};
 
-    if (MODE != COL_INV) line_fft<N, FWD>(v, lds, tabF, tl);
+    if (MODE != COL_INV) line_fft<N, FWD, false>(v, lds, tw, tl);
 
     if (MODE == COL_ITER || (MODE == COL_FWD && a.tau != nullptr)) {
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
@@ -320,30 +395,33 @@ __global__ __launch_bounds__(T* Plan<N>::TPL) void col_kernel(const ColArgs a)
         return;
     }
 
-    if (MODE == COL_ITER || MODE == COL_INV) line_fft<N, INV>(v, lds, tabI, tl);
+    if (MODE == COL_ITER || MODE == COL_INV) line_fft<N, INV, false>(v, lds, tw, tl);
 
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) a.out[base + (size_t)(tl + TPL * q) * a.n2] = v[q];
+        for (int q = 0; q < PPT; ++q) outb[eoff(a.out_std, tl + TPL * q)] = v[q];
     }
 }
 
 // ---- launch helpers, one instantiation set per line length --------------------------------------
+// columns per workgroup of the column pass: keep 512..1024 threads and <= ~80 KiB of LDS
 template <int N>
 constexpr int col_tile()
 {
-    return N <= 1024 ? 16 : (N == 2048 ? 8 : 2);
+    return N >= 4096 ? 2 : (N >= 1024 ? 8 : (N == 512 ? 16 : (N == 256 ? 32 : 64)));
 }
 
 template <int N>
 constexpr size_t row_lds_bytes()
 {
-    return sizeof(c32) * (2 * N + (ROW_THREADS / Plan<N>::TPL) * LdsRow::stride(N));
+    return sizeof(c32) * (tw_slots(N) + (ROW_THREADS / Plan<N>::TPL) * LdsRow::stride(N));
 }
 template <int N>
 constexpr size_t col_lds_bytes()
 {
-    return sizeof(c32) * (2 * N + (size_t)N * col_tile<N>());
+    constexpr int T = col_tile<N>();
+    constexpr int CW = T < 8 ? T : 8;
+    return sizeof(c32) * (tw_slots(N) + (size_t)(T / CW) * LdsColW<CW>::stride(N));
 }
 
 template <class K>
@@ -353,68 +431,63 @@ inline hipError_t allow_lds(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int N>
-hipError_t launch_row(int mode, const RowArgs& a, hipStream_t st)
+template <int N, int MODE, bool BITS>
+hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
 {
     constexpr int LB = ROW_THREADS / Plan<N>::TPL;
     const dim3 grid((a.n1 + LB - 1) / LB, a.nslices);
     constexpr size_t lds = row_lds_bytes<N>();
-    hipError_t e = hipSuccess;
+    hipError_t e = allow_lds(row_kernel<N, MODE, BITS>, lds);
+    if (e != hipSuccess) return e;
+    row_kernel<N, MODE, BITS><<<grid, ROW_THREADS, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <int N>
+hipError_t launch_row(int mode, const RowArgs& a, hipStream_t st)
+{
+    const bool bits = a.bits != nullptr;
     switch (mode) {
-        case ROW_FIRST:
-            if ((e = allow_lds(row_kernel<N, ROW_FIRST>, lds)) != hipSuccess) return e;
-            row_kernel<N, ROW_FIRST><<<grid, ROW_THREADS, lds, st>>>(a);
-            break;
-        case ROW_MID:
-            if ((e = allow_lds(row_kernel<N, ROW_MID>, lds)) != hipSuccess) return e;
-            row_kernel<N, ROW_MID><<<grid, ROW_THREADS, lds, st>>>(a);
-            break;
-        case ROW_LAST:
-            if ((e = allow_lds(row_kernel<N, ROW_LAST>, lds)) != hipSuccess) return e;
-            row_kernel<N, ROW_LAST><<<grid, ROW_THREADS, lds, st>>>(a);
-            break;
+        case ROW_FIRST: return bits ? launch_row_one<N, ROW_FIRST, true>(a, st) : launch_row_one<N, ROW_FIRST, false>(a, st);
+        case ROW_MID: return bits ? launch_row_one<N, ROW_MID, true>(a, st) : launch_row_one<N, ROW_MID, false>(a, st);
+        case ROW_LAST: return bits ? launch_row_one<N, ROW_LAST, true>(a, st) : launch_row_one<N, ROW_LAST, false>(a, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int N, int MODE>
+hipError_t launch_col_one(const ColArgs& a, hipStream_t st)
+{
+    constexpr int T = col_tile<N>();
+    constexpr int THREADS = T * Plan<N>::TPL;
+    const dim3 grid((a.n2 + T - 1) / T, a.nslices);
+    constexpr size_t lds = col_lds_bytes<N>();
+    hipError_t e = allow_lds(col_kernel<N, T, MODE>, lds);
+    if (e != hipSuccess) return e;
+    col_kernel<N, T, MODE><<<grid, THREADS, lds, st>>>(a);
     return hipGetLastError();
 }
 
 template <int N>
 hipError_t launch_col(int mode, const ColArgs& a, hipStream_t st)
 {
-    constexpr int T = col_tile<N>();
-    constexpr int THREADS = T * Plan<N>::TPL;
-    const dim3 grid((a.n2 + T - 1) / T, a.nslices);
-    constexpr size_t lds = col_lds_bytes<N>();
-    hipError_t e = hipSuccess;
     switch (mode) {
-        case COL_ITER:
-            if ((e = allow_lds(col_kernel<N, T, COL_ITER>, lds)) != hipSuccess) return e;
-            col_kernel<N, T, COL_ITER><<<grid, THREADS, lds, st>>>(a);
-            break;
-        case COL_STATS:
-            if ((e = allow_lds(col_kernel<N, T, COL_STATS>, lds)) != hipSuccess) return e;
-            col_kernel<N, T, COL_STATS><<<grid, THREADS, lds, st>>>(a);
-            break;
-        case COL_FWD:
-            if ((e = allow_lds(col_kernel<N, T, COL_FWD>, lds)) != hipSuccess) return e;
-            col_kernel<N, T, COL_FWD><<<grid, THREADS, lds, st>>>(a);
-            break;
-        case COL_INV:
-            if ((e = allow_lds(col_kernel<N, T, COL_INV>, lds)) != hipSuccess) return e;
-            col_kernel<N, T, COL_INV><<<grid, THREADS, lds, st>>>(a);
-            break;
+        case COL_ITER: return launch_col_one<N, COL_ITER>(a, st);
+        case COL_STATS: return launch_col_one<N, COL_STATS>(a, st);
+        case COL_FWD: return launch_col_one<N, COL_FWD>(a, st);
+        case COL_INV: return launch_col_one<N, COL_INV>(a, st);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 // what the API layer sees of one line length
 struct LineOps {
     int n;
     int col_tile;
+    int tpl;  // threads per line (layout of the packed mask words)
+    int ppt;
     hipError_t (*row)(int mode, const RowArgs&, hipStream_t);
     hipError_t (*col)(int mode, const ColArgs&, hipStream_t);
-    void (*twiddles)(int dir, c32* out);
 };
 
 }  // namespace p3d

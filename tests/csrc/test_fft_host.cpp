@@ -39,15 +39,14 @@ double check()
     using PL = Plan<N>;
     std::vector<cd> x(N);
     for (int i = 0; i < N; ++i) x[i] = cd(std::sin(0.37 * i * i + 0.1) + 0.25, std::cos(1.3 * i) - 0.5 * (i % 3));
-    std::vector<c32> tab(N);
-    build_twiddles<N>(DIR, tab.data());
+    std::vector<c32> tab(tw_slots(N));
+    build_twiddles(N, tab.data());
     std::vector<std::vector<c32>> regs(PL::TPL, std::vector<c32>(PL::PPT));
     for (int tl = 0; tl < PL::TPL; ++tl)
         for (int q = 0; q < PL::PPT; ++q) regs[tl][q] = c32{float(x[tl + PL::TPL * q].real()), float(x[tl + PL::TPL * q].imag())};
-    constexpr int T = 4;
-    std::vector<c32> lds(COLVIEW ? N * T : LdsRow::stride(N) + 1);
+    std::vector<c32> lds(COLVIEW ? LdsColBlk::stride(N) : LdsRow::stride(N) + 1);
     if constexpr (COLVIEW) {
-        auto mk = [&]() { return LdsCol<T>{lds.data() + 1}; };
+        auto mk = [&]() { return LdsColBlk{lds.data() + 3}; };
         Emu<N, DIR, 0, decltype(mk)>::run(regs, mk, tab.data());
     } else {
         auto mk = [&]() { return LdsRow{lds.data()}; };
@@ -98,10 +97,6 @@ void sweep()
     report("row", N, INV, check<N, INV, false>(), 1e-6);
     report("col", N, FWD, check<N, FWD, true>(), 1e-6);
     report("col", N, INV, check<N, INV, true>(), 1e-6);
-    if (Plan<N>::tw_len(FWD) > N || Plan<N>::tw_len(INV) > N) {
-        std::printf("twiddle table of N=%d does not fit N entries FAIL\n", N);
-        ++fails;
-    }
 }
 
 int main()
