@@ -41,6 +41,22 @@ static const LineOps* find_ops(int n)
 
 using namespace p3d;
 
+// ---- per-slice sum of the per-row sums, fixed order (bitwise reproducible) ----------------------------------
+static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row, int n1)
+{
+    __shared__ double sh[256];
+    const int s = blockIdx.x;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n1; i += 256) t += rowsum[(size_t)s * n1 + i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums_row[s] = sh[0];
+}
+
 // ---- convergence bookkeeping (POCS.py:622, 631) ------------------------------------------------
 static __global__ void conv_kernel(const double* sums, int* done, int nslices, int iter, double eps)
 {
@@ -103,13 +119,16 @@ struct p3d_plan {
     c32* work = nullptr;                        // column-blocked work buffer
     uint16_t* bits = nullptr;                   // packed binary trace mask [nil][tpl(nxl)]
     int* flag = nullptr;                        // device int: mask has entries other than 0 / 1
-    double* sums = nullptr;
+    double* sums = nullptr;     // [(niter+1)][nslices]
     size_t sums_cap = 0;
+    double* rowsum = nullptr;   // [max_slices][nil] per-row partial sums of the current row pass
     c32* tau = nullptr;
     size_t tau_cap = 0;
     int* done = nullptr;
     float* partials = nullptr;
     int tiles = 0;
+    int cus = 0;          // compute units of the device
+    int pipe_wgs = 0;     // grid of the persistent row pass (0: not available for this shape)
     // staging for host-pointer entry points
     void* st_x = nullptr;
     void* st_out = nullptr;
@@ -123,10 +142,11 @@ struct p3d_plan {
     size_t slice_elems() const { return (size_t)nil * nxl; }
 };
 
-static int upload_table(p3d_plan* p, const LineOps* ops, c32** dst)
+static int upload_table(p3d_plan* p, const LineOps* ops, bool for_rows, c32** dst)
 {
-    std::vector<c32> host(tw_slots(ops->n));
-    build_twiddles(ops->n, host.data());
+    std::vector<c32> host(for_rows ? ops->row_tw_slots : tw_slots(ops->n));
+    if (for_rows) ops->build_row_tw(host.data());
+    else build_twiddles(ops->n, host.data());
     HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * host.size()));
     HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
     return P3D_OK;
@@ -153,7 +173,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->sums, p->tau,
+    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->sums, p->rowsum, p->tau,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -188,6 +208,17 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     p->ops_col = oc;
     p->ops_row = orow;
     p->tiles = (nxl + oc->col_tile - 1) / oc->col_tile;
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        p->cus = prop.multiProcessorCount;
+        // resident workgroups per CU of the persistent row pass: LDS (160 KiB per CU) and registers
+        // (P3D_PIPE_WAVES_PER_EU waves per SIMD) both allow this many
+        const int by_lds = (int)((160 * 1024) / orow->row_lds);
+        const int by_regs = (P3D_PIPE_WAVES_PER_EU * 4 * 64) / ROW_THREADS;
+        const int per_cu = by_lds < by_regs ? by_lds : by_regs;
+        p->pipe_wgs = (orow->tpl <= 64 && per_cu >= 1 && !getenv("P3D_NO_PIPE")) ? p->cus * per_cu : 0;
+    }
     int rc = P3D_OK;
     auto bail = [&](int code) {
         std::string keep = g_err;
@@ -206,11 +237,12 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     TRY_OR_BAIL(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     TRY_OR_BAIL(hipEventCreate(&p->ev0));
     TRY_OR_BAIL(hipEventCreate(&p->ev1));
-    if ((rc = upload_table(p, oc, &p->tw_col)) != P3D_OK) return bail(rc);
-    if ((rc = upload_table(p, orow, &p->tw_row)) != P3D_OK) return bail(rc);
+    if ((rc = upload_table(p, oc, false, &p->tw_col)) != P3D_OK) return bail(rc);
+    if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
     TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * wk_slice_stride(nil, nxl) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
     TRY_OR_BAIL(hipMalloc((void**)&p->flag, sizeof(int)));
+    TRY_OR_BAIL(hipMalloc((void**)&p->rowsum, sizeof(double) * (size_t)nil * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
 #undef TRY_OR_BAIL
@@ -513,20 +545,26 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.bits = nonbinary ? nullptr : p->bits;
     r.work = p->work;
     r.out = out;
-    r.sums = p->sums;
-    r.done = p->done;
+    // the per-slice state array is only consulted when a slice can actually be switched off
+    bool any_off = early;
+    for (int s = 0; s < nslices; ++s) any_off = any_off || done_h[s] != 0;
+    r.sums = p->rowsum;
+    r.done = any_off ? p->done : nullptr;
     r.dtype = dtype;
     r.adaptive = adaptive ? 1 : 0;
     r.write_out = early ? 1 : 0;
     r.alpha = (float)prm->alpha;
     r.sum_row = 0;
+    // rows of finished / empty slices are skipped by the kernels: their partial sums must read as zero
+    HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
     HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+    reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil);
 
     ColArgs c = col_args(p, nslices);
     c.in = p->work;
     c.out = p->work;
     c.tau = p->tau;
-    c.done = p->done;
+    c.done = any_off ? p->done : nullptr;
     c.niter = niter;
     c.op = prm->thresh_op;
 
@@ -536,9 +574,20 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
         HIP_TRY(stamp());
         r.sum_row = k + 1;
-        HIP_TRY(p->ops_row->row(k + 1 < niter ? ROW_MID : ROW_LAST, r, p->stream));
+        bool piped = false;
+        if (k + 1 < niter && p->pipe_wgs > 0) {  // steady state: persistent, software-pipelined row pass
+            const hipError_t pe = p->ops_row->row_pipe(r, p->pipe_wgs, p->stream);
+            if (pe == hipSuccess) piped = true;
+            else if (pe != hipErrorNotSupported) HIP_TRY(pe);
+        }
+        if (!piped) HIP_TRY(p->ops_row->row(k + 1 < niter ? ROW_MID : ROW_LAST, r, p->stream));
         HIP_TRY(stamp());
-        if (early) conv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+        reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums + (size_t)(k + 1) * nslices, p->nil);
+        if (early) {
+            conv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+            // slices that just finished are skipped from now on: their rows must read as zero afterwards
+            HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p->ev1, p->stream));

@@ -42,7 +42,16 @@ struct __attribute__((aligned(8))) c32 {
 
 P3D_HD c32 operator+(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
 P3D_HD c32 operator-(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
-P3D_HD c32 operator*(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// Complex product with the fused operations spelled out.  The library is compiled with -ffp-contract=off so
+// that the SAME source expression yields the SAME bits in every kernel it is inlined into (the compiler would
+// otherwise fuse multiply-adds differently from one kernel to the next, and a hard threshold turns a
+// last-bit difference into a kept-or-zeroed coefficient).
+P3D_HD c32 operator*(c32 a, c32 b)
+{
+    return {__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
+}
+// a*s + b*t with real s, t
+P3D_HD c32 axpby(c32 a, float s, c32 b, float t) { return {__builtin_fmaf(a.x, s, b.x * t), __builtin_fmaf(a.y, s, b.y * t)}; }
 P3D_HD c32 operator*(c32 a, float s) { return {a.x * s, a.y * s}; }
 
 constexpr int FWD = -1;  // exp(-i...)  (numpy fft2)
@@ -169,11 +178,12 @@ struct Plan {
     }
 };
 
-// ---- twiddle table ---------------------------------------------------------------------------
+// ---- twiddle tables ----------------------------------------------------------------------------
+// (a) master table: tw[tw_slot(k)] = exp(-2*pi*i*k/n); every pass of both directions indexes it with a
+//     computed slot (one multiply-add per twiddle).  Smallest LDS footprint: used by the column pass.
 constexpr int tw_slot(int k) { return k + (k >> 5); }       // padded position of entry k
 constexpr int tw_slots(int n) { return n + (n >> 5) + 1; }  // length of the padded table
 
-// Host side: tw[tw_slot(k)] = exp(-2*pi*i*k/n), double precision rounded once to float.
 inline void build_twiddles(int n, c32* out)
 {
     for (int i = 0; i < tw_slots(n); ++i) out[i] = c32{0.f, 0.f};
@@ -183,48 +193,113 @@ inline void build_twiddles(int n, c32* out)
     }
 }
 
+// (b) per-pass ordered tables: for every pass p >= 1 of a direction, (R-1) rows of Ns entries, row t-1
+//     holding exp(dir*2*pi*i*t*jm/(Ns*R)), jm = 0..Ns-1 -- the order in which neighbouring threads read
+//     them, at compile-time offsets from one per-thread base (no address arithmetic, no extra registers).
+//     Forward table first, inverse table at offset N.  Twice the LDS: used by the row pass, which is
+//     limited by registers, not by LDS.
+template <int N>
+struct PassTables {
+    static constexpr int off(int dir, int p)
+    {
+        int o = dir == FWD ? 0 : N;
+        for (int q = 1; q < p; ++q) o += (Plan<N>::radix(dir, q) - 1) * Plan<N>::ns(dir, q);
+        return o;
+    }
+    static constexpr int slots() { return 2 * N; }
+    static void build(c32* out)
+    {
+        using PL = Plan<N>;
+        for (int i = 0; i < slots(); ++i) out[i] = c32{0.f, 0.f};
+        for (int dir = -1; dir <= 1; dir += 2)
+            for (int p = 1; p < PL::NPASS; ++p) {
+                const int R = PL::radix(dir, p), NS = PL::ns(dir, p), o = off(dir, p);
+                for (int t = 1; t < R; ++t)
+                    for (int jm = 0; jm < NS; ++jm) {
+                        const double ang = dir * 6.283185307179586476925286766559 * double(t) * double(jm) / (double(NS) * R);
+                        out[o + (t - 1) * NS + jm] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
+                    }
+            }
+    }
+};
+
+// twiddle access policies for pass_compute
+struct TwMaster {
+    const c32* tw;
+    template <int N, int DIR, int P, int T>
+    P3D_HD c32 get(int jm) const
+    {
+        constexpr int STEP = N / (Plan<N>::ns(DIR, P) * Plan<N>::radix(DIR, P));
+        c32 w = tw[tw_slot(T * STEP * jm)];
+        if (DIR > 0) w.y = -w.y;
+        return w;
+    }
+};
+struct TwOrdered {
+    const c32* tw;
+    template <int N, int DIR, int P, int T>
+    P3D_HD c32 get(int jm) const
+    {
+        return (tw + (PassTables<N>::off(DIR, P) + (T - 1) * Plan<N>::ns(DIR, P)))[jm];
+    }
+};
+
 // ---- LDS views ---------------------------------------------------------------------------------
-// Row view: one line is contiguous; one padding slot after every 16 points keeps the strided
-// Stockham scatter (stride R*8 B) off a single bank.
+// One padding slot after every 16 points keeps the strided Stockham scatter (stride R*8 B) off a single
+// bank.  pad(base + c) == pad(base) + c + (c >> 4) whenever (base mod 16) + (c mod 16) < 16; the engine only
+// asks for such (base, c) pairs, so a thread needs ONE computed LDS address per scatter / gather and the
+// 16 accesses use instruction-immediate offsets.
+// Row view: one line is contiguous.
 struct LdsRow {
     c32* base;
     static constexpr int stride(int n) { return n + (n >> 4); }
     P3D_HD c32& at(int pos) const { return base[pos + (pos >> 4)]; }
+    P3D_HD c32* ptr(int pos) const { return base + pos + (pos >> 4); }
+    static constexpr int rel(int c) { return c + (c >> 4); }
 };
 // Column-block view: W (<= 8) columns of one 64-byte column block interleaved, element-major
-// ([pos][W]) with the same padding; `base` already points at this thread's column.
+// ([pos][W]); `base` already points at this thread's column.
 template <int W>
 struct LdsColW {
     c32* base;
     static constexpr int stride(int n) { return (n + (n >> 4)) * W; }  // elements per column block
     P3D_HD c32& at(int pos) const { return base[(pos + (pos >> 4)) * W]; }
+    P3D_HD c32* ptr(int pos) const { return base + (pos + (pos >> 4)) * W; }
+    static constexpr int rel(int c) { return (c + (c >> 4)) * W; }
 };
 using LdsColBlk = LdsColW<8>;
 
 // One pass, all in registers: twiddle, radix-R DFTs, re-order to "output k of butterfly s at
 // register s + NB*k".
-template <int N, int DIR, int P>
-P3D_HD void pass_compute(c32 (&v)[Plan<N>::PPT], const c32* __restrict__ tw, int tl)
+template <int N, int DIR, int P, int T, class TW>
+struct TwApply {  // a[t] = v[s + NB*t] * w_t for t = T..R-1 (compile-time t: table offsets fold into the instruction)
+    template <int R, int NB>
+    static P3D_HD void run(c32* a, const c32* v, int s, TW tw, int jm)
+    {
+        if constexpr (T < R) {
+            a[T] = v[s + NB * T] * tw.template get<N, DIR, P, T>(jm);
+            TwApply<N, DIR, P, T + 1, TW>::template run<R, NB>(a, v, s, tw, jm);
+        }
+    }
+};
+
+template <int N, int DIR, int P, class TW>
+P3D_HD void pass_compute(c32 (&v)[Plan<N>::PPT], TW tw, int tl)
 {
     using PL = Plan<N>;
     constexpr int R = PL::radix(DIR, P);
     constexpr int NS = PL::ns(DIR, P);
     constexpr int NB = PL::PPT / R;
-    constexpr int STEP = N / (NS * R);  // tw index of exp(-2*pi*i/(NS*R))
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         c32 a[R];
         const int jm = (tl + s * PL::TPL) & (NS - 1);
         a[0] = v[s];
+        if constexpr (P == 0) {
 #pragma unroll
-        for (int t = 1; t < R; ++t) {
-            if constexpr (P == 0) {
-                a[t] = v[s + NB * t];
-            } else {
-                c32 w = tw[tw_slot(t * STEP * jm)];
-                if (DIR > 0) w.y = -w.y;
-                a[t] = v[s + NB * t] * w;
-            }
+            for (int t = 1; t < R; ++t) a[t] = v[s + NB * t];
+        } else {
+            TwApply<N, DIR, P, 1, TW>::template run<R, NB>(a, v, s, tw, jm);
         }
         Dft<R, DIR>::run(a);
 #pragma unroll
@@ -239,20 +314,35 @@ P3D_HD void pass_scatter(const c32 (&v)[Plan<N>::PPT], LDS lds, int tl)
     constexpr int R = PL::radix(DIR, P);
     constexpr int NS = PL::ns(DIR, P);
     constexpr int NB = PL::PPT / R;
+    // j0 = hi*NS*R + lo with lo < NS: (j0 mod 16) + (k*NS mod 16) <= 15 whenever NS*R is a multiple of 16
+    constexpr bool FOLD = (NS * R) % 16 == 0 && (NS >= 16 || 16 % NS == 0);
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         const int jb = tl + s * PL::TPL;
         const int j0 = (jb & ~(NS - 1)) * R + (jb & (NS - 1));
+        if constexpr (FOLD) {
+            c32* p = lds.ptr(j0);
 #pragma unroll
-        for (int k = 0; k < R; ++k) lds.at(j0 + k * NS) = v[s + NB * k];
+            for (int k = 0; k < R; ++k) p[LDS::rel(k * NS)] = v[s + NB * k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) lds.at(j0 + k * NS) = v[s + NB * k];
+        }
     }
 }
 
 template <int N, class LDS>
 P3D_HD void canonical_gather(c32 (&v)[Plan<N>::PPT], LDS lds, int tl)
 {
+    constexpr int TPL = Plan<N>::TPL;
+    if constexpr (TPL % 16 == 0) {
+        const c32* p = lds.ptr(tl);
 #pragma unroll
-    for (int q = 0; q < Plan<N>::PPT; ++q) v[q] = lds.at(tl + Plan<N>::TPL * q);
+        for (int q = 0; q < Plan<N>::PPT; ++q) v[q] = p[LDS::rel(TPL * q)];
+    } else {
+#pragma unroll
+        for (int q = 0; q < Plan<N>::PPT; ++q) v[q] = lds.at(tl + TPL * q);
+    }
 }
 
 #if defined(__HIPCC__)
@@ -271,9 +361,9 @@ P3D_D void exchange_sync()
     }
 }
 
-template <int N, int DIR, int P, bool WAVE, class LDS>
+template <int N, int DIR, int P, bool WAVE, class LDS, class TW>
 struct PassLoop {
-    static P3D_D void run(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tw, int tl)
+    static P3D_D void run(c32 (&v)[Plan<N>::PPT], LDS lds, TW tw, int tl)
     {
         if constexpr (P > 0) canonical_gather<N>(v, lds, tl);
         pass_compute<N, DIR, P>(v, tw, tl);
@@ -281,17 +371,17 @@ struct PassLoop {
             exchange_sync<WAVE>();  // everybody is done reading the previous contents
             pass_scatter<N, DIR, P>(v, lds, tl);
             exchange_sync<WAVE>();
-            PassLoop<N, DIR, P + 1, WAVE, LDS>::run(v, lds, tw, tl);
+            PassLoop<N, DIR, P + 1, WAVE, LDS, TW>::run(v, lds, tw, tl);
         }
     }
 };
 
 // Transform one line held in canonical register layout; result is canonical again.
 // Every thread of the workgroup (WAVE = false) / wavefront (WAVE = true) must call this.
-template <int N, int DIR, bool WAVE, class LDS>
-P3D_D void line_fft(c32 (&v)[Plan<N>::PPT], LDS lds, const c32* __restrict__ tw, int tl)
+template <int N, int DIR, bool WAVE, class LDS, class TW>
+P3D_D void line_fft(c32 (&v)[Plan<N>::PPT], LDS lds, TW tw, int tl)
 {
-    PassLoop<N, DIR, 0, WAVE, LDS>::run(v, lds, tw, tl);
+    PassLoop<N, DIR, 0, WAVE, LDS, TW>::run(v, lds, tw, tl);
 }
 #endif  // __HIPCC__
 

@@ -46,6 +46,12 @@
 #ifndef P3D_ABL
 #define P3D_ABL 0        // ablations for timing only (results wrong): 1 no transforms, 2 no forward, 4 no work store
 #endif
+#ifndef P3D_PIPE_WAVES_PER_EU
+#define P3D_PIPE_WAVES_PER_EU 2  // persistent row pass: v[], bx[], by[] + transform temporaries need ~220 VGPRs
+#endif
+#ifndef P3D_PIPE_LOCKSTEP
+#define P3D_PIPE_LOCKSTEP 1
+#endif
 #ifndef P3D_ROW_WAVES_PER_EU
 #define P3D_ROW_WAVES_PER_EU (P3D_ROW_THREADS >= 512 ? 4 : 3)
 #endif
@@ -62,14 +68,33 @@ constexpr int STATS_PARTIAL = 8;  // floats per (slice, tile) written by COL_STA
 __host__ __device__ inline size_t wk_slice_stride(int n1, int n2) { return (size_t)((n2 + 7) / 8) * 8 * n1; }
 __host__ __device__ inline size_t wk_off(int row, int col, int n1) { return ((size_t)(col >> 3) * n1 + row) * 8 + (col & 7); }
 
+
+// Work-buffer element (row, e = tl + TPL*q) of a slice whose base is `ws`: written as a wave-uniform pointer
+// (ws + q*qstride, scalar registers) plus ONE per-lane 32-bit offset shared by all q, so that 16 accesses do
+// not pin 16 offsets (or 16 64-bit addresses) in vector registers.
+template <int TPL>
+__device__ __forceinline__ unsigned wk_lane_off(int tl, int row, unsigned wblk)
+{
+    if constexpr (TPL % 8 == 0) return (unsigned)(tl >> 3) * wblk + (unsigned)row * 8 + (tl & 7);
+    else return (unsigned)row * 8;  // short lines: the q-dependent part carries everything
+}
+template <int TPL, class P>
+__device__ __forceinline__ P wk_q_ptr(P ws, int q, int tl, unsigned wblk)
+{
+    if constexpr (TPL % 8 == 0) return ws + (size_t)q * (TPL / 8) * wblk;
+    else { const int e = tl + TPL * q; return ws + (size_t)(e >> 3) * wblk + (e & 7); }
+}
+
 struct RowArgs {
     const void* x;         // observed cube (c64 or f32), [nslices][n1][N]
     const float* mask;     // [n1][N] float weights (generic path) or nullptr
     const uint16_t* bits;  // [n1][TPL] packed binary mask: bit q of entry (row, tl) = mask[row][tl + TPL*q]
     c32* work;             // column-blocked work buffer
     void* out;             // result cube (c64 or f32), row-major         (MID if write_out, LAST)
-    const c32* tw;         // padded twiddle table of length N (device)
-    double* sums;          // row `sum_row` of [(niter+1)][nslices] receives sum|x| per slice, or nullptr
+    const c32* tw;         // per-pass ordered twiddle tables of length N, both directions (device)
+    double* sums;          // [nslices][n1] per-row sums of |x| (plain stores; reduce_rows_kernel adds them up in a
+                           // fixed order -- same-address atomics from 1024 rows serialise at the memory side and,
+                           // sitting in the in-order vmcnt queue, delay every later load of the wave), or nullptr
     const int* done;       // per slice: 0 running, >0 finished at that iteration, <0 all-zero slice; or nullptr
     int n1;
     int nslices;
@@ -145,8 +170,9 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
     constexpr int LSTR = LdsRow::stride(N);
     constexpr bool WAVE = TPL <= 64;       // a line never leaves its wavefront
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    c32* tw = reinterpret_cast<c32*>(smem_raw);
-    c32* data = tw + tw_slots(N);
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + PassTables<N>::slots();
+    const TwOrdered tw{twl};
 
     const int tid = threadIdx.x;
     const int line = tid / TPL;
@@ -174,7 +200,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
         return;
     }
 
-    for (int i = tid; i < tw_slots(N); i += ROW_THREADS) tw[i] = a.tw[i];
+    for (int i = tid; i < PassTables<N>::slots(); i += ROW_THREADS) twl[i] = a.tw[i];
     __syncthreads();
 
     const LdsRow lds{data + line * LSTR};
@@ -185,10 +211,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
     const unsigned off = (unsigned)vrow * N + tl;                                   // + TPL*q
     c32* const wslice = a.work + (size_t)slice * wk_slice_stride(a.n1, N);          // column-blocked work buffer
     const unsigned wblk = (unsigned)a.n1 * 8;                                       // elements per column block
-    auto woff = [&](int q, int lane_in_line) -> unsigned {
-        const int e = lane_in_line + TPL * q;
-        return (unsigned)(e >> 3) * wblk + (unsigned)vrow * 8 + (e & 7);
-    };
+    const unsigned wlane = wk_lane_off<TPL>(tl, vrow, wblk);
     c32 v[PPT];
 
     // observed data (every mode except a plain inverse transform) and the mask word of this thread
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = valid ? wslice[woff(q, tl)] : c32{0.f, 0.f};
+        for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
         if (!(P3D_ABL & 1)) line_fft<N, INV, WAVE>(v, lds, tw, tl);
         // The observed samples are fetched here, a few at a time, instead of being prefetched ahead of
         // the inverse transform: holding 16 of them across the transform costs 32 VGPRs and the 16
@@ -251,7 +274,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
                 if (!a.plain) {
                     m = mask_at(q);
                     const float w = 1.0f - a.alpha * m;       // POCS.py:616
-                    xn = xn * w + xo[i] * a.alpha;            // POCS.py:619
+                    xn = axpby(xn, w, xo[i], a.alpha);        // POCS.py:619
                 }
                 acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
                 if (MODE == ROW_LAST || a.write_out) {
@@ -274,21 +297,187 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
         }
     }
 
-    if (a.sums != nullptr) {
-        const double ws = wave_sum(valid ? (double)acc : 0.0);
-        if ((tid & 63) == 0) atomicAdd(&a.sums[(size_t)a.sum_row * a.nslices + slice], ws);
+    if (a.sums != nullptr) {  // one line = TPL consecutive lanes (TPL > 64: several waves, combined through LDS below)
+        double ws = valid ? (double)acc : 0.0;
+        if constexpr (TPL <= 64) {
+#pragma unroll
+            for (int o = TPL / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, TPL);
+            if (tl == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = ws;
+        } else {
+            ws = wave_sum(ws);
+            double* red = reinterpret_cast<double*>(data + LB * LSTR);  // scratch behind the line buffers
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = ws;
+            __syncthreads();
+            if (tl == 0 && valid) {
+                double t = 0.0;
+                for (int w = 0; w < TPL / 64; ++w) t += red[line * (TPL / 64) + w];
+                a.sums[(size_t)slice * a.n1 + row] = t;
+            }
+            __syncthreads();
+        }
     }
 
     if (MODE != ROW_LAST) {
         if (!(P3D_ABL & 3)) line_fft<N, FWD, WAVE>(v, lds, tw, tl);
         if (valid && !(P3D_ABL & 4)) {
-            // recompute the store offsets from a laundered copy of the lane index: otherwise the compiler keeps
-            // the 16 load offsets alive across both transforms (16 VGPRs the 128-register budget does not have)
-            int tls = tl;
-            asm volatile("" : "+v"(tls));
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) wslice[woff(q, tls)] = v[q];
+            for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] = v[q];
         }
+    }
+}
+
+// =================================================================================================
+// space (row) pass, steady state: persistent, software pipelined across rows
+// =================================================================================================
+// Same arithmetic as row_kernel<N, ROW_MID, BITS> (bit for bit), different schedule.  Both passes are bound
+// by the bytes a CU keeps in flight, and that is capped by registers: a row in progress occupies ~155
+// VGPRs per thread, i.e. 12 waves per CU.  Here every wave walks over many rows and keeps one row's worth
+// of loads in flight WHILE it computes: the observed samples of row r arrive during the inverse transform
+// of row r, and the work-buffer loads of the NEXT row arrive during the forward transform of row r, in the
+// registers the observed samples just vacated (no extra VGPRs).
+// Requires TPL <= 64 (a line never leaves its wavefront: no workgroup barrier inside the loop).
+// EXTRA: the rarely used options (APOCS input mix, per-iteration output for early exit) are compiled in.
+template <int N, bool BITS, int DT, bool EXTRA>
+__global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_kernel(const RowArgs a)
+{
+    using PL = Plan<N>;
+    constexpr int TPL = PL::TPL, PPT = PL::PPT;
+    static_assert(TPL <= 64, "line must fit a wavefront");
+    constexpr int LB = ROW_THREADS / TPL;
+    constexpr int LSTR = LdsRow::stride(N);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + PassTables<N>::slots();
+    const TwOrdered tw{twl};
+
+    const int tid = threadIdx.x;
+    const int line = tid / TPL;
+    const int tl = tid - line * TPL;
+    for (int i = tid; i < PassTables<N>::slots(); i += ROW_THREADS) twl[i] = a.tw[i];
+    __syncthreads();
+    const LdsRow lds{data + line * LSTR};
+
+    // Addressing: every cube pointer stays wave-uniform (a.work + q*qstride etc., scalar registers); the
+    // position of a line is ONE 32-bit element offset per lane (the launcher guarantees the batch has
+    // fewer than 2^32 elements), because lines sharing a wave (N < 1024) sit in different rows or slices.
+    const unsigned total = (unsigned)a.nslices * a.n1;   // lines of the whole batch
+    const unsigned step = gridDim.x * LB;                // lines per sweep of the grid
+    const unsigned wblk = (unsigned)a.n1 * 8;
+    const unsigned wstride = (unsigned)wk_slice_stride(a.n1, N);
+
+    struct Where { unsigned slice, row; bool on; };
+    // NOTE on ordering: s_waitcnt vmcnt counts vector-memory operations IN ISSUE ORDER, so a small load issued
+    // after a bulk prefetch cannot be consumed without draining the prefetch as well.  Every small per-row load
+    // (mask word, `done` flag of the slice) is therefore issued one row early and AHEAD of the bulk loads of
+    // that iteration; the fast path (EXTRA = false) has no `done` lookup at all.
+    auto locate = [&](unsigned g) -> Where {
+        Where w;
+        w.on = g < total;
+        const unsigned gg = w.on ? g : 0u;
+        w.slice = gg / (unsigned)a.n1;
+        w.row = gg - w.slice * (unsigned)a.n1;
+        if (EXTRA) {
+            if (w.on && a.done && a.done[w.slice] != 0) w.on = false;   // finished / empty slice: leave it alone
+        }
+        return w;
+    };
+    auto wlane = [&](const Where& w) -> unsigned { return w.slice * wstride + wk_lane_off<TPL>(tl, (int)w.row, wblk); };
+
+    unsigned g = blockIdx.x * LB + line;
+    Where cur = locate(g);
+    Where nxt = locate(g + step);
+    // Software pipeline, one full row deep.  While row r is being transformed, two sets of loads are in
+    // flight per wave: by[] <- work buffer of row r+1 (issued at the top of row r, consumed at the top of row
+    // r+1) and bx[] <- observed samples of row r+1 (issued right after the re-insertion of row r freed bx[],
+    // consumed by the re-insertion of row r+1).  Loads are never predicated: a line that is switched off
+    // (beyond the end, finished or empty slice) reads line 0 instead (locate() clamps) and its results are
+    // simply not stored or summed.
+    c32 v[PPT], bx[PPT], by[PPT];
+    auto load_work = [&](c32 (&dst)[PPT], const Where& w) {
+        const unsigned wl = wlane(w);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            dst[q] = (P3D_ABL & 8) ? c32{(float)wl, (float)q} : wk_q_ptr<TPL>((const c32*)a.work, q, tl, wblk)[wl];
+    };
+    auto load_obs = [&](c32 (&dst)[PPT], const Where& w) {
+        const unsigned off = (w.slice * (unsigned)a.n1 + w.row) * N + tl;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (P3D_ABL & 8) dst[q] = c32{(float)off, 1.0f};
+            else if (DT == 0) dst[q] = (reinterpret_cast<const c32*>(a.x) + TPL * q)[off];
+            else dst[q] = c32{(reinterpret_cast<const float*>(a.x) + TPL * q)[off], 0.f};
+        }
+    };
+    unsigned mbits = 0;
+    if (BITS) mbits = a.bits[cur.row * TPL + tl];
+    load_work(by, cur);
+    load_obs(bx, cur);
+
+    // every line of the workgroup runs the same number of sweeps (uniform loop, predicated work)
+    for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
+#if P3D_PIPE_LOCKSTEP
+        // The lines of a workgroup are ADJACENT rows, and in the column-blocked work buffer adjacent rows share
+        // 128-byte lines (64 bytes each).  Keeping the waves in step makes the two halves of a line arrive at
+        // L2 together; waves that drift apart turn every line into two partial-line transactions.
+        __syncthreads();
+#endif
+        // small loads of the rows ahead first (see NOTE), then the bulk prefetch of row r+1
+        const Where nxt2 = locate(g + 2 * step);
+        unsigned mbits_nxt = 0;
+        if (BITS) mbits_nxt = a.bits[nxt.row * TPL + tl];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = by[q];
+        load_work(by, nxt);
+        const unsigned off = (cur.slice * (unsigned)a.n1 + cur.row) * N + tl;
+
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(P3D_ABL & 1)) line_fft<N, INV, true>(v, lds, tw, tl);
+        __builtin_amdgcn_sched_barrier(0);
+
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            c32 xn = v[q] * a.scale;
+            float m;
+            if (BITS) m = (float)((mbits >> q) & 1u);
+            else m = (a.mask + TPL * q)[cur.row * N + tl];
+            const float w = 1.0f - a.alpha * m;       // POCS.py:616
+            xn = axpby(xn, w, bx[q], a.alpha);        // POCS.py:619
+            acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+            if (EXTRA && a.write_out && cur.on) {
+                if (DT == 0) (reinterpret_cast<c32*>(a.out) + TPL * q)[off] = xn;
+                else (reinterpret_cast<float*>(a.out) + TPL * q)[off] = xn.x;
+            }
+            if (EXTRA && a.adaptive) {  // x_input of the next iteration (POCS.py:574-575)
+                const c32 blend = bx[q] * a.alpha + xn * w;
+                v[q] = blend + (bx[q] - xn * m) * (1.0f - a.alpha);
+            } else {
+                v[q] = xn;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // bx[] is free only now: keep the next loads below this point
+        load_obs(bx, nxt);
+
+        if (a.sums != nullptr) {  // one line = TPL consecutive lanes: segmented reduction
+            double ws = cur.on ? (double)acc : 0.0;
+#pragma unroll
+            for (int o = TPL / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, TPL);
+            if (tl == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row] = ws;
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(P3D_ABL & 1)) line_fft<N, FWD, true>(v, lds, tw, tl);
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (cur.on && (!(P3D_ABL & 8) || v[0].x == 1.2345e30f)) {
+            const unsigned wl = wlane(cur);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(a.work, q, tl, wblk)[wl] = v[q];
+        }
+        g += step;
+        cur = nxt;
+        nxt = nxt2;
+        mbits = mbits_nxt;
     }
 }
 
@@ -310,8 +499,9 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     constexpr int CW = T < 8 ? T : 8;
     using LDS = LdsColW<CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    c32* tw = reinterpret_cast<c32*>(smem_raw);
-    c32* data = tw + tw_slots(N);
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + tw_slots(N);
+    const TwMaster tw{twl};
 
     const int tid = threadIdx.x;
     const int c_lo = tid % CW;
@@ -323,7 +513,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 
     if (a.done && a.done[slice] != 0) return;
 
-    for (int i = tid; i < tw_slots(N); i += THREADS) tw[i] = a.tw[i];
+    for (int i = tid; i < tw_slots(N); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
 
     const LDS lds{data + cbl * LDS::stride(N) + c_lo};
@@ -414,7 +604,7 @@ constexpr int col_tile()
 template <int N>
 constexpr size_t row_lds_bytes()
 {
-    return sizeof(c32) * (tw_slots(N) + (ROW_THREADS / Plan<N>::TPL) * LdsRow::stride(N));
+    return sizeof(c32) * (PassTables<N>::slots() + (ROW_THREADS / Plan<N>::TPL) * LdsRow::stride(N)) + 8 * sizeof(double);
 }
 template <int N>
 constexpr size_t col_lds_bytes()
@@ -441,6 +631,40 @@ hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     row_kernel<N, MODE, BITS><<<grid, ROW_THREADS, lds, st>>>(a);
     return hipGetLastError();
+}
+
+// persistent steady-state row pass: `wgs` workgroups (CUs x resident workgroups per CU)
+template <int N>
+hipError_t launch_row_pipe(const RowArgs& a, int wgs, hipStream_t st)
+{
+    if constexpr (Plan<N>::TPL > 64) {
+        return hipErrorNotSupported;
+    } else {
+        constexpr int LB = ROW_THREADS / Plan<N>::TPL;
+        if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0) return hipErrorNotSupported;  // 32-bit offsets
+        const long groups = ((long)a.nslices * a.n1 + LB - 1) / LB;
+        const dim3 grid((unsigned)(groups < wgs ? groups : wgs));
+        constexpr size_t lds = row_lds_bytes<N>();
+        hipError_t e = hipSuccess;
+#define P3D_PIPE(BITS, DT)                                                                          \
+    do {                                                                                            \
+        if (extra) {                                                                                \
+            if ((e = allow_lds(row_pipe_kernel<N, BITS, DT, true>, lds)) != hipSuccess) return e;   \
+            row_pipe_kernel<N, BITS, DT, true><<<grid, ROW_THREADS, lds, st>>>(a);                  \
+        } else {                                                                                    \
+            if ((e = allow_lds(row_pipe_kernel<N, BITS, DT, false>, lds)) != hipSuccess) return e;  \
+            row_pipe_kernel<N, BITS, DT, false><<<grid, ROW_THREADS, lds, st>>>(a);                 \
+        }                                                                                           \
+    } while (0)
+        const bool bits = a.bits != nullptr;
+        const bool extra = a.adaptive || a.write_out || a.done != nullptr;
+        if (bits && a.dtype == 0) P3D_PIPE(true, 0);
+        else if (bits) P3D_PIPE(true, 1);
+        else if (a.dtype == 0) P3D_PIPE(false, 0);
+        else P3D_PIPE(false, 1);
+#undef P3D_PIPE
+        return hipGetLastError();
+    }
 }
 
 template <int N>
@@ -488,6 +712,10 @@ struct LineOps {
     int ppt;
     hipError_t (*row)(int mode, const RowArgs&, hipStream_t);
     hipError_t (*col)(int mode, const ColArgs&, hipStream_t);
+    hipError_t (*row_pipe)(const RowArgs&, int wgs, hipStream_t);  // hipErrorNotSupported when a line spans waves
+    size_t row_lds;
+    int row_tw_slots;                    // length of the row pass's twiddle tables ...
+    void (*build_row_tw)(c32* out);      // ... and their builder
 };
 
 }  // namespace p3d

@@ -6,6 +6,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "p3d_fft.hpp"
@@ -13,9 +14,9 @@
 using namespace p3d;
 using cd = std::complex<double>;
 
-template <int N, int DIR, int P, class MakeLds>
+template <int N, int DIR, int P, class MakeLds, class TW>
 struct Emu {
-    static void run(std::vector<std::vector<c32>>& regs, MakeLds mk, const c32* tab)
+    static void run(std::vector<std::vector<c32>>& regs, MakeLds mk, TW tab)
     {
         using PL = Plan<N>;
         for (int tl = 0; tl < PL::TPL; ++tl) {
@@ -28,29 +29,32 @@ struct Emu {
                 c32(&v)[PL::PPT] = *reinterpret_cast<c32(*)[PL::PPT]>(regs[tl].data());
                 pass_scatter<N, DIR, P>(v, mk(), tl);
             }
-            Emu<N, DIR, P + 1, MakeLds>::run(regs, mk, tab);
+            Emu<N, DIR, P + 1, MakeLds, TW>::run(regs, mk, tab);
         }
     }
 };
 
-template <int N, int DIR, bool COLVIEW>
+template <int N, int DIR, bool COLVIEW, bool ORDERED = false>
 double check()
 {
     using PL = Plan<N>;
     std::vector<cd> x(N);
     for (int i = 0; i < N; ++i) x[i] = cd(std::sin(0.37 * i * i + 0.1) + 0.25, std::cos(1.3 * i) - 0.5 * (i % 3));
-    std::vector<c32> tab(tw_slots(N));
-    build_twiddles(N, tab.data());
+    std::vector<c32> tab(ORDERED ? PassTables<N>::slots() : tw_slots(N));
+    if (ORDERED) PassTables<N>::build(tab.data());
+    else build_twiddles(N, tab.data());
+    using TW = std::conditional_t<ORDERED, TwOrdered, TwMaster>;
+    const TW tw{tab.data()};
     std::vector<std::vector<c32>> regs(PL::TPL, std::vector<c32>(PL::PPT));
     for (int tl = 0; tl < PL::TPL; ++tl)
         for (int q = 0; q < PL::PPT; ++q) regs[tl][q] = c32{float(x[tl + PL::TPL * q].real()), float(x[tl + PL::TPL * q].imag())};
     std::vector<c32> lds(COLVIEW ? LdsColBlk::stride(N) : LdsRow::stride(N) + 1);
     if constexpr (COLVIEW) {
         auto mk = [&]() { return LdsColBlk{lds.data() + 3}; };
-        Emu<N, DIR, 0, decltype(mk)>::run(regs, mk, tab.data());
+        Emu<N, DIR, 0, decltype(mk), TW>::run(regs, mk, tw);
     } else {
         auto mk = [&]() { return LdsRow{lds.data()}; };
-        Emu<N, DIR, 0, decltype(mk)>::run(regs, mk, tab.data());
+        Emu<N, DIR, 0, decltype(mk), TW>::run(regs, mk, tw);
     }
     double err = 0, nrm = 0;
     for (int k = 0; k < N; ++k) {
@@ -97,6 +101,8 @@ void sweep()
     report("row", N, INV, check<N, INV, false>(), 1e-6);
     report("col", N, FWD, check<N, FWD, true>(), 1e-6);
     report("col", N, INV, check<N, INV, true>(), 1e-6);
+    report("row/ord", N, FWD, check<N, FWD, false, true>(), 1e-6);
+    report("row/ord", N, INV, check<N, INV, false, true>(), 1e-6);
 }
 
 int main()

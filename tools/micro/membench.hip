@@ -120,6 +120,32 @@ __global__ void copy4(const float4* a, float4* b, size_t n) {   // each WG a con
     for (int k = 0; k < 16; ++k) { const size_t i = base + k * 256 + threadIdx.x; if (i < n) b[i] = a[i]; }
 }
 
+
+// row pattern on the blocked layout with limited residency (dynamic LDS as ballast) and R rows per wave in flight
+template <int R> __global__ __launch_bounds__(256) void rowblk_occ(float2* p, const float2* x) {
+    extern __shared__ char dummy[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float2 v[R][16], w[R][16];
+    #pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const size_t rowg = ((size_t)blockIdx.x * R + r) * 4 + wave;
+        const size_t slice = rowg / N1, row = rowg % N1;
+        float2* sb = p + slice * N1 * N2; const float2* xr = x + rowg * N2;
+        #pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = lane + 64 * q; v[r][q] = sb[((size_t)(e >> 3) * N1 + row) * 8 + (e & 7)]; }
+        #pragma unroll
+        for (int q = 0; q < 16; ++q) w[r][q] = xr[lane + 64 * q];
+    }
+    #pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const size_t rowg = ((size_t)blockIdx.x * R + r) * 4 + wave;
+        const size_t slice = rowg / N1, row = rowg % N1;
+        float2* sb = p + slice * N1 * N2;
+        #pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = lane + 64 * q; v[r][q].x = v[r][q].x * 1.0001f + w[r][q].y; sb[((size_t)(e >> 3) * N1 + row) * 8 + (e & 7)] = v[r][q]; }
+    }
+}
+
 template <class F> float timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -169,5 +195,18 @@ int main(int argc, char** argv) {
     col8(colblk, 36, "col T=8 BLOCKED layout (contiguous tile), 4 WG/CU");
     rep("row on BLOCKED layout 8B/lane r+w", timeit([&] { rowblk<0><<<rowblocks, 256>>>(p, x); }, 5), 2 * gb);
     rep("row on BLOCKED layout 8B/lane r+r+w", timeit([&] { rowblk<1><<<rowblocks, 256>>>(p, x); }, 5), 3 * gb);
+    auto rocc = [&](auto kern, int R, int ldskb, const char* name) {
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldskb * 1024));
+        rep(name, timeit([&] { kern<<<rowblocks / R, 256, ldskb * 1024>>>(p, x); }, 5), 3 * gb);
+    };
+    rocc(rowblk_occ<1>, 1, 1, "rowblk r+r+w 1 row/wave, no LDS limit");
+    rocc(rowblk_occ<1>, 1, 20, "rowblk r+r+w 1 row/wave, 8 WG/CU (32 waves)");
+    rocc(rowblk_occ<1>, 1, 32, "rowblk r+r+w 1 row/wave, 5 WG/CU (20 waves)");
+    rocc(rowblk_occ<1>, 1, 40, "rowblk r+r+w 1 row/wave, 4 WG/CU (16 waves)");
+    rocc(rowblk_occ<1>, 1, 52, "rowblk r+r+w 1 row/wave, 3 WG/CU (12 waves)");
+    rocc(rowblk_occ<1>, 1, 80, "rowblk r+r+w 1 row/wave, 2 WG/CU (8 waves)");
+    rocc(rowblk_occ<1>, 1, 150, "rowblk r+r+w 1 row/wave, 1 WG/CU (4 waves)");
+    rocc(rowblk_occ<2>, 2, 52, "rowblk r+r+w 2 rows/wave, 3 WG/CU (12 waves)");
+    rocc(rowblk_occ<2>, 2, 80, "rowblk r+r+w 2 rows/wave, 2 WG/CU (8 waves)");
     return 0;
 }
