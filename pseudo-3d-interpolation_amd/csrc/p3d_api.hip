@@ -41,6 +41,25 @@ static const LineOps* find_ops(int n)
 
 using namespace p3d;
 
+// ---- rowbase[r] = number of observed positions in rows < r (rowbase[n1] = total), from the packed mask ---------
+static __global__ void rowbase_kernel(const uint16_t* bits, unsigned* rowbase, int n1, int tpl)
+{
+    __shared__ unsigned cnt[4096 + 1];
+    for (int r = threadIdx.x; r < n1; r += blockDim.x) {
+        unsigned c = 0;
+        for (int t = 0; t < tpl; ++t) c += __popc((unsigned)bits[(size_t)r * tpl + t]);
+        cnt[r] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int r = 0; r < n1; ++r) { const unsigned c = cnt[r]; cnt[r] = run; run += c; }
+        cnt[n1] = run;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r <= n1; r += blockDim.x) rowbase[r] = cnt[r];
+}
+
 // ---- per-slice sum of the per-row sums, fixed order (bitwise reproducible) ----------------------------------
 static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row, int n1)
 {
@@ -118,7 +137,10 @@ struct p3d_plan {
     c32 *tw_col = nullptr, *tw_row = nullptr;  // padded twiddle tables of length nil / nxl
     c32* work = nullptr;                        // column-blocked work buffer
     uint16_t* bits = nullptr;                   // packed binary trace mask [nil][tpl(nxl)]
-    int* flag = nullptr;                        // device int: mask has entries other than 0 / 1
+    int* flag = nullptr;                        // device int[2]: mask not binary / x non-zero at a missing trace
+    unsigned* rowbase = nullptr;                // [nil+1] observed positions before each row
+    void* xc = nullptr;                         // compact observed samples [nslices][nobs]
+    size_t xc_cap = 0;
     double* sums = nullptr;     // [(niter+1)][nslices]
     size_t sums_cap = 0;
     double* rowsum = nullptr;   // [max_slices][nil] per-row partial sums of the current row pass
@@ -173,7 +195,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->sums, p->rowsum, p->tau,
+    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -241,7 +263,8 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
     TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * wk_slice_stride(nil, nxl) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
-    TRY_OR_BAIL(hipMalloc((void**)&p->flag, sizeof(int)));
+    TRY_OR_BAIL(hipMalloc((void**)&p->flag, 2 * sizeof(int)));
+    TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
     TRY_OR_BAIL(hipMalloc((void**)&p->rowsum, sizeof(double) * (size_t)nil * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
@@ -529,20 +552,41 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // travel as one 16-bit word per thread and row; anything else keeps the float weights
     {
         const int words = p->nil * p->ops_row->tpl;
-        HIP_TRY(hipMemsetAsync(p->flag, 0, sizeof(int), p->stream));
+        HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
         pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl,
                                                                     p->ops_row->ppt);
+        if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
         HIP_TRY(hipGetLastError());
     }
     int nonbinary = 0;
+    unsigned nobs = 0;
     HIP_TRY(hipMemcpyAsync(&nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(&nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (getenv("P3D_NO_MASK_BITS")) nonbinary = 1;  // experiments only
+    // Compact observed samples for the steady-state row pass: only the observed positions of x are non-zero in
+    // the workflow (x = stacked traces, mask = fold >= 1); ROW_FIRST verifies that and the full cube is used if not.
+    bool compact = !nonbinary && p->pipe_wgs > 0 && p->nil <= 4096 && niter > 1 && !getenv("P3D_NO_COMPACT") &&
+                   nobs > 0 && (double)nobs < 0.75 * (double)p->slice_elems();
+    if (compact) {
+        const size_t need = (size_t)nslices * nobs * (dtype == P3D_C64 ? sizeof(c32) : sizeof(float));
+        if (p->xc_cap < need) {
+            if (p->xc) hipFree(p->xc);
+            p->xc = nullptr;
+            p->xc_cap = 0;
+            HIP_TRY(hipMalloc(&p->xc, need));
+            p->xc_cap = need;
+        }
+    }
 
     RowArgs r = row_args(p, nslices);
     r.x = x;
     r.mask = nonbinary ? mask : nullptr;
     r.bits = nonbinary ? nullptr : p->bits;
+    r.xc = compact ? p->xc : nullptr;
+    r.rowbase = p->rowbase;
+    r.nobs = nobs;
+    r.violation = p->flag + 1;
     r.work = p->work;
     r.out = out;
     // the per-slice state array is only consulted when a slice can actually be switched off
@@ -559,6 +603,12 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
     HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
     reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil);
+    if (compact) {  // did every unobserved position hold a zero?
+        int violation = 0;
+        HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (violation) r.xc = nullptr;
+    }
 
     ColArgs c = col_args(p, nslices);
     c.in = p->work;

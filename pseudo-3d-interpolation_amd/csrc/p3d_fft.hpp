@@ -46,10 +46,50 @@ P3D_HD c32 operator-(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
 // that the SAME source expression yields the SAME bits in every kernel it is inlined into (the compiler would
 // otherwise fuse multiply-adds differently from one kernel to the next, and a hard threshold turns a
 // last-bit difference into a kept-or-zeroed coefficient).
+//
+// On the device the three primitives that need a lane swap -- complex product, a + i*b, a - i*b -- are written
+// as packed-f32 instructions with op_sel / neg modifiers (CDNA3+ VOP3P: op_sel picks the 32-bit half of each
+// 64-bit source for the low result, op_sel_hi for the high result).  hipcc emits v_pk_* for the plain sums but
+// builds the swaps with v_mov pairs (13-16 % of all instructions of both passes before this).  Same arithmetic,
+// same rounding as the portable expressions below.
+#ifndef P3D_PK_ASM
+#define P3D_PK_ASM 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && P3D_PK_ASM
+typedef float p3d_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ p3d_f2 as_f2(c32 a) { return p3d_f2{a.x, a.y}; }
+__device__ __forceinline__ c32 as_c32(p3d_f2 a) { return c32{a.x, a.y}; }
+__device__ __forceinline__ c32 operator*(c32 a, c32 b)
+{
+    p3d_f2 t, r;
+    // t = (a.y*b.y, a.y*b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(as_f2(a)), "v"(as_f2(b)));
+    // r = (a.x*b.x - t.x, a.x*b.y + t.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=v"(r) : "v"(as_f2(a)), "v"(as_f2(b)), "v"(t));
+    return as_c32(r);
+}
+// a + i*b = (a.x - b.y, a.y + b.x);  a - i*b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ c32 add_ib(c32 a, c32 b)
+{
+    p3d_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(as_f2(a)), "v"(as_f2(b)));
+    return as_c32(r);
+}
+__device__ __forceinline__ c32 sub_ib(c32 a, c32 b)
+{
+    p3d_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(as_f2(a)), "v"(as_f2(b)));
+    return as_c32(r);
+}
+#else
 P3D_HD c32 operator*(c32 a, c32 b)
 {
     return {__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
 }
+P3D_HD c32 add_ib(c32 a, c32 b) { return {a.x - b.y, a.y + b.x}; }
+P3D_HD c32 sub_ib(c32 a, c32 b) { return {a.x + b.y, a.y - b.x}; }
+#endif
 // a*s + b*t with real s, t
 P3D_HD c32 axpby(c32 a, float s, c32 b, float t) { return {__builtin_fmaf(a.x, s, b.x * t), __builtin_fmaf(a.y, s, b.y * t)}; }
 P3D_HD c32 operator*(c32 a, float s) { return {a.x * s, a.y * s}; }
@@ -75,12 +115,13 @@ P3D_HD void dft2(c32& a, c32& b)
 template <int DIR>
 P3D_HD void dft4(c32& v0, c32& v1, c32& v2, c32& v3)
 {
-    c32 s0 = v0 + v2, d0 = v0 - v2;
-    c32 s1 = v1 + v3, d1 = mul_i<DIR>(v1 - v3);
+    const c32 s0 = v0 + v2, d0 = v0 - v2;
+    const c32 s1 = v1 + v3, t = v1 - v3;
     v0 = s0 + s1;
     v2 = s0 - s1;
-    v1 = d0 + d1;
-    v3 = d0 - d1;
+    // v1 = d0 + DIR*i*t, v3 = d0 - DIR*i*t
+    v1 = DIR > 0 ? add_ib(d0, t) : sub_ib(d0, t);
+    v3 = DIR > 0 ? sub_ib(d0, t) : add_ib(d0, t);
 }
 
 // ---- in-place radix-R DFT; result k ends up at position digit_rev<R>(k) --------------------

@@ -59,7 +59,7 @@
 namespace p3d {
 
 enum RowMode { ROW_FIRST = 0, ROW_MID = 1, ROW_LAST = 2 };
-enum ColMode { COL_ITER = 0, COL_STATS = 1, COL_FWD = 2, COL_INV = 3 };
+enum ColMode { COL_ITER = 0, COL_STATS = 1, COL_FWD = 2, COL_INV = 3, COL_ITER_SOFT = 4, COL_ITER_GARROTE = 5 };  // COL_ITER = hard
 
 constexpr int ROW_THREADS = P3D_ROW_THREADS;
 constexpr int STATS_PARTIAL = 8;  // floats per (slice, tile) written by COL_STATS
@@ -85,10 +85,41 @@ __device__ __forceinline__ P wk_q_ptr(P ws, int q, int tl, unsigned wblk)
     else { const int e = tl + TPL * q; return ws + (size_t)(e >> 3) * wblk + (e & 7); }
 }
 
+// Observed samples in compact form.  For a line (TPL lanes of one wave) and register q, the lanes whose mask
+// bit q is set hold consecutive observed positions (element e = tl + TPL*q grows with tl), so their samples
+// are consecutive in the compact array: index = rowbase + (observed positions with smaller q) + (rank of
+// the lane among the set lanes of its line).  Everything comes from wave ballots of the mask word.
+template <int TPL>
+struct CompactIndex {
+    unsigned long long line_mask;  // lanes of this thread's line
+    unsigned long long below;      // lanes of the line below this lane
+    unsigned running;              // observed positions of the line in registers < q
+    __device__ __forceinline__ CompactIndex(int lane, unsigned base)
+    {
+        const int first = lane & ~(TPL - 1);
+        line_mask = TPL == 64 ? ~0ull : (((1ull << TPL) - 1ull) << first);
+        below = line_mask & ((1ull << lane) - 1ull);
+        running = base;
+    }
+    // index of this lane's sample for register q (valid when `set`), then advance to q+1
+    __device__ __forceinline__ unsigned next(bool set)
+    {
+        const unsigned long long b = __ballot(set);
+        const unsigned idx = running + (unsigned)__popcll(b & below);
+        running += (unsigned)__popcll(b & line_mask);
+        return idx;
+    }
+};
+
 struct RowArgs {
     const void* x;         // observed cube (c64 or f32), [nslices][n1][N]
     const float* mask;     // [n1][N] float weights (generic path) or nullptr
     const uint16_t* bits;  // [n1][TPL] packed binary mask: bit q of entry (row, tl) = mask[row][tl + TPL*q]
+    void* xc;              // compact observed samples [nslices][nobs] (type of x), row-major order of the observed
+                           // positions; written by ROW_FIRST, read by the persistent row pass        (or nullptr)
+    const unsigned* rowbase;  // [n1+1] number of observed positions before each row
+    unsigned nobs;         // observed positions per slice = rowbase[n1]
+    int* violation;        // raised by ROW_FIRST when x != 0 at a position the mask calls missing
     c32* work;             // column-blocked work buffer
     void* out;             // result cube (c64 or f32), row-major         (MID if write_out, LAST)
     const c32* tw;         // per-pass ordered twiddle tables of length N, both directions (device)
@@ -236,9 +267,24 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
 
     float acc = 0.f;
     if (MODE == ROW_FIRST) {
+        constexpr bool CAN_COMPACT = BITS && TPL <= 64;  // ranks come from wave ballots: a line must not span waves
+        const bool compact = CAN_COMPACT && a.xc != nullptr;
+        CompactIndex<(TPL <= 64 ? TPL : 64)> ci(tid & 63, compact ? a.rowbase[vrow] : 0u);
+        bool bad = false;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const c32 x = obs_at(q);
+            if (CAN_COMPACT) {
+                if (compact) {  // uniform
+                    const bool set = ((mbits >> q) & 1u) != 0;
+                    const unsigned idx = ci.next(set);
+                    if (set && valid) {
+                        if (a.dtype == 0) reinterpret_cast<c32*>(a.xc)[(size_t)slice * a.nobs + idx] = x;
+                        else reinterpret_cast<float*>(a.xc)[(size_t)slice * a.nobs + idx] = x.x;
+                    }
+                    bad = bad || (!set && (x.x != 0.f || x.y != 0.f));
+                }
+            }
             acc += sqrtf(x.x * x.x + x.y * x.y);
             if (a.adaptive) {
                 // x_old = x at the first iteration (POCS.py:549, 574-575)
@@ -249,6 +295,9 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
             } else {
                 v[q] = x;
             }
+        }
+        if (CAN_COMPACT) {
+            if (compact && bad && valid) atomicOr(a.violation, 1);
         }
     } else {
 #pragma unroll
@@ -337,7 +386,8 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
 // registers the observed samples just vacated (no extra VGPRs).
 // Requires TPL <= 64 (a line never leaves its wavefront: no workgroup barrier inside the loop).
 // EXTRA: the rarely used options (APOCS input mix, per-iteration output for early exit) are compiled in.
-template <int N, bool BITS, int DT, bool EXTRA>
+// COMPACT: the observed samples are read from the compact array (BITS only).
+template <int N, bool BITS, int DT, bool EXTRA, bool COMPACT>
 __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
@@ -399,19 +449,36 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
         for (int q = 0; q < PPT; ++q)
             dst[q] = (P3D_ABL & 8) ? c32{(float)wl, (float)q} : wk_q_ptr<TPL>((const c32*)a.work, q, tl, wblk)[wl];
     };
-    auto load_obs = [&](c32 (&dst)[PPT], const Where& w) {
-        const unsigned off = (w.slice * (unsigned)a.n1 + w.row) * N + tl;
+    // (wbits, wbase): mask word / compact row base of the row being loaded (fetched a row earlier, see NOTE)
+    auto load_obs = [&](c32 (&dst)[PPT], const Where& w, unsigned wbits, unsigned wbase) {
+        if constexpr (COMPACT) {
+            CompactIndex<TPL> ci(tid & 63, w.slice * a.nobs + wbase);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            if (P3D_ABL & 8) dst[q] = c32{(float)off, 1.0f};
-            else if (DT == 0) dst[q] = (reinterpret_cast<const c32*>(a.x) + TPL * q)[off];
-            else dst[q] = c32{(reinterpret_cast<const float*>(a.x) + TPL * q)[off], 0.f};
+            for (int q = 0; q < PPT; ++q) {
+                const bool set = ((wbits >> q) & 1u) != 0;
+                const unsigned idx = ci.next(set);
+                c32 val{0.f, 0.f};
+                if (set) {
+                    if (DT == 0) val = reinterpret_cast<const c32*>(a.xc)[idx];
+                    else val.x = reinterpret_cast<const float*>(a.xc)[idx];
+                }
+                dst[q] = val;
+            }
+        } else {
+            const unsigned off = (w.slice * (unsigned)a.n1 + w.row) * N + tl;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                if (P3D_ABL & 8) dst[q] = c32{(float)off, 1.0f};
+                else if (DT == 0) dst[q] = (reinterpret_cast<const c32*>(a.x) + TPL * q)[off];
+                else dst[q] = c32{(reinterpret_cast<const float*>(a.x) + TPL * q)[off], 0.f};
+            }
         }
     };
-    unsigned mbits = 0;
+    unsigned mbits = 0, rbase = 0;
     if (BITS) mbits = a.bits[cur.row * TPL + tl];
+    if (COMPACT) rbase = a.rowbase[cur.row];
     load_work(by, cur);
-    load_obs(bx, cur);
+    load_obs(bx, cur, mbits, rbase);
 
     // every line of the workgroup runs the same number of sweeps (uniform loop, predicated work)
     for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
@@ -423,8 +490,9 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
 #endif
         // small loads of the rows ahead first (see NOTE), then the bulk prefetch of row r+1
         const Where nxt2 = locate(g + 2 * step);
-        unsigned mbits_nxt = 0;
+        unsigned mbits_nxt = 0, rbase_nxt = 0;
         if (BITS) mbits_nxt = a.bits[nxt.row * TPL + tl];
+        if (COMPACT) rbase_nxt = a.rowbase[nxt.row];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = by[q];
         load_work(by, nxt);
@@ -456,7 +524,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // bx[] is free only now: keep the next loads below this point
-        load_obs(bx, nxt);
+        load_obs(bx, nxt, mbits_nxt, rbase_nxt);
 
         if (a.sums != nullptr) {  // one line = TPL consecutive lanes: segmented reduction
             double ws = cur.on ? (double)acc : 0.0;
@@ -478,6 +546,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
         cur = nxt;
         nxt = nxt2;
         mbits = mbits_nxt;
+        rbase = rbase_nxt;
     }
 }
 
@@ -517,6 +586,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     __syncthreads();
 
     const LDS lds{data + cbl * LDS::stride(N) + c_lo};
+    constexpr bool ITER = MODE == COL_ITER || MODE == COL_ITER_SOFT || MODE == COL_ITER_GARROTE;
     const int vcol = valid ? col : 0;
     // wave-uniform slice bases + 32-bit element offsets (see row_kernel)
     const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
@@ -527,14 +597,15 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     };
     c32 v[PPT];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) v[q] = valid ? inb[eoff(a.in_std, tl + TPL * q)] : c32{0.f, 0.f};
+    for (int q = 0; q < PPT; ++q) v[q] = inb[eoff(a.in_std, tl + TPL * q)];  // columns past the edge re-read column 0; never stored
 
     if (MODE != COL_INV) line_fft<N, FWD, false>(v, lds, tw, tl);
 
-    if (MODE == COL_ITER || (MODE == COL_FWD && a.tau != nullptr)) {
+    if (ITER || (MODE == COL_FWD && a.tau != nullptr)) {
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
+        const int op = MODE == COL_ITER ? 0 : (MODE == COL_ITER_SOFT ? 1 : (MODE == COL_ITER_GARROTE ? 2 : a.op));
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = shrink(v[q], tau, a.op);
+        for (int q = 0; q < PPT; ++q) v[q] = shrink(v[q], tau, op);
     }
 
     if (MODE == COL_STATS) {
@@ -585,7 +656,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         return;
     }
 
-    if (MODE == COL_ITER || MODE == COL_INV) line_fft<N, INV, false>(v, lds, tw, tl);
+    if (ITER || MODE == COL_INV) line_fft<N, INV, false>(v, lds, tw, tl);
 
     if (valid) {
 #pragma unroll
@@ -646,22 +717,23 @@ hipError_t launch_row_pipe(const RowArgs& a, int wgs, hipStream_t st)
         const dim3 grid((unsigned)(groups < wgs ? groups : wgs));
         constexpr size_t lds = row_lds_bytes<N>();
         hipError_t e = hipSuccess;
-#define P3D_PIPE(BITS, DT)                                                                          \
-    do {                                                                                            \
-        if (extra) {                                                                                \
-            if ((e = allow_lds(row_pipe_kernel<N, BITS, DT, true>, lds)) != hipSuccess) return e;   \
-            row_pipe_kernel<N, BITS, DT, true><<<grid, ROW_THREADS, lds, st>>>(a);                  \
-        } else {                                                                                    \
-            if ((e = allow_lds(row_pipe_kernel<N, BITS, DT, false>, lds)) != hipSuccess) return e;  \
-            row_pipe_kernel<N, BITS, DT, false><<<grid, ROW_THREADS, lds, st>>>(a);                 \
-        }                                                                                           \
+#define P3D_PIPE(BITS, DT, EXTRA, COMPACT)                                                                  \
+    do {                                                                                                    \
+        if ((e = allow_lds(row_pipe_kernel<N, BITS, DT, EXTRA, COMPACT>, lds)) != hipSuccess) return e;     \
+        row_pipe_kernel<N, BITS, DT, EXTRA, COMPACT><<<grid, ROW_THREADS, lds, st>>>(a);                    \
     } while (0)
         const bool bits = a.bits != nullptr;
         const bool extra = a.adaptive || a.write_out || a.done != nullptr;
-        if (bits && a.dtype == 0) P3D_PIPE(true, 0);
-        else if (bits) P3D_PIPE(true, 1);
-        else if (a.dtype == 0) P3D_PIPE(false, 0);
-        else P3D_PIPE(false, 1);
+        const bool compact = bits && a.xc != nullptr;
+        if (a.dtype == 0) {
+            if (compact) { if (extra) P3D_PIPE(true, 0, true, true); else P3D_PIPE(true, 0, false, true); }
+            else if (bits) { if (extra) P3D_PIPE(true, 0, true, false); else P3D_PIPE(true, 0, false, false); }
+            else { if (extra) P3D_PIPE(false, 0, true, false); else P3D_PIPE(false, 0, false, false); }
+        } else {
+            if (compact) { if (extra) P3D_PIPE(true, 1, true, true); else P3D_PIPE(true, 1, false, true); }
+            else if (bits) { if (extra) P3D_PIPE(true, 1, true, false); else P3D_PIPE(true, 1, false, false); }
+            else { if (extra) P3D_PIPE(false, 1, true, false); else P3D_PIPE(false, 1, false, false); }
+        }
 #undef P3D_PIPE
         return hipGetLastError();
     }
@@ -696,7 +768,10 @@ template <int N>
 hipError_t launch_col(int mode, const ColArgs& a, hipStream_t st)
 {
     switch (mode) {
-        case COL_ITER: return launch_col_one<N, COL_ITER>(a, st);
+        case COL_ITER:
+            if (a.op == 1) return launch_col_one<N, COL_ITER_SOFT>(a, st);
+            if (a.op == 2) return launch_col_one<N, COL_ITER_GARROTE>(a, st);
+            return launch_col_one<N, COL_ITER>(a, st);
         case COL_STATS: return launch_col_one<N, COL_STATS>(a, st);
         case COL_FWD: return launch_col_one<N, COL_FWD>(a, st);
         case COL_INV: return launch_col_one<N, COL_INV>(a, st);

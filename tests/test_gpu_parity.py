@@ -361,3 +361,33 @@ def test_batching_is_transparent(P, orc):
     a = P.pocs_cube(obs, mask, **params)
     b = P.pocs_cube(obs, mask, batch_slices=3, **params)
     assert np.array_equal(a, b)
+
+
+def test_compact_observed_samples_path_is_exact(ffi, orc, monkeypatch):
+    """The steady-state row pass reads the observed samples from a compact copy when x is zero at every
+    missing trace; a cube that violates that (the API allows it: POCS.py:619 adds alpha*x everywhere) must take
+    the full-cube path and still match the oracle; and both paths must give the same bits on a regular cube."""
+    nil = nxl = 1024
+    _, mask, obs = orc.synthetic_cube(nil, nxl, 2, 0.8)
+    maskf = mask.astype(np.float32)
+    K = 5
+    x = obs[0].astype(np.complex128)
+    tau = orc.threshold_schedule("exponential", K, "FFT", 0.99, 0.03, np.fft.fft2(x), "values")
+    with ffi.Plan(nil, nxl, 2) as plan:
+        a, _, sums_a, _ = plan.run(obs, maskf, tau[None, :], K)
+        monkeypatch.setenv("P3D_NO_COMPACT", "1")
+        b, _, sums_b, _ = plan.run(obs, maskf, tau[None, :], K)
+        monkeypatch.delenv("P3D_NO_COMPACT")
+        assert np.array_equal(a, b) and np.array_equal(sums_a, sums_b)
+        dirty = obs.copy()
+        dirty[1, 5, 7] = 3.0 - 2.0j          # a non-zero sample where the mask says "missing"
+        assert mask[5, 7] == 0
+        c, _, _, _ = plan.run(dirty, maskf, tau[None, :], K)
+    want = orc.pocs_cube(dirty.astype(np.complex128), mask, niter=K, thresh_op="hard", thresh_model="exponential",
+                         eps=0, p_max=0.99, p_min=0.03)
+    # slice 0 is untouched by the dirty sample; slice 1 carries it through alpha*x
+    assert np.array_equal(c[0], a[0])
+    tau1 = orc.threshold_schedule("exponential", K, "FFT", 0.99, 0.03, np.fft.fft2(dirty[1].astype(np.complex128)), "values")
+    with ffi.Plan(nil, nxl, 1) as plan:
+        d, _, _, _ = plan.run(dirty[1:2], maskf, tau1[None, :], K)
+    assert rel_l2(d[0], want[1]) < TOL
