@@ -150,7 +150,7 @@ struct p3d_plan {
     float* partials = nullptr;
     int tiles = 0;
     int cus = 0;          // compute units of the device
-    int pipe_wgs = 0;     // grid of the persistent row pass (0: not available for this shape)
+    int pipe_wgs = 0;     // compute units handed to the persistent row pass (0: not available for this shape)
     // staging for host-pointer entry points
     void* st_x = nullptr;
     void* st_out = nullptr;
@@ -234,12 +234,7 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         p->cus = prop.multiProcessorCount;
-        // resident workgroups per CU of the persistent row pass: LDS (160 KiB per CU) and registers
-        // (P3D_PIPE_WAVES_PER_EU waves per SIMD) both allow this many
-        const int by_lds = (int)((160 * 1024) / orow->row_lds);
-        const int by_regs = (P3D_PIPE_WAVES_PER_EU * 4 * 64) / ROW_THREADS;
-        const int per_cu = by_lds < by_regs ? by_lds : by_regs;
-        p->pipe_wgs = (orow->tpl <= 64 && per_cu >= 1 && !getenv("P3D_NO_PIPE")) ? p->cus * per_cu : 0;
+        p->pipe_wgs = (orow->tpl <= 64 && !getenv("P3D_NO_PIPE")) ? p->cus : 0;  // the launcher sizes the grid per variant
     }
     int rc = P3D_OK;
     auto bail = [&](int code) {

@@ -46,8 +46,16 @@
 #ifndef P3D_ABL
 #define P3D_ABL 0        // ablations for timing only (results wrong): 1 no transforms, 2 no forward, 4 no work store
 #endif
+// persistent row pass, waves per SIMD: with the full-cube observed samples v[], bx[], by[] are live across both
+// transforms (~220 VGPRs -> 2); with compact samples, fetched after the inverse transform, 157 VGPRs -> 3
 #ifndef P3D_PIPE_WAVES_PER_EU
-#define P3D_PIPE_WAVES_PER_EU 2  // persistent row pass: v[], bx[], by[] + transform temporaries need ~220 VGPRs
+#define P3D_PIPE_WAVES_PER_EU 2
+#endif
+#ifndef P3D_PIPE_WAVES_PER_EU_COMPACT
+#define P3D_PIPE_WAVES_PER_EU_COMPACT 3
+#endif
+#ifndef P3D_COMPACT_LATE
+#define P3D_COMPACT_LATE 1  // 1: fetch the compact observed samples after the inverse transform (frees 32 VGPRs across it)
 #endif
 #ifndef P3D_PIPE_LOCKSTEP
 #define P3D_PIPE_LOCKSTEP 1
@@ -388,7 +396,8 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
 // EXTRA: the rarely used options (APOCS input mix, per-iteration output for early exit) are compiled in.
 // COMPACT: the observed samples are read from the compact array (BITS only).
 template <int N, bool BITS, int DT, bool EXTRA, bool COMPACT>
-__global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_kernel(const RowArgs a)
+__global__ __launch_bounds__(ROW_THREADS, (COMPACT && P3D_COMPACT_LATE) ? P3D_PIPE_WAVES_PER_EU_COMPACT : P3D_PIPE_WAVES_PER_EU) void
+row_pipe_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
@@ -478,7 +487,8 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
     if (BITS) mbits = a.bits[cur.row * TPL + tl];
     if (COMPACT) rbase = a.rowbase[cur.row];
     load_work(by, cur);
-    load_obs(bx, cur, mbits, rbase);
+    constexpr bool LATE = COMPACT && P3D_COMPACT_LATE;
+    if (!LATE) load_obs(bx, cur, mbits, rbase);
 
     // every line of the workgroup runs the same number of sweeps (uniform loop, predicated work)
     for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
@@ -501,6 +511,10 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
         __builtin_amdgcn_sched_barrier(0);
         if (!(P3D_ABL & 1)) line_fft<N, INV, true>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
+        if (LATE) {
+            load_obs(bx, cur, mbits, rbase);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         float acc = 0.f;
 #pragma unroll
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_PIPE_WAVES_PER_EU) void row_pipe_k
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // bx[] is free only now: keep the next loads below this point
-        load_obs(bx, nxt, mbits_nxt, rbase_nxt);
+        if (!LATE) load_obs(bx, nxt, mbits_nxt, rbase_nxt);
 
         if (a.sums != nullptr) {  // one line = TPL consecutive lanes: segmented reduction
             double ws = cur.on ? (double)acc : 0.0;
@@ -704,15 +718,23 @@ hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-// persistent steady-state row pass: `wgs` workgroups (CUs x resident workgroups per CU)
+// persistent steady-state row pass on a device with `cus` compute units
 template <int N>
-hipError_t launch_row_pipe(const RowArgs& a, int wgs, hipStream_t st)
+hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
 {
     if constexpr (Plan<N>::TPL > 64) {
         return hipErrorNotSupported;
     } else {
         constexpr int LB = ROW_THREADS / Plan<N>::TPL;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0) return hipErrorNotSupported;  // 32-bit offsets
+        const bool compact_path = a.bits != nullptr && a.xc != nullptr;
+        // resident workgroups per CU: LDS (160 KiB per CU) and the register budget of the variant
+        const int by_lds = (int)((160 * 1024) / row_lds_bytes<N>());
+        const int wpe = (compact_path && P3D_COMPACT_LATE) ? P3D_PIPE_WAVES_PER_EU_COMPACT : P3D_PIPE_WAVES_PER_EU;
+        const int by_regs = (wpe * 4 * 64) / ROW_THREADS;
+        const int per_cu = by_lds < by_regs ? by_lds : by_regs;
+        if (per_cu < 1) return hipErrorNotSupported;
+        const long wgs = (long)cus * per_cu;
         const long groups = ((long)a.nslices * a.n1 + LB - 1) / LB;
         const dim3 grid((unsigned)(groups < wgs ? groups : wgs));
         constexpr size_t lds = row_lds_bytes<N>();
@@ -787,7 +809,7 @@ struct LineOps {
     int ppt;
     hipError_t (*row)(int mode, const RowArgs&, hipStream_t);
     hipError_t (*col)(int mode, const ColArgs&, hipStream_t);
-    hipError_t (*row_pipe)(const RowArgs&, int wgs, hipStream_t);  // hipErrorNotSupported when a line spans waves
+    hipError_t (*row_pipe)(const RowArgs&, int cus, hipStream_t);  // hipErrorNotSupported when a line spans waves
     size_t row_lds;
     int row_tw_slots;                    // length of the row pass's twiddle tables ...
     void (*build_row_tw)(c32* out);      // ... and their builder
