@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "p3d.h"
+#include "p3d_generic.hpp"
 #include "p3d_kernels.hpp"
 
 namespace p3d {
@@ -132,6 +133,9 @@ struct p3d_plan {
     int device = 0;
     int nil = 0, nxl = 0, max_slices = 0;
     hipStream_t stream = nullptr;
+    bool generic = false;              // any-length fallback (p3d_generic.hip): row-major work buffer, unfused passes
+    GenPlan gcol{}, grow{};            // factorisations of nil / nxl
+    static constexpr int GEN_STAT_BLOCKS = 64;
     const LineOps* ops_col = nullptr;  // length nil (transform along iline = down the columns)
     const LineOps* ops_row = nullptr;  // length nxl (transform along xline = along the rows)
     c32 *tw_col = nullptr, *tw_row = nullptr;  // padded twiddle tables of length nil / nxl
@@ -188,7 +192,13 @@ int p3d_device_count(int* n)
     return P3D_OK;
 }
 
-int p3d_shape_supported(int nil, int nxl) { return (find_ops(nil) != nullptr && find_ops(nxl) != nullptr) ? 1 : 0; }
+static bool generic_ok(int n) { return n >= 1 && n <= GEN_MAX_N && gen_make_plan(n).nf >= 0; }
+
+int p3d_shape_supported(int nil, int nxl)
+{
+    if (find_ops(nil) != nullptr && find_ops(nxl) != nullptr) return 1;
+    return (generic_ok(nil) && generic_ok(nxl)) ? 1 : 0;
+}
 
 int p3d_plan_destroy(p3d_plan* p)
 {
@@ -215,8 +225,9 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     if (max_slices > 65535) return fail(P3D_ERR_INVALID, "max_slices > 65535: split the cube into batches");
     const LineOps* oc = find_ops(nil);
     const LineOps* orow = find_ops(nxl);
-    if (!oc || !orow)
-        return fail(P3D_ERR_UNSUPPORTED, "slice shape %d x %d: HIP kernels cover power-of-two extents 2..4096", nil, nxl);
+    const bool generic = !oc || !orow;
+    if (generic && !(generic_ok(nil) && generic_ok(nxl)))
+        return fail(P3D_ERR_UNSUPPORTED, "slice shape %d x %d: extents up to %d are supported", nil, nxl, GEN_MAX_N);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(P3D_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -227,10 +238,15 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     p->nil = nil;
     p->nxl = nxl;
     p->max_slices = max_slices;
-    p->ops_col = oc;
-    p->ops_row = orow;
-    p->tiles = (nxl + oc->col_tile - 1) / oc->col_tile;
-    {
+    p->generic = generic;
+    p->ops_col = generic ? nullptr : oc;
+    p->ops_row = generic ? nullptr : orow;
+    if (generic) {
+        p->gcol = gen_make_plan(nil);
+        p->grow = gen_make_plan(nxl);
+        p->tiles = p3d_plan::GEN_STAT_BLOCKS;
+    } else {
+        p->tiles = (nxl + oc->col_tile - 1) / oc->col_tile;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         p->cus = prop.multiProcessorCount;
@@ -254,12 +270,24 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     TRY_OR_BAIL(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     TRY_OR_BAIL(hipEventCreate(&p->ev0));
     TRY_OR_BAIL(hipEventCreate(&p->ev1));
-    if ((rc = upload_table(p, oc, false, &p->tw_col)) != P3D_OK) return bail(rc);
-    if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
-    TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * wk_slice_stride(nil, nxl) * max_slices));
-    TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
+    if (generic) {
+        for (int which = 0; which < 2; ++which) {
+            const int n = which ? nxl : nil;
+            std::vector<c32> host(n);
+            gen_build_twiddles(n, host.data());
+            c32** dst = which ? &p->tw_row : &p->tw_col;
+            TRY_OR_BAIL(hipMalloc((void**)dst, sizeof(c32) * n));
+            TRY_OR_BAIL(hipMemcpy(*dst, host.data(), sizeof(c32) * n, hipMemcpyHostToDevice));
+        }
+        TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * p->slice_elems() * max_slices));
+    } else {
+        if ((rc = upload_table(p, oc, false, &p->tw_col)) != P3D_OK) return bail(rc);
+        if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
+        TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * wk_slice_stride(nil, nxl) * max_slices));
+        TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
+        TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
+    }
     TRY_OR_BAIL(hipMalloc((void**)&p->flag, 2 * sizeof(int)));
-    TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
     TRY_OR_BAIL(hipMalloc((void**)&p->rowsum, sizeof(double) * (size_t)nil * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
@@ -345,6 +373,41 @@ static int ensure_staging(p3d_plan* p, size_t bytes_per_cube)
     return P3D_OK;
 }
 
+
+// ---- any-length fallback (p3d_generic.hip) -------------------------------------------------------------------
+static int gen_fft2(p3d_plan* p, const c32* in, c32* out, int nslices, int inverse, const int* done)
+{
+    const float scale = (float)(1.0 / ((double)p->nil * (double)p->nxl));
+    if (!inverse) {
+        HIP_TRY(gen_launch_line_fft(in, out, p->tw_row, p->grow, FWD, 1.0f, nslices, p->nil, p->nxl, true, done, p->stream));
+        HIP_TRY(gen_launch_line_fft(out, out, p->tw_col, p->gcol, FWD, 1.0f, nslices, p->nil, p->nxl, false, done, p->stream));
+    } else {
+        HIP_TRY(gen_launch_line_fft(in, out, p->tw_col, p->gcol, INV, 1.0f, nslices, p->nil, p->nxl, false, done, p->stream));
+        HIP_TRY(gen_launch_line_fft(out, out, p->tw_row, p->grow, INV, scale, nslices, p->nil, p->nxl, true, done, p->stream));
+    }
+    return P3D_OK;
+}
+
+static int reduce_partials(p3d_plan* p, int nslices, double* stats)
+{
+    std::vector<float> part((size_t)STATS_PARTIAL * p->tiles * nslices);
+    HIP_TRY(hipMemcpyAsync(part.data(), p->partials, sizeof(float) * part.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int s = 0; s < nslices; ++s) {
+        double lr = -INFINITY, li = -INFINITY, mx = 0.0, mn = INFINITY, sq = 0.0;
+        for (int t = 0; t < p->tiles; ++t) {
+            const float* q = &part[((size_t)s * p->tiles + t) * STATS_PARTIAL];
+            if (q[0] > lr || (q[0] == lr && q[1] > li)) { lr = q[0]; li = q[1]; }
+            if (q[2] > mx) mx = q[2];
+            if (q[3] < mn) mn = q[3];
+            sq += q[4];
+        }
+        double* o = stats + (size_t)s * P3D_STATS_PER_SLICE;
+        o[0] = lr; o[1] = li; o[2] = mx; o[3] = mn; o[4] = sq; o[5] = 0.0;
+    }
+    return P3D_OK;
+}
+
 extern "C" {
 
 int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
@@ -353,6 +416,11 @@ int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int in
     if (rc) return rc;
     if (!in || !out) return fail(P3D_ERR_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(p->device));
+    if (p->generic) {
+        if ((rc = gen_fft2(p, (const c32*)in, (c32*)out, nslices, inverse, nullptr))) return rc;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return P3D_OK;
+    }
     if (!inverse) {
         RowArgs r = row_args(p, nslices);
         r.x = in;
@@ -415,6 +483,13 @@ int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, 
     for (int s = 0; s < nslices; ++s) tau_f[s] = c32{(float)tau[2 * s], (float)tau[2 * s + 1]};
     HIP_TRY(hipMemcpy(p->tau, tau_f.data(), sizeof(c32) * nslices, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->st_x, in, bytes, hipMemcpyHostToDevice));
+    if (p->generic) {
+        if ((rc = gen_fft2(p, (const c32*)p->st_x, (c32*)p->st_out, nslices, 0, nullptr))) return rc;
+        HIP_TRY(gen_launch_shrink((c32*)p->st_out, p->tau, 1, 0, op, nslices, p->slice_elems(), nullptr, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpy(out, p->st_out, bytes, hipMemcpyDeviceToHost));
+        return P3D_OK;
+    }
     RowArgs r = row_args(p, nslices);
     r.x = p->st_x;
     r.work = p->work;
@@ -441,6 +516,14 @@ int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, doubl
     if (!x || !stats) return fail(P3D_ERR_INVALID, "NULL buffer");
     if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
     HIP_TRY(hipSetDevice(p->device));
+    if (p->generic) {
+        HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * nslices, p->stream));
+        HIP_TRY(gen_launch_update(p->work, x, dtype, nullptr, nullptr, p->rowsum, 0, 0, 0, 1.0f, nslices, p->slice_elems(), nullptr, 0,
+                                  p->stream));
+        if ((rc = gen_fft2(p, p->work, p->work, nslices, 0, nullptr))) return rc;
+        HIP_TRY(gen_launch_stats(p->work, p->partials, nslices, p->slice_elems(), p->tiles, p->stream));
+        return reduce_partials(p, nslices, stats);
+    }
     RowArgs r = row_args(p, nslices);
     r.x = x;
     r.work = p->work;
@@ -450,22 +533,7 @@ int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, doubl
     c.in = p->work;
     c.partials = p->partials;
     HIP_TRY(p->ops_col->col(COL_STATS, c, p->stream));
-    std::vector<float> part((size_t)STATS_PARTIAL * p->tiles * nslices);
-    HIP_TRY(hipMemcpyAsync(part.data(), p->partials, sizeof(float) * part.size(), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    for (int s = 0; s < nslices; ++s) {
-        double lr = -INFINITY, li = -INFINITY, mx = 0.0, mn = INFINITY, sq = 0.0;
-        for (int t = 0; t < p->tiles; ++t) {
-            const float* q = &part[((size_t)s * p->tiles + t) * STATS_PARTIAL];
-            if (q[0] > lr || (q[0] == lr && q[1] > li)) { lr = q[0]; li = q[1]; }
-            if (q[2] > mx) mx = q[2];
-            if (q[3] < mn) mn = q[3];
-            sq += q[4];
-        }
-        double* o = stats + (size_t)s * P3D_STATS_PER_SLICE;
-        o[0] = lr; o[1] = li; o[2] = mx; o[3] = mn; o[4] = sq; o[5] = 0.0;
-    }
-    return P3D_OK;
+    return reduce_partials(p, nslices, stats);
 }
 
 int p3d_pocs_stats(p3d_plan* p, const void* x, int dtype, int nslices, double* stats)
@@ -542,6 +610,40 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     };
 
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
+
+    if (p->generic) {
+        // unfused any-length pipeline: first input, then per iteration fft2 -> threshold -> ifft2 -> re-insertion
+        const size_t per_slice = p->slice_elems();
+        bool any_off = early;
+        for (int s = 0; s < nslices; ++s) any_off = any_off || done_h[s] != 0;
+        const int* done_d = any_off ? p->done : nullptr;
+        HIP_TRY(hipEventRecord(p->ev0, p->stream));
+        HIP_TRY(gen_launch_update(p->work, x, dtype, mask, out, p->sums, 0, adaptive ? 1 : 0, 0, (float)prm->alpha, nslices, per_slice,
+                                  done_d, 0, p->stream));
+        for (int k = 0; k < niter; ++k) {
+            const bool last = k + 1 == niter;
+            if ((rc = gen_fft2(p, p->work, p->work, nslices, 0, done_d))) return rc;
+            HIP_TRY(gen_launch_shrink(p->work, p->tau, niter, k, prm->thresh_op, nslices, per_slice, done_d, p->stream));
+            if ((rc = gen_fft2(p, p->work, p->work, nslices, 1, done_d))) return rc;
+            HIP_TRY(gen_launch_update(p->work, x, dtype, mask, out, p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0,
+                                      (early || last) ? 1 : 0, (float)prm->alpha, nslices, per_slice, p->done, last ? 1 : 0, p->stream));
+            if (early) conv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(p->ev1, p->stream));
+        HIP_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
+        if (sums) HIP_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (niter_done)
+            for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
+        if (elapsed_ms) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+            *elapsed_ms = ms;
+        }
+        p->prof_col_n = p->prof_row_n = 0;
+        return P3D_OK;
+    }
 
     // packed trace mask: binary masks (the workflow's fold-derived mask, cube_POCS_interpolation_3D.py:242-244)
     // travel as one 16-bit word per thread and row; anything else keeps the float weights

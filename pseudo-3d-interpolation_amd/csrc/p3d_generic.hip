@@ -1,0 +1,291 @@
+// p3d_generic.hip -- any-length fallback of the POCS path (slice extents that are not powers of two).
+//
+// numpy.fft (pocketfft) accepts every length, and so does the reference (cube_POCS_interpolation_3D.py:255-257);
+// the tuned kernels of p3d_kernels.hpp cover powers of two only.  This file provides the same pipeline
+// for arbitrary (nil, nxl) from simple building blocks: an LDS-resident mixed-radix Stockham line FFT whose
+// factor list is computed at run time (prime factors larger than 8 fall back to a direct O(p^2) butterfly), and
+// element-wise kernels for thresholding, re-insertion and the reductions.  One iteration is NOT fused here
+// (4 transform passes + 2 element-wise passes): correctness and coverage first, the hot sizes have their own path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "p3d_generic.hpp"
+
+namespace p3d {
+
+// radix-R butterfly with compile-time R (registers, no dynamic indexing): v[t] = A[j + t*m] * w^(t*jm), then the
+// direct R-point DFT with constants taken from the same table
+template <int R>
+__device__ inline void small_butterfly(const c32* A, c32* B, const c32* tw, int j, int m, int jm, int j0, int ns, int tstep,
+                                       int rstep, int dir)
+{
+    c32 v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        c32 w = tw[t * jm * tstep];
+        if (dir > 0) w.y = -w.y;
+        v[t] = A[j + t * m] * w;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        c32 acc = v[0];
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+            c32 w = tw[((t * k) % R) * rstep];
+            if (dir > 0) w.y = -w.y;
+            const c32 pr = v[t] * w;
+            acc = acc + pr;
+        }
+        B[j0 + k * ns] = acc;
+    }
+}
+
+// ---- line FFT: one workgroup per line, line resident in LDS (ping-pong) --------------------------------------
+// in/out element (line l, index i) at  base_of(l) + i*es,  base_of(l) = (l / lpo)*outer + (l % lpo)*inner
+//   rows of a [slice][n1][n2] cube:    es = 1,  lpo = n1,  outer = n1*n2, inner = n2   (n = n2)
+//   columns:                            es = n2, lpo = n2,  outer = n1*n2, inner = 1    (n = n1)
+// tw[k] = exp(-2*pi*i*k/n) (double precision, rounded once); dir = -1 forward, +1 inverse (conjugated table).
+__global__ void gen_line_fft(const c32* in, c32* out, const c32* tw, GenPlan pl, int dir, float scale, int es, int lpo,
+                             size_t outer, size_t inner, const int* done, int lines_per_slice)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = pl.n;
+    c32* A = reinterpret_cast<c32*>(smem_raw);
+    c32* B = A + n;
+    const size_t l = blockIdx.x;
+    if (done && done[l / lines_per_slice] != 0) return;
+    const size_t base = (l / lpo) * outer + (l % lpo) * inner;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) A[i] = in[base + (size_t)i * es];
+    __syncthreads();
+    int ns = 1;
+    for (int p = 0; p < pl.nf; ++p) {
+        const int R = pl.f[p];
+        const int m = n / R;              // butterflies of this pass
+        const int tstep = n / (ns * R);   // tw index of exp(-2*pi*i/(ns*R))
+        const int rstep = n / R;          // tw index of exp(-2*pi*i/R)
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            const int jm = j % ns;
+            const int j0 = (j / ns) * ns * R + jm;
+            if (R <= 8) {
+                switch (R) {
+                    case 2: small_butterfly<2>(A, B, tw, j, m, jm, j0, ns, tstep, rstep, dir); break;
+                    case 3: small_butterfly<3>(A, B, tw, j, m, jm, j0, ns, tstep, rstep, dir); break;
+                    case 4: small_butterfly<4>(A, B, tw, j, m, jm, j0, ns, tstep, rstep, dir); break;
+                    case 5: small_butterfly<5>(A, B, tw, j, m, jm, j0, ns, tstep, rstep, dir); break;
+                    case 7: small_butterfly<7>(A, B, tw, j, m, jm, j0, ns, tstep, rstep, dir); break;
+                    default: break;  // the factoriser only emits 2, 4 and odd primes
+                }
+            } else {  // large prime factor: direct butterfly, inputs re-read from LDS
+                for (int k = 0; k < R; ++k) {
+                    c32 acc{0.f, 0.f};
+                    for (int t = 0; t < R; ++t) {
+                        // twiddle of the pass and of the butterfly combined: exp(-+2*pi*i*(t*jm*tstep + ((t*k)%R)*rstep)/n)
+                        const long idx = ((long)t * jm * tstep + (long)((long)t * k % R) * rstep) % n;
+                        c32 w = tw[idx];
+                        if (dir > 0) w.y = -w.y;
+                        const c32 pr = A[j + t * m] * w;
+                        acc = acc + pr;
+                    }
+                    B[j0 + k * ns] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        c32* t = A; A = B; B = t;
+        ns *= R;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const c32 v = A[i];
+        out[base + (size_t)i * es] = c32{v.x * scale, v.y * scale};
+    }
+}
+
+// ---- element-wise kernels -----------------------------------------------------------------------------------------
+__device__ inline c32 gen_shrink(c32 X, c32 tau, int op)
+{
+    const float m = sqrtf(X.x * X.x + X.y * X.y);
+    if (op == 0) {
+        const bool below = (m < tau.x) || (m == tau.x && 0.0f < tau.y);
+        return below ? c32{0.f, 0.f} : X;
+    }
+    if (m == 0.0f) return c32{0.f, 0.f};
+    float gr, gi;
+    if (op == 1) {
+        const float r = 1.0f / m;
+        gr = 1.0f - tau.x * r;
+        gi = -tau.y * r;
+    } else {
+        const float r = 1.0f / (m * m);
+        gr = 1.0f - (tau.x * tau.x - tau.y * tau.y) * r;
+        gi = -(2.0f * tau.x * tau.y) * r;
+    }
+    const bool keep = (gr > 0.0f) || (gr == 0.0f && gi >= 0.0f);
+    return keep ? X * c32{gr, gi} : c32{0.f, 0.f};
+}
+
+__global__ void gen_shrink_kernel(c32* w, const c32* tau, int niter, int iter, int op, size_t per_slice, const int* done)
+{
+    const int s = blockIdx.y;
+    if (done && done[s] != 0) return;
+    const c32 t = tau[(size_t)s * niter + iter];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x)
+        w[(size_t)s * per_slice + i] = gen_shrink(w[(size_t)s * per_slice + i], t, op);
+}
+
+__device__ inline double block_sum(double v, double* sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// mode 0: first input  (w = x or its APOCS mix, sums[0] += |x|)
+// mode 1: re-insertion (xn = w*(1-alpha*m) + alpha*x; sums += |xn|; optional out = xn; w = xn or its APOCS mix)
+__global__ void gen_update_kernel(c32* w, const void* x, int dtype, const float* mask, void* out, double* sums, int mode,
+                                  int adaptive, int write_out, float alpha, size_t per_slice, const int* done, int zero_fill)
+{
+    __shared__ double sh[256];
+    const int s = blockIdx.y;
+    const int dn = done ? done[s] : 0;
+    if (zero_fill) {  // final pass: an empty slice is handed back untouched (zeros)
+        if (dn < 0)
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x) {
+                if (dtype == 0) reinterpret_cast<c32*>(out)[(size_t)s * per_slice + i] = c32{0.f, 0.f};
+                else reinterpret_cast<float*>(out)[(size_t)s * per_slice + i] = 0.f;
+            }
+    }
+    if (dn != 0) return;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t g = (size_t)s * per_slice + i;
+        c32 xo;
+        if (dtype == 0) xo = reinterpret_cast<const c32*>(x)[g];
+        else xo = c32{reinterpret_cast<const float*>(x)[g], 0.f};
+        const float m = mask ? mask[i] : 0.f;
+        const float wgt = 1.0f - alpha * m;
+        c32 xn;
+        if (mode == 0) {
+            xn = xo;
+        } else {
+            xn = axpby(w[g], wgt, xo, alpha);
+            if (write_out) {
+                if (dtype == 0) reinterpret_cast<c32*>(out)[g] = xn;
+                else reinterpret_cast<float*>(out)[g] = xn.x;
+            }
+        }
+        acc += (double)sqrtf(xn.x * xn.x + xn.y * xn.y);
+        if (adaptive) {
+            const c32 blend = xo * alpha + xn * wgt;
+            w[g] = blend + (xo - xn * m) * (1.0f - alpha);
+        } else {
+            w[g] = xn;
+        }
+    }
+    const double tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(sums + s, tot);
+}
+
+// per block: lexicographic max, max |X|^2, min |X|^2, sum |X|^2 -> partial[(s*gridDim.x + b)*8 ..]
+__global__ void gen_stats_kernel(const c32* w, float* partial, size_t per_slice)
+{
+    __shared__ float sh[256 * 5];
+    const int s = blockIdx.y;
+    float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x) {
+        const c32 v = w[(size_t)s * per_slice + i];
+        const float p = v.x * v.x + v.y * v.y;
+        if (v.x > lr || (v.x == lr && v.y > li)) { lr = v.x; li = v.y; }
+        mx = fmaxf(mx, p);
+        mn = fminf(mn, p);
+        sq += p;
+    }
+    float* me = sh + threadIdx.x * 5;
+    me[0] = lr; me[1] = li; me[2] = mx; me[3] = mn; me[4] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 1; t < (int)blockDim.x; ++t) {
+            const float* o = sh + t * 5;
+            if (o[0] > lr || (o[0] == lr && o[1] > li)) { lr = o[0]; li = o[1]; }
+            mx = fmaxf(mx, o[2]);
+            mn = fminf(mn, o[3]);
+            sq += o[4];
+        }
+        float* p = partial + ((size_t)s * gridDim.x + blockIdx.x) * 8;
+        p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+GenPlan gen_make_plan(int n)
+{
+    GenPlan pl{};
+    pl.n = n;
+    pl.nf = 0;
+    int r = n;
+    // radix 4 first (fewer passes), then 2, then odd primes; anything left is one (possibly large) prime
+    while (r % 4 == 0 && pl.nf < GEN_MAX_FACTORS) { pl.f[pl.nf++] = 4; r /= 4; }
+    while (r % 2 == 0 && pl.nf < GEN_MAX_FACTORS) { pl.f[pl.nf++] = 2; r /= 2; }
+    for (int p = 3; (long)p * p <= r; p += 2)
+        while (r % p == 0 && pl.nf < GEN_MAX_FACTORS) { pl.f[pl.nf++] = p; r /= p; }
+    if (r > 1 && pl.nf < GEN_MAX_FACTORS) { pl.f[pl.nf++] = r; r = 1; }
+    if (r != 1) pl.nf = -1;  // too many factors for the table (cannot happen below 2^31 with 32 slots)
+    return pl;
+}
+
+void gen_build_twiddles(int n, c32* out)
+{
+    for (int k = 0; k < n; ++k) {
+        const double ang = -6.283185307179586476925286766559 * double(k) / double(n);
+        out[k] = c32{float(std::cos(ang)), float(std::sin(ang))};
+    }
+}
+
+hipError_t gen_launch_line_fft(const c32* in, c32* out, const c32* tw, const GenPlan& pl, int dir, float scale, int nslices,
+                               int n1, int n2, bool rows, const int* done, hipStream_t st)
+{
+    const size_t lds = sizeof(c32) * 2 * (size_t)pl.n;
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    hipError_t e = hipSuccess;
+    if (lds > 64 * 1024)
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_line_fft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+            return e;
+    const size_t outer = (size_t)n1 * n2;
+    const int lines_per_slice = rows ? n1 : n2;
+    const size_t nlines = (size_t)nslices * lines_per_slice;
+    int threads = 64;
+    while (threads < 256 && threads * 4 < pl.n) threads *= 2;
+    if (rows) gen_line_fft<<<dim3((unsigned)nlines), threads, lds, st>>>(in, out, tw, pl, dir, scale, 1, n1, outer, (size_t)n2, done, lines_per_slice);
+    else gen_line_fft<<<dim3((unsigned)nlines), threads, lds, st>>>(in, out, tw, pl, dir, scale, n2, n2, outer, (size_t)1, done, lines_per_slice);
+    return hipGetLastError();
+}
+
+hipError_t gen_launch_shrink(c32* w, const c32* tau, int niter, int iter, int op, int nslices, size_t per_slice, const int* done,
+                             hipStream_t st)
+{
+    const unsigned bx = (unsigned)((per_slice + 255) / 256 < 1024 ? (per_slice + 255) / 256 : 1024);
+    gen_shrink_kernel<<<dim3(bx, nslices), 256, 0, st>>>(w, tau, niter, iter, op, per_slice, done);
+    return hipGetLastError();
+}
+
+hipError_t gen_launch_update(c32* w, const void* x, int dtype, const float* mask, void* out, double* sums, int mode, int adaptive,
+                             int write_out, float alpha, int nslices, size_t per_slice, const int* done, int zero_fill, hipStream_t st)
+{
+    const unsigned bx = (unsigned)((per_slice + 255) / 256 < 256 ? (per_slice + 255) / 256 : 256);
+    gen_update_kernel<<<dim3(bx, nslices), 256, 0, st>>>(w, x, dtype, mask, out, sums, mode, adaptive, write_out, alpha, per_slice, done,
+                                                       zero_fill);
+    return hipGetLastError();
+}
+
+hipError_t gen_launch_stats(const c32* w, float* partial, int nslices, size_t per_slice, int blocks, hipStream_t st)
+{
+    gen_stats_kernel<<<dim3(blocks, nslices), 256, 0, st>>>(w, partial, per_slice);
+    return hipGetLastError();
+}
+
+}  // namespace p3d

@@ -41,7 +41,10 @@ def _rand_c(shape, seed):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 2), (4, 8), (8, 4), (16, 16), (32, 64), (64, 64), (64, 32), (128, 16),
                                    (256, 512), (512, 256), (1024, 64), (2, 1024), (2048, 8), (16, 2048),
-                                   (4096, 4), (4, 4096), (1024, 1024)])
+                                   (4096, 4), (4, 4096), (1024, 1024),
+                                   # any-length fallback (mixed radix 2/3/4/5/7 + direct butterflies for larger primes)
+                                   (90, 50), (31, 17), (48, 20), (3, 5), (1, 7), (100, 128), (128, 100), (1000, 6),
+                                   (11, 13), (121, 49), (4501, 4), (6, 2500)])
 def test_fft2_matches_numpy(ffi, shape):
     n = 3 if shape[0] * shape[1] <= 1 << 18 else 2
     x = _rand_c((n,) + shape, 1)
@@ -87,7 +90,9 @@ def test_stats_match_numpy(ffi):
 # golden vectors of the reference (power-of-two cases; the others need the generic path)
 # ------------------------------------------------------------------------------------------------
 GOLDEN_POW2 = ["fft_hard_exp", "fft_real_in", "fft_soft_lin", "fft_garrote_exp2", "fft_sqrt_decay", "fft_alpha08",
-               "fft_factors", "fft_datadriven", "apocs_doc", "apocs_soft", "fpocs", "tiny_8x8", "niter1"]
+               "fft_factors", "fft_datadriven", "apocs_doc", "apocs_soft", "fpocs", "tiny_8x8", "niter1",
+               # any-length fallback
+               "rect_90x50", "rect_48x20_real", "prime_31x17"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_POW2)
@@ -181,6 +186,12 @@ WELL_CONDITIONED = [
     dict(nil=128, nxl=128, n=2, missing=0.5, niter=10, thresh_op="soft", p_min=0.05, thresh_model="linear"),
     dict(nil=1024, nxl=1024, n=1, missing=0.8, niter=8, thresh_op="soft", p_min=0.03),        # headline slice size
     dict(nil=1024, nxl=1024, n=1, missing=0.8, niter=8, thresh_op="hard", p_min=0.03),
+    # any-length fallback
+    dict(nil=90, nxl=50, n=3, missing=0.5, niter=12, thresh_op="hard", p_min=0.1),
+    dict(nil=100, nxl=128, n=2, missing=0.6, niter=10, thresh_op="soft", p_min=0.1),
+    dict(nil=75, nxl=45, n=2, missing=0.5, niter=10, thresh_op="hard", p_min=0.1, version="adaptive", alpha=0.8),
+    dict(nil=60, nxl=36, n=3, missing=0.5, niter=10, thresh_op="soft", p_min=0.1, real=True),
+    dict(nil=250, nxl=300, n=1, missing=0.7, niter=8, thresh_op="hard", p_min=0.1),
 ]
 
 
@@ -353,6 +364,21 @@ def test_properties_full_size(P, orc):
     # (5) the interpolation does its job: error vs the fully sampled field drops
     truth = orc.synthetic_slice(nil, nxl, 0)
     assert rel_l2(out[0], truth) < rel_l2(obs[0], truth)
+
+
+def test_generic_path_early_exit_and_zero_slice(P, orc):
+    _, mask, obs = orc.synthetic_cube(45, 30, 3, 0.3)
+    obs[1] = 0
+    params = dict(niter=40, thresh_op="hard", thresh_model="exponential", eps=1e-7, p_max=0.99, p_min=0.05)
+    res = []
+    got = P.pocs_cube(obs, mask, results=res, **params)
+    infos = []
+    want = orc.pocs_cube(obs.astype(np.complex128), mask, infos=infos, **params)
+    assert not got[1].any() and res[1]["niterations"] == 0
+    for s in (0, 2):
+        assert abs(res[s]["niterations"] - infos[s]["niterations"]) <= 1, (res[s]["niterations"], infos[s]["niterations"])
+        if res[s]["niterations"] == infos[s]["niterations"]:
+            assert rel_l2(got[s], want[s]) < TOL
 
 
 def test_batching_is_transparent(P, orc):
