@@ -129,6 +129,25 @@ int p3d_pocs_run(p3d_plan* plan, const void* x_host, int dtype, const float* mas
                  const uint8_t* active, const p3d_pocs_params* params, void* out_host, int nslices,
                  int32_t* niter_done, double* sums, double* elapsed_ms);
 
+/* Steps 12 / 14 of the workflow: transform every trace of a (nt, ntraces) time-domain cube (ntraces = nil*nxl, the
+ * slice-major layout: sample index slowest) to the frequency domain and back, with the conventions of
+ *     xrft.fft(da, dim='twt', shift=False, true_phase=True, true_amplitude=True, shape={dim: nfft})
+ *                                                                                  cube_apply_FFT.py:240-254
+ *     xrft.ifft(da, dim='freq_twt', true_phase=True, true_amplitude=True)          cube_apply_IFFT.py:83-94
+ * i.e. F[k] = dt * exp(-2*pi*i*f_k*t0) * sum_n x[n] exp(-2*pi*i*k*n/nfft), f_k = fftfreq(nfft, dt)[k], and its exact
+ * inverse.  (The xrft fork the reference pins is not available; this is upstream xrft's documented convention.)
+ *   p3d_time2freq: x HOST float32 [nt][ntraces] -> out HOST complex64 [nfreq][ntraces]; the trace is zero-padded to
+ *       nfft >= nt (--upsampling-factor); real_only != 0 keeps k = 0..nfft/2 (--compute_real, nfreq = nfft/2+1) else
+ *       nfreq = nfft; window (HOST float32 [nfreq] or NULL) multiplies every frequency sample (cube_apply_FFT.py:273-278).
+ *   p3d_freq2time: X HOST complex64 [nfreq][ntraces] -> out HOST float32 [nfft][ntraces] (real part).  kidx (HOST int32
+ *       [nfreq]) gives the FFT bin k of every stored frequency sample (0..nfft-1), so spectra whose filtered samples were
+ *       dropped (--drop-filtered-freq) are zero-filled; real_only != 0 completes the Hermitian half.
+ * Any nfft up to 10240 (any-length line FFT).  Both allocate their own device buffers on `device`. */
+int p3d_time2freq(int device, const float* x, int nt, size_t ntraces, double dt, double t0, int nfft, int real_only,
+                  const float* window, void* out);
+int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntraces, double dt, double t0, int nfft,
+                  int real_only, float* out);
+
 /* After a run with P3D_FLAG_PROFILE: average duration (ms) and launch count of the spectrum
  * (column) pass and of the space (row) pass kernels of the iteration loop. */
 int p3d_last_profile(p3d_plan* plan, double* colpass_ms, int* colpass_launches, double* rowpass_ms,

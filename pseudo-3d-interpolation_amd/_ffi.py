@@ -57,6 +57,10 @@ PROTOTYPES = {
     "p3d_pocs_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_double)]),
+    "p3d_time2freq": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                C.c_void_p]),
+    "p3d_freq2time": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
+                                C.c_void_p]),
     "p3d_last_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),
 }
@@ -251,3 +255,36 @@ class Plan:
         check(lib().p3d_last_profile(self.handle, C.byref(cm), C.byref(cn), C.byref(rm), C.byref(rn)))
         return {"colpass_ms": cm.value, "colpass_launches": cn.value, "rowpass_ms": rm.value,
                 "rowpass_launches": rn.value}
+
+
+# ---- steps 12 / 14: time <-> frequency along the slice axis ------------------------------------------------
+def time2freq(x, dt, t0=0.0, nfft=None, real_only=False, window=None, device=0):
+    """(nt, ...) float32 -> (nfreq, ...) complex64 with xrft's true_phase / true_amplitude convention
+    (include/p3d.h, p3d_time2freq).  Trailing axes are flattened to traces and restored."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    nt = x.shape[0]
+    ntr = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
+    nfft = int(nfft or nt)
+    nfreq = nfft // 2 + 1 if real_only else nfft
+    out = np.empty((nfreq,) + x.shape[1:], np.complex64)
+    win = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
+    if win is not None and win.shape != (nfreq,):
+        raise ValueError(f"window must have {nfreq} entries")
+    check(lib().p3d_time2freq(int(device), _ptr(x), nt, ntr, float(dt), float(t0), nfft, int(bool(real_only)),
+                              None if win is None else _ptr(win), _ptr(out)))
+    return out
+
+
+def freq2time(X, dt, t0=0.0, nfft=None, real_only=False, kidx=None, device=0):
+    """(nfreq, ...) complex64 -> (nfft, ...) float32: exact inverse of :func:`time2freq` (real part)."""
+    X = np.ascontiguousarray(X, dtype=np.complex64)
+    nfreq = X.shape[0]
+    ntr = int(np.prod(X.shape[1:])) if X.ndim > 1 else 1
+    if nfft is None:
+        nfft = 2 * (nfreq - 1) if real_only else nfreq
+    nfft = int(nfft)
+    k = np.arange(nfreq, dtype=np.int32) if kidx is None else np.ascontiguousarray(kidx, dtype=np.int32)
+    out = np.empty((nfft,) + X.shape[1:], np.float32)
+    check(lib().p3d_freq2time(int(device), _ptr(X), nfreq, _ptr(k), ntr, float(dt), float(t0), nfft, int(bool(real_only)),
+                              _ptr(out)))
+    return out

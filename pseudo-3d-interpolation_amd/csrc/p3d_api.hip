@@ -2,6 +2,7 @@
 // the POCS iteration driver, staging for host-pointer callers.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -786,6 +787,106 @@ int p3d_pocs_run(p3d_plan* p, const void* x, int dtype, const float* mask, const
                                elapsed_ms)))
         return rc;
     HIP_TRY(hipMemcpy(out, p->st_out, bytes, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+namespace {
+struct DevBuf {  // frees on scope exit
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+}  // namespace
+
+static int helper_check(int device, size_t ntraces, int nfft)
+{
+    if (ntraces < 1 || nfft < 1) return fail(P3D_ERR_INVALID, "ntraces and nfft must be positive");
+    if (nfft > GEN_MAX_N || gen_make_plan(nfft).nf < 0) return fail(P3D_ERR_UNSUPPORTED, "nfft = %d: lengths up to %d are supported", nfft, GEN_MAX_N);
+    if (ntraces > 2147483647u) return fail(P3D_ERR_INVALID, "too many traces for one call: split the cube");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(P3D_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    return P3D_OK;
+}
+
+static double fft_freq(int k, int nfft, double dt) { return (k < (nfft + 1) / 2 ? k : k - nfft) / (nfft * dt); }  // np.fft.fftfreq
+
+int p3d_time2freq(int device, const float* x, int nt, size_t ntr, double dt, double t0, int nfft, int real_only, const float* window,
+                  void* out)
+{
+    if (!x || !out) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (nt < 1 || nfft < nt) return fail(P3D_ERR_INVALID, "need 1 <= nt <= nfft");
+    int rc = helper_check(device, ntr, nfft);
+    if (rc) return rc;
+    const int nfreq = real_only ? nfft / 2 + 1 : nfft;
+    const GenPlan pl = gen_make_plan(nfft);
+    std::vector<c32> tw(nfft), fac(nfreq);
+    gen_build_twiddles(nfft, tw.data());
+    for (int k = 0; k < nfreq; ++k) {
+        // rfft bins are the non-negative frequencies k/(nfft*dt) (np.fft.rfftfreq), also for k = nfft/2
+        const double f = real_only ? k / (nfft * dt) : fft_freq(k, nfft, dt);
+        const double ang = -6.283185307179586476925286766559 * f * t0, w = window ? (double)window[k] : 1.0;
+        fac[k] = c32{(float)(dt * w * std::cos(ang)), (float)(dt * w * std::sin(ang))};
+    }
+    DevBuf dx, dwork, dtw, dfac;
+    HIP_TRY(hipMalloc(&dx.p, sizeof(float) * (size_t)nt * ntr));
+    HIP_TRY(hipMalloc(&dwork.p, sizeof(c32) * (size_t)nfft * ntr));
+    HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * nfft));
+    HIP_TRY(hipMalloc(&dfac.p, sizeof(c32) * nfreq));
+    HIP_TRY(hipMemcpy(dx.p, x, sizeof(float) * (size_t)nt * ntr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dtw.p, tw.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dfac.p, fac.data(), sizeof(c32) * nfreq, hipMemcpyHostToDevice));
+    c32* work = (c32*)dwork.p;
+    HIP_TRY(gen_launch_t2f_pad((const float*)dx.p, work, nt, nfft, ntr, nullptr));
+    HIP_TRY(gen_launch_line_fft(work, work, (const c32*)dtw.p, pl, FWD, 1.0f, 1, nfft, (int)ntr, false, nullptr, nullptr));
+    HIP_TRY(gen_launch_scale_rows(work, work, (const c32*)dfac.p, nfreq, ntr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, work, sizeof(c32) * (size_t)nfreq * ntr, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntr, double dt, double t0, int nfft, int real_only,
+                  float* out)
+{
+    if (!X || !out || !kidx) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (nfreq < 1 || nfreq > nfft) return fail(P3D_ERR_INVALID, "need 1 <= nfreq <= nfft");
+    int rc = helper_check(device, ntr, nfft);
+    if (rc) return rc;
+    const GenPlan pl = gen_make_plan(nfft);
+    std::vector<c32> tw(nfft), fac(nfft, c32{0.f, 0.f});
+    std::vector<int> src(nfft, INT_MIN);
+    gen_build_twiddles(nfft, tw.data());
+    for (int r = 0; r < nfreq; ++r) {
+        const int k = kidx[r];
+        if (k < 0 || k >= nfft) return fail(P3D_ERR_INVALID, "kidx[%d] = %d outside 0..nfft-1", r, k);
+        src[k] = r;
+        if (real_only && k > 0 && 2 * k != nfft) src[nfft - k] = -(r + 1);  // Hermitian partner: conj(X[k])
+    }
+    for (int k = 0; k < nfft; ++k) {
+        // undo the phase of the forward transform; for the mirrored bins conj(X) carries exp(+i..), undone by its own f_k
+        // (the half spectrum stores the Nyquist bin at +f_nyq, np.fft.rfftfreq; the full one at -f_nyq, np.fft.fftfreq)
+        const double f = (real_only && 2 * k == nfft) ? k / (nfft * dt) : fft_freq(k, nfft, dt);
+        const double ang = 6.283185307179586476925286766559 * f * t0;
+        fac[k] = c32{(float)std::cos(ang), (float)std::sin(ang)};
+    }
+    DevBuf dX, dwork, dtw, dfac, dsrc, dout;
+    HIP_TRY(hipMalloc(&dX.p, sizeof(c32) * (size_t)nfreq * ntr));
+    HIP_TRY(hipMalloc(&dwork.p, sizeof(c32) * (size_t)nfft * ntr));
+    HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * nfft));
+    HIP_TRY(hipMalloc(&dfac.p, sizeof(c32) * nfft));
+    HIP_TRY(hipMalloc(&dsrc.p, sizeof(int) * nfft));
+    HIP_TRY(hipMalloc(&dout.p, sizeof(float) * (size_t)nfft * ntr));
+    HIP_TRY(hipMemcpy(dX.p, X, sizeof(c32) * (size_t)nfreq * ntr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dtw.p, tw.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dfac.p, fac.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dsrc.p, src.data(), sizeof(int) * nfft, hipMemcpyHostToDevice));
+    c32* work = (c32*)dwork.p;
+    HIP_TRY(gen_launch_f2t_fill((const c32*)dX.p, work, (const c32*)dfac.p, (const int*)dsrc.p, nfft, ntr, nullptr));
+    // true_amplitude: the inverse carries 1/(nfft*dt)
+    HIP_TRY(gen_launch_line_fft(work, work, (const c32*)dtw.p, pl, INV, (float)(1.0 / (nfft * dt)), 1, nfft, (int)ntr, false, nullptr, nullptr));
+    HIP_TRY(gen_launch_real_part(work, (float*)dout.p, (size_t)nfft * ntr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(float) * (size_t)nfft * ntr, hipMemcpyDeviceToHost));
     return P3D_OK;
 }
 

@@ -8,6 +8,7 @@
 // (4 transform passes + 2 element-wise passes): correctness and coverage first, the hot sizes have their own path.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <vector>
 
@@ -219,6 +220,67 @@ __global__ void gen_stats_kernel(const c32* w, float* partial, size_t per_slice)
         float* p = partial + ((size_t)s * gridDim.x + blockIdx.x) * 8;
         p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
     }
+}
+
+// ---- time <-> frequency helpers (cube_apply_FFT.py:240-254, cube_apply_IFFT.py:83-94) ---------------------------------
+// xrft.fft(..., shift=False, true_phase=True, true_amplitude=True):
+//     F[k] = dt * exp(-2*pi*i*f_k*t0) * sum_n x[n] exp(-2*pi*i*k*n/nfft),   f_k = fftfreq(nfft, dt)[k]
+// (the xrft fork the reference pins is not on disk; this is upstream xrft's documented convention).
+// pad_kernel: work[k][j] = (x[k][j], 0) for k < nt, 0 for nt <= k < nfft
+__global__ void t2f_pad_kernel(const float* x, c32* work, int nt, int nfft, size_t ntr)
+{
+    const size_t total = (size_t)nfft * ntr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        work[i] = (i / ntr) < (size_t)nt ? c32{x[i], 0.f} : c32{0.f, 0.f};
+}
+// out[k][j] = work[k][j] * factor[k]  (factor = dt * phase * optional window, complex, per frequency sample)
+__global__ void scale_rows_kernel(const c32* work, c32* out, const c32* factor, int nrows, size_t ntr)
+{
+    const size_t total = (size_t)nrows * ntr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = work[i] * factor[i / ntr];
+}
+// inverse side: work[k][j] = X[src[k]][j] * factor[k] (conjugated when src[k] < 0 -> Hermitian half), 0 when src[k] == INT_MIN
+__global__ void f2t_fill_kernel(const c32* X, c32* work, const c32* factor, const int* src, int nfft, size_t ntr)
+{
+    const size_t total = (size_t)nfft * ntr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = i / ntr, j = i - k * ntr;
+        const int sk = src[k];
+        c32 v{0.f, 0.f};
+        if (sk != INT_MIN) {
+            const int row = sk < 0 ? -(sk + 1) : sk;
+            v = X[(size_t)row * ntr + j];
+            if (sk < 0) v.y = -v.y;
+            v = v * factor[k];
+        }
+        work[i] = v;
+    }
+}
+__global__ void real_part_kernel(const c32* work, float* out, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) out[i] = work[i].x;
+}
+
+hipError_t gen_launch_t2f_pad(const float* x, c32* work, int nt, int nfft, size_t ntr, hipStream_t st)
+{
+    t2f_pad_kernel<<<4096, 256, 0, st>>>(x, work, nt, nfft, ntr);
+    return hipGetLastError();
+}
+hipError_t gen_launch_scale_rows(const c32* work, c32* out, const c32* factor, int nrows, size_t ntr, hipStream_t st)
+{
+    scale_rows_kernel<<<4096, 256, 0, st>>>(work, out, factor, nrows, ntr);
+    return hipGetLastError();
+}
+hipError_t gen_launch_f2t_fill(const c32* X, c32* work, const c32* factor, const int* src, int nfft, size_t ntr, hipStream_t st)
+{
+    f2t_fill_kernel<<<4096, 256, 0, st>>>(X, work, factor, src, nfft, ntr);
+    return hipGetLastError();
+}
+hipError_t gen_launch_real_part(const c32* work, float* out, size_t total, hipStream_t st)
+{
+    real_part_kernel<<<4096, 256, 0, st>>>(work, out, total);
+    return hipGetLastError();
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------

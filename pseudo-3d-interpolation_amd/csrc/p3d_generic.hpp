@@ -29,4 +29,10 @@ hipError_t gen_launch_update(c32* w, const void* x, int dtype, const float* mask
                              int write_out, float alpha, int nslices, size_t per_slice, const int* done, int zero_fill, hipStream_t st);
 hipError_t gen_launch_stats(const c32* w, float* partial, int nslices, size_t per_slice, int blocks, hipStream_t st);
 
+// time <-> frequency helper kernels
+hipError_t gen_launch_t2f_pad(const float* x, c32* work, int nt, int nfft, size_t ntr, hipStream_t st);
+hipError_t gen_launch_scale_rows(const c32* work, c32* out, const c32* factor, int nrows, size_t ntr, hipStream_t st);
+hipError_t gen_launch_f2t_fill(const c32* X, c32* work, const c32* factor, const int* src, int nfft, size_t ntr, hipStream_t st);
+hipError_t gen_launch_real_part(const c32* work, float* out, size_t total, hipStream_t st);
+
 }  // namespace p3d

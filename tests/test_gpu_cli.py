@@ -1,0 +1,99 @@
+"""Steps 12 -> 13 -> 14 end to end through the command-line drivers on a small .npz cube (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _time_cube(nt, nil, nxl, missing, seed=3):
+    rng = np.random.default_rng(seed)
+    t = np.arange(nt)[:, None, None]
+    il = np.arange(nil)[None, :, None] / nil
+    xl = np.arange(nxl)[None, None, :] / nxl
+    x = np.zeros((nt, nil, nxl))
+    for _ in range(4):   # dipping events: band-limited in time, plane waves in space
+        f, k1, k2, a = rng.uniform(0.05, 0.2), rng.integers(-3, 4), rng.integers(-3, 4), rng.standard_normal()
+        x += a * np.cos(2 * np.pi * (f * t + k1 * il + k2 * xl))
+    fold = (rng.random((nil, nxl)) >= missing).astype(np.uint8) * rng.integers(1, 4, (nil, nxl)).astype(np.uint8)
+    return (x * (fold > 0)).astype(np.float32), fold
+
+
+def test_fft_pocs_ifft_pipeline(tmp_path):
+    from oracle import pocs_oracle as orc
+    from pseudo_3d_interpolation_amd import cube_POCS_interpolation_3D as step13
+    from pseudo_3d_interpolation_amd import cube_apply_FFT as step12
+    from pseudo_3d_interpolation_amd import cube_apply_IFFT as step14
+    from pseudo_3d_interpolation_amd.cube_io import Cube, open_cube, save_cube
+    from pseudo_3d_interpolation_amd.functions.POCS import release_plans
+
+    nt, nil, nxl, dt, t0 = 48, 32, 64, 0.05, 7.0
+    x, fold = _time_cube(nt, nil, nxl, 0.5)
+    cube = Cube({'env': x, 'fold': fold}, {'env': ('twt', 'iline', 'xline'), 'fold': ('iline', 'xline')},
+                {'twt': t0 + dt * np.arange(nt), 'iline': np.arange(nil), 'xline': np.arange(nxl)},
+                {'long_name': 'test cube', 'description': 'synthetic', 'history': 'made;', 'text': ''}, {},
+                {'twt': {'units': 'ms'}})
+    path = save_cube(cube, str(tmp_path / 'cube_twt.npz'))
+    nc_yml = tmp_path / 'netcdf.yml'
+    nc_yml.write_text(yaml.safe_dump({'attrs_freq': {'data': {'units': 'amplitude'}, 'new_dim': {'units': 'kHz'}},
+                                      'attrs_time': {'env': {'units': 'amplitude'}, 'twt': {'units': 'ms', 'spacing': dt}}}))
+    pocs_yml = tmp_path / 'pocs.yml'
+    metadata = dict(transform_kind='fft', niter=15, eps=0, thresh_op='soft', thresh_model='exponential', decay_kind='values',
+                    p_max=0.99, p_min=0.1, alpha=1.0, sqrt_decay=False, version='regular', verbose=False)
+    pocs_yml.write_text(yaml.safe_dump({'dim': 'freq_twt', 'var': 'freq_env', 'batch_chunk': 10, 'n_workers': 4, 'processes': True,
+                                        'threads_per_worker': 1, 'memory_limit': '2GB', 'output_runtime_results': True,
+                                        'metadata': metadata}))
+
+    # step 12
+    step12.main(['12_cube_apply_FFT', path, '--params_netcdf', str(nc_yml), '--compute_real'])
+    fpath = str(tmp_path / 'cube_freq.npz')
+    fcube = open_cube(fpath)
+    f = np.fft.rfftfreq(nt, dt)
+    X = np.fft.rfft(x.astype(np.float64), axis=0) * (dt * np.exp(-2j * np.pi * f * t0))[:, None, None]
+    assert fcube.dims['freq_env'] == ('freq_twt', 'iline', 'xline') and fcube.data_vars['freq_env'].dtype == np.complex64
+    assert np.allclose(fcube.coords['freq_twt'], f)
+    assert rel_l2(fcube.data_vars['freq_env'], X) < 2e-6
+    assert 'FFT(env)' in fcube.attrs['history'] and fcube.var_attrs['freq_env']['original_var'] == 'env'
+
+    # step 13
+    step13.main(['13_cube_interpolate_POCS', fpath, '--path_pocs_parameter', str(pocs_yml)])
+    prefix = 'cube_freq_FFT_soft_niter-15'
+    out_dir = tmp_path / prefix
+    assert (out_dir / f'parameter_{prefix}.yml').exists() and (out_dir / f'runtimes_{prefix}.txt').exists()
+    batch_files = sorted(p for p in os.listdir(out_dir) if p.endswith('.npz'))
+    assert len(batch_files) == 3                                      # 25 frequency slices in batches of 10
+    lines = (out_dir / f'runtimes_{prefix}.txt').read_text().strip().splitlines()
+    assert len(lines) == 25 and all(len(l.split(';')) == 2 + 15 for l in lines if not l.startswith('0;'))
+    icube = open_cube(str(tmp_path / f'{prefix}.npz'))
+    assert set(icube.data_vars) == {'freq_env_interp.real', 'freq_env_interp.imag', 'fold'}
+    Y = icube.data_vars['freq_env_interp.real'] + 1j * icube.data_vars['freq_env_interp.imag']
+    mask = np.where(fold <= 1, fold, 1)
+    params = {k: v for k, v in metadata.items() if k not in ('verbose',)}
+    params['transform_kind'] = 'FFT'
+    want = orc.pocs_cube(fcube.data_vars['freq_env'].astype(np.complex128), mask, **params)
+    for s in range(want.shape[0]):
+        if 0 < s < want.shape[0] - 1:
+            assert rel_l2(Y[s], want[s]) < 1e-5, s
+        else:
+            # DC and Nyquist slices of a real cube are real up to rounding; the imaginary part of the (complex,
+            # lexicographic-max) threshold is then rounding noise of either sign, and so is Im of the result
+            assert rel_l2(Y[s].real, want[s].real) < 1e-4, s
+    assert 'interp_params_keys' in icube.attrs and 'niter' in icube.attrs['interp_params_keys']
+
+    # step 14
+    step14.main(['14_cube_apply_IFFT', str(tmp_path / f'{prefix}.npz'), '--params_netcdf', str(nc_yml), '--compute_real'])
+    tcube = open_cube(str(tmp_path / f'{prefix.replace("freq", "twt")}_interp-freq.npz'))
+    y = tcube.data_vars['env']
+    assert y.dtype == np.float32 and tcube.dims['env'] == ('twt', 'iline', 'xline')
+    want_t = np.fft.irfft(want * (np.exp(2j * np.pi * f * t0) / dt)[:, None, None], n=nt, axis=0)
+    assert rel_l2(y, want_t) < 2e-5
+    assert np.allclose(tcube.coords['twt'], t0 + dt * np.arange(nt), atol=1e-4)
+    # the interpolation filled the empty traces and kept the observed ones
+    obs = fold > 0
+    assert np.abs(y[:, ~obs]).max() > 0.05 * np.abs(x).max()
+    assert rel_l2(y[:, obs], x[:, obs]) < 1e-4
+    release_plans()

@@ -417,3 +417,40 @@ def test_compact_observed_samples_path_is_exact(ffi, orc, monkeypatch):
     with ffi.Plan(nil, nxl, 1) as plan:
         d, _, _, _ = plan.run(dirty[1:2], maskf, tau1[None, :], K)
     assert rel_l2(d[0], want[1]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# steps 12 / 14: time <-> frequency helpers (closed form with numpy.fft; the xrft fork is not on disk)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nt,shape,up,real_only", [(64, (5, 7), 1, False), (100, (3, 4), 1, True), (90, (6,), 2, True),
+                                                   (250, (4, 4), 1, False), (512, (16, 8), 1, True), (37, (2, 3), 1, False)])
+def test_time2freq_closed_form_and_round_trip(ffi, nt, shape, up, real_only):
+    rng = np.random.default_rng(nt)
+    x = rng.standard_normal((nt,) + shape).astype(np.float32)
+    dt, t0 = 0.025, 12.5
+    nfft = up * nt
+    X = ffi.time2freq(x, dt, t0, nfft=nfft, real_only=real_only)
+    if real_only:
+        f = np.fft.rfftfreq(nfft, dt)
+        ref = np.fft.rfft(x.astype(np.float64), n=nfft, axis=0)
+    else:
+        f = np.fft.fftfreq(nfft, dt)
+        ref = np.fft.fft(x.astype(np.float64), n=nfft, axis=0)
+    ref = ref * (dt * np.exp(-2j * np.pi * f * t0)).reshape((-1,) + (1,) * len(shape))
+    assert X.shape == ref.shape and X.dtype == np.complex64
+    assert rel_l2(X, ref) < 2e-6
+    back = ffi.freq2time(X, dt, t0, nfft=nfft, real_only=real_only)
+    assert back.shape == (nfft,) + shape and back.dtype == np.float32
+    assert rel_l2(back[:nt], x) < 3e-6
+    if up > 1:
+        assert np.abs(back[nt:]).max() < 1e-5 * np.abs(x).max()
+    # window + dropped samples (lowpass --drop-filtered-freq): only the kept bins travel
+    if real_only:
+        nf = nfft // 2 + 1
+        win = np.clip(1.5 - np.arange(nf) / (0.5 * nf), 0, 1).astype(np.float32)
+        Xw = ffi.time2freq(x, dt, t0, nfft=nfft, real_only=True, window=win)
+        assert rel_l2(Xw, ref * win.reshape((-1,) + (1,) * len(shape))) < 2e-6
+        keep = np.flatnonzero(win > 0)
+        lo = ffi.freq2time(Xw[keep], dt, t0, nfft=nfft, real_only=True, kidx=keep)
+        want = np.fft.irfft(np.fft.rfft(x.astype(np.float64), n=nfft, axis=0) * win.reshape((-1,) + (1,) * len(shape)), n=nfft, axis=0)
+        assert rel_l2(lo, want) < 5e-6
