@@ -47,6 +47,10 @@ extern "C" {
 #define P3D_OP_HARD 0
 #define P3D_OP_SOFT 1
 #define P3D_OP_GARROTE 2
+/* '-percentile' variants (POCS.py:43-58, 95-102): Re(tau) of every iteration is a PERCENTAGE; the threshold applied to a
+ * slice is np.percentile(abs(X), tau) of that slice's spectrum at that iteration (linear interpolation).  These run on the
+ * unfused pipeline (the spectrum has to exist in memory to be ranked). */
+#define P3D_OP_PERCENTILE 16 /* OR-ed with P3D_OP_HARD / _SOFT / _GARROTE */
 
 /* version (POCS.py:564-575).  FAST is accepted and runs REGULAR: in the reference the momentum
  * term of 'fast' is identically zero (POCS.py:549-550, 566-571, 629). */

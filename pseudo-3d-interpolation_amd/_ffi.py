@@ -12,6 +12,8 @@ P3D_OK = 0
 P3D_ERR_INVALID, P3D_ERR_UNSUPPORTED, P3D_ERR_HIP = -1, -2, -3
 P3D_C64, P3D_F32 = 0, 1
 P3D_OP = {"hard": 0, "soft": 1, "garrote": 2, "garotte": 2}
+P3D_OP_PERCENTILE = 16
+P3D_OP.update({f"{k}-percentile": v | P3D_OP_PERCENTILE for k, v in list(P3D_OP.items())})
 P3D_VER = {"regular": 0, "fast": 1, "adaptive": 2}
 P3D_FLAG_PROFILE = 1
 STATS_PER_SLICE = 6

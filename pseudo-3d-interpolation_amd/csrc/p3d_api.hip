@@ -4,6 +4,7 @@
 
 #include <climits>
 #include <cmath>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,10 @@ struct p3d_plan {
     int device = 0;
     int nil = 0, nxl = 0, max_slices = 0;
     hipStream_t stream = nullptr;
+    p3d_plan* pct_plan = nullptr;      // generic twin of a tuned plan, created on first use of a percentile operator
+    unsigned* pct_sel = nullptr;       // [2][max_slices][8] radix-select state
+    unsigned* pct_hist = nullptr;      // [max_slices][2048]
+    float* pct_frac = nullptr;         // [max_slices]
     bool generic = false;              // any-length fallback (p3d_generic.hip): row-major work buffer, unfused passes
     GenPlan gcol{}, grow{};            // factorisations of nil / nxl
     static constexpr int GEN_STAT_BLOCKS = 64;
@@ -204,9 +209,10 @@ int p3d_shape_supported(int nil, int nxl)
 int p3d_plan_destroy(p3d_plan* p)
 {
     if (!p) return P3D_OK;
+    if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau,
+    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -226,7 +232,7 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     if (max_slices > 65535) return fail(P3D_ERR_INVALID, "max_slices > 65535: split the cube into batches");
     const LineOps* oc = find_ops(nil);
     const LineOps* orow = find_ops(nxl);
-    const bool generic = !oc || !orow;
+    const bool generic = !oc || !orow || getenv("P3D_FORCE_GENERIC") != nullptr;
     if (generic && !(generic_ok(nil) && generic_ok(nxl)))
         return fail(P3D_ERR_UNSUPPORTED, "slice shape %d x %d: extents up to %d are supported", nil, nxl, GEN_MAX_N);
     int ndev = 0;
@@ -281,6 +287,9 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
             TRY_OR_BAIL(hipMemcpy(*dst, host.data(), sizeof(c32) * n, hipMemcpyHostToDevice));
         }
         TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * p->slice_elems() * max_slices));
+        TRY_OR_BAIL(hipMalloc((void**)&p->pct_sel, sizeof(unsigned) * 16 * (size_t)max_slices));
+        TRY_OR_BAIL(hipMalloc((void**)&p->pct_hist, sizeof(unsigned) * 2048 * (size_t)max_slices));
+        TRY_OR_BAIL(hipMalloc((void**)&p->pct_frac, sizeof(float) * (size_t)max_slices));
     } else {
         if ((rc = upload_table(p, oc, false, &p->tw_col)) != P3D_OK) return bail(rc);
         if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
@@ -559,7 +568,9 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     if (!x || !mask || !tau || !prm || !out) return fail(P3D_ERR_INVALID, "NULL argument");
     if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
     if (prm->niter < 1) return fail(P3D_ERR_INVALID, "niter must be >= 1");
-    if (prm->thresh_op < P3D_OP_HARD || prm->thresh_op > P3D_OP_GARROTE)
+    const bool percentile = (prm->thresh_op & P3D_OP_PERCENTILE) != 0;
+    const int base_op = prm->thresh_op & ~P3D_OP_PERCENTILE;
+    if (base_op < P3D_OP_HARD || base_op > P3D_OP_GARROTE)
         return fail(P3D_ERR_UNSUPPORTED, "thresh_op %d is not implemented by the HIP kernels", prm->thresh_op);
     if (prm->version < P3D_VER_REGULAR || prm->version > P3D_VER_ADAPTIVE)
         return fail(P3D_ERR_INVALID, "unknown version %d", prm->version);
@@ -612,6 +623,19 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
 
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
 
+    if (percentile && !p->generic) {
+        // the tuned kernels never materialise the spectrum; ranking it needs the unfused pipeline -> a second, generic plan
+        if (!p->pct_plan) {
+            const int keep = p->device;
+            p3d_plan* q = nullptr;
+            setenv("P3D_FORCE_GENERIC", "1", 1);
+            const int prc = p3d_plan_create(&q, keep, p->nil, p->nxl, p->max_slices);
+            unsetenv("P3D_FORCE_GENERIC");
+            if (prc) return prc;
+            p->pct_plan = q;
+        }
+        return p3d_pocs_run_dev(p->pct_plan, x, dtype, mask, tau, active, prm, out, nslices, niter_done, sums, elapsed_ms);
+    }
     if (p->generic) {
         // unfused any-length pipeline: first input, then per iteration fft2 -> threshold -> ifft2 -> re-insertion
         const size_t per_slice = p->slice_elems();
@@ -624,7 +648,33 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         for (int k = 0; k < niter; ++k) {
             const bool last = k + 1 == niter;
             if ((rc = gen_fft2(p, p->work, p->work, nslices, 0, done_d))) return rc;
-            HIP_TRY(gen_launch_shrink(p->work, p->tau, niter, k, prm->thresh_op, nslices, per_slice, done_d, p->stream));
+            if (percentile) {  // tau[s][k] <- np.percentile(|X_s|, perc_k): two order statistics + linear interpolation
+                std::vector<unsigned> sel_h((size_t)nslices * 16, 0u);
+                std::vector<float> frac_h(nslices);
+                for (int s = 0; s < nslices; ++s) {
+                    const double perc = tau[2 * ((size_t)s * niter + k)];
+                    double pos = perc / 100.0 * (double)(per_slice - 1);
+                    if (!(pos >= 0.0)) pos = 0.0;
+                    if (pos > (double)(per_slice - 1)) pos = (double)(per_slice - 1);
+                    const double fl = std::floor(pos);
+                    sel_h[(size_t)s * 8] = (unsigned)fl;
+                    sel_h[((size_t)nslices + s) * 8] = (unsigned)std::min(fl + 1.0, (double)(per_slice - 1));
+                    frac_h[s] = (float)(pos - fl);
+                }
+                HIP_TRY(hipMemcpyAsync(p->pct_sel, sel_h.data(), sizeof(unsigned) * sel_h.size(), hipMemcpyHostToDevice, p->stream));
+                HIP_TRY(hipMemcpyAsync(p->pct_frac, frac_h.data(), sizeof(float) * nslices, hipMemcpyHostToDevice, p->stream));
+                HIP_TRY(hipMemsetAsync(p->pct_hist, 0, sizeof(unsigned) * 2048 * (size_t)nslices, p->stream));
+                for (int which = 0; which < 2; ++which) {
+                    unsigned* sel = p->pct_sel + (size_t)which * nslices * 8;
+                    for (int level = 0; level < 3; ++level) {
+                        HIP_TRY(gen_launch_pct_hist(p->work, per_slice, sel, p->pct_hist, level, nslices, p->stream));
+                        HIP_TRY(gen_launch_pct_scan(sel, p->pct_hist, level, nslices, p->stream));
+                    }
+                }
+                HIP_TRY(gen_launch_pct_tau(p->pct_sel, p->pct_sel + (size_t)nslices * 8, p->pct_frac, p->tau, niter, k, nslices, p->stream));
+                HIP_TRY(hipStreamSynchronize(p->stream));  // sel_h / frac_h are reused next iteration
+            }
+            HIP_TRY(gen_launch_shrink(p->work, p->tau, niter, k, base_op, nslices, per_slice, done_d, p->stream));
             if ((rc = gen_fft2(p, p->work, p->work, nslices, 1, done_d))) return rc;
             HIP_TRY(gen_launch_update(p->work, x, dtype, mask, out, p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0,
                                       (early || last) ? 1 : 0, (float)prm->alpha, nslices, per_slice, p->done, last ? 1 : 0, p->stream));
@@ -714,7 +764,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     c.tau = p->tau;
     c.done = any_off ? p->done : nullptr;
     c.niter = niter;
-    c.op = prm->thresh_op;
+    c.op = base_op;
 
     HIP_TRY(stamp());
     for (int k = 0; k < niter; ++k) {

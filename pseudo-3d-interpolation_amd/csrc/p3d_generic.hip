@@ -222,6 +222,68 @@ __global__ void gen_stats_kernel(const c32* w, float* partial, size_t per_slice)
     }
 }
 
+// ---- percentile thresholds (POCS.py:43-58): tau = np.percentile(|X|, perc) per slice ----------------------------------------
+// Exact k-th order statistic of the moduli of one slice by a 3-level radix select on the float bit pattern (moduli are
+// non-negative, so their bits order like unsigned integers): 11 + 11 + 10 bits, one histogram pass per level.
+// sel[s*8 + ..]: [0] rank still to find inside the current prefix, [1] prefix bits found so far, [2] result bits
+__global__ void pct_hist_kernel(const c32* w, size_t per_slice, const unsigned* sel, unsigned* hist, int level)
+{
+    const int s = blockIdx.y;
+    const unsigned prefix = sel[s * 8 + 1];
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    const int bits = level == 2 ? 10 : 11;
+    const unsigned pmask = level == 0 ? 0u : (level == 1 ? 0xFFE00000u : 0xFFFFFC00u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x) {
+        const c32 v = w[(size_t)s * per_slice + i];
+        const unsigned key = __float_as_uint(sqrtf(v.x * v.x + v.y * v.y));
+        if ((key & pmask) == prefix) atomicAdd(&hist[(size_t)s * 2048 + ((key >> shift) & ((1u << bits) - 1u))], 1u);
+    }
+}
+__global__ void pct_scan_kernel(unsigned* sel, unsigned* hist, int level, int nslices)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    const int nb = level == 2 ? 1024 : 2048;
+    unsigned rank = sel[s * 8 + 0], run = 0;
+    int b = 0;
+    for (; b < nb; ++b) {
+        const unsigned c = hist[(size_t)s * 2048 + b];
+        if (rank < run + c) break;
+        run += c;
+    }
+    if (b == nb) b = nb - 1;
+    sel[s * 8 + 0] = rank - run;
+    sel[s * 8 + 1] |= (unsigned)b << shift;
+    for (int i = 0; i < 2048; ++i) hist[(size_t)s * 2048 + i] = 0;
+}
+// tau[s] = lo + (hi - lo) * frac   (np.percentile, linear interpolation between the two neighbouring order statistics)
+__global__ void pct_tau_kernel(const unsigned* sel_lo, const unsigned* sel_hi, const float* frac, c32* tau, int niter, int iter, int nslices)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices) return;
+    const double lo = __uint_as_float(sel_lo[s * 8 + 1]), hi = __uint_as_float(sel_hi[s * 8 + 1]);
+    tau[(size_t)s * niter + iter] = c32{(float)(lo + (hi - lo) * (double)frac[s]), 0.f};
+}
+
+hipError_t gen_launch_pct_hist(const c32* w, size_t per_slice, const unsigned* sel, unsigned* hist, int level, int nslices, hipStream_t st)
+{
+    const unsigned bx = (unsigned)((per_slice + 255) / 256 < 512 ? (per_slice + 255) / 256 : 512);
+    pct_hist_kernel<<<dim3(bx, nslices), 256, 0, st>>>(w, per_slice, sel, hist, level);
+    return hipGetLastError();
+}
+hipError_t gen_launch_pct_scan(unsigned* sel, unsigned* hist, int level, int nslices, hipStream_t st)
+{
+    pct_scan_kernel<<<(nslices + 63) / 64, 64, 0, st>>>(sel, hist, level, nslices);
+    return hipGetLastError();
+}
+hipError_t gen_launch_pct_tau(const unsigned* sel_lo, const unsigned* sel_hi, const float* frac, c32* tau, int niter, int iter, int nslices,
+                              hipStream_t st)
+{
+    pct_tau_kernel<<<(nslices + 63) / 64, 64, 0, st>>>(sel_lo, sel_hi, frac, tau, niter, iter, nslices);
+    return hipGetLastError();
+}
+
 // ---- time <-> frequency helpers (cube_apply_FFT.py:240-254, cube_apply_IFFT.py:83-94) ---------------------------------
 // xrft.fft(..., shift=False, true_phase=True, true_amplitude=True):
 //     F[k] = dt * exp(-2*pi*i*f_k*t0) * sum_n x[n] exp(-2*pi*i*k*n/nfft),   f_k = fftfreq(nfft, dt)[k]

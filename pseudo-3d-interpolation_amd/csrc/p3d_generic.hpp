@@ -29,6 +29,12 @@ hipError_t gen_launch_update(c32* w, const void* x, int dtype, const float* mask
                              int write_out, float alpha, int nslices, size_t per_slice, const int* done, int zero_fill, hipStream_t st);
 hipError_t gen_launch_stats(const c32* w, float* partial, int nslices, size_t per_slice, int blocks, hipStream_t st);
 
+// percentile thresholds: exact order statistics of |X| per slice (3-level radix select)
+hipError_t gen_launch_pct_hist(const c32* w, size_t per_slice, const unsigned* sel, unsigned* hist, int level, int nslices, hipStream_t st);
+hipError_t gen_launch_pct_scan(unsigned* sel, unsigned* hist, int level, int nslices, hipStream_t st);
+hipError_t gen_launch_pct_tau(const unsigned* sel_lo, const unsigned* sel_hi, const float* frac, c32* tau, int niter, int iter, int nslices,
+                              hipStream_t st);
+
 // time <-> frequency helper kernels
 hipError_t gen_launch_t2f_pad(const float* x, c32* work, int nt, int nfft, size_t ntr, hipStream_t st);
 hipError_t gen_launch_scale_rows(const c32* work, c32* out, const c32* factor, int nrows, size_t ntr, hipStream_t st);

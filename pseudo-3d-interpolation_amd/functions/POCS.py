@@ -10,8 +10,9 @@ keep working, plus :func:`pocs_cube`, which hands a whole batch of slices to the
 What runs where
 ---------------
 * GPU (libp3d_hip.so, hand-written HIP): the forward transform of the observed slice and its
-  statistics, and the whole iteration loop (forward FFT2, thresholding, inverse FFT2, re-insertion
-  of the observed traces, cost sums, early exit).
+  statistics, and the whole iteration loop (forward FFT2, thresholding -- for the ``-percentile``
+  operators including the exact ``np.percentile`` of the spectrum moduli --, inverse FFT2,
+  re-insertion of the observed traces, cost sums, early exit).
 * Host (this file, a few scalars per slice): argument checks and the threshold schedule
   tau_k, k = 1..niter, evaluated with NumPy in complex128 exactly like POCS.py:251-368 so that the
   reference's NumPy conventions (lexicographic complex max, complex log/exp) carry over.
@@ -195,8 +196,6 @@ def _check_common(mask, transform_kind, thresh_op):
             f'{kind} transform is not implemented by the HIP kernels yet (available: {_HIP_TRANSFORMS})')
     if thresh_op not in _THRESH_OPS:
         raise ValueError(f'Unknown threshold operator {thresh_op!r}. Please select one of: {_THRESH_OPS}')
-    if thresh_op.endswith('-percentile'):
-        raise NotImplementedError(f'thresh_op={thresh_op!r} is not implemented by the HIP kernels yet')
     return kind
 
 

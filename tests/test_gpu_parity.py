@@ -92,7 +92,9 @@ def test_stats_match_numpy(ffi):
 GOLDEN_POW2 = ["fft_hard_exp", "fft_real_in", "fft_soft_lin", "fft_garrote_exp2", "fft_sqrt_decay", "fft_alpha08",
                "fft_factors", "fft_datadriven", "apocs_doc", "apocs_soft", "fpocs", "tiny_8x8", "niter1",
                # any-length fallback
-               "rect_90x50", "rect_48x20_real", "prime_31x17"]
+               "rect_90x50", "rect_48x20_real", "prime_31x17",
+               # percentile operator: tau_k = np.percentile(|X|, perc_k) (POCS.py:43-58)
+               "hard_pct"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_POW2)
@@ -379,6 +381,18 @@ def test_generic_path_early_exit_and_zero_slice(P, orc):
         assert abs(res[s]["niterations"] - infos[s]["niterations"]) <= 1, (res[s]["niterations"], infos[s]["niterations"])
         if res[s]["niterations"] == infos[s]["niterations"]:
             assert rel_l2(got[s], want[s]) < TOL
+
+
+@pytest.mark.parametrize("op,shape", [("hard-percentile", (64, 64)), ("soft-percentile", (48, 40)), ("garrote-percentile", (128, 32))])
+def test_percentile_operators_vs_oracle(P, orc, op, shape):
+    _, mask, obs = orc.synthetic_cube(shape[0], shape[1], 3, 0.5)
+    # percentages well inside the bulk of the distribution: neighbouring order statistics are then far apart compared to
+    # float32 rounding and the kept / zeroed sets are unambiguous
+    params = dict(niter=8, thresh_op=op, thresh_model="linear", decay_kind="factors", eps=0, p_max=97.0, p_min=60.0)
+    got = P.pocs_cube(obs, mask, **params)
+    want = orc.pocs_cube(obs.astype(np.complex128), mask, **params)
+    for s in range(3):
+        assert rel_l2(got[s], want[s]) < (TOL if op != "garrote-percentile" else 2e-4), (s, rel_l2(got[s], want[s]))
 
 
 def test_batching_is_transparent(P, orc):

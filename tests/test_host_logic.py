@@ -92,8 +92,8 @@ def test_error_contract_matches_reference():
     # options the HIP build does not cover yet fail loudly instead of falling back to the CPU
     with pytest.raises(NotImplementedError):
         P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET")
-    with pytest.raises(NotImplementedError):
-        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="FFT", thresh_op="hard-percentile")
+    with pytest.raises(ValueError):
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="FFT", thresh_op="median")
 
 
 def test_product_never_imports_oracle():
