@@ -157,6 +157,31 @@ int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, siz
 int p3d_last_profile(p3d_plan* plan, double* colpass_ms, int* colpass_launches, double* rowpass_ms,
                      int* rowpass_launches);
 
+/* ---- WAVELET variant (transform_kind = 'WAVELET') ---------------------------------------------------------------------------
+ * Replaces the pywt.wavedec2 / pywt.waverec2(wavelet, mode='smooth') pair the reference passes to POCS_algorithm
+ * (cube_POCS_interpolation_3D.py:260-264; POCS.py:524-525, 585-588, 608-609) and the per-level, per-detail thresholding of
+ * threshold_wavelet (POCS.py:105-166).  The caller passes the four filters of the orthogonal / biorthogonal bank (doubles,
+ * PyWavelets' dec_lo, dec_hi, rec_lo, rec_hi; 2..64 taps); `level` < 0 selects pywt.dwt_max_level(min(nil, nxl), flen).
+ * Coefficients of one slice are a flat complex64 vector: cA, then (cH, cV, cD) of every level, coarsest first (PyWavelets'
+ * list order); p3d_wavelet_info reports nlev, the vector length and the (rows, cols) of cA and of each level's details. */
+typedef struct p3d_wplan p3d_wplan;
+int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int nxl, int max_slices, const double* dec_lo,
+                            const double* dec_hi, const double* rec_lo, const double* rec_hi, int flen, int level);
+int p3d_wavelet_plan_destroy(p3d_wplan* plan);
+int p3d_wavelet_info(p3d_wplan* plan, int* nlev, int64_t* ncoef, int32_t* shapes);
+/* test hooks: x HOST complex64 [nslices][nil][nxl] <-> coef HOST complex64 [nslices][ncoef] (waverec2 crops to nil x nxl) */
+int p3d_wavedec2_c64(p3d_wplan* plan, const void* x, void* coef, int nslices);
+int p3d_waverec2_c64(p3d_wplan* plan, const void* coef, void* x, int nslices);
+/* statistics for the threshold schedule (POCS.py:253-254, 281): stats HOST double [nslices][nlev][3][4] =
+ * (Re, Im of the lexicographic max; max |d|; min |d|) of each detail array, levels coarsest first. dtype as p3d_pocs_run. */
+int p3d_wavelet_stats(p3d_wplan* plan, const void* x, int dtype, int nslices, double* stats);
+/* the loop (POCS.py:549-632, WAVELET branches).  x/out HOST [nslices][nil][nxl] (dtype), mask HOST float32 [nil][nxl],
+ * tau HOST double [nslices][niter][nlev][3][2] (Re, Im), active HOST uint8 [nslices] or NULL, niter_done HOST int32
+ * [nslices] or NULL, sums HOST double [niter + 1][nslices] or NULL (sum |x| per iteration; row 0 = the input). */
+int p3d_wavelet_run(p3d_wplan* plan, const void* x, int dtype, const float* mask, const double* tau, const uint8_t* active,
+                    const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
+                    double* elapsed_ms);
+
 #ifdef __cplusplus
 }
 #endif

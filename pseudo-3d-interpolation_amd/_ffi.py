@@ -65,6 +65,15 @@ PROTOTYPES = {
                                 C.c_void_p]),
     "p3d_last_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),
+    "p3d_wavelet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "p3d_wavelet_plan_destroy": (C.c_int, [C.c_void_p]),
+    "p3d_wavelet_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_void_p]),
+    "p3d_wavedec2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "p3d_waverec2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "p3d_wavelet_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_wavelet_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 
@@ -260,6 +269,123 @@ class Plan:
 
 
 # ---- steps 12 / 14: time <-> frequency along the slice axis ------------------------------------------------
+
+# ---- WAVELET variant -----------------------------------------------------------------------
+_BANKS = None
+
+
+def wavelet_filters(name):
+    """(dec_lo, dec_hi, rec_lo, rec_hi) of a PyWavelets wavelet name (data file wavelets.json; pywt is not required)."""
+    global _BANKS
+    if _BANKS is None:
+        import json
+        with open(os.path.join(_HERE, "wavelets.json")) as f:
+            _BANKS = json.load(f)["wavelets"]
+    try:
+        b = _BANKS[str(name)]
+    except KeyError:
+        raise ValueError(f"Unknown wavelet name {name!r}, check wavelets.json for the list of available builtin wavelets.") from None
+    return tuple(np.ascontiguousarray(b[k], dtype=np.float64) for k in ("dec_lo", "dec_hi", "rec_lo", "rec_hi"))
+
+
+class WaveletPlan:
+    """p3d_wplan wrapper: multilevel 2-D DWT ('smooth' extension) of (nil, nxl) slices and the WAVELET POCS loop."""
+
+    def __init__(self, nil, nxl, max_slices, wavelet="coif5", level=None, device=0):
+        self.nil, self.nxl, self.max_slices, self.device = int(nil), int(nxl), int(max_slices), int(device)
+        self.wavelet = wavelet
+        bank = wavelet if isinstance(wavelet, (tuple, list)) else wavelet_filters(wavelet)
+        bank = [np.ascontiguousarray(b, dtype=np.float64) for b in bank]
+        if len(bank) != 4 or len({b.size for b in bank}) != 1:
+            raise ValueError("a filter bank is (dec_lo, dec_hi, rec_lo, rec_hi) of equal length")
+        h = C.c_void_p()
+        check(lib().p3d_wavelet_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.max_slices, *map(_ptr, bank),
+                                            bank[0].size, -1 if level is None else int(level)))
+        self.handle = h
+        nlev, ncoef = C.c_int(0), C.c_int64(0)
+        check(lib().p3d_wavelet_info(self.handle, C.byref(nlev), C.byref(ncoef), None))
+        self.nlev, self.ncoef = nlev.value, ncoef.value
+        shapes = np.zeros((self.nlev + 1, 2), np.int32)
+        check(lib().p3d_wavelet_info(self.handle, None, None, _ptr(shapes)))
+        self.shapes = [tuple(int(v) for v in r) for r in shapes]   # cA, then details coarsest -> finest
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().p3d_wavelet_plan_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    _cube = Plan._cube
+
+    def unpack(self, vec):
+        """flat coefficient vector of ONE slice -> [cA, (cH, cV, cD), ...] like pywt.wavedec2."""
+        r, c = self.shapes[0]
+        out, off = [vec[:r * c].reshape(r, c)], r * c
+        for r, c in self.shapes[1:]:
+            det = []
+            for _ in range(3):
+                det.append(vec[off:off + r * c].reshape(r, c))
+                off += r * c
+            out.append(tuple(det))
+        return out
+
+    def pack(self, coeffs):
+        return np.concatenate([np.ravel(coeffs[0])] + [np.ravel(d) for lvl in coeffs[1:] for d in lvl]).astype(np.complex64)
+
+    def wavedec2(self, x):
+        x = np.asarray(x)
+        squeeze = x.ndim == 2
+        xc, _ = self._cube(x.astype(np.complex64, copy=False))
+        coef = np.empty((xc.shape[0], self.ncoef), np.complex64)
+        check(lib().p3d_wavedec2_c64(self.handle, _ptr(xc), _ptr(coef), xc.shape[0]))
+        return coef[0] if squeeze else coef
+
+    def waverec2(self, coef):
+        coef = np.ascontiguousarray(coef, dtype=np.complex64)
+        squeeze = coef.ndim == 1
+        coef = coef.reshape(-1, self.ncoef)
+        if coef.shape[0] > self.max_slices:
+            raise ValueError(f"{coef.shape[0]} slices > max_slices {self.max_slices}")
+        out = np.empty((coef.shape[0], self.nil, self.nxl), np.complex64)
+        check(lib().p3d_waverec2_c64(self.handle, _ptr(coef), _ptr(out), coef.shape[0]))
+        return out[0] if squeeze else out
+
+    def stats(self, x):
+        """(nslices, nlev, 3, 4): Re/Im of the lexicographic max, max |d|, min |d| per detail array (coarsest level first)."""
+        xc, dt = self._cube(x)
+        st = np.empty((xc.shape[0], self.nlev, 3, 4), np.float64)
+        check(lib().p3d_wavelet_stats(self.handle, _ptr(xc), dt, xc.shape[0], _ptr(st)))
+        return st
+
+    def run(self, x, mask, tau, niter, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """tau: (nslices, niter, nlev, 3) real or complex.  Returns (out, niter_done, sums, elapsed_ms)."""
+        xc, dt = self._cube(x)
+        n = xc.shape[0]
+        m = np.ascontiguousarray(mask, dtype=np.float32)
+        if m.shape != (self.nil, self.nxl):
+            raise ValueError(f"mask shape {m.shape} != {(self.nil, self.nxl)}")
+        tau = np.broadcast_to(np.asarray(tau), (n, niter, self.nlev, 3))
+        t = np.empty(tau.shape + (2,), np.float64)
+        t[..., 0] = tau.real
+        t[..., 1] = tau.imag if np.iscomplexobj(tau) else 0.0
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        out = np.empty_like(xc)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_wavelet_run(self.handle, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act),
+                                    C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return out, done, sums, ms.value
+
+
 def time2freq(x, dt, t0=0.0, nfft=None, real_only=False, window=None, device=0):
     """(nt, ...) float32 -> (nfreq, ...) complex64 with xrft's true_phase / true_amplitude convention
     (include/p3d.h, p3d_time2freq).  Trailing axes are flattened to traces and restored."""

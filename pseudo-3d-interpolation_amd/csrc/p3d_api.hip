@@ -125,6 +125,9 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// p3d_wavelet.hip reports through the same thread-local string
+namespace p3d { void set_last_error(const char* msg) { g_err = msg; } }
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \

@@ -1,0 +1,553 @@
+// p3d_wavelet.hip -- WAVELET variant of the POCS path (transform_kind = 'WAVELET').
+//
+// The reference hands pywt.wavedec2 / pywt.waverec2(wavelet, mode='smooth') to POCS_algorithm
+// (pseudo_3D_interpolation/cube_POCS_interpolation_3D.py:260-264; used at functions/POCS.py:524-525, 585-588, 608-609) and
+// thresholds every detail array of every level with its own tau (threshold_wavelet, POCS.py:105-166; schedule POCS.py:279-281,
+// 338-339).  PyWavelets is a third-party C extension that is not part of the reference; its published algorithm is restated
+// here (and, in NumPy, in oracle/wavelet_oracle.py, which is pinned against PyWavelets 1.1.1 outputs):
+//   * single level along an axis: out[o] = sum_j f[j] * xe[2o + 1 - j], o < floor((n + L - 1) / 2), xe = x extended on both
+//     sides by straight lines through the edge pairs ('smooth');
+//   * inverse: out[m] = sum_k a[k] * rec_lo[m + L - 2 - 2k] + d[k] * rec_hi[m + L - 2 - 2k], m < 2n - L + 2;
+//   * multilevel 2-D: level count floor(log2(min(shape) / (L - 1))); when an approximation is one sample longer than the
+//     details of the next finer level its last sample is ignored;
+//   * complex input = real and imaginary parts transformed independently (the filters are real).
+// Kernels are deliberately simple (one thread per output sample, every pass through HBM): this path exists for coverage and
+// parity (BASELINE configs[3]); the FFT path is the tuned one.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "p3d.h"
+#include "p3d_fft.hpp"
+
+using p3d::c32;
+namespace p3d { void set_last_error(const char* msg); }  // p3d_api.hip
+
+namespace {
+
+constexpr int MAXL = 64;  // longest filter (PyWavelets: db38 has 76 taps; those are refused)
+
+struct Filters {
+    float dec_lo[MAXL], dec_hi[MAXL], rec_lo[MAXL], rec_hi[MAXL];
+    int len;
+};
+
+__device__ __forceinline__ c32 cmulf(c32 a, float s) { return c32{a.x * s, a.y * s}; }
+
+// sample k of a line of n samples at stride `st`, extended by straight lines through the edge pairs
+__device__ __forceinline__ c32 smooth_at(const c32* line, int n, size_t st, int k)
+{
+    if (k >= 0 && k < n) return line[(size_t)k * st];
+    if (n == 1) return line[0];
+    if (k < 0) {
+        const c32 e = line[0], f = line[st];
+        const float t = (float)(-k);
+        return c32{e.x + (e.x - f.x) * t, e.y + (e.y - f.y) * t};
+    }
+    const c32 e = line[(size_t)(n - 1) * st], f = line[(size_t)(n - 2) * st];
+    const float t = (float)(k - n + 1);
+    return c32{e.x + (e.x - f.x) * t, e.y + (e.y - f.y) * t};
+}
+
+// forward step along one axis of a batch of 2-D arrays.
+//   in : [slice][nlines x n] with element (line, k) at line*lin_st + k*el_st (+ slice*in_slice)
+//   lo/hi: same addressing with n -> nout (+ slice*out_slice)
+__global__ void dwt_axis_kernel(const c32* in, c32* lo, c32* hi, Filters f, int nlines, int n, int nout, size_t in_lin, size_t in_el,
+                                size_t in_slice, size_t out_lin, size_t out_el, size_t lo_slice, size_t hi_slice)
+{
+    const int s = blockIdx.y;
+    const size_t total = (size_t)nlines * nout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // neighbouring threads walk along the contiguous direction of the data
+        int line, o;
+        if (in_el == 1) { line = (int)(i / nout); o = (int)(i - (size_t)line * nout); }
+        else { o = (int)(i / nlines); line = (int)(i - (size_t)o * nlines); }
+        const c32* src = in + (size_t)s * in_slice + (size_t)line * in_lin;
+        c32 a{0.f, 0.f}, d{0.f, 0.f};
+        for (int j = 0; j < f.len; ++j) {
+            const c32 v = smooth_at(src, n, in_el, 2 * o + 1 - j);
+            a.x += f.dec_lo[j] * v.x; a.y += f.dec_lo[j] * v.y;
+            d.x += f.dec_hi[j] * v.x; d.y += f.dec_hi[j] * v.y;
+        }
+        const size_t dst = (size_t)line * out_lin + (size_t)o * out_el;
+        lo[(size_t)s * lo_slice + dst] = a;
+        hi[(size_t)s * hi_slice + dst] = d;
+    }
+}
+
+// inverse step along one axis: a, d hold n valid samples per line (their buffers may be longer: trimmed approximation)
+__global__ void idwt_axis_kernel(const c32* a, const c32* d, c32* out, Filters f, int nlines, int n, int nout, size_t a_lin, size_t a_el,
+                                 size_t a_slice, size_t d_lin, size_t d_el, size_t d_slice, size_t out_lin, size_t out_el, size_t out_slice)
+{
+    const int s = blockIdx.y;
+    const size_t total = (size_t)nlines * nout;
+    const int L = f.len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int line, m;
+        if (out_el == 1) { line = (int)(i / nout); m = (int)(i - (size_t)line * nout); }
+        else { m = (int)(i / nlines); line = (int)(i - (size_t)m * nlines); }
+        const c32* pa = a + (size_t)s * a_slice + (size_t)line * a_lin;
+        const c32* pd = d + (size_t)s * d_slice + (size_t)line * d_lin;
+        // taps j = m + L - 2 - 2k in [0, L): k from ceil((m - 1) / 2) to floor((m + L - 2) / 2)
+        int k0 = (m - 1 + 1) / 2;  // ceil((m-1)/2) for m >= 0 (m = 0 -> 0)
+        if (m == 0) k0 = 0;
+        int k1 = (m + L - 2) / 2;
+        if (k1 > n - 1) k1 = n - 1;
+        c32 acc{0.f, 0.f};
+        for (int k = k0; k <= k1; ++k) {
+            const int j = m + L - 2 - 2 * k;
+            const c32 va = pa[(size_t)k * a_el], vd = pd[(size_t)k * d_el];
+            acc.x += f.rec_lo[j] * va.x + f.rec_hi[j] * vd.x;
+            acc.y += f.rec_lo[j] * va.y + f.rec_hi[j] * vd.y;
+        }
+        out[(size_t)s * out_slice + (size_t)line * out_lin + (size_t)m * out_el] = acc;
+    }
+}
+
+__device__ inline c32 wshrink(c32 X, c32 tau, int op)
+{
+    const float m = sqrtf(X.x * X.x + X.y * X.y);
+    if (op == 0) {
+        const bool below = (m < tau.x) || (m == tau.x && 0.0f < tau.y);
+        return below ? c32{0.f, 0.f} : X;
+    }
+    if (m == 0.0f) return c32{0.f, 0.f};
+    float gr, gi;
+    if (op == 1) {
+        const float r = 1.0f / m;
+        gr = 1.0f - tau.x * r;
+        gi = -tau.y * r;
+    } else {
+        const float r = 1.0f / (m * m);
+        gr = 1.0f - (tau.x * tau.x - tau.y * tau.y) * r;
+        gi = -(2.0f * tau.x * tau.y) * r;
+    }
+    const bool keep = (gr > 0.0f) || (gr == 0.0f && gi >= 0.0f);
+    return keep ? X * c32{gr, gi} : c32{0.f, 0.f};
+}
+
+// details of one level: coef + off + z*count (z = 0..2); tau[((s*niter + iter)*nlev + lvl)*3 + z]
+__global__ void wthreshold_kernel(c32* coef, size_t coef_slice, size_t off, size_t count, const c32* tau, int niter, int iter, int nlev, int lvl,
+                                  int op, const int* done)
+{
+    const int s = blockIdx.y, z = blockIdx.z;
+    if (done && done[s] != 0) return;
+    const c32 t = tau[(((size_t)s * niter + iter) * nlev + lvl) * 3 + z];
+    c32* p = coef + (size_t)s * coef_slice + off + (size_t)z * count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = wshrink(p[i], t, op);
+}
+
+// per (slice, level, detail): lexicographic max, max |d|, min |d| -> stats[((s*nlev + lvl)*3 + z)*4 ..]; one block each
+__global__ void wstats_kernel(const c32* coef, size_t coef_slice, size_t off, size_t count, float* stats, int nlev, int lvl)
+{
+    __shared__ float sh[256 * 4];
+    const int s = blockIdx.y, z = blockIdx.z;
+    const c32* p = coef + (size_t)s * coef_slice + off + (size_t)z * count;
+    float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY;
+    for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const c32 v = p[i];
+        const float q = v.x * v.x + v.y * v.y;
+        if (v.x > lr || (v.x == lr && v.y > li)) { lr = v.x; li = v.y; }
+        mx = fmaxf(mx, q);
+        mn = fminf(mn, q);
+    }
+    float* me = sh + threadIdx.x * 4;
+    me[0] = lr; me[1] = li; me[2] = mx; me[3] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 1; t < (int)blockDim.x; ++t) {
+            const float* o = sh + t * 4;
+            if (o[0] > lr || (o[0] == lr && o[1] > li)) { lr = o[0]; li = o[1]; }
+            mx = fmaxf(mx, o[2]);
+            mn = fminf(mn, o[3]);
+        }
+        float* q = stats + (((size_t)s * nlev + lvl) * 3 + z) * 4;
+        q[0] = lr; q[1] = li; q[2] = sqrtf(mx); q[3] = sqrtf(mn);
+    }
+}
+
+// mode 0: first input (feed = x or its APOCS mix; sums += |x|)
+// mode 1: crop of the reconstruction + re-insertion (POCS.py:609, 616-619), sums += |x_new|, feed for the next iteration
+__global__ void wupdate_kernel(const c32* rec, size_t rec_ld, size_t rec_slice, c32* feed, const void* x, int dtype, const float* mask, void* out,
+                               double* sums, int mode, int adaptive, int write_out, float alpha, int n1, int n2, const int* done, int zero_fill)
+{
+    __shared__ double sh[256];
+    const int s = blockIdx.y;
+    const size_t per = (size_t)n1 * n2;
+    const int dn = done ? done[s] : 0;
+    if (zero_fill && dn < 0)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+            if (dtype == 0) reinterpret_cast<c32*>(out)[(size_t)s * per + i] = c32{0.f, 0.f};
+            else reinterpret_cast<float*>(out)[(size_t)s * per + i] = 0.f;
+        }
+    double acc = 0.0;
+    if (dn == 0) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t g = (size_t)s * per + i;
+            const int r = (int)(i / n2), c = (int)(i - (size_t)r * n2);
+            c32 xo;
+            if (dtype == 0) xo = reinterpret_cast<const c32*>(x)[g];
+            else xo = c32{reinterpret_cast<const float*>(x)[g], 0.f};
+            const float m = mask ? mask[i] : 0.f;
+            const float wgt = 1.0f - alpha * m;
+            c32 xn;
+            if (mode == 0) {
+                xn = xo;
+            } else {
+                xn = p3d::axpby(rec[(size_t)s * rec_slice + (size_t)r * rec_ld + c], wgt, xo, alpha);
+                if (write_out) {
+                    if (dtype == 0) reinterpret_cast<c32*>(out)[g] = xn;
+                    else reinterpret_cast<float*>(out)[g] = xn.x;
+                }
+            }
+            acc += (double)sqrtf(xn.x * xn.x + xn.y * xn.y);
+            if (adaptive) {
+                const c32 blend = cmulf(xo, alpha) + cmulf(xn, wgt);
+                feed[g] = blend + cmulf(xo - cmulf(xn, m), 1.0f - alpha);
+            } else {
+                feed[g] = xn;
+            }
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && dn == 0) atomicAdd(sums + s, sh[0]);
+}
+
+__global__ void wconv_kernel(const double* sums, int* done, int nslices, int iter, double eps)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslices || done[s] != 0) return;
+    const double cur = sums[(size_t)(iter + 1) * nslices + s], prev = sums[(size_t)iter * nslices + s];
+    const double d = cur - prev;
+    if (iter > 2 && (d * d) / (cur * cur) < eps) done[s] = iter + 1;
+}
+
+int wfail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    p3d::set_last_error(buf);
+    return code;
+}
+#define W_TRY(expr)                                                                                     \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return wfail(P3D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline unsigned blocks_for(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+
+}  // namespace
+
+struct p3d_wplan {
+    int device = 0, nil = 0, nxl = 0, max_slices = 0, nlev = 0;
+    Filters f{};
+    std::vector<int> h, w;          // h[l], w[l], l = 0..nlev  (level 0 = the slice itself)
+    std::vector<int> rh, rw;        // shape of the reconstruction OF level l (l = 0..nlev-1): 2*h[l+1] - L + 2
+    std::vector<size_t> doff;       // offset of level-l details (l = 1..nlev) in the coefficient vector of one slice
+    size_t ncoef = 0;               // cA first, then details of level nlev (coarsest) ... level 1: PyWavelets' order
+    hipStream_t stream = nullptr;
+    c32 *coef = nullptr, *feed = nullptr, *lo = nullptr, *hi = nullptr, *tau = nullptr;
+    std::vector<c32*> approx;       // approx[l], l = 1..nlev-1 (approx[nlev] = coef, approx[0] = feed)
+    std::vector<c32*> rec;          // rec[l], l = 0..nlev-1
+    double* sums = nullptr;
+    size_t sums_cap = 0, tau_cap = 0;
+    int* done = nullptr;
+    float *stats = nullptr, *mask = nullptr;
+    void *st_x = nullptr, *st_out = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t per() const { return (size_t)nil * nxl; }
+};
+
+extern "C" int p3d_wavelet_plan_destroy(p3d_wplan* p)
+{
+    if (!p) return P3D_OK;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    void* bufs[] = {p->coef, p->feed, p->lo, p->hi, p->tau, p->sums, p->done, p->stats, p->mask, p->st_x, p->st_out};
+    for (void* b : bufs) if (b) hipFree(b);
+    for (c32* b : p->approx) if (b) hipFree(b);
+    for (c32* b : p->rec) if (b) hipFree(b);
+    if (p->ev0) hipEventDestroy(p->ev0);
+    if (p->ev1) hipEventDestroy(p->ev1);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+    return P3D_OK;
+}
+
+extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int nxl, int max_slices, const double* dec_lo, const double* dec_hi,
+                                       const double* rec_lo, const double* rec_hi, int flen, int level)
+{
+    if (!out || !dec_lo || !dec_hi || !rec_lo || !rec_hi) return wfail(P3D_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (nil < 1 || nxl < 1 || max_slices < 1 || max_slices > 65535) return wfail(P3D_ERR_INVALID, "bad shape / batch size");
+    if (flen < 2 || flen > MAXL) return wfail(P3D_ERR_UNSUPPORTED, "filter length %d: 2..%d taps are supported", flen, MAXL);
+    int ndev = 0;
+    W_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return wfail(P3D_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    W_TRY(hipSetDevice(device));
+    const int nmin = nil < nxl ? nil : nxl;
+    int maxlev = 0;  // pywt.dwt_max_level(min(shape), flen)
+    if (nmin >= flen - 1) maxlev = (int)std::floor(std::log2((double)nmin / (flen - 1.0)));
+    if (maxlev < 0) maxlev = 0;
+    if (level < 0) level = maxlev;
+    if (level < 1) return wfail(P3D_ERR_UNSUPPORTED, "a %d x %d slice is too small for a %d-tap wavelet (0 levels)", nil, nxl, flen);
+
+    p3d_wplan* p = new p3d_wplan;
+    p->device = device; p->nil = nil; p->nxl = nxl; p->max_slices = max_slices; p->nlev = level;
+    p->f.len = flen;
+    for (int j = 0; j < flen; ++j) {
+        p->f.dec_lo[j] = (float)dec_lo[j]; p->f.dec_hi[j] = (float)dec_hi[j];
+        p->f.rec_lo[j] = (float)rec_lo[j]; p->f.rec_hi[j] = (float)rec_hi[j];
+    }
+    p->h.assign(level + 1, 0); p->w.assign(level + 1, 0);
+    p->h[0] = nil; p->w[0] = nxl;
+    for (int l = 1; l <= level; ++l) { p->h[l] = (p->h[l - 1] + flen - 1) / 2; p->w[l] = (p->w[l - 1] + flen - 1) / 2; }
+    p->rh.assign(level, 0); p->rw.assign(level, 0);
+    for (int l = 0; l < level; ++l) { p->rh[l] = 2 * p->h[l + 1] - flen + 2; p->rw[l] = 2 * p->w[l + 1] - flen + 2; }
+    p->doff.assign(level + 1, 0);
+    size_t off = (size_t)p->h[level] * p->w[level];
+    for (int l = level; l >= 1; --l) { p->doff[l] = off; off += 3 * (size_t)p->h[l] * p->w[l]; }
+    p->ncoef = off;
+
+    auto bail = [&](const char* what, hipError_t e) {
+        p3d_wavelet_plan_destroy(p);
+        return wfail(P3D_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+#define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(#ptr, e)
+    if ((e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess) return bail("stream", e);
+    if ((e = hipEventCreate(&p->ev0)) != hipSuccess) return bail("event", e);
+    if ((e = hipEventCreate(&p->ev1)) != hipSuccess) return bail("event", e);
+    const size_t S = (size_t)max_slices;
+    ALLOC(p->coef, sizeof(c32) * p->ncoef * S);
+    ALLOC(p->feed, sizeof(c32) * p->per() * S);
+    // row-filtered intermediates of the forward step / column-reconstructed intermediates of the inverse step: the
+    // largest are (h[0] x w[1]) and (rh[0] x w[1])
+    const size_t tmp = (size_t)std::max(p->h[0], p->rh[0]) * p->w[1];
+    ALLOC(p->lo, sizeof(c32) * tmp * S);
+    ALLOC(p->hi, sizeof(c32) * tmp * S);
+    p->approx.assign(level + 1, nullptr);
+    for (int l = 1; l < level; ++l) ALLOC(p->approx[l], sizeof(c32) * (size_t)p->h[l] * p->w[l] * S);
+    p->rec.assign(level, nullptr);
+    for (int l = 0; l < level; ++l) ALLOC(p->rec[l], sizeof(c32) * (size_t)p->rh[l] * p->rw[l] * S);
+    ALLOC(p->done, sizeof(int) * S);
+    ALLOC(p->stats, sizeof(float) * 4 * 3 * (size_t)level * S);
+    ALLOC(p->mask, sizeof(float) * p->per());
+    ALLOC(p->st_x, sizeof(c32) * p->per() * S);
+    ALLOC(p->st_out, sizeof(c32) * p->per() * S);
+#undef ALLOC
+    *out = p;
+    return P3D_OK;
+}
+
+extern "C" int p3d_wavelet_info(p3d_wplan* p, int* nlev, int64_t* ncoef, int32_t* shapes /* [(nlev+1)*2]: cA, then levels coarse -> fine */)
+{
+    if (!p) return wfail(P3D_ERR_INVALID, "NULL plan");
+    if (nlev) *nlev = p->nlev;
+    if (ncoef) *ncoef = (int64_t)p->ncoef;
+    if (shapes) {
+        shapes[0] = p->h[p->nlev]; shapes[1] = p->w[p->nlev];
+        for (int l = p->nlev, i = 1; l >= 1; --l, ++i) { shapes[2 * i] = p->h[l]; shapes[2 * i + 1] = p->w[l]; }
+    }
+    return P3D_OK;
+}
+
+// ---- transforms on device buffers ------------------------------------------------------------------------------------------
+// feed (nil x nxl per slice) -> coefficient vectors (cA, details coarse -> fine)
+static int w_forward(p3d_wplan* p, int ns)
+{
+    const dim3 blk(256);
+    for (int l = 1; l <= p->nlev; ++l) {
+        const c32* src = l == 1 ? p->feed : p->approx[l - 1];
+        const int H = p->h[l - 1], W = p->w[l - 1], Ho = p->h[l], Wo = p->w[l];
+        const size_t cnt = (size_t)Ho * Wo;
+        // along axis 1 (rows are contiguous): (H x W) -> lo, hi (H x Wo)
+        dwt_axis_kernel<<<dim3(blocks_for((size_t)H * Wo), ns), blk, 0, p->stream>>>(src, p->lo, p->hi, p->f, H, W, Wo, (size_t)W, 1, (size_t)H * W,
+                                                                                 (size_t)Wo, 1, (size_t)H * Wo, (size_t)H * Wo);
+        // along axis 0 (lines = columns): lo -> (aa, da = cH), hi -> (ad = cV, dd = cD), each (Ho x Wo)
+        c32* cA = l == p->nlev ? p->coef : p->approx[l];
+        const size_t cA_slice = l == p->nlev ? p->ncoef : cnt;
+        c32* det = p->coef + p->doff[l];
+        dwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * Ho), ns), blk, 0, p->stream>>>(p->lo, cA, det, p->f, Wo, H, Ho, 1, (size_t)Wo, (size_t)H * Wo, 1,
+                                                                                  (size_t)Wo, cA_slice, p->ncoef);
+        dwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * Ho), ns), blk, 0, p->stream>>>(p->hi, det + cnt, det + 2 * cnt, p->f, Wo, H, Ho, 1, (size_t)Wo,
+                                                                                  (size_t)H * Wo, 1, (size_t)Wo, p->ncoef, p->ncoef);
+    }
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+// coefficient vectors -> rec[0] (rh[0] x rw[0] per slice; its top-left nil x nxl block is the slice)
+static int w_inverse(p3d_wplan* p, int ns)
+{
+    const dim3 blk(256);
+    for (int l = p->nlev; l >= 1; --l) {
+        const int Ho = p->h[l], Wo = p->w[l];          // valid extent of the level-l arrays
+        const int RH = p->rh[l - 1], RW = p->rw[l - 1];  // shape of the reconstruction of level l-1
+        const size_t cnt = (size_t)Ho * Wo;
+        // approximation of level l: cA itself at the coarsest level, otherwise the reconstruction of level l (which may be one
+        // row / column larger than Ho x Wo: the extra samples are ignored, as in pywt.waverec2)
+        const c32* a = l == p->nlev ? p->coef : p->rec[l];
+        const size_t a_ld = l == p->nlev ? (size_t)Wo : (size_t)p->rw[l];
+        const size_t a_slice = l == p->nlev ? p->ncoef : (size_t)p->rh[l] * p->rw[l];
+        const c32* det = p->coef + p->doff[l];
+        // undo axis 0: (a, cH) -> lo (RH x Wo);  (cV, cD) -> hi (RH x Wo)
+        idwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * RH), ns), blk, 0, p->stream>>>(a, det, p->lo, p->f, Wo, Ho, RH, 1, a_ld, a_slice, 1, (size_t)Wo,
+                                                                                   p->ncoef, 1, (size_t)Wo, (size_t)RH * Wo);
+        idwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * RH), ns), blk, 0, p->stream>>>(det + cnt, det + 2 * cnt, p->hi, p->f, Wo, Ho, RH, 1, (size_t)Wo,
+                                                                                   p->ncoef, 1, (size_t)Wo, p->ncoef, 1, (size_t)Wo, (size_t)RH * Wo);
+        // undo axis 1: (lo, hi) (RH x Wo) -> rec[l-1] (RH x RW)
+        idwt_axis_kernel<<<dim3(blocks_for((size_t)RH * RW), ns), blk, 0, p->stream>>>(p->lo, p->hi, p->rec[l - 1], p->f, RH, Wo, RW, (size_t)Wo, 1,
+                                                                                   (size_t)RH * Wo, (size_t)Wo, 1, (size_t)RH * Wo, (size_t)RW, 1,
+                                                                                   (size_t)RH * RW);
+    }
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+static int w_check(p3d_wplan* p, int nslices, int dtype)
+{
+    if (!p) return wfail(P3D_ERR_INVALID, "NULL plan");
+    if (nslices < 1 || nslices > p->max_slices) return wfail(P3D_ERR_INVALID, "nslices = %d outside 1..max_slices (%d)", nslices, p->max_slices);
+    if (dtype != P3D_C64 && dtype != P3D_F32) return wfail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    W_TRY(hipSetDevice(p->device));
+    return P3D_OK;
+}
+
+extern "C" {
+
+// test hooks: multilevel decomposition of complex64 slices into coefficient vectors [nslices][ncoef] and back
+int p3d_wavedec2_c64(p3d_wplan* p, const void* x, void* coef, int nslices)
+{
+    int rc = w_check(p, nslices, P3D_C64);
+    if (rc) return rc;
+    W_TRY(hipMemcpy(p->feed, x, sizeof(c32) * p->per() * nslices, hipMemcpyHostToDevice));
+    if ((rc = w_forward(p, nslices))) return rc;
+    W_TRY(hipStreamSynchronize(p->stream));
+    W_TRY(hipMemcpy(coef, p->coef, sizeof(c32) * p->ncoef * nslices, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+int p3d_waverec2_c64(p3d_wplan* p, const void* coef, void* x, int nslices)
+{
+    int rc = w_check(p, nslices, P3D_C64);
+    if (rc) return rc;
+    W_TRY(hipMemcpy(p->coef, coef, sizeof(c32) * p->ncoef * nslices, hipMemcpyHostToDevice));
+    if ((rc = w_inverse(p, nslices))) return rc;
+    // crop to the slice shape (POCS.py:513, 609)
+    W_TRY(hipMemcpy2DAsync(p->feed, sizeof(c32) * p->nxl, p->rec[0], sizeof(c32) * p->rw[0], sizeof(c32) * p->nxl, (size_t)p->nil, hipMemcpyDeviceToDevice,
+                           p->stream));
+    for (int s = 1; s < nslices; ++s)
+        W_TRY(hipMemcpy2DAsync(p->feed + (size_t)s * p->per(), sizeof(c32) * p->nxl, p->rec[0] + (size_t)s * p->rh[0] * p->rw[0], sizeof(c32) * p->rw[0],
+                               sizeof(c32) * p->nxl, (size_t)p->nil, hipMemcpyDeviceToDevice, p->stream));
+    W_TRY(hipStreamSynchronize(p->stream));
+    W_TRY(hipMemcpy(x, p->feed, sizeof(c32) * p->per() * nslices, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+// statistics of the detail arrays of transform(x) for the schedule (POCS.py:253-254, 281): stats [nslices][nlev][3][4] doubles =
+// Re, Im of the lexicographic max, max |d|, min |d|; levels coarse -> fine (PyWavelets' order)
+int p3d_wavelet_stats(p3d_wplan* p, const void* x, int dtype, int nslices, double* stats)
+{
+    int rc = w_check(p, nslices, dtype);
+    if (rc) return rc;
+    if (!x || !stats) return wfail(P3D_ERR_INVALID, "NULL buffer");
+    const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
+    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyHostToDevice));
+    if (!p->sums) { W_TRY(hipMalloc((void**)&p->sums, sizeof(double) * 2 * p->max_slices)); p->sums_cap = 2 * (size_t)p->max_slices; }
+    W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nslices, p->stream));
+    wupdate_kernel<<<dim3(blocks_for(p->per()), nslices), 256, 0, p->stream>>>(nullptr, 0, 0, p->feed, p->st_x, dtype, nullptr, nullptr, p->sums, 0, 0, 0, 1.0f,
+                                                                             p->nil, p->nxl, nullptr, 0);
+    if ((rc = w_forward(p, nslices))) return rc;
+    for (int l = p->nlev, i = 0; l >= 1; --l, ++i)
+        wstats_kernel<<<dim3(1, nslices, 3), 256, 0, p->stream>>>(p->coef, p->ncoef, p->doff[l], (size_t)p->h[l] * p->w[l], p->stats, p->nlev, i);
+    W_TRY(hipGetLastError());
+    std::vector<float> host((size_t)nslices * p->nlev * 12);
+    W_TRY(hipMemcpyAsync(host.data(), p->stats, sizeof(float) * host.size(), hipMemcpyDeviceToHost, p->stream));
+    W_TRY(hipStreamSynchronize(p->stream));
+    for (size_t i = 0; i < host.size(); ++i) stats[i] = host[i];
+    return P3D_OK;
+}
+
+// the loop (POCS.py:549-632 with the WAVELET branches); tau: HOST [nslices][niter][nlev][3][2] doubles, levels coarse -> fine
+int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, const double* tau, const uint8_t* active, const p3d_pocs_params* prm,
+                    void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms)
+{
+    int rc = w_check(p, nslices, dtype);
+    if (rc) return rc;
+    if (!x || !mask || !tau || !prm || !out) return wfail(P3D_ERR_INVALID, "NULL argument");
+    if (prm->niter < 1) return wfail(P3D_ERR_INVALID, "niter must be >= 1");
+    if (prm->thresh_op < P3D_OP_HARD || prm->thresh_op > P3D_OP_GARROTE)
+        return wfail(P3D_ERR_UNSUPPORTED, "thresh_op %d is not implemented for the wavelet transform", prm->thresh_op);
+    const int niter = prm->niter;
+    const bool early = prm->eps > 0.0, adaptive = prm->version == P3D_VER_ADAPTIVE;
+    const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
+    const size_t ntau = (size_t)nslices * niter * p->nlev * 3, nsum = (size_t)(niter + 1) * nslices;
+    if (p->tau_cap < ntau) {
+        if (p->tau) hipFree(p->tau);
+        p->tau = nullptr; p->tau_cap = 0;
+        W_TRY(hipMalloc((void**)&p->tau, sizeof(c32) * ntau));
+        p->tau_cap = ntau;
+    }
+    if (p->sums_cap < nsum) {
+        if (p->sums) hipFree(p->sums);
+        p->sums = nullptr; p->sums_cap = 0;
+        W_TRY(hipMalloc((void**)&p->sums, sizeof(double) * nsum));
+        p->sums_cap = nsum;
+    }
+    std::vector<c32> tau_f(ntau);
+    for (size_t i = 0; i < ntau; ++i) tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+    std::vector<int> done_h(nslices, 0);
+    if (active) for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;
+    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyHostToDevice));
+    W_TRY(hipMemcpy(p->mask, mask, sizeof(float) * p->per(), hipMemcpyHostToDevice));
+    W_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
+    W_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
+    W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
+    W_TRY(hipEventRecord(p->ev0, p->stream));
+    const dim3 ugrid(blocks_for(p->per()) > 256 ? 256 : blocks_for(p->per()), nslices);
+    wupdate_kernel<<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, p->feed, p->st_x, dtype, p->mask, p->st_out, p->sums, 0, adaptive ? 1 : 0, 0, (float)prm->alpha,
+                                                p->nil, p->nxl, p->done, 0);
+    for (int k = 0; k < niter; ++k) {
+        const bool last = k + 1 == niter;
+        if ((rc = w_forward(p, nslices))) return rc;
+        for (int l = p->nlev, i = 0; l >= 1; --l, ++i) {
+            const size_t cnt = (size_t)p->h[l] * p->w[l];
+            wthreshold_kernel<<<dim3(blocks_for(cnt) > 64 ? 64 : blocks_for(cnt), nslices, 3), 256, 0, p->stream>>>(p->coef, p->ncoef, p->doff[l], cnt, p->tau, niter,
+                                                                                                                 k, p->nlev, i, prm->thresh_op, p->done);
+        }
+        if ((rc = w_inverse(p, nslices))) return rc;
+        wupdate_kernel<<<ugrid, 256, 0, p->stream>>>(p->rec[0], (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], p->feed, p->st_x, dtype, p->mask, p->st_out,
+                                                    p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
+                                                    (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
+        if (early) wconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+    }
+    W_TRY(hipGetLastError());
+    W_TRY(hipEventRecord(p->ev1, p->stream));
+    W_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
+    if (sums) W_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
+    W_TRY(hipStreamSynchronize(p->stream));
+    W_TRY(hipMemcpy(out, p->st_out, esz * p->per() * nslices, hipMemcpyDeviceToHost));
+    if (niter_done) for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
+    if (elapsed_ms) {
+        float ms = 0.f;
+        W_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        *elapsed_ms = ms;
+    }
+    return P3D_OK;
+}
+
+}  // extern "C"

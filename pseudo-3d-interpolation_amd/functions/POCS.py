@@ -27,7 +27,8 @@ import numpy as np
 from .. import _ffi
 
 TRANSFORMS = ('FFT', 'WAVELET', 'SHEARLET', 'CURVELET', 'DCT')
-_HIP_TRANSFORMS = ('FFT',)
+_HIP_TRANSFORMS = ('FFT', 'WAVELET')
+_WAVELET_OPS = ('soft', 'hard', 'garrote', 'garotte')
 _THRESH_OPS = ('soft', 'hard', 'garrote', 'garotte', 'soft-percentile', 'hard-percentile',
                'garrote-percentile', 'garotte-percentile')
 
@@ -48,7 +49,7 @@ def _tail_number(name, default=1.0, strict=False):
         return default
 
 
-def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, sumsq, size):
+def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, sumsq, size, transform_kind='FFT'):
     """tau[..., k] for k = 1..niter from the statistics of X0 = transform(x).
 
     ``peak`` is the (lexicographic) complex maximum of X0, ``abs_max`` / ``abs_min`` the extrema of
@@ -70,6 +71,8 @@ def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, s
     if kind == 'values':
         peak = np.asarray(peak)[..., None]
         if isinstance(p_min, str) and p_min == 'adaptive':
+            if transform_kind == 'WAVELET':  # POCS.py:322-325
+                raise NotImplementedError(f'p_min=`adaptive` is not implemented for {transform_kind} transform')
             tau_min = 0.01 * np.sqrt(np.asarray(sumsq)[..., None] / size)
         else:
             tau_min = p_min * peak
@@ -86,7 +89,7 @@ def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, s
         if 'exponential' in thresh_model:
             q = _tail_number(thresh_model, strict=True)
             return tau_max * np.exp(np.log(tau_min / tau_max) * ramp ** q)
-    raise NotImplementedError(f'{thresh_model} is not implemented for FFT transform!')
+    raise NotImplementedError(f'{thresh_model} is not implemented for {transform_kind} transform!')
 
 
 def _data_driven(x_fwd, niter, p_max, p_min):
@@ -118,7 +121,7 @@ def get_threshold_decay(
     Iteration-based decay of the threshold (same signature as the reference, POCS.py:169-177).
 
     ``x_fwd`` is the forward-transformed input as a NumPy array; only the single-scale transforms
-    (`FFT`, `DCT`, `CURVELET`) are covered.  Returns ``tau`` with ``niter`` entries: complex when the
+    (`FFT`, `DCT`, `CURVELET`) and `WAVELET` (``x_fwd`` = list of detail tuples) are covered.  Returns ``tau`` with ``niter`` entries: complex when the
     'values' kind scales by the (complex) maximum of ``x_fwd``, real otherwise.
     """
     if transform_kind is None:
@@ -127,8 +130,19 @@ def get_threshold_decay(
         raise ValueError(f'Unsupported transform. Please select one of: {TRANSFORMS}')
     else:
         transform_kind = transform_kind.upper()
-    if transform_kind in ('WAVELET', 'SHEARLET'):
+    if transform_kind == 'SHEARLET':
         raise NotImplementedError(f'{transform_kind} schedules are not available in the HIP build yet')
+    if transform_kind == 'WAVELET' and x_fwd is not None:
+        # x_fwd: list of (cH, cV, cD) per level (the low-pass array already removed, POCS.py:524-525) -> tau (niter, nlev, 3)
+        inverse_prop = all(s in thresh_model for s in ['inverse', 'proportional'])
+        peak = abs_max = abs_min = None
+        if inverse_prop:
+            abs_max = np.asarray([[np.abs(d).max() for d in level] for level in x_fwd])
+            abs_min = np.asarray([[np.abs(d).min() for d in level] for level in x_fwd])
+        elif kind == 'values':
+            peak = np.asarray([[np.asarray(d).max() for d in level] for level in x_fwd])
+        tau = _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, None, None, 'WAVELET')
+        return np.moveaxis(tau, -1, 0) if np.ndim(tau) == 3 else np.reshape(tau, (-1, 1, 1))
 
     if x_fwd is None and (kind == 'values' or thresh_model == 'data-driven'):
         raise ValueError('`x_fwd` must be specified for thresh_model="data-driven" or kind="values"!')
@@ -178,11 +192,45 @@ def _get_plan(nil, nxl, nslices, device):
     return plan
 
 
+def _get_wavelet_plan(nil, nxl, nslices, wavelet, device):
+    key = ('wavelet', nil, nxl, str(wavelet), device)
+    plan = _plans.get(key)
+    if plan is None or plan.max_slices < nslices:
+        if plan is not None:
+            plan.close()
+        plan = _ffi.WaveletPlan(nil, nxl, max(nslices, 1), wavelet=wavelet, device=device)
+        _plans[key] = plan
+    return plan
+
+
 def release_plans():
     """Free the cached GPU plans (work buffers) of this process."""
     for plan in _plans.values():
         plan.close()
     _plans.clear()
+
+
+def _wavelet_name(transform, wavelet):
+    """Wavelet of a ``partial(pywt.wavedec2, wavelet=..., mode='smooth')`` transform (cube_POCS_interpolation_3D.py:261-264)."""
+    kw = getattr(transform, 'keywords', None) or {}
+    if wavelet is None:
+        wavelet = kw.get('wavelet', 'coif5')
+    mode = kw.get('mode', 'smooth')
+    if mode != 'smooth':
+        raise NotImplementedError(f"wavelet signal extension mode {mode!r}: only 'smooth' (the workflow's) is implemented")
+    return getattr(wavelet, 'name', wavelet)  # pywt.Wavelet objects carry .name
+
+
+def _wavelet_schedule_from_stats(stats, thresh_model, niter, p_max, p_min, kind):
+    """stats (n, nlev, 3, 4) from ``p3d_wavelet_stats`` -> tau (n, niter, nlev, 3)."""
+    peak = stats[..., 0] + 1j * stats[..., 1]
+    if not np.any(stats[..., 1]):
+        peak = peak.real
+    tau = _schedule(thresh_model, niter, p_max, p_min, kind, peak, stats[..., 2], stats[..., 3], None, None, 'WAVELET')
+    tau = np.asarray(tau)
+    if tau.ndim == 4:
+        return np.moveaxis(tau, -1, 1)
+    return np.broadcast_to(np.reshape(tau, (1, niter, 1, 1)), (stats.shape[0], niter) + stats.shape[1:3])
 
 
 def _check_common(mask, transform_kind, thresh_op):
@@ -216,6 +264,7 @@ def pocs_cube(
     results=None,
     device=0,
     batch_slices=None,
+    wavelet=None,
     **ignored,
 ):
     """
@@ -251,15 +300,29 @@ def pocs_cube(
     if niter < 1:  # the reference's loop body never runs and it then fails on `iiter`; be explicit
         raise ValueError('niter must be >= 1')
     step = int(batch_slices) if batch_slices else nslices
-    plan = _get_plan(nil, nxl, min(step, nslices), device)
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
+    if kind == 'WAVELET':
+        if thresh_op not in _WAVELET_OPS:  # threshold_wavelet (POCS.py:105-166) has no percentile variants
+            raise NotImplementedError(f'thresh_op {thresh_op!r} is not available for the WAVELET transform')
+        if decay_kind == 'factors' and not all(s in thresh_model for s in ['inverse', 'proportional']):
+            # the reference builds a (niter, 1, 1) schedule here and threshold_wavelet (POCS.py:135-166) then indexes it per
+            # level and detail: it fails for every decomposition; keep the failure instead of inventing a behaviour
+            raise IndexError('list index out of range (decay_kind="factors" yields one tau per iteration, the WAVELET '
+                             'thresholding needs one per level and detail)')
+        plan = _get_wavelet_plan(nil, nxl, min(step, nslices), _wavelet_name(ignored.get('transform'), wavelet), device)
+    else:
+        plan = _get_plan(nil, nxl, min(step, nslices), device)
 
     for lo in range(0, nslices, step):
         chunk = cube[lo:lo + step]
         n = chunk.shape[0]
         active = chunk.reshape(n, -1).any(axis=1)  # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         t0 = time.perf_counter()
-        if thresh_model == 'data-driven':
+        if kind == 'WAVELET':
+            stats = plan.stats(chunk)
+            stats[~active] = 1.0
+            tau = _wavelet_schedule_from_stats(stats, thresh_model, niter, p_max, p_min, decay_kind)
+        elif thresh_model == 'data-driven':
             X0 = plan.fft2(chunk.astype(np.complex64))
             tau = np.zeros((n, niter), np.complex128)
             for s in np.flatnonzero(active):
@@ -321,8 +384,9 @@ def POCS_algorithm(
     ``niterations`` / ``runtime`` / ``cost``; one ``niter;runtime;cost_1;..`` line appended to
     ``path_results``; POCS.py:644-651) and return value (complex in -> complex out, real in -> real
     part; POCS.py:653-656) follow the reference.  Differences: ``transform`` / ``itransform`` must be
-    supplied but are not called (the transform is chosen by ``transform_kind``; only ``'FFT'`` is
-    implemented so far), and arithmetic is float32 on the GPU.
+    supplied but are not called (the transform is chosen by ``transform_kind``: ``'FFT'``, or ``'WAVELET'`` with the
+    wavelet name read from ``transform.keywords['wavelet']`` as set up by the step-13 driver), and arithmetic is float32 on
+    the GPU.
     """
     if np.max(mask) > 1:
         raise ValueError(f'mask should be quasi-boolean (0 or 1) but has maximum of {np.max(mask)}')
@@ -341,7 +405,7 @@ def POCS_algorithm(
     out = pocs_cube(
         x[None], mask, transform_kind=transform_kind, niter=niter, thresh_op=thresh_op,
         thresh_model=thresh_model, eps=eps, alpha=alpha, p_max=p_max, p_min=p_min, sqrt_decay=sqrt_decay,
-        decay_kind=decay_kind, version=version, results=results,
+        decay_kind=decay_kind, version=version, results=results, transform=transform, itransform=itransform,
     )[0]
     info = results[0]
 

@@ -91,7 +91,11 @@ def test_error_contract_matches_reference():
     assert str(e.value) == tab["shearlet_no_psi"][1]
     # options the HIP build does not cover yet fail loudly instead of falling back to the CPU
     with pytest.raises(NotImplementedError):
-        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET")
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="CURVELET")
+    with pytest.raises(NotImplementedError):
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET", thresh_op="soft-percentile")
+    with pytest.raises(IndexError):  # the reference's threshold_wavelet indexes a (1, 1) tau per level (POCS.py:135-166)
+        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET", decay_kind="factors")
     with pytest.raises(ValueError):
         P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="FFT", thresh_op="median")
 
