@@ -7,8 +7,8 @@ into ``POCS_algorithm``; ``n_workers / processes / threads_per_worker / memory_l
 dask ``LocalCluster`` slice farm (:291-340) is replaced by whole batches of slices on the GPU), same mask rule
 ``fold <= 1 ? fold : 1`` (:242-244), same output naming (:146-157, :223-228), ``.real`` / ``.imag`` split (:160-164),
 per-batch ``slice-XXXX-YYYY.out`` runtime files merged into ``runtimes_<prefix>.txt`` (:177-195), same attributes
-(:346-367).  Cubes are ``.npz`` files (cube_io.py) or netCDF when xarray is installed.  Only ``transform_kind: FFT`` is
-implemented by the HIP kernels so far.
+(:346-367).  Cubes are ``.npz`` files (cube_io.py) or netCDF when xarray is installed.  ``transform_kind``: FFT or WAVELET (with the ``wavelet`` key, default
+coif5, :261); the other kinds raise as the reference does when their third-party package is missing (:287-288).
 """
 import argparse
 import datetime
@@ -111,10 +111,18 @@ def main(argv=sys.argv, return_dataset=False):
     with open(os.path.join(out_path, f'parameter_{prefix}.yml'), mode='w', newline='\n') as f:
         yaml.safe_dump(metadata, f)
 
-    if TRANSFORM != 'FFT':
+    # the GPU path selects the transform by `transform_kind` (+ `wavelet`); the callables are kept for signature compatibility
+    if TRANSFORM == 'FFT':
+        metadata['transform'] = np.fft.fft2
+        metadata['itransform'] = np.fft.ifft2
+    elif TRANSFORM == 'WAVELET':                             # cube_POCS_interpolation_3D.py:260-266
+        wavelet = metadata.get('wavelet', 'coif5')
+        wavelet_mode = 'smooth'
+        metadata['wavelet'] = wavelet
+        metadata['transform'] = metadata['itransform'] = None
+        prefix += f'_{wavelet}-{wavelet_mode}'
+    else:
         raise ValueError(f'Transform < {metadata["transform_kind"]} > is not supported.')
-    metadata['transform'] = np.fft.fft2      # kept for signature compatibility; the GPU path selects by transform_kind
-    metadata['itransform'] = np.fft.ifft2
 
     coord = np.asarray(cube.coords[dim])
     step = int(cfg['batch_chunk'])

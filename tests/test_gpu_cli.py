@@ -97,3 +97,37 @@ def test_fft_pocs_ifft_pipeline(tmp_path):
     assert np.abs(y[:, ~obs]).max() > 0.05 * np.abs(x).max()
     assert rel_l2(y[:, obs], x[:, obs]) < 1e-4
     release_plans()
+
+
+def test_wavelet_step13_time_domain(tmp_path):
+    """transform_kind: wavelet on a time-domain cube (BASELINE configs[3] in miniature): file naming with the
+    `_{wavelet}-smooth` suffix (cube_POCS_interpolation_3D.py:266) and results against the wavelet oracle."""
+    from oracle import wavelet_oracle as wo
+    from pseudo_3d_interpolation_amd import cube_POCS_interpolation_3D as step13
+    from pseudo_3d_interpolation_amd.cube_io import Cube, open_cube, save_cube
+
+    nt, nil, nxl, dt = 12, 48, 64, 0.05
+    x, fold = _time_cube(nt, nil, nxl, 0.4, seed=5)
+    cube = Cube({'env': x, 'fold': fold}, {'env': ('twt', 'iline', 'xline'), 'fold': ('iline', 'xline')},
+                {'twt': dt * np.arange(nt), 'iline': np.arange(nil), 'xline': np.arange(nxl)},
+                {'long_name': 'test cube', 'description': 'synthetic', 'history': 'made;', 'text': ''}, {}, {'twt': {'units': 'ms'}})
+    path = save_cube(cube, str(tmp_path / 'cube_twt.npz'))
+    metadata = dict(transform_kind='wavelet', wavelet='db4', niter=8, eps=0, thresh_op='soft', thresh_model='linear',
+                    decay_kind='values', p_max=0.9, p_min=0.05, alpha=1.0, sqrt_decay=False, version='regular', verbose=False)
+    pocs_yml = tmp_path / 'pocs.yml'
+    pocs_yml.write_text(yaml.safe_dump({'dim': 'twt', 'var': 'env', 'batch_chunk': 5, 'n_workers': 1, 'processes': True,
+                                        'threads_per_worker': 1, 'memory_limit': '2GB', 'output_runtime_results': False,
+                                        'metadata': metadata}))
+    step13.main(['13_cube_interpolate_POCS', path, '--path_pocs_parameter', str(pocs_yml)])
+    prefix = 'cube_twt_WAVELET_soft_niter-8'
+    out_dir = tmp_path / prefix                                         # directory: name before the suffix is appended (:223-228)
+    files = sorted(p for p in os.listdir(out_dir) if p.endswith('.npz'))
+    assert len(files) == 3 and all(p.startswith(prefix + '_db4-smooth_') for p in files)
+    icube = open_cube(str(tmp_path / f'{prefix}.npz'))
+    Y = icube.data_vars['env_interp']
+    assert Y.dtype == np.float32 and 'WAVELET (time domain)' in icube.attrs['history']
+    mask = np.where(fold <= 1, fold, 1)
+    params = {k: v for k, v in metadata.items() if k not in ('verbose', 'transform_kind')}
+    want = wo.pocs_cube_wavelet(x.astype(np.float64), mask, **params)
+    for s in range(nt):
+        assert rel_l2(Y[s], want[s]) < 1e-5, s
