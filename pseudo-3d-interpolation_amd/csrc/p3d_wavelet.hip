@@ -36,78 +36,29 @@ struct Filters {
     int len;
 };
 
+// ---- arithmetic shared by the real (float) and complex (c32) instantiations ------------------------------------------------------
 __device__ __forceinline__ c32 cmulf(c32 a, float s) { return c32{a.x * s, a.y * s}; }
+__device__ __forceinline__ float cmulf(float a, float s) { return a * s; }
+__device__ __forceinline__ void acc_tap(c32& acc, float f, c32 v) { acc.x += f * v.x; acc.y += f * v.y; }
+__device__ __forceinline__ void acc_tap(float& acc, float f, float v) { acc += f * v; }
+__device__ __forceinline__ float mag(c32 v) { return sqrtf(v.x * v.x + v.y * v.y); }
+__device__ __forceinline__ float mag(float v) { return fabsf(v); }
+template <typename T> __device__ __forceinline__ T zero_of() { return T{}; }
+// straight line through the edge pair (e = edge sample, f = its neighbour), t samples beyond the edge
+__device__ __forceinline__ c32 extrapolate(c32 e, c32 f, float t) { return c32{e.x + (e.x - f.x) * t, e.y + (e.y - f.y) * t}; }
+__device__ __forceinline__ float extrapolate(float e, float f, float t) { return e + (e - f) * t; }
 
-// sample k of a line of n samples at stride `st`, extended by straight lines through the edge pairs
-__device__ __forceinline__ c32 smooth_at(const c32* line, int n, size_t st, int k)
+// sample k of a line of n samples at stride `st`, extended by straight lines through the edge pairs ('smooth')
+template <typename T>
+__device__ __forceinline__ T smooth_at(const T* line, int n, size_t st, int k)
 {
     if (k >= 0 && k < n) return line[(size_t)k * st];
     if (n == 1) return line[0];
-    if (k < 0) {
-        const c32 e = line[0], f = line[st];
-        const float t = (float)(-k);
-        return c32{e.x + (e.x - f.x) * t, e.y + (e.y - f.y) * t};
-    }
-    const c32 e = line[(size_t)(n - 1) * st], f = line[(size_t)(n - 2) * st];
-    const float t = (float)(k - n + 1);
-    return c32{e.x + (e.x - f.x) * t, e.y + (e.y - f.y) * t};
+    if (k < 0) return extrapolate(line[0], line[st], (float)(-k));
+    return extrapolate(line[(size_t)(n - 1) * st], line[(size_t)(n - 2) * st], (float)(k - n + 1));
 }
 
-// forward step along one axis of a batch of 2-D arrays.
-//   in : [slice][nlines x n] with element (line, k) at line*lin_st + k*el_st (+ slice*in_slice)
-//   lo/hi: same addressing with n -> nout (+ slice*out_slice)
-__global__ void dwt_axis_kernel(const c32* in, c32* lo, c32* hi, Filters f, int nlines, int n, int nout, size_t in_lin, size_t in_el,
-                                size_t in_slice, size_t out_lin, size_t out_el, size_t lo_slice, size_t hi_slice)
-{
-    const int s = blockIdx.y;
-    const size_t total = (size_t)nlines * nout;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // neighbouring threads walk along the contiguous direction of the data
-        int line, o;
-        if (in_el == 1) { line = (int)(i / nout); o = (int)(i - (size_t)line * nout); }
-        else { o = (int)(i / nlines); line = (int)(i - (size_t)o * nlines); }
-        const c32* src = in + (size_t)s * in_slice + (size_t)line * in_lin;
-        c32 a{0.f, 0.f}, d{0.f, 0.f};
-        for (int j = 0; j < f.len; ++j) {
-            const c32 v = smooth_at(src, n, in_el, 2 * o + 1 - j);
-            a.x += f.dec_lo[j] * v.x; a.y += f.dec_lo[j] * v.y;
-            d.x += f.dec_hi[j] * v.x; d.y += f.dec_hi[j] * v.y;
-        }
-        const size_t dst = (size_t)line * out_lin + (size_t)o * out_el;
-        lo[(size_t)s * lo_slice + dst] = a;
-        hi[(size_t)s * hi_slice + dst] = d;
-    }
-}
-
-// inverse step along one axis: a, d hold n valid samples per line (their buffers may be longer: trimmed approximation)
-__global__ void idwt_axis_kernel(const c32* a, const c32* d, c32* out, Filters f, int nlines, int n, int nout, size_t a_lin, size_t a_el,
-                                 size_t a_slice, size_t d_lin, size_t d_el, size_t d_slice, size_t out_lin, size_t out_el, size_t out_slice)
-{
-    const int s = blockIdx.y;
-    const size_t total = (size_t)nlines * nout;
-    const int L = f.len;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int line, m;
-        if (out_el == 1) { line = (int)(i / nout); m = (int)(i - (size_t)line * nout); }
-        else { m = (int)(i / nlines); line = (int)(i - (size_t)m * nlines); }
-        const c32* pa = a + (size_t)s * a_slice + (size_t)line * a_lin;
-        const c32* pd = d + (size_t)s * d_slice + (size_t)line * d_lin;
-        // taps j = m + L - 2 - 2k in [0, L): k from ceil((m - 1) / 2) to floor((m + L - 2) / 2)
-        int k0 = (m - 1 + 1) / 2;  // ceil((m-1)/2) for m >= 0 (m = 0 -> 0)
-        if (m == 0) k0 = 0;
-        int k1 = (m + L - 2) / 2;
-        if (k1 > n - 1) k1 = n - 1;
-        c32 acc{0.f, 0.f};
-        for (int k = k0; k <= k1; ++k) {
-            const int j = m + L - 2 - 2 * k;
-            const c32 va = pa[(size_t)k * a_el], vd = pd[(size_t)k * d_el];
-            acc.x += f.rec_lo[j] * va.x + f.rec_hi[j] * vd.x;
-            acc.y += f.rec_lo[j] * va.y + f.rec_hi[j] * vd.y;
-        }
-        out[(size_t)s * out_slice + (size_t)line * out_lin + (size_t)m * out_el] = acc;
-    }
-}
-
+// threshold operators of threshold_operator.py with NumPy's complex-tau semantics (see p3d_kernels.hpp: shrink)
 __device__ inline c32 wshrink(c32 X, c32 tau, int op)
 {
     const float m = sqrtf(X.x * X.x + X.y * X.y);
@@ -129,29 +80,110 @@ __device__ inline c32 wshrink(c32 X, c32 tau, int op)
     const bool keep = (gr > 0.0f) || (gr == 0.0f && gi >= 0.0f);
     return keep ? X * c32{gr, gi} : c32{0.f, 0.f};
 }
-
-// details of one level: coef + off + z*count (z = 0..2); tau[((s*niter + iter)*nlev + lvl)*3 + z]
-__global__ void wthreshold_kernel(c32* coef, size_t coef_slice, size_t off, size_t count, const c32* tau, int niter, int iter, int nlev, int lvl,
-                                  int op, const int* done)
+// real data: only used with real tau (the host side switches to the complex instantiation otherwise)
+__device__ inline float wshrink(float x, c32 tau, int op)
 {
-    const int s = blockIdx.y, z = blockIdx.z;
-    if (done && done[s] != 0) return;
-    const c32 t = tau[(((size_t)s * niter + iter) * nlev + lvl) * 3 + z];
-    c32* p = coef + (size_t)s * coef_slice + off + (size_t)z * count;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) p[i] = wshrink(p[i], t, op);
+    const float m = fabsf(x);
+    if (op == 0) return m < tau.x ? 0.f : x;
+    if (m == 0.0f) return 0.f;
+    const float g = op == 1 ? 1.0f - tau.x / m : 1.0f - (tau.x * tau.x) / (m * m);
+    return g > 0.0f ? x * g : 0.f;
+}
+
+// thresholds fused into the last analysis step of a level: z < 0 = leave that output alone (approximation / statistics pass)
+struct Thresh {
+    const c32* tau;  // [slice][niter][nlev][3]
+    int niter, iter, nlev, lvl, op, z_lo, z_hi;
+};
+
+// forward step along one axis of a batch of 2-D arrays.
+//   in : [slice][nlines x n] with element (line, k) at line*in_lin + k*in_el (+ slice*in_slice)
+//   lo/hi: same addressing with n -> nout (+ slice*lo_slice / hi_slice)
+template <typename T>
+__global__ void dwt_axis_kernel(const T* in, T* lo, T* hi, Filters f, int nlines, int n, int nout, size_t in_lin, size_t in_el, size_t in_slice,
+                                size_t out_lin, size_t out_el, size_t lo_slice, size_t hi_slice, Thresh th)
+{
+    const int s = blockIdx.y;
+    const size_t total = (size_t)nlines * nout;
+    const int L = f.len;
+    c32 t_lo{0.f, 0.f}, t_hi{0.f, 0.f};
+    if (th.z_lo >= 0) t_lo = th.tau[(((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3 + th.z_lo];
+    if (th.z_hi >= 0) t_hi = th.tau[(((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3 + th.z_hi];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // neighbouring threads walk along the contiguous direction of the data
+        int line, o;
+        if (in_el == 1) { line = (int)(i / nout); o = (int)(i - (size_t)line * nout); }
+        else { o = (int)(i / nlines); line = (int)(i - (size_t)o * nlines); }
+        const T* src = in + (size_t)s * in_slice + (size_t)line * in_lin;
+        T a = zero_of<T>(), d = zero_of<T>();
+        const int top = 2 * o + 1;
+        if (top - (L - 1) >= 0 && top < n) {  // interior: no extension
+            const T* q = src + (size_t)top * in_el;
+            for (int j = 0; j < L; ++j) {
+                const T v = q[-(ptrdiff_t)((size_t)j * in_el)];
+                acc_tap(a, f.dec_lo[j], v);
+                acc_tap(d, f.dec_hi[j], v);
+            }
+        } else {
+            for (int j = 0; j < L; ++j) {
+                const T v = smooth_at(src, n, in_el, top - j);
+                acc_tap(a, f.dec_lo[j], v);
+                acc_tap(d, f.dec_hi[j], v);
+            }
+        }
+        if (th.z_lo >= 0) a = wshrink(a, t_lo, th.op);
+        if (th.z_hi >= 0) d = wshrink(d, t_hi, th.op);
+        const size_t dst = (size_t)line * out_lin + (size_t)o * out_el;
+        lo[(size_t)s * lo_slice + dst] = a;
+        hi[(size_t)s * hi_slice + dst] = d;
+    }
+}
+
+// inverse step along one axis: a, d hold n valid samples per line (their buffers may be longer: trimmed approximation)
+template <typename T>
+__global__ void idwt_axis_kernel(const T* a, const T* d, T* out, Filters f, int nlines, int n, int nout, size_t a_lin, size_t a_el, size_t a_slice,
+                                 size_t d_lin, size_t d_el, size_t d_slice, size_t out_lin, size_t out_el, size_t out_slice)
+{
+    const int s = blockIdx.y;
+    const size_t total = (size_t)nlines * nout;
+    const int L = f.len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int line, m;
+        if (out_el == 1) { line = (int)(i / nout); m = (int)(i - (size_t)line * nout); }
+        else { m = (int)(i / nlines); line = (int)(i - (size_t)m * nlines); }
+        const T* pa = a + (size_t)s * a_slice + (size_t)line * a_lin;
+        const T* pd = d + (size_t)s * d_slice + (size_t)line * d_lin;
+        // taps j = m + L - 2 - 2k in [0, L): k from ceil((m - 1) / 2) = floor(m / 2) to floor((m + L - 2) / 2)
+        const int k0 = m / 2;
+        int k1 = (m + L - 2) / 2;
+        if (k1 > n - 1) k1 = n - 1;
+        T acc = zero_of<T>();
+        for (int k = k0; k <= k1; ++k) {
+            const int j = m + L - 2 - 2 * k;
+            acc_tap(acc, f.rec_lo[j], pa[(size_t)k * a_el]);
+            acc_tap(acc, f.rec_hi[j], pd[(size_t)k * d_el]);
+        }
+        out[(size_t)s * out_slice + (size_t)line * out_lin + (size_t)m * out_el] = acc;
+    }
 }
 
 // per (slice, level, detail): lexicographic max, max |d|, min |d| -> stats[((s*nlev + lvl)*3 + z)*4 ..]; one block each
-__global__ void wstats_kernel(const c32* coef, size_t coef_slice, size_t off, size_t count, float* stats, int nlev, int lvl)
+__device__ __forceinline__ float re_of(c32 v) { return v.x; }
+__device__ __forceinline__ float im_of(c32 v) { return v.y; }
+__device__ __forceinline__ float re_of(float v) { return v; }
+__device__ __forceinline__ float im_of(float) { return 0.f; }
+
+template <typename T>
+__global__ void wstats_kernel(const T* coef, size_t coef_slice, size_t off, size_t count, float* stats, int nlev, int lvl)
 {
     __shared__ float sh[256 * 4];
     const int s = blockIdx.y, z = blockIdx.z;
-    const c32* p = coef + (size_t)s * coef_slice + off + (size_t)z * count;
+    const T* p = coef + (size_t)s * coef_slice + off + (size_t)z * count;
     float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY;
     for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const c32 v = p[i];
-        const float q = v.x * v.x + v.y * v.y;
-        if (v.x > lr || (v.x == lr && v.y > li)) { lr = v.x; li = v.y; }
+        const T v = p[i];
+        const float vr = re_of(v), vi = im_of(v), q = mag(v);
+        if (vr > lr || (vr == lr && vi > li)) { lr = vr; li = vi; }
         mx = fmaxf(mx, q);
         mn = fminf(mn, q);
     }
@@ -166,47 +198,54 @@ __global__ void wstats_kernel(const c32* coef, size_t coef_slice, size_t off, si
             mn = fminf(mn, o[3]);
         }
         float* q = stats + (((size_t)s * nlev + lvl) * 3 + z) * 4;
-        q[0] = lr; q[1] = li; q[2] = sqrtf(mx); q[3] = sqrtf(mn);
+        q[0] = lr; q[1] = li; q[2] = mx; q[3] = mn;
     }
 }
 
+__device__ __forceinline__ c32 load_x(const void* x, int dtype, size_t g, c32*)
+{
+    return dtype == 0 ? reinterpret_cast<const c32*>(x)[g] : c32{reinterpret_cast<const float*>(x)[g], 0.f};
+}
+__device__ __forceinline__ float load_x(const void* x, int, size_t g, float*) { return reinterpret_cast<const float*>(x)[g]; }
+__device__ __forceinline__ void store_out(void* out, int dtype, size_t g, c32 v)
+{
+    if (dtype == 0) reinterpret_cast<c32*>(out)[g] = v;
+    else reinterpret_cast<float*>(out)[g] = v.x;
+}
+__device__ __forceinline__ void store_out(void* out, int, size_t g, float v) { reinterpret_cast<float*>(out)[g] = v; }
+
 // mode 0: first input (feed = x or its APOCS mix; sums += |x|)
 // mode 1: crop of the reconstruction + re-insertion (POCS.py:609, 616-619), sums += |x_new|, feed for the next iteration
-__global__ void wupdate_kernel(const c32* rec, size_t rec_ld, size_t rec_slice, c32* feed, const void* x, int dtype, const float* mask, void* out,
-                               double* sums, int mode, int adaptive, int write_out, float alpha, int n1, int n2, const int* done, int zero_fill)
+// T = element type of the work buffers (float requires dtype == P3D_F32)
+template <typename T>
+__global__ void wupdate_kernel(const T* rec, size_t rec_ld, size_t rec_slice, T* feed, const void* x, int dtype, const float* mask, void* out, double* sums,
+                               int mode, int adaptive, int write_out, float alpha, int n1, int n2, const int* done, int zero_fill)
 {
     __shared__ double sh[256];
     const int s = blockIdx.y;
     const size_t per = (size_t)n1 * n2;
     const int dn = done ? done[s] : 0;
     if (zero_fill && dn < 0)
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
-            if (dtype == 0) reinterpret_cast<c32*>(out)[(size_t)s * per + i] = c32{0.f, 0.f};
-            else reinterpret_cast<float*>(out)[(size_t)s * per + i] = 0.f;
-        }
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x)
+            store_out(out, dtype, (size_t)s * per + i, zero_of<T>());
     double acc = 0.0;
     if (dn == 0) {
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
             const size_t g = (size_t)s * per + i;
             const int r = (int)(i / n2), c = (int)(i - (size_t)r * n2);
-            c32 xo;
-            if (dtype == 0) xo = reinterpret_cast<const c32*>(x)[g];
-            else xo = c32{reinterpret_cast<const float*>(x)[g], 0.f};
+            const T xo = load_x(x, dtype, g, (T*)nullptr);
             const float m = mask ? mask[i] : 0.f;
             const float wgt = 1.0f - alpha * m;
-            c32 xn;
+            T xn;
             if (mode == 0) {
                 xn = xo;
             } else {
-                xn = p3d::axpby(rec[(size_t)s * rec_slice + (size_t)r * rec_ld + c], wgt, xo, alpha);
-                if (write_out) {
-                    if (dtype == 0) reinterpret_cast<c32*>(out)[g] = xn;
-                    else reinterpret_cast<float*>(out)[g] = xn.x;
-                }
+                xn = cmulf(rec[(size_t)s * rec_slice + (size_t)r * rec_ld + c], wgt) + cmulf(xo, alpha);
+                if (write_out) store_out(out, dtype, g, xn);
             }
-            acc += (double)sqrtf(xn.x * xn.x + xn.y * xn.y);
+            acc += (double)mag(xn);
             if (adaptive) {
-                const c32 blend = cmulf(xo, alpha) + cmulf(xn, wgt);
+                const T blend = cmulf(xo, alpha) + cmulf(xn, wgt);
                 feed[g] = blend + cmulf(xo - cmulf(xn, m), 1.0f - alpha);
             } else {
                 feed[g] = xn;
@@ -366,53 +405,69 @@ extern "C" int p3d_wavelet_info(p3d_wplan* p, int* nlev, int64_t* ncoef, int32_t
 }
 
 // ---- transforms on device buffers ------------------------------------------------------------------------------------------
-// feed (nil x nxl per slice) -> coefficient vectors (cA, details coarse -> fine)
-static int w_forward(p3d_wplan* p, int ns)
+// The work buffers are allocated for complex64; the real instantiation (float32 cubes with real thresholds: half the bytes)
+// uses the same buffers with the same element counts.
+template <typename T> static T* as(c32* p) { return reinterpret_cast<T*>(p); }
+
+// feed (nil x nxl per slice) -> coefficient vectors (cA, details coarse -> fine).  With `th` (tau != nullptr) the details are
+// thresholded as they are produced (threshold_wavelet, POCS.py:105-166) -- the approximation is never touched (POCS.py:586-587).
+template <typename T>
+static int w_forward(p3d_wplan* p, int ns, const Thresh* th)
 {
     const dim3 blk(256);
+    const Thresh none{nullptr, 0, 0, 0, 0, 0, -1, -1};
+    T *lo = as<T>(p->lo), *hi = as<T>(p->hi), *coef = as<T>(p->coef);
     for (int l = 1; l <= p->nlev; ++l) {
-        const c32* src = l == 1 ? p->feed : p->approx[l - 1];
+        const T* src = l == 1 ? as<T>(p->feed) : as<T>(p->approx[l - 1]);
         const int H = p->h[l - 1], W = p->w[l - 1], Ho = p->h[l], Wo = p->w[l];
         const size_t cnt = (size_t)Ho * Wo;
         // along axis 1 (rows are contiguous): (H x W) -> lo, hi (H x Wo)
-        dwt_axis_kernel<<<dim3(blocks_for((size_t)H * Wo), ns), blk, 0, p->stream>>>(src, p->lo, p->hi, p->f, H, W, Wo, (size_t)W, 1, (size_t)H * W,
-                                                                                 (size_t)Wo, 1, (size_t)H * Wo, (size_t)H * Wo);
+        dwt_axis_kernel<T><<<dim3(blocks_for((size_t)H * Wo), ns), blk, 0, p->stream>>>(src, lo, hi, p->f, H, W, Wo, (size_t)W, 1, (size_t)H * W, (size_t)Wo, 1,
+                                                                                    (size_t)H * Wo, (size_t)H * Wo, none);
         // along axis 0 (lines = columns): lo -> (aa, da = cH), hi -> (ad = cV, dd = cD), each (Ho x Wo)
-        c32* cA = l == p->nlev ? p->coef : p->approx[l];
+        T* cA = l == p->nlev ? coef : as<T>(p->approx[l]);
         const size_t cA_slice = l == p->nlev ? p->ncoef : cnt;
-        c32* det = p->coef + p->doff[l];
-        dwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * Ho), ns), blk, 0, p->stream>>>(p->lo, cA, det, p->f, Wo, H, Ho, 1, (size_t)Wo, (size_t)H * Wo, 1,
-                                                                                  (size_t)Wo, cA_slice, p->ncoef);
-        dwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * Ho), ns), blk, 0, p->stream>>>(p->hi, det + cnt, det + 2 * cnt, p->f, Wo, H, Ho, 1, (size_t)Wo,
-                                                                                  (size_t)H * Wo, 1, (size_t)Wo, p->ncoef, p->ncoef);
+        T* det = coef + p->doff[l];
+        Thresh t1 = none, t2 = none;
+        if (th) {
+            t1 = t2 = *th;
+            t1.lvl = t2.lvl = p->nlev - l;  // PyWavelets' order: coarsest level first
+            t1.z_lo = -1; t1.z_hi = 0;
+            t2.z_lo = 1; t2.z_hi = 2;
+        }
+        dwt_axis_kernel<T><<<dim3(blocks_for((size_t)Wo * Ho), ns), blk, 0, p->stream>>>(lo, cA, det, p->f, Wo, H, Ho, 1, (size_t)Wo, (size_t)H * Wo, 1, (size_t)Wo,
+                                                                                     cA_slice, p->ncoef, t1);
+        dwt_axis_kernel<T><<<dim3(blocks_for((size_t)Wo * Ho), ns), blk, 0, p->stream>>>(hi, det + cnt, det + 2 * cnt, p->f, Wo, H, Ho, 1, (size_t)Wo, (size_t)H * Wo,
+                                                                                     1, (size_t)Wo, p->ncoef, p->ncoef, t2);
     }
     W_TRY(hipGetLastError());
     return P3D_OK;
 }
 
 // coefficient vectors -> rec[0] (rh[0] x rw[0] per slice; its top-left nil x nxl block is the slice)
+template <typename T>
 static int w_inverse(p3d_wplan* p, int ns)
 {
     const dim3 blk(256);
+    T *lo = as<T>(p->lo), *hi = as<T>(p->hi), *coef = as<T>(p->coef);
     for (int l = p->nlev; l >= 1; --l) {
-        const int Ho = p->h[l], Wo = p->w[l];          // valid extent of the level-l arrays
+        const int Ho = p->h[l], Wo = p->w[l];            // valid extent of the level-l arrays
         const int RH = p->rh[l - 1], RW = p->rw[l - 1];  // shape of the reconstruction of level l-1
         const size_t cnt = (size_t)Ho * Wo;
         // approximation of level l: cA itself at the coarsest level, otherwise the reconstruction of level l (which may be one
         // row / column larger than Ho x Wo: the extra samples are ignored, as in pywt.waverec2)
-        const c32* a = l == p->nlev ? p->coef : p->rec[l];
+        const T* a = l == p->nlev ? coef : as<T>(p->rec[l]);
         const size_t a_ld = l == p->nlev ? (size_t)Wo : (size_t)p->rw[l];
         const size_t a_slice = l == p->nlev ? p->ncoef : (size_t)p->rh[l] * p->rw[l];
-        const c32* det = p->coef + p->doff[l];
+        const T* det = coef + p->doff[l];
         // undo axis 0: (a, cH) -> lo (RH x Wo);  (cV, cD) -> hi (RH x Wo)
-        idwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * RH), ns), blk, 0, p->stream>>>(a, det, p->lo, p->f, Wo, Ho, RH, 1, a_ld, a_slice, 1, (size_t)Wo,
-                                                                                   p->ncoef, 1, (size_t)Wo, (size_t)RH * Wo);
-        idwt_axis_kernel<<<dim3(blocks_for((size_t)Wo * RH), ns), blk, 0, p->stream>>>(det + cnt, det + 2 * cnt, p->hi, p->f, Wo, Ho, RH, 1, (size_t)Wo,
-                                                                                   p->ncoef, 1, (size_t)Wo, p->ncoef, 1, (size_t)Wo, (size_t)RH * Wo);
+        idwt_axis_kernel<T><<<dim3(blocks_for((size_t)Wo * RH), ns), blk, 0, p->stream>>>(a, det, lo, p->f, Wo, Ho, RH, 1, a_ld, a_slice, 1, (size_t)Wo, p->ncoef, 1,
+                                                                                      (size_t)Wo, (size_t)RH * Wo);
+        idwt_axis_kernel<T><<<dim3(blocks_for((size_t)Wo * RH), ns), blk, 0, p->stream>>>(det + cnt, det + 2 * cnt, hi, p->f, Wo, Ho, RH, 1, (size_t)Wo, p->ncoef, 1,
+                                                                                      (size_t)Wo, p->ncoef, 1, (size_t)Wo, (size_t)RH * Wo);
         // undo axis 1: (lo, hi) (RH x Wo) -> rec[l-1] (RH x RW)
-        idwt_axis_kernel<<<dim3(blocks_for((size_t)RH * RW), ns), blk, 0, p->stream>>>(p->lo, p->hi, p->rec[l - 1], p->f, RH, Wo, RW, (size_t)Wo, 1,
-                                                                                   (size_t)RH * Wo, (size_t)Wo, 1, (size_t)RH * Wo, (size_t)RW, 1,
-                                                                                   (size_t)RH * RW);
+        idwt_axis_kernel<T><<<dim3(blocks_for((size_t)RH * RW), ns), blk, 0, p->stream>>>(lo, hi, as<T>(p->rec[l - 1]), p->f, RH, Wo, RW, (size_t)Wo, 1, (size_t)RH * Wo,
+                                                                                      (size_t)Wo, 1, (size_t)RH * Wo, (size_t)RW, 1, (size_t)RH * RW);
     }
     W_TRY(hipGetLastError());
     return P3D_OK;
@@ -427,6 +482,42 @@ static int w_check(p3d_wplan* p, int nslices, int dtype)
     return P3D_OK;
 }
 
+template <typename T>
+static int w_stats(p3d_wplan* p, int dtype, int nslices)
+{
+    wupdate_kernel<T><<<dim3(blocks_for(p->per()), nslices), 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->st_x, dtype, nullptr, nullptr, p->sums, 0, 0, 0, 1.0f,
+                                                                                p->nil, p->nxl, nullptr, 0);
+    int rc = w_forward<T>(p, nslices, nullptr);
+    if (rc) return rc;
+    for (int l = p->nlev, i = 0; l >= 1; --l, ++i)
+        wstats_kernel<T><<<dim3(1, nslices, 3), 256, 0, p->stream>>>(as<T>(p->coef), p->ncoef, p->doff[l], (size_t)p->h[l] * p->w[l], p->stats, p->nlev, i);
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+template <typename T>
+static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* prm)
+{
+    const int niter = prm->niter;
+    const bool early = prm->eps > 0.0, adaptive = prm->version == P3D_VER_ADAPTIVE;
+    const dim3 ugrid(blocks_for(p->per()) > 256 ? 256 : blocks_for(p->per()), nslices);
+    wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->st_x, dtype, p->mask, p->st_out, p->sums, 0, adaptive ? 1 : 0, 0,
+                                                   (float)prm->alpha, p->nil, p->nxl, p->done, 0);
+    for (int k = 0; k < niter; ++k) {
+        const bool last = k + 1 == niter;
+        const Thresh th{p->tau, niter, k, p->nlev, 0, prm->thresh_op, -1, -1};
+        int rc = w_forward<T>(p, nslices, &th);
+        if (rc) return rc;
+        if ((rc = w_inverse<T>(p, nslices))) return rc;
+        wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->st_x, dtype, p->mask, p->st_out,
+                                                       p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
+                                                       (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
+        if (early) wconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+    }
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
 extern "C" {
 
 // test hooks: multilevel decomposition of complex64 slices into coefficient vectors [nslices][ncoef] and back
@@ -434,8 +525,9 @@ int p3d_wavedec2_c64(p3d_wplan* p, const void* x, void* coef, int nslices)
 {
     int rc = w_check(p, nslices, P3D_C64);
     if (rc) return rc;
+    if (!x || !coef) return wfail(P3D_ERR_INVALID, "NULL buffer");
     W_TRY(hipMemcpy(p->feed, x, sizeof(c32) * p->per() * nslices, hipMemcpyHostToDevice));
-    if ((rc = w_forward(p, nslices))) return rc;
+    if ((rc = w_forward<c32>(p, nslices, nullptr))) return rc;
     W_TRY(hipStreamSynchronize(p->stream));
     W_TRY(hipMemcpy(coef, p->coef, sizeof(c32) * p->ncoef * nslices, hipMemcpyDeviceToHost));
     return P3D_OK;
@@ -445,12 +537,11 @@ int p3d_waverec2_c64(p3d_wplan* p, const void* coef, void* x, int nslices)
 {
     int rc = w_check(p, nslices, P3D_C64);
     if (rc) return rc;
+    if (!x || !coef) return wfail(P3D_ERR_INVALID, "NULL buffer");
     W_TRY(hipMemcpy(p->coef, coef, sizeof(c32) * p->ncoef * nslices, hipMemcpyHostToDevice));
-    if ((rc = w_inverse(p, nslices))) return rc;
+    if ((rc = w_inverse<c32>(p, nslices))) return rc;
     // crop to the slice shape (POCS.py:513, 609)
-    W_TRY(hipMemcpy2DAsync(p->feed, sizeof(c32) * p->nxl, p->rec[0], sizeof(c32) * p->rw[0], sizeof(c32) * p->nxl, (size_t)p->nil, hipMemcpyDeviceToDevice,
-                           p->stream));
-    for (int s = 1; s < nslices; ++s)
+    for (int s = 0; s < nslices; ++s)
         W_TRY(hipMemcpy2DAsync(p->feed + (size_t)s * p->per(), sizeof(c32) * p->nxl, p->rec[0] + (size_t)s * p->rh[0] * p->rw[0], sizeof(c32) * p->rw[0],
                                sizeof(c32) * p->nxl, (size_t)p->nil, hipMemcpyDeviceToDevice, p->stream));
     W_TRY(hipStreamSynchronize(p->stream));
@@ -467,14 +558,14 @@ int p3d_wavelet_stats(p3d_wplan* p, const void* x, int dtype, int nslices, doubl
     if (!x || !stats) return wfail(P3D_ERR_INVALID, "NULL buffer");
     const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
     W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyHostToDevice));
-    if (!p->sums) { W_TRY(hipMalloc((void**)&p->sums, sizeof(double) * 2 * p->max_slices)); p->sums_cap = 2 * (size_t)p->max_slices; }
+    if (p->sums_cap < (size_t)nslices) {
+        if (p->sums) hipFree(p->sums);
+        p->sums = nullptr; p->sums_cap = 0;
+        W_TRY(hipMalloc((void**)&p->sums, sizeof(double) * 2 * p->max_slices));
+        p->sums_cap = 2 * (size_t)p->max_slices;
+    }
     W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nslices, p->stream));
-    wupdate_kernel<<<dim3(blocks_for(p->per()), nslices), 256, 0, p->stream>>>(nullptr, 0, 0, p->feed, p->st_x, dtype, nullptr, nullptr, p->sums, 0, 0, 0, 1.0f,
-                                                                             p->nil, p->nxl, nullptr, 0);
-    if ((rc = w_forward(p, nslices))) return rc;
-    for (int l = p->nlev, i = 0; l >= 1; --l, ++i)
-        wstats_kernel<<<dim3(1, nslices, 3), 256, 0, p->stream>>>(p->coef, p->ncoef, p->doff[l], (size_t)p->h[l] * p->w[l], p->stats, p->nlev, i);
-    W_TRY(hipGetLastError());
+    if ((rc = dtype == P3D_F32 ? w_stats<float>(p, dtype, nslices) : w_stats<c32>(p, dtype, nslices))) return rc;
     std::vector<float> host((size_t)nslices * p->nlev * 12);
     W_TRY(hipMemcpyAsync(host.data(), p->stats, sizeof(float) * host.size(), hipMemcpyDeviceToHost, p->stream));
     W_TRY(hipStreamSynchronize(p->stream));
@@ -493,7 +584,6 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     if (prm->thresh_op < P3D_OP_HARD || prm->thresh_op > P3D_OP_GARROTE)
         return wfail(P3D_ERR_UNSUPPORTED, "thresh_op %d is not implemented for the wavelet transform", prm->thresh_op);
     const int niter = prm->niter;
-    const bool early = prm->eps > 0.0, adaptive = prm->version == P3D_VER_ADAPTIVE;
     const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
     const size_t ntau = (size_t)nslices * niter * p->nlev * 3, nsum = (size_t)(niter + 1) * nslices;
     if (p->tau_cap < ntau) {
@@ -509,7 +599,13 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
         p->sums_cap = nsum;
     }
     std::vector<c32> tau_f(ntau);
-    for (size_t i = 0; i < ntau; ++i) tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+    bool real_tau = true;
+    for (size_t i = 0; i < ntau; ++i) {
+        tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+        real_tau = real_tau && tau[2 * i + 1] == 0.0;
+    }
+    // float32 cubes with real thresholds stay real through the whole loop (what PyWavelets does for real input)
+    const bool real_path = dtype == P3D_F32 && real_tau;
     std::vector<int> done_h(nslices, 0);
     if (active) for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;
     W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyHostToDevice));
@@ -518,24 +614,7 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     W_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
     W_TRY(hipEventRecord(p->ev0, p->stream));
-    const dim3 ugrid(blocks_for(p->per()) > 256 ? 256 : blocks_for(p->per()), nslices);
-    wupdate_kernel<<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, p->feed, p->st_x, dtype, p->mask, p->st_out, p->sums, 0, adaptive ? 1 : 0, 0, (float)prm->alpha,
-                                                p->nil, p->nxl, p->done, 0);
-    for (int k = 0; k < niter; ++k) {
-        const bool last = k + 1 == niter;
-        if ((rc = w_forward(p, nslices))) return rc;
-        for (int l = p->nlev, i = 0; l >= 1; --l, ++i) {
-            const size_t cnt = (size_t)p->h[l] * p->w[l];
-            wthreshold_kernel<<<dim3(blocks_for(cnt) > 64 ? 64 : blocks_for(cnt), nslices, 3), 256, 0, p->stream>>>(p->coef, p->ncoef, p->doff[l], cnt, p->tau, niter,
-                                                                                                                 k, p->nlev, i, prm->thresh_op, p->done);
-        }
-        if ((rc = w_inverse(p, nslices))) return rc;
-        wupdate_kernel<<<ugrid, 256, 0, p->stream>>>(p->rec[0], (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], p->feed, p->st_x, dtype, p->mask, p->st_out,
-                                                    p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
-                                                    (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
-        if (early) wconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
-    }
-    W_TRY(hipGetLastError());
+    if ((rc = real_path ? w_loop<float>(p, dtype, nslices, prm) : w_loop<c32>(p, dtype, nslices, prm))) return rc;
     W_TRY(hipEventRecord(p->ev1, p->stream));
     W_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) W_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
