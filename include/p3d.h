@@ -182,6 +182,25 @@ int p3d_wavelet_run(p3d_wplan* plan, const void* x, int dtype, const float* mask
                     const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
                     double* elapsed_ms);
 
+/* ---- SHEARLET variant (transform_kind = 'SHEARLET') --------------------------------------------------------------------------
+ * Replaces FFST.shearletTransformSpect / inverseShearletTransformSpect (cube_POCS_interpolation_3D.py:269-274; POCS.py:526-527,
+ * 589-590, 610-611) for spectra Psi supplied by the caller (the reference's `auxiliary_data`): ST_s = ifft2(Psi_s * fft2(x)),
+ * x = ifft2(sum_s fft2(ST_s) * Psi_s); per-shearlet thresholds (POCS.py:598 with a (nsh,) tau).  psi: HOST float32
+ * [nsh][nil][nxl], FFT order (what fftshift_spectra=True yields), real.  float32 cubes keep real coefficients. */
+typedef struct p3d_splan p3d_splan;
+int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, int nxl, int nsh, const float* psi, int max_slices);
+int p3d_shearlet_plan_destroy(p3d_splan* plan);
+/* test hooks: x HOST complex64 [nslices][nil][nxl] <-> st HOST complex64 [nslices][nsh][nil][nxl] */
+int p3d_shearlet_transform_c64(p3d_splan* plan, const void* x, void* st, int nslices);
+int p3d_shearlet_inverse_c64(p3d_splan* plan, const void* st, void* x, int nslices);
+/* statistics for the schedule (POCS.py:257-258, 285, 318): stats HOST double [nslices][nsh][5] = (Re, Im of the lexicographic
+ * maximum -- signed maximum for float32 cubes; max |c|; min |c|; sum |c|^2) of each shearlet's coefficients */
+int p3d_shearlet_stats(p3d_splan* plan, const void* x, int dtype, int nslices, double* stats);
+/* the loop (POCS.py:549-632, SHEARLET branches); arguments as p3d_wavelet_run with tau HOST double [nslices][niter][nsh][2] */
+int p3d_shearlet_run(p3d_splan* plan, const void* x, int dtype, const float* mask, const double* tau, const uint8_t* active,
+                     const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
+                     double* elapsed_ms);
+
 #ifdef __cplusplus
 }
 #endif

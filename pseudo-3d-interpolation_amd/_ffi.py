@@ -74,6 +74,13 @@ PROTOTYPES = {
     "p3d_wavelet_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_wavelet_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "p3d_shearlet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "p3d_shearlet_plan_destroy": (C.c_int, [C.c_void_p]),
+    "p3d_shearlet_transform_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "p3d_shearlet_inverse_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "p3d_shearlet_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_shearlet_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 
@@ -383,6 +390,89 @@ class WaveletPlan:
         ms = C.c_double(0.0)
         check(lib().p3d_wavelet_run(self.handle, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act),
                                     C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return out, done, sums, ms.value
+
+# ---- SHEARLET variant ----------------------------------------------------------------------
+class ShearletPlan:
+    """p3d_splan wrapper: frequency-domain shearlet frame with caller-supplied spectra ``psi`` (nil, nxl, nsh) -- the layout of
+    ``FFST.scalesShearsAndSpectra`` -- and the SHEARLET POCS loop for up to ``max_slices`` slices per call."""
+
+    def __init__(self, psi, max_slices=1, device=0):
+        psi = np.asarray(psi)
+        if psi.ndim != 3:
+            raise ValueError(f"Psi must be (nil, nxl, nshearlets), got shape {psi.shape}")
+        if np.iscomplexobj(psi):
+            raise NotImplementedError("complex shearlet spectra (realCoefficients=False) are not implemented")
+        self.nil, self.nxl, self.nsh = (int(v) for v in psi.shape)
+        self.max_slices, self.device = int(max_slices), int(device)
+        dev_psi = np.ascontiguousarray(np.moveaxis(psi, -1, 0), dtype=np.float32)
+        h = C.c_void_p()
+        check(lib().p3d_shearlet_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.nsh, _ptr(dev_psi), self.max_slices))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().p3d_shearlet_plan_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    _cube = Plan._cube
+
+    def transform(self, x):
+        """(…, nil, nxl) -> (…, nil, nxl, nsh) complex64 (the reference's layout: shearlets on the last axis)."""
+        x = np.asarray(x)
+        squeeze = x.ndim == 2
+        xc, _ = self._cube(x.astype(np.complex64, copy=False))
+        st = np.empty((xc.shape[0], self.nsh, self.nil, self.nxl), np.complex64)
+        check(lib().p3d_shearlet_transform_c64(self.handle, _ptr(xc), _ptr(st), xc.shape[0]))
+        st = np.moveaxis(st, 1, -1)
+        return st[0] if squeeze else st
+
+    def inverse(self, st):
+        st = np.asarray(st)
+        squeeze = st.ndim == 3
+        if squeeze:
+            st = st[None]
+        if st.shape[1:] != (self.nil, self.nxl, self.nsh) or st.shape[0] > self.max_slices:
+            raise ValueError(f"expected (<= {self.max_slices}, {self.nil}, {self.nxl}, {self.nsh}), got {st.shape}")
+        dev = np.ascontiguousarray(np.moveaxis(st, -1, 1), dtype=np.complex64)
+        out = np.empty((st.shape[0], self.nil, self.nxl), np.complex64)
+        check(lib().p3d_shearlet_inverse_c64(self.handle, _ptr(dev), _ptr(out), st.shape[0]))
+        return out[0] if squeeze else out
+
+    def stats(self, x):
+        """(nslices, nsh, 5): Re/Im of the lexicographic (real cubes: signed) max, max |c|, min |c|, sum |c|^2 per shearlet."""
+        xc, dt = self._cube(x)
+        st = np.empty((xc.shape[0], self.nsh, 5), np.float64)
+        check(lib().p3d_shearlet_stats(self.handle, _ptr(xc), dt, xc.shape[0], _ptr(st)))
+        return st
+
+    def run(self, x, mask, tau, niter, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """tau: (nslices, niter, nsh) real or complex.  Returns (out, niter_done, sums, elapsed_ms)."""
+        xc, dt = self._cube(x)
+        n = xc.shape[0]
+        m = np.ascontiguousarray(mask, dtype=np.float32)
+        if m.shape != (self.nil, self.nxl):
+            raise ValueError(f"mask shape {m.shape} != {(self.nil, self.nxl)}")
+        tau = np.broadcast_to(np.asarray(tau), (n, niter, self.nsh))
+        t = np.empty(tau.shape + (2,), np.float64)
+        t[..., 0] = tau.real
+        t[..., 1] = tau.imag if np.iscomplexobj(tau) else 0.0
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        out = np.empty_like(xc)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_shearlet_run(self.handle, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act),
+                                     C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return out, done, sums, ms.value
 
 

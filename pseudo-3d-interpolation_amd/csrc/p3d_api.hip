@@ -14,6 +14,7 @@
 
 #include "p3d.h"
 #include "p3d_generic.hpp"
+#include "p3d_internal.hpp"
 #include "p3d_kernels.hpp"
 
 namespace p3d {
@@ -125,7 +126,7 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
-// p3d_wavelet.hip reports through the same thread-local string
+// the other translation units report through the same thread-local string (p3d_internal.hpp)
 namespace p3d { void set_last_error(const char* msg) { g_err = msg; } }
 
 #define HIP_TRY(expr)                                                                              \
@@ -421,18 +422,14 @@ static int reduce_partials(p3d_plan* p, int nslices, double* stats)
     return P3D_OK;
 }
 
-extern "C" {
-
-int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
+static int fft2_enqueue(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
 {
     int rc = check_batch(p, nslices);
     if (rc) return rc;
     if (!in || !out) return fail(P3D_ERR_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(p->device));
     if (p->generic) {
-        if ((rc = gen_fft2(p, (const c32*)in, (c32*)out, nslices, inverse, nullptr))) return rc;
-        HIP_TRY(hipStreamSynchronize(p->stream));
-        return P3D_OK;
+        return gen_fft2(p, (const c32*)in, (c32*)out, nslices, inverse, nullptr);
     }
     if (!inverse) {
         RowArgs r = row_args(p, nslices);
@@ -458,6 +455,20 @@ int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int in
         r.plain = 1;
         HIP_TRY(p->ops_row->row(ROW_LAST, r, p->stream));
     }
+    return P3D_OK;
+}
+
+namespace p3d {
+hipStream_t plan_stream(p3d_plan* plan) { return plan->stream; }
+int fft2_async(p3d_plan* plan, const c32* in, c32* out, int nslices, int inverse) { return fft2_enqueue(plan, in, out, nslices, inverse); }
+}  // namespace p3d
+
+extern "C" {
+
+int p3d_fft2_c64_dev(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
+{
+    int rc = fft2_enqueue(p, in, out, nslices, inverse);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     return P3D_OK;
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "p3d_generic.hpp"
+#include "p3d_shrink.hpp"
 
 namespace p3d {
 
@@ -104,35 +105,13 @@ __global__ void gen_line_fft(const c32* in, c32* out, const c32* tw, GenPlan pl,
 }
 
 // ---- element-wise kernels -----------------------------------------------------------------------------------------
-__device__ inline c32 gen_shrink(c32 X, c32 tau, int op)
-{
-    const float m = sqrtf(X.x * X.x + X.y * X.y);
-    if (op == 0) {
-        const bool below = (m < tau.x) || (m == tau.x && 0.0f < tau.y);
-        return below ? c32{0.f, 0.f} : X;
-    }
-    if (m == 0.0f) return c32{0.f, 0.f};
-    float gr, gi;
-    if (op == 1) {
-        const float r = 1.0f / m;
-        gr = 1.0f - tau.x * r;
-        gi = -tau.y * r;
-    } else {
-        const float r = 1.0f / (m * m);
-        gr = 1.0f - (tau.x * tau.x - tau.y * tau.y) * r;
-        gi = -(2.0f * tau.x * tau.y) * r;
-    }
-    const bool keep = (gr > 0.0f) || (gr == 0.0f && gi >= 0.0f);
-    return keep ? X * c32{gr, gi} : c32{0.f, 0.f};
-}
-
 __global__ void gen_shrink_kernel(c32* w, const c32* tau, int niter, int iter, int op, size_t per_slice, const int* done)
 {
     const int s = blockIdx.y;
     if (done && done[s] != 0) return;
     const c32 t = tau[(size_t)s * niter + iter];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x)
-        w[(size_t)s * per_slice + i] = gen_shrink(w[(size_t)s * per_slice + i], t, op);
+        w[(size_t)s * per_slice + i] = shrink(w[(size_t)s * per_slice + i], t, op);
 }
 
 __device__ inline double block_sum(double v, double* sh)

@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "p3d_fft.hpp"
+#include "p3d_shrink.hpp"
 
 // build-time knobs for experiments (tools/build_variant.sh)
 #ifndef P3D_ROW_THREADS
@@ -169,31 +170,6 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
-}
-
-// ---- thresholding of one coefficient ---------------------------------------------------------
-// tau is complex because the reference scales its schedule with numpy's lexicographic complex
-// max (POCS.py:288); comparisons and clipping against it are lexicographic as well.
-__device__ __forceinline__ c32 shrink(c32 X, c32 tau, int op)
-{
-    const float m = sqrtf(X.x * X.x + X.y * X.y);
-    if (op == 0) {  // hard: where(|X| < tau, 0, X)          threshold_operator.py:110-112
-        const bool below = (m < tau.x) || (m == tau.x && 0.0f < tau.y);
-        return below ? c32{0.f, 0.f} : X;
-    }
-    if (m == 0.0f) return c32{0.f, 0.f};  // 1 - tau/0 = -inf -> clipped to 0
-    float gr, gi;
-    if (op == 1) {  // soft: X * clip(1 - tau/|X|, 0)           threshold_operator.py:36-39
-        const float r = 1.0f / m;
-        gr = 1.0f - tau.x * r;
-        gi = -tau.y * r;
-    } else {        // garrote: X * clip(1 - tau^2/|X|^2, 0)    threshold_operator.py:75-78
-        const float r = 1.0f / (m * m);
-        gr = 1.0f - (tau.x * tau.x - tau.y * tau.y) * r;
-        gi = -(2.0f * tau.x * tau.y) * r;
-    }
-    const bool keep = (gr > 0.0f) || (gr == 0.0f && gi >= 0.0f);  // lexicographic max(g, 0)
-    return keep ? X * c32{gr, gi} : c32{0.f, 0.f};
 }
 
 // =================================================================================================

@@ -23,9 +23,10 @@
 
 #include "p3d.h"
 #include "p3d_fft.hpp"
+#include "p3d_internal.hpp"
+#include "p3d_shrink.hpp"
 
 using p3d::c32;
-namespace p3d { void set_last_error(const char* msg); }  // p3d_api.hip
 
 namespace {
 
@@ -56,38 +57,6 @@ __device__ __forceinline__ T smooth_at(const T* line, int n, size_t st, int k)
     if (n == 1) return line[0];
     if (k < 0) return extrapolate(line[0], line[st], (float)(-k));
     return extrapolate(line[(size_t)(n - 1) * st], line[(size_t)(n - 2) * st], (float)(k - n + 1));
-}
-
-// threshold operators of threshold_operator.py with NumPy's complex-tau semantics (see p3d_kernels.hpp: shrink)
-__device__ inline c32 wshrink(c32 X, c32 tau, int op)
-{
-    const float m = sqrtf(X.x * X.x + X.y * X.y);
-    if (op == 0) {
-        const bool below = (m < tau.x) || (m == tau.x && 0.0f < tau.y);
-        return below ? c32{0.f, 0.f} : X;
-    }
-    if (m == 0.0f) return c32{0.f, 0.f};
-    float gr, gi;
-    if (op == 1) {
-        const float r = 1.0f / m;
-        gr = 1.0f - tau.x * r;
-        gi = -tau.y * r;
-    } else {
-        const float r = 1.0f / (m * m);
-        gr = 1.0f - (tau.x * tau.x - tau.y * tau.y) * r;
-        gi = -(2.0f * tau.x * tau.y) * r;
-    }
-    const bool keep = (gr > 0.0f) || (gr == 0.0f && gi >= 0.0f);
-    return keep ? X * c32{gr, gi} : c32{0.f, 0.f};
-}
-// real data: only used with real tau (the host side switches to the complex instantiation otherwise)
-__device__ inline float wshrink(float x, c32 tau, int op)
-{
-    const float m = fabsf(x);
-    if (op == 0) return m < tau.x ? 0.f : x;
-    if (m == 0.0f) return 0.f;
-    const float g = op == 1 ? 1.0f - tau.x / m : 1.0f - (tau.x * tau.x) / (m * m);
-    return g > 0.0f ? x * g : 0.f;
 }
 
 // thresholds fused into the last analysis step of a level: z < 0 = leave that output alone (approximation / statistics pass)
@@ -131,8 +100,8 @@ __global__ void dwt_axis_kernel(const T* in, T* lo, T* hi, Filters f, int nlines
                 acc_tap(d, f.dec_hi[j], v);
             }
         }
-        if (th.z_lo >= 0) a = wshrink(a, t_lo, th.op);
-        if (th.z_hi >= 0) d = wshrink(d, t_hi, th.op);
+        if (th.z_lo >= 0) a = p3d::shrink(a, t_lo, th.op);
+        if (th.z_hi >= 0) d = p3d::shrink(d, t_hi, th.op);
         const size_t dst = (size_t)line * out_lin + (size_t)o * out_el;
         lo[(size_t)s * lo_slice + dst] = a;
         hi[(size_t)s * hi_slice + dst] = d;

@@ -25,9 +25,10 @@ from functools import partial
 import numpy as np
 
 from .. import _ffi
+from .shearlets import get_number_scales
 
 TRANSFORMS = ('FFT', 'WAVELET', 'SHEARLET', 'CURVELET', 'DCT')
-_HIP_TRANSFORMS = ('FFT', 'WAVELET')
+_HIP_TRANSFORMS = ('FFT', 'WAVELET', 'SHEARLET')
 _WAVELET_OPS = ('soft', 'hard', 'garrote', 'garotte')
 _THRESH_OPS = ('soft', 'hard', 'garrote', 'garotte', 'soft-percentile', 'hard-percentile',
                'garrote-percentile', 'garotte-percentile')
@@ -49,7 +50,7 @@ def _tail_number(name, default=1.0, strict=False):
         return default
 
 
-def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, sumsq, size, transform_kind='FFT'):
+def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, sumsq, size, transform_kind='FFT', tau_min=None):
     """tau[..., k] for k = 1..niter from the statistics of X0 = transform(x).
 
     ``peak`` is the (lexicographic) complex maximum of X0, ``abs_max`` / ``abs_min`` the extrema of
@@ -70,7 +71,9 @@ def _schedule(thresh_model, niter, p_max, p_min, kind, peak, abs_max, abs_min, s
 
     if kind == 'values':
         peak = np.asarray(peak)[..., None]
-        if isinstance(p_min, str) and p_min == 'adaptive':
+        if tau_min is not None:        # SHEARLET with p_min='adaptive': one value per slice (POCS.py:302-320)
+            tau_min = np.asarray(tau_min)[..., None]
+        elif isinstance(p_min, str) and p_min == 'adaptive':
             if transform_kind == 'WAVELET':  # POCS.py:322-325
                 raise NotImplementedError(f'p_min=`adaptive` is not implemented for {transform_kind} transform')
             tau_min = 0.01 * np.sqrt(np.asarray(sumsq)[..., None] / size)
@@ -130,8 +133,16 @@ def get_threshold_decay(
         raise ValueError(f'Unsupported transform. Please select one of: {TRANSFORMS}')
     else:
         transform_kind = transform_kind.upper()
-    if transform_kind == 'SHEARLET':
-        raise NotImplementedError(f'{transform_kind} schedules are not available in the HIP build yet')
+    if transform_kind == 'SHEARLET' and x_fwd is not None:
+        # x_fwd: (nil, nxl, nsh) coefficients -> tau (niter, nsh); maxima per shearlet over axes (0, 1) (POCS.py:256-259, 282-285)
+        x_fwd = np.asarray(x_fwd)
+        st = np.empty((1, x_fwd.shape[-1], 5))
+        peak = np.max(x_fwd, axis=(0, 1))
+        st[0, :, 0], st[0, :, 1] = peak.real, peak.imag if np.iscomplexobj(peak) else 0.0
+        mag = np.abs(x_fwd)
+        st[0, :, 2], st[0, :, 3], st[0, :, 4] = mag.max(axis=(0, 1)), mag.min(axis=(0, 1)), (mag ** 2).sum(axis=(0, 1))
+        tau = _shearlet_schedule_from_stats(st, x_fwd.shape[:2], thresh_model, niter, p_max, p_min, kind)
+        return tau[0] if np.ndim(tau) == 3 else tau
     if transform_kind == 'WAVELET' and x_fwd is not None:
         # x_fwd: list of (cH, cV, cD) per level (the low-pass array already removed, POCS.py:524-525) -> tau (niter, nlev, 3)
         inverse_prop = all(s in thresh_model for s in ['inverse', 'proportional'])
@@ -203,11 +214,53 @@ def _get_wavelet_plan(nil, nxl, nslices, wavelet, device):
     return plan
 
 
+def _shearlet_adaptive_tau_min(sumsq, shape2d):
+    """1/3 median_s(log10(j_s + 1) sqrt(||ST_s||^2 / ST.size)) with j_s the scale of shearlet s (POCS.py:302-320)."""
+    nsh = sumsq.shape[-1]
+    nscales = get_number_scales(tuple(shape2d) + (nsh,))   # the reference passes the 3-D coefficient array
+    j = np.hstack((np.array([0]), np.repeat(np.arange(1, nscales + 1), [2 ** (i + 2) for i in range(nscales)])))
+    size = shape2d[0] * shape2d[1] * nsh
+    return 1 / 3 * np.median(np.log10(j + 1) * np.sqrt(sumsq / size), axis=-1)
+
+
+def _shearlet_schedule_from_stats(stats, shape2d, thresh_model, niter, p_max, p_min, kind):
+    """stats (n, nsh, 5) from ``p3d_shearlet_stats`` -> tau (n, niter, nsh) (or (niter, 1) for kind='factors')."""
+    peak = stats[..., 0] + 1j * stats[..., 1]
+    if not np.any(stats[..., 1]):
+        peak = peak.real
+    tau_min = None
+    inverse_prop = all(s in thresh_model for s in ['inverse', 'proportional'])
+    if kind == 'values' and not inverse_prop and isinstance(p_min, str) and p_min == 'adaptive':
+        tau_min = _shearlet_adaptive_tau_min(stats[..., 4], shape2d)[..., None]   # same value for every shearlet of a slice
+    tau = np.asarray(_schedule(thresh_model, niter, p_max, p_min, kind, peak, stats[..., 2], stats[..., 3], None, None, 'SHEARLET', tau_min))
+    if tau.ndim == 3:
+        return np.moveaxis(tau, -1, 1)
+    return np.reshape(tau, (niter, 1))
+
+
+_shearlet_plans = {}
+
+
+def _get_shearlet_plan(psi, nslices, device):
+    """Plans hold the spectra on the device; they are cached per Psi array (identity + shape + a few samples)."""
+    psi = np.asarray(psi)
+    probe = psi[::max(psi.shape[0] // 7, 1), ::max(psi.shape[1] // 5, 1), ::max(psi.shape[2] // 3, 1)]
+    key = (psi.shape, str(psi.dtype), float(np.sum(probe)), float(np.sum(np.abs(probe) ** 2)), device)
+    plan = _shearlet_plans.get(key)
+    if plan is None or plan.max_slices < nslices:
+        if plan is not None:
+            plan.close()
+        plan = _ffi.ShearletPlan(psi, max_slices=max(nslices, 1), device=device)
+        _shearlet_plans[key] = plan
+    return plan
+
+
 def release_plans():
     """Free the cached GPU plans (work buffers) of this process."""
-    for plan in _plans.values():
-        plan.close()
-    _plans.clear()
+    for cache in (_plans, _shearlet_plans):
+        for plan in cache.values():
+            plan.close()
+        cache.clear()
 
 
 def _wavelet_name(transform, wavelet):
@@ -265,6 +318,7 @@ def pocs_cube(
     device=0,
     batch_slices=None,
     wavelet=None,
+    auxiliary_data=None,
     **ignored,
 ):
     """
@@ -301,7 +355,19 @@ def pocs_cube(
         raise ValueError('niter must be >= 1')
     step = int(batch_slices) if batch_slices else nslices
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
-    if kind == 'WAVELET':
+    if kind == 'SHEARLET':
+        if auxiliary_data is None:
+            raise ValueError(f'{kind} requires pre-computed shearlets in Fourier domain (Psi)')
+        if thresh_op not in _WAVELET_OPS:
+            raise NotImplementedError(f'thresh_op {thresh_op!r} is not available for the SHEARLET transform')
+        psi = np.asarray(auxiliary_data)
+        if psi.ndim != 3 or psi.shape[:2] != (nil, nxl):
+            raise ValueError(f'Psi must be ({nil}, {nxl}, nshearlets), got shape {psi.shape}')
+        # coefficients of one slice are nsh full-size arrays on the device: bound the batch by memory (<= 8 GiB of coefficients)
+        fit = max(1, min(int((8 << 30) // (psi.shape[2] * nil * nxl * 8)), 65535 // psi.shape[2]))
+        step = min(step, fit)
+        plan = _get_shearlet_plan(psi, min(step, nslices), device)
+    elif kind == 'WAVELET':
         if thresh_op not in _WAVELET_OPS:  # threshold_wavelet (POCS.py:105-166) has no percentile variants
             raise NotImplementedError(f'thresh_op {thresh_op!r} is not available for the WAVELET transform')
         if decay_kind == 'factors' and not all(s in thresh_model for s in ['inverse', 'proportional']):
@@ -320,8 +386,14 @@ def pocs_cube(
         t0 = time.perf_counter()
         if kind == 'WAVELET':
             stats = plan.stats(chunk)
-            stats[~active] = 1.0
+            stats[~active] = 1.0      # keep NaNs of empty slices out of the (unused) schedule rows ...
+            stats[~active, ..., 1] = 0.0  # ... without making them complex
             tau = _wavelet_schedule_from_stats(stats, thresh_model, niter, p_max, p_min, decay_kind)
+        elif kind == 'SHEARLET':
+            stats = plan.stats(chunk)
+            stats[~active] = 1.0
+            stats[~active, ..., 1] = 0.0
+            tau = _shearlet_schedule_from_stats(stats, (nil, nxl), thresh_model, niter, p_max, p_min, decay_kind)
         elif thresh_model == 'data-driven':
             X0 = plan.fft2(chunk.astype(np.complex64))
             tau = np.zeros((n, niter), np.complex128)
@@ -385,8 +457,8 @@ def POCS_algorithm(
     ``path_results``; POCS.py:644-651) and return value (complex in -> complex out, real in -> real
     part; POCS.py:653-656) follow the reference.  Differences: ``transform`` / ``itransform`` must be
     supplied but are not called (the transform is chosen by ``transform_kind``: ``'FFT'``, or ``'WAVELET'`` with the
-    wavelet name read from ``transform.keywords['wavelet']`` as set up by the step-13 driver), and arithmetic is float32 on
-    the GPU.
+    wavelet name read from ``transform.keywords['wavelet']`` as set up by the step-13 driver, or ``'SHEARLET'`` with the
+    spectra in ``auxiliary_data``), and arithmetic is float32 on the GPU.
     """
     if np.max(mask) > 1:
         raise ValueError(f'mask should be quasi-boolean (0 or 1) but has maximum of {np.max(mask)}')
@@ -406,6 +478,7 @@ def POCS_algorithm(
         x[None], mask, transform_kind=transform_kind, niter=niter, thresh_op=thresh_op,
         thresh_model=thresh_model, eps=eps, alpha=alpha, p_max=p_max, p_min=p_min, sqrt_decay=sqrt_decay,
         decay_kind=decay_kind, version=version, results=results, transform=transform, itransform=itransform,
+        auxiliary_data=auxiliary_data,
     )[0]
     info = results[0]
 

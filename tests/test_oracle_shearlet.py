@@ -60,3 +60,20 @@ def test_shearlet_pocs_runs():
         assert info["niterations"] == int(g[name + "_niter"][0])
         if ok.all():
             assert np.isclose(info["costs"][-1], g[name + "_cost"][0], rtol=1e-6)
+
+
+def test_product_host_side_matches():
+    """The product's host code (spectra generator, SHEARLET schedule) against the oracle / the reference's recorded schedules."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    for shape in [(32, 32), (33, 33), (24, 40), (33, 64), (17, 16)]:
+        assert np.abs(shearlets.scalesShearsAndSpectra(shape) - so.scales_shears_and_spectra(shape)).max() < 1e-13
+    assert shearlets.get_number_scales((2048, 1024)) == 5
+    g = load_golden("shearlet.npz")
+    psi = so.scales_shears_and_spectra(g["decay_x"].shape)
+    coeffs = {"r": so.shearlet_transform(g["decay_x"], psi), "c": so.shearlet_transform(g["decay_xc"], psi)}
+    for key in sorted(k[:-5] for k in g.files if k.startswith("decay") and k.endswith("_meta")):
+        tag, model, kind, p_min = [str(v) for v in g[key + "_meta"]]
+        tau = P.get_threshold_decay(model, 7, transform_kind="SHEARLET", p_max=0.99, p_min=ast.literal_eval(p_min), x_fwd=coeffs[tag], kind=kind)
+        want = g[key + "_tau"]
+        assert np.shape(tau) == want.shape and np.array_equal(tau, want), key
