@@ -7,8 +7,8 @@ into ``POCS_algorithm``; ``n_workers / processes / threads_per_worker / memory_l
 dask ``LocalCluster`` slice farm (:291-340) is replaced by whole batches of slices on the GPU), same mask rule
 ``fold <= 1 ? fold : 1`` (:242-244), same output naming (:146-157, :223-228), ``.real`` / ``.imag`` split (:160-164),
 per-batch ``slice-XXXX-YYYY.out`` runtime files merged into ``runtimes_<prefix>.txt`` (:177-195), same attributes
-(:346-367).  Cubes are ``.npz`` files (cube_io.py) or netCDF when xarray is installed.  ``transform_kind``: FFT or WAVELET (with the ``wavelet`` key, default
-coif5, :261); the other kinds raise as the reference does when their third-party package is missing (:287-288).
+(:346-367).  Cubes are ``.npz`` files (cube_io.py) or netCDF when xarray is installed.  ``transform_kind``: FFT, WAVELET (with the ``wavelet`` key, default
+coif5, :261) or SHEARLET (spectra from functions/shearlets.py instead of FFST, :269-272); the other kinds raise as the reference does when their third-party package is missing (:287-288).
 """
 import argparse
 import datetime
@@ -121,6 +121,10 @@ def main(argv=sys.argv, return_dataset=False):
         metadata['wavelet'] = wavelet
         metadata['transform'] = metadata['itransform'] = None
         prefix += f'_{wavelet}-{wavelet_mode}'
+    elif TRANSFORM == 'SHEARLET':                            # cube_POCS_interpolation_3D.py:269-274
+        from .functions.shearlets import scalesShearsAndSpectra
+        Psi = scalesShearsAndSpectra(data.shape[1:], numOfScales=None, realCoefficients=True, fftshift_spectra=True, dtype=np.float32)
+        metadata['transform'] = metadata['itransform'] = None
     else:
         raise ValueError(f'Transform < {metadata["transform_kind"]} > is not supported.')
 
@@ -155,7 +159,8 @@ def main(argv=sys.argv, return_dataset=False):
     merged = np.empty_like(data)
     for sl in batches:
         results = []
-        block = pocs_cube(data[sl], mask, results=results, **kwargs)
+        aux = Psi if TRANSFORM == 'SHEARLET' else None      # :307
+        block = pocs_cube(data[sl], mask, results=results, auxiliary_data=aux, **kwargs)
         merged[sl] = block
         save_cube(wrap(block, sl), create_file_path(coord[sl], prefix=prefix, root_path=out_path, suffix=suffix))
         if cfg.get('output_runtime_results'):

@@ -131,3 +131,33 @@ def test_wavelet_step13_time_domain(tmp_path):
     want = wo.pocs_cube_wavelet(x.astype(np.float64), mask, **params)
     for s in range(nt):
         assert rel_l2(Y[s], want[s]) < 1e-5, s
+
+
+def test_shearlet_step13_time_domain(tmp_path):
+    """transform_kind: shearlet through the step-13 driver (spectra built by functions/shearlets.py, the stand-in for
+    FFST.scalesShearsAndSpectra) against the shearlet oracle."""
+    from oracle import shearlet_oracle as so
+    from pseudo_3d_interpolation_amd import cube_POCS_interpolation_3D as step13
+    from pseudo_3d_interpolation_amd.cube_io import Cube, open_cube, save_cube
+
+    nt, nil, nxl, dt = 6, 32, 48, 0.05
+    x, fold = _time_cube(nt, nil, nxl, 0.4, seed=9)
+    cube = Cube({'env': x, 'fold': fold}, {'env': ('twt', 'iline', 'xline'), 'fold': ('iline', 'xline')},
+                {'twt': dt * np.arange(nt), 'iline': np.arange(nil), 'xline': np.arange(nxl)},
+                {'long_name': 'test cube', 'description': 'synthetic', 'history': 'made;', 'text': ''}, {}, {'twt': {'units': 'ms'}})
+    path = save_cube(cube, str(tmp_path / 'cube_twt.npz'))
+    metadata = dict(transform_kind='shearlet', niter=6, eps=0, thresh_op='soft', thresh_model='exponential', decay_kind='values',
+                    p_max=0.99, p_min=0.01, alpha=1.0, sqrt_decay=False, version='regular', verbose=False)
+    pocs_yml = tmp_path / 'pocs.yml'
+    pocs_yml.write_text(yaml.safe_dump({'dim': 'twt', 'var': 'env', 'batch_chunk': 4, 'n_workers': 1, 'processes': True,
+                                        'threads_per_worker': 1, 'memory_limit': '2GB', 'output_runtime_results': False,
+                                        'metadata': metadata}))
+    step13.main(['13_cube_interpolate_POCS', path, '--path_pocs_parameter', str(pocs_yml)])
+    prefix = 'cube_twt_SHEARLET_soft_niter-6'
+    icube = open_cube(str(tmp_path / f'{prefix}.npz'))
+    Y = icube.data_vars['env_interp']
+    mask = np.where(fold <= 1, fold, 1)
+    params = {k: v for k, v in metadata.items() if k not in ('verbose', 'transform_kind')}
+    want = so.pocs_cube_shearlet(x.astype(np.float64), mask, so.scales_shears_and_spectra((nil, nxl)), **params)
+    for s in range(nt):
+        assert rel_l2(Y[s], want[s]) < 1e-5, s
