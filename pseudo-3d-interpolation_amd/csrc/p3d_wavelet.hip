@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,40 @@ template <typename T> __device__ __forceinline__ T zero_of() { return T{}; }
 // straight line through the edge pair (e = edge sample, f = its neighbour), t samples beyond the edge
 __device__ __forceinline__ c32 extrapolate(c32 e, c32 f, float t) { return c32{e.x + (e.x - f.x) * t, e.y + (e.y - f.y) * t}; }
 __device__ __forceinline__ float extrapolate(float e, float f, float t) { return e + (e - f) * t; }
+
+// Two filter outputs that consume the same samples (low-/high-pass of the analysis, even/odd sample of the synthesis), kept as
+// one packed pair so that a tap is a single v_pk_fma_f32: these kernels are VALU-bound, not memory-bound.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Acc;
+template <> struct Acc<float> {
+    f2 v{0.f, 0.f};
+    __device__ __forceinline__ void tap(float g0, float g1, float x) { v = __builtin_elementwise_fma(f2{g0, g1}, f2{x, x}, v); }
+    __device__ __forceinline__ float first() const { return v.x; }
+    __device__ __forceinline__ float second() const { return v.y; }
+};
+template <> struct Acc<c32> {
+    f2 a{0.f, 0.f}, b{0.f, 0.f};
+    __device__ __forceinline__ void tap(float g0, float g1, c32 x)
+    {
+        const f2 xx{x.x, x.y};
+        a = __builtin_elementwise_fma(f2{g0, g0}, xx, a);
+        b = __builtin_elementwise_fma(f2{g1, g1}, xx, b);
+    }
+    __device__ __forceinline__ c32 first() const { return c32{a.x, a.y}; }
+    __device__ __forceinline__ c32 second() const { return c32{b.x, b.y}; }
+};
+
+// threshold of a real detail coefficient with a real tau, reciprocal instead of division (1 ulp; the operators are continuous
+// or, for 'hard', do not divide)
+__device__ __forceinline__ float shrink_fast(float x, c32 tau, int op)
+{
+    const float m = fabsf(x);
+    if (op == 0) return m < tau.x ? 0.f : x;
+    const float r = __builtin_amdgcn_rcpf(m);
+    const float g = op == 1 ? 1.0f - tau.x * r : 1.0f - (tau.x * tau.x) * (r * r);
+    return (m > 0.0f && g > 0.0f) ? x * g : 0.f;
+}
+__device__ __forceinline__ c32 shrink_fast(c32 x, c32 tau, int op) { return p3d::shrink(x, tau, op); }
 
 // sample k of a line of n samples at stride `st`, extended by straight lines through the edge pairs ('smooth')
 template <typename T>
@@ -136,6 +171,373 @@ __global__ void idwt_axis_kernel(const T* a, const T* d, T* out, Filters f, int 
     }
 }
 
+// ---- fused 2-D steps: one level per launch, a tile per workgroup, both axes through LDS ----------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  All tiles of a slice are
+// given to one XCD (slice = 8 * group + xcd) so that the halo re-reads of neighbouring tiles and the partial cache lines they
+// write meet in the same L2.  Grid: ntiles * (ns rounded up to a multiple of 8) workgroups, 1-D.
+__device__ __forceinline__ bool xcd_decode(int ntiles, int ns, int& slice, int& tile)
+{
+    const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
+    slice = (j / ntiles) * 8 + xcd;
+    tile = j % ntiles;
+    return slice < ns;
+}
+
+// value of the 'smooth'-extended level array at (r, c), any integers: extension along axis 1 of the extension along axis 0.
+// Branch-free (clamped addresses, zero weights inside) so that a tile's loads can all be in flight together.
+template <typename T>
+__device__ __forceinline__ T smooth2_at(const T* a, size_t ld, int H, int W, int r, int c)
+{
+    const int rc = min(max(r, 0), H - 1), cc = min(max(c, 0), W - 1);
+    const int rn = r < 0 ? min(1, H - 1) : max(H - 2, 0);   // inward neighbour of the edge sample (weight 0 when r is inside)
+    const int cn = c < 0 ? min(1, W - 1) : max(W - 2, 0);
+    const float tr = r < 0 ? (float)(-r) : (r >= H ? (float)(r - H + 1) : 0.f);
+    const float tc = c < 0 ? (float)(-c) : (c >= W ? (float)(c - W + 1) : 0.f);
+    const T x00 = a[(size_t)rc * ld + cc], x10 = a[(size_t)rn * ld + cc], x01 = a[(size_t)rc * ld + cn], x11 = a[(size_t)rn * ld + cn];
+    return extrapolate(extrapolate(x00, x10, tr), extrapolate(x01, x11, tr), tc);
+}
+
+// analysis of one level: in (H x W) -> cA, cH, cV, cD (Ho x Wo each).  Workgroup (256 threads as TILE lanes x 256/TILE rows) =
+// TILE x TILE coefficients of every subband.  LDS traffic is what bounds these kernels, so axis 1 reads sample pairs (8 B per
+// lane, conflict-free) and axis 0 slides a window down a column, every loaded sample feeding all outputs it belongs to.
+template <typename T, int TILE>
+__global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_slice, int H, int W, T* cA, size_t cA_slice, T* det, size_t det_slice, int Ho, int Wo,
+                                                        Filters f, int tiles_x, int ntiles, int ns, Thresh th)
+{
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    constexpr int LX = TILE, LY = 256 / TILE, R = TILE / LY > 0 ? TILE / LY : 1;
+    const int L = f.len, IH = 2 * TILE + L - 2, IW = IH;  // L is even: IW is even, rows of s_in start 8-byte aligned for float
+    T* s_in = reinterpret_cast<T*>(w_smem);
+    T* s_lo = s_in + (size_t)IH * IW;
+    T* s_hi = s_lo + (size_t)IH * TILE;
+    const int tx = threadIdx.x % LX, ty = threadIdx.x / LX;
+    int s, tile;
+    if (!xcd_decode(ntiles, ns, s, tile)) return;
+    const int by = tile / tiles_x, bx = tile - by * tiles_x;
+    const int or0 = by * TILE, oc0 = bx * TILE, r0 = 2 * or0 - L + 2, c0 = 2 * oc0 - L + 2;
+    const T* src = in + (size_t)s * in_slice;
+    const bool inside = r0 >= 0 && c0 >= 0 && r0 + IH <= H && c0 + IW <= W;
+    __shared__ float4 s_tap[MAXL / 2];
+    if ((int)threadIdx.x < L / 2) {
+        const int j = 2 * threadIdx.x;
+        s_tap[threadIdx.x] = float4{f.dec_lo[j], f.dec_hi[j], f.dec_lo[j + 1], f.dec_hi[j + 1]};
+    }
+    // loads in batches of KR rows x MC column steps per thread: all of a batch are issued before the first LDS write waits.
+    // 32-bit element offsets from the slice base (a level of one slice has < 2^31 samples) keep the address arithmetic short --
+    // it, not the filtering, is most of the VALU work of this kernel.
+    constexpr int KR = TILE == 32 ? 9 : 6, MC = (2 * TILE + MAXL - 2 + LX - 1) / LX;   // db4 .. coif2 at TILE 32: one batch
+    if (inside) {
+        const T* g = src + (size_t)r0 * W + c0;
+        for (int rb = ty; rb < IH; rb += KR * LY) {
+            T v[KR][MC];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const unsigned ro = (unsigned)(rb + k * LY) * (unsigned)W + tx;
+#pragma unroll
+                for (int m = 0; m < MC; ++m) {
+                    v[k][m] = zero_of<T>();
+                    if (rb + k * LY < IH && tx + m * LX < IW) v[k][m] = g[ro + m * LX];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                T* d = s_in + (rb + k * LY) * IW + tx;
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+                    if (rb + k * LY < IH && tx + m * LX < IW) d[m * LX] = v[k][m];
+            }
+        }
+    } else {
+        // boundary tile: 'smooth' extension = straight lines through the edge pairs, along axis 0 then along axis 1; clamped
+        // addresses and zero weights inside keep it branch-free (smooth2_at spelled out per row / per column)
+        unsigned cc[MC], cn[MC];
+        float tc[MC];
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+            const int c = c0 + tx + m * LX;
+            cc[m] = (unsigned)min(max(c, 0), W - 1);
+            cn[m] = (unsigned)(c < 0 ? min(1, W - 1) : max(W - 2, 0));
+            tc[m] = c < 0 ? (float)(-c) : (c >= W ? (float)(c - W + 1) : 0.f);
+        }
+        for (int rb = ty; rb < IH; rb += KR * LY) {
+            T v[KR][MC];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int r = r0 + rb + k * LY;
+                const unsigned rc = (unsigned)min(max(r, 0), H - 1) * (unsigned)W, rn = (unsigned)(r < 0 ? min(1, H - 1) : max(H - 2, 0)) * (unsigned)W;
+                const float tr = r < 0 ? (float)(-r) : (r >= H ? (float)(r - H + 1) : 0.f);
+#pragma unroll
+                for (int m = 0; m < MC; ++m) {
+                    v[k][m] = zero_of<T>();
+                    if (rb + k * LY < IH && tx + m * LX < IW)
+                        v[k][m] = extrapolate(extrapolate(src[rc + cc[m]], src[rn + cc[m]], tr), extrapolate(src[rc + cn[m]], src[rn + cn[m]], tr), tc[m]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                T* d = s_in + (rb + k * LY) * IW + tx;
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+                    if (rb + k * LY < IH && tx + m * LX < IW) d[m * LX] = v[k][m];
+            }
+        }
+    }
+    __syncthreads();
+    // The taps come from LDS (one broadcast read serves both filters and two taps): scalar loads inside these loops would share
+    // the wait counter with the LDS reads and serialise every step.
+    // axis 1: row r, output tx: sum_j f[j] * row[2 tx + L - 1 - j], two taps = one aligned pair of samples at a time
+    struct alignas(2 * sizeof(T)) Pair { T lo, hi; };
+    for (int r = ty; r < IH; r += LY) {
+        const Pair* q = reinterpret_cast<const Pair*>(s_in + r * IW + 2 * tx + L - 2);
+        Acc<T> ad;
+        for (int jj = 0; jj < L / 2; ++jj) {
+            const float4 g = s_tap[jj];       // dec_lo[2jj], dec_hi[2jj], dec_lo[2jj+1], dec_hi[2jj+1]
+            const Pair v = q[-jj];            // samples 2tx + L-2 - 2jj (tap 2jj+1) and the next one (tap 2jj)
+            ad.tap(g.x, g.y, v.hi);
+            ad.tap(g.z, g.w, v.lo);
+        }
+        s_lo[r * TILE + tx] = ad.first();
+        s_hi[r * TILE + tx] = ad.second();
+    }
+    __syncthreads();
+    // axis 0: column tx, outputs o = ty*R + q: sum_j f[j] * col[2o + L - 1 - j]
+    Acc<T> fl[R], fh[R];   // (aa, da) from the low-pass rows, (ad, dd) from the high-pass rows
+    const T* cl = s_lo + (2 * ty * R + L - 1) * TILE + tx;
+    const T* ch = s_hi + (2 * ty * R + L - 1) * TILE + tx;
+    for (int jj = 0; jj < L / 2; ++jj) {
+        const float4 g = s_tap[jj];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int o = (2 * q - 2 * jj) * TILE;
+            fl[q].tap(g.x, g.y, cl[o]);
+            fh[q].tap(g.x, g.y, ch[o]);
+            fl[q].tap(g.z, g.w, cl[o - TILE]);
+            fh[q].tap(g.z, g.w, ch[o - TILE]);
+        }
+    }
+    c32 t0{0.f, 0.f}, t1{0.f, 0.f}, t2{0.f, 0.f};
+    if (th.tau) {
+        const c32* t = th.tau + (((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3;
+        t0 = t[0]; t1 = t[1]; t2 = t[2];
+    }
+    const size_t cnt = (size_t)Ho * Wo;
+    const int gc = oc0 + tx;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int go = or0 + ty * R + q;
+        if (go >= Ho || gc >= Wo) continue;
+        T da = fl[q].second(), ad = fh[q].first(), dd = fh[q].second();
+        if (th.tau) {   // threshold_wavelet: details only
+            da = shrink_fast(da, t0, th.op);
+            ad = shrink_fast(ad, t1, th.op);
+            dd = shrink_fast(dd, t2, th.op);
+        }
+        const size_t o = (size_t)go * Wo + gc;
+        cA[(size_t)s * cA_slice + o] = fl[q].first();
+        T* dp = det + (size_t)s * det_slice + o;
+        dp[0] = da;
+        dp[cnt] = ad;
+        dp[2 * cnt] = dd;
+    }
+}
+
+// what the last synthesis step (level 1) does with its output instead of storing it: crop + re-insertion (POCS.py:609, 616-619)
+struct Update {
+    int enabled;
+    void* feed;         // T*
+    const void* x;      // observed slices (dtype)
+    int dtype;
+    const float* mask;
+    void* out;
+    double* sums;       // [nslices] of this iteration
+    int adaptive, write_out, zero_fill;
+    float alpha;
+    int n1, n2;
+    const int* done;
+};
+
+__device__ __forceinline__ c32 load_x(const void* x, int dtype, size_t g, c32*)
+{
+    return dtype == 0 ? reinterpret_cast<const c32*>(x)[g] : c32{reinterpret_cast<const float*>(x)[g], 0.f};
+}
+__device__ __forceinline__ float load_x(const void* x, int, size_t g, float*) { return reinterpret_cast<const float*>(x)[g]; }
+__device__ __forceinline__ void store_out(void* out, int dtype, size_t g, c32 v)
+{
+    if (dtype == 0) reinterpret_cast<c32*>(out)[g] = v;
+    else reinterpret_cast<float*>(out)[g] = v.x;
+}
+__device__ __forceinline__ void store_out(void* out, int, size_t g, float v) { reinterpret_cast<float*>(out)[g] = v; }
+
+// synthesis of one level: (a, cH, cV, cD) (Ho x Wo valid samples each; a may sit in a larger array) -> rec (RH x RW).
+// Workgroup = 2 TILE x 2 TILE output samples; same thread layout and LDS economy as the analysis kernel.
+template <typename T, int TILE>
+__global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det, size_t det_slice, int Ho, int Wo, T* rec,
+                                                         size_t rec_slice, int RH, int RW, Filters f, int tiles_x, int ntiles, int ns, Update u)
+{
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    __shared__ double red[256];
+    constexpr int LX = TILE, LY = 256 / TILE, OH = 2 * TILE, OW = 2 * TILE, R = OH / LY;   // R output rows per thread along axis 0
+    const int L = f.len, HL = L / 2, KH = TILE + HL - 1, KW = KH;
+    T* s_a = reinterpret_cast<T*>(w_smem);
+    T* s_h = s_a + (size_t)KH * KW;
+    T* s_v = s_h + (size_t)KH * KW;
+    T* s_d = s_v + (size_t)KH * KW;
+    T* s_lo = s_d + (size_t)KH * KW;   // [OH][KW]
+    T* s_hi = s_lo + (size_t)OH * KW;
+    const int tx = threadIdx.x % LX, ty = threadIdx.x / LX;
+    int s, tile;
+    if (!xcd_decode(ntiles, ns, s, tile)) return;
+    const int by = tile / tiles_x, bx = tile - by * tiles_x;
+    const int m0 = by * OH, n0 = bx * OW, kr0 = m0 / 2, kc0 = n0 / 2;
+    const int dn = u.enabled && u.done ? u.done[s] : 0;
+    const size_t cnt = (size_t)Ho * Wo;
+    const T* pa = a + (size_t)s * a_slice;
+    const T* pd = det + (size_t)s * det_slice;
+    __shared__ float4 s_tap[MAXL / 2];
+    if ((int)threadIdx.x < HL) {
+        const int j = L - 2 - 2 * threadIdx.x;
+        s_tap[threadIdx.x] = float4{f.rec_lo[j], f.rec_hi[j], f.rec_lo[j + 1], f.rec_hi[j + 1]};
+    }
+    constexpr int KR = TILE == 32 ? 5 : 3, MC = (TILE + MAXL / 2 - 1 + LX - 1) / LX;
+    for (int rb = ty; rb < KH; rb += KR * LY) {
+        T va[KR][MC], vh[KR][MC], vv[KR][MC], vd[KR][MC];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int kr = rb + k * LY, gr = kr0 + kr;
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                const int kc = tx + m * LX, gc = kc0 + kc;
+                va[k][m] = vh[k][m] = vv[k][m] = vd[k][m] = zero_of<T>();
+                if (kr < KH && kc < KW && gr < Ho && gc < Wo) {
+                    const size_t o = (size_t)gr * Wo + gc;
+                    va[k][m] = pa[(size_t)gr * a_ld + gc];
+                    vh[k][m] = pd[o];
+                    vv[k][m] = pd[cnt + o];
+                    vd[k][m] = pd[2 * cnt + o];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int kr = rb + k * LY;
+#pragma unroll
+            for (int m = 0; m < MC; ++m) {
+                const int kc = tx + m * LX, i = kr * KW + kc;
+                if (kr < KH && kc < KW) { s_a[i] = va[k][m]; s_h[i] = vh[k][m]; s_v[i] = vv[k][m]; s_d[i] = vd[k][m]; }
+            }
+        }
+    }
+    __syncthreads();
+    // undo axis 0: out[m] = sum_t a[m/2 + t] rec_lo[(m&1) + L-2 - 2t] + d[...] rec_hi[...], t < L/2.  Column kc, output rows
+    // ml = ty*R + q; rows 2i and 2i+1 read the same coefficients.  Taps from LDS, as in the analysis kernel.
+    for (int kc = tx; kc < KW; kc += LX) {
+        Acc<T> lo[R / 2], hi[R / 2];   // (even row, odd row) pairs
+        const int i0 = (ty * R / 2) * KW + kc;
+        for (int t = 0; t < HL; ++t) {
+            const float4 g = s_tap[t];        // rec_lo[L-2-2t], rec_hi[L-2-2t] (even rows), rec_lo[L-1-2t], rec_hi[L-1-2t] (odd rows)
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) {
+                const int i = i0 + (q + t) * KW;
+                lo[q].tap(g.x, g.z, s_a[i]);
+                lo[q].tap(g.y, g.w, s_h[i]);
+                hi[q].tap(g.x, g.z, s_v[i]);
+                hi[q].tap(g.y, g.w, s_d[i]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            s_lo[(ty * R + 2 * q) * KW + kc] = lo[q].first();
+            s_lo[(ty * R + 2 * q + 1) * KW + kc] = lo[q].second();
+            s_hi[(ty * R + 2 * q) * KW + kc] = hi[q].first();
+            s_hi[(ty * R + 2 * q + 1) * KW + kc] = hi[q].second();
+        }
+    }
+    __syncthreads();
+    // undo axis 1: row ml = ty + LY*i, outputs n = 2 tx and 2 tx + 1 share the coefficients k = tx .. tx + L/2 - 1
+    constexpr int NR = OH / LY;
+    T ve[NR], vo[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        Acc<T> eo;
+        const T* ql = s_lo + (ty + LY * i) * KW + tx;
+        const T* qh = s_hi + (ty + LY * i) * KW + tx;
+        for (int t = 0; t < HL; ++t) {
+            const float4 g = s_tap[t];
+            eo.tap(g.x, g.z, ql[t]);
+            eo.tap(g.y, g.w, qh[t]);
+        }
+        ve[i] = eo.first();
+        vo[i] = eo.second();
+    }
+    double acc = 0.0;
+    const int n = n0 + 2 * tx;
+    if (!u.enabled) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int m = m0 + ty + LY * i;
+            if (m >= RH) continue;
+            T* o = rec + (size_t)s * rec_slice + (size_t)m * RW + n;
+            if (n < RW) o[0] = ve[i];
+            if (n + 1 < RW) o[1] = vo[i];
+        }
+    } else if (dn != 0) {
+        if (dn < 0 && u.zero_fill) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int m = m0 + ty + LY * i;
+                if (m >= u.n1) continue;
+                const size_t g = (size_t)s * u.n1 * u.n2 + (size_t)m * u.n2 + n;
+                if (n < u.n2) store_out(u.out, u.dtype, g, zero_of<T>());
+                if (n + 1 < u.n2) store_out(u.out, u.dtype, g + 1, zero_of<T>());
+            }
+        }
+    } else {
+        // crop to the slice + re-insertion (POCS.py:609, 616-619): all loads first, then the arithmetic and the stores
+        const size_t per = (size_t)u.n1 * u.n2;
+        T xo[NR][2];
+        float mk[NR][2];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int m = m0 + ty + LY * i;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                xo[i][e] = zero_of<T>();
+                mk[i][e] = 0.f;
+                if (m < u.n1 && n + e < u.n2) {
+                    const size_t li = (size_t)m * u.n2 + n + e;
+                    xo[i][e] = load_x(u.x, u.dtype, (size_t)s * per + li, (T*)nullptr);
+                    mk[i][e] = u.mask[li];
+                }
+            }
+        }
+        T* feed = reinterpret_cast<T*>(u.feed);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int m = m0 + ty + LY * i;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (m >= u.n1 || n + e >= u.n2) continue;
+                const size_t g = (size_t)s * per + (size_t)m * u.n2 + n + e;
+                const float wgt = 1.0f - u.alpha * mk[i][e];
+                const T xn = cmulf(e ? vo[i] : ve[i], wgt) + cmulf(xo[i][e], u.alpha);
+                if (u.write_out) store_out(u.out, u.dtype, g, xn);
+                acc += (double)mag(xn);
+                if (u.adaptive) feed[g] = (cmulf(xo[i][e], u.alpha) + cmulf(xn, wgt)) + cmulf(xo[i][e] - cmulf(xn, mk[i][e]), 1.0f - u.alpha);
+                else feed[g] = xn;
+            }
+        }
+    }
+    if (u.enabled) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && dn == 0) atomicAdd(u.sums + s, red[0]);
+    }
+}
+
 // per (slice, level, detail): lexicographic max, max |d|, min |d| -> stats[((s*nlev + lvl)*3 + z)*4 ..]; one block each
 __device__ __forceinline__ float re_of(c32 v) { return v.x; }
 __device__ __forceinline__ float im_of(c32 v) { return v.y; }
@@ -170,18 +572,6 @@ __global__ void wstats_kernel(const T* coef, size_t coef_slice, size_t off, size
         q[0] = lr; q[1] = li; q[2] = mx; q[3] = mn;
     }
 }
-
-__device__ __forceinline__ c32 load_x(const void* x, int dtype, size_t g, c32*)
-{
-    return dtype == 0 ? reinterpret_cast<const c32*>(x)[g] : c32{reinterpret_cast<const float*>(x)[g], 0.f};
-}
-__device__ __forceinline__ float load_x(const void* x, int, size_t g, float*) { return reinterpret_cast<const float*>(x)[g]; }
-__device__ __forceinline__ void store_out(void* out, int dtype, size_t g, c32 v)
-{
-    if (dtype == 0) reinterpret_cast<c32*>(out)[g] = v;
-    else reinterpret_cast<float*>(out)[g] = v.x;
-}
-__device__ __forceinline__ void store_out(void* out, int, size_t g, float v) { reinterpret_cast<float*>(out)[g] = v; }
 
 // mode 0: first input (feed = x or its APOCS mix; sums += |x|)
 // mode 1: crop of the reconstruction + re-insertion (POCS.py:609, 616-619), sums += |x_new|, feed for the next iteration
@@ -276,8 +666,25 @@ struct p3d_wplan {
     float *stats = nullptr, *mask = nullptr;
     void *st_x = nullptr, *st_out = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool fused = true;              // tile kernels (one launch per level and direction); P3D_WAVELET_UNFUSED=1 selects the per-axis kernels
+    int tile_c = 0, tile_r = 0;     // coefficients per tile edge for complex64 / float32 work buffers
     size_t per() const { return (size_t)nil * nxl; }
 };
+
+// LDS bytes of the tile kernels for `tile` coefficients per subband and edge (analysis) / 2*tile output samples per edge (synthesis)
+static size_t tile_lds(int tile, int L, size_t esz)
+{
+    const size_t ih = 2 * (size_t)tile + L - 2, kh = (size_t)tile + L / 2 - 1;
+    const size_t fwd = esz * (ih * ih + 2 * ih * tile);
+    const size_t inv = esz * (4 * kh * kh + 2 * 2 * (size_t)tile * kh);
+    return fwd > inv ? fwd : inv;
+}
+static int pick_tile(int L, size_t esz)
+{
+    if (L % 2) return 0;                                   // the pair loads of the tile kernels need an even tap count
+    if (tile_lds(32, L, esz) <= 80 * 1024) return 32;      // two or more workgroups per CU
+    return tile_lds(16, L, esz) <= 150 * 1024 ? 16 : 0;
+}
 
 extern "C" int p3d_wavelet_plan_destroy(p3d_wplan* p)
 {
@@ -357,6 +764,18 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
     ALLOC(p->st_x, sizeof(c32) * p->per() * S);
     ALLOC(p->st_out, sizeof(c32) * p->per() * S);
 #undef ALLOC
+    p->tile_c = pick_tile(flen, sizeof(c32));
+    p->tile_r = pick_tile(flen, sizeof(float));
+    const char* env = getenv("P3D_WAVELET_UNFUSED");
+    p->fused = !(env && env[0] == '1') && p->tile_c > 0 && p->tile_r > 0;
+    if (p->fused) {
+        const int big = 150 * 1024;
+        const void* kernels[] = {(const void*)dwt2_tile_kernel<c32, 32>,  (const void*)dwt2_tile_kernel<c32, 16>,  (const void*)dwt2_tile_kernel<float, 32>,
+                                 (const void*)dwt2_tile_kernel<float, 16>, (const void*)idwt2_tile_kernel<c32, 32>, (const void*)idwt2_tile_kernel<c32, 16>,
+                                 (const void*)idwt2_tile_kernel<float, 32>, (const void*)idwt2_tile_kernel<float, 16>};
+        for (const void* k : kernels)
+            if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, big)) != hipSuccess) return bail("hipFuncSetAttribute", e);
+    }
     *out = p;
     return P3D_OK;
 }
@@ -380,9 +799,63 @@ template <typename T> static T* as(c32* p) { return reinterpret_cast<T*>(p); }
 
 // feed (nil x nxl per slice) -> coefficient vectors (cA, details coarse -> fine).  With `th` (tau != nullptr) the details are
 // thresholded as they are produced (threshold_wavelet, POCS.py:105-166) -- the approximation is never touched (POCS.py:586-587).
+template <typename T> static int tile_of(const p3d_wplan* p) { return sizeof(T) == sizeof(float) ? p->tile_r : p->tile_c; }
+
+template <typename T>
+static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th)
+{
+    const int tile = tile_of<T>(p), ns8 = (ns + 7) / 8 * 8;
+    const size_t lds = tile_lds(tile, p->f.len, sizeof(T));
+    T* coef = as<T>(p->coef);
+    for (int l = 1; l <= p->nlev; ++l) {
+        const T* src = l == 1 ? as<T>(p->feed) : as<T>(p->approx[l - 1]);
+        const int H = p->h[l - 1], W = p->w[l - 1], Ho = p->h[l], Wo = p->w[l];
+        T* cA = l == p->nlev ? coef : as<T>(p->approx[l]);
+        const size_t cA_slice = l == p->nlev ? p->ncoef : (size_t)Ho * Wo;
+        Thresh t{nullptr, 0, 0, 0, 0, 0, -1, -1};
+        if (th) { t = *th; t.lvl = p->nlev - l; }
+        const int tx = (Wo + tile - 1) / tile, ty = (Ho + tile - 1) / tile;
+        if (tile == 32)
+            dwt2_tile_kernel<T, 32><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, coef + p->doff[l], p->ncoef, Ho, Wo, p->f, tx, tx * ty, ns, t);
+        else
+            dwt2_tile_kernel<T, 16><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, coef + p->doff[l], p->ncoef, Ho, Wo, p->f, tx, tx * ty, ns, t);
+    }
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+// `u`: what to do with the level-0 reconstruction (nullptr: store it in rec[0])
+template <typename T>
+static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u)
+{
+    const int tile = tile_of<T>(p), ns8 = (ns + 7) / 8 * 8;
+    const size_t lds = tile_lds(tile, p->f.len, sizeof(T));
+    T* coef = as<T>(p->coef);
+    for (int l = p->nlev; l >= 1; --l) {
+        const int Ho = p->h[l], Wo = p->w[l], RH = p->rh[l - 1], RW = p->rw[l - 1];
+        const T* a = l == p->nlev ? coef : as<T>(p->rec[l]);
+        const size_t a_ld = l == p->nlev ? (size_t)Wo : (size_t)p->rw[l];
+        const size_t a_slice = l == p->nlev ? p->ncoef : (size_t)p->rh[l] * p->rw[l];
+        Update none{};
+        const Update& up = (l == 1 && u) ? *u : none;
+        // with the re-insertion fused only the nil x nxl crop of the level-0 reconstruction is needed
+        const int OHt = up.enabled ? up.n1 : RH, OWt = up.enabled ? up.n2 : RW;
+        const int tx = (OWt + 2 * tile - 1) / (2 * tile), ty = (OHt + 2 * tile - 1) / (2 * tile);
+        if (tile == 32)
+            idwt2_tile_kernel<T, 32><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, coef + p->doff[l], p->ncoef, Ho, Wo, as<T>(p->rec[l - 1]),
+                                                                            (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up);
+        else
+            idwt2_tile_kernel<T, 16><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, coef + p->doff[l], p->ncoef, Ho, Wo, as<T>(p->rec[l - 1]),
+                                                                            (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up);
+    }
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
 template <typename T>
 static int w_forward(p3d_wplan* p, int ns, const Thresh* th)
 {
+    if (p->fused) return w_forward_fused<T>(p, ns, th);
     const dim3 blk(256);
     const Thresh none{nullptr, 0, 0, 0, 0, 0, -1, -1};
     T *lo = as<T>(p->lo), *hi = as<T>(p->hi), *coef = as<T>(p->coef);
@@ -417,6 +890,7 @@ static int w_forward(p3d_wplan* p, int ns, const Thresh* th)
 template <typename T>
 static int w_inverse(p3d_wplan* p, int ns)
 {
+    if (p->fused) return w_inverse_fused<T>(p, ns, nullptr);
     const dim3 blk(256);
     T *lo = as<T>(p->lo), *hi = as<T>(p->hi), *coef = as<T>(p->coef);
     for (int l = p->nlev; l >= 1; --l) {
@@ -477,10 +951,19 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
         const Thresh th{p->tau, niter, k, p->nlev, 0, prm->thresh_op, -1, -1};
         int rc = w_forward<T>(p, nslices, &th);
         if (rc) return rc;
-        if ((rc = w_inverse<T>(p, nslices))) return rc;
-        wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->st_x, dtype, p->mask, p->st_out,
-                                                       p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
-                                                       (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
+        if (p->fused) {
+            Update u{};
+            u.enabled = 1; u.feed = p->feed; u.x = p->st_x; u.dtype = dtype; u.mask = p->mask; u.out = p->st_out;
+            u.sums = p->sums + (size_t)(k + 1) * nslices;
+            u.adaptive = (adaptive && !last) ? 1 : 0; u.write_out = (early || last) ? 1 : 0; u.zero_fill = last ? 1 : 0;
+            u.alpha = (float)prm->alpha; u.n1 = p->nil; u.n2 = p->nxl; u.done = p->done;
+            if ((rc = w_inverse_fused<T>(p, nslices, &u))) return rc;
+        } else {
+            if ((rc = w_inverse<T>(p, nslices))) return rc;
+            wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->st_x, dtype, p->mask,
+                                                           p->st_out, p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
+                                                           (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
+        }
         if (early) wconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
     }
     W_TRY(hipGetLastError());

@@ -40,10 +40,10 @@ def test_wavedec2_waverec2(ffi, wo, shape, wavelet):
         coef = plan.wavedec2(np.stack([x, 2 * x]))
         got = plan.unpack(coef[0])
         scale = max(np.abs(ref[0]).max(), 1.0)
-        assert np.abs(got[0] - ref[0]).max() <= 5e-6 * scale
+        assert np.abs(got[0] - ref[0]).max() <= 2e-5 * scale      # the tile kernels extrapolate the input, not the filtered rows: a little more rounding at the edges
         for lvl_g, lvl_r in zip(got[1:], ref[1:]):
             for g, r in zip(lvl_g, lvl_r):
-                assert np.abs(g - r).max() <= 5e-6 * scale
+                assert np.abs(g - r).max() <= 2e-5 * scale
         assert rel_l2(coef[1], 2 * coef[0]) <= 1e-6
         back = plan.waverec2(coef)
         assert rel_l2(back[0], x) <= 2e-6          # perfect reconstruction
