@@ -459,6 +459,52 @@ static int fft2_enqueue(p3d_plan* p, const void* in, void* out, int nslices, int
 }
 
 namespace p3d {
+// ---- the three fused passes of one SHEARLET iteration (p3d_shearlet.hip); power-of-two plans only ----------------------------
+bool shearlet_fused_supported(p3d_plan* plan) { return plan && !plan->generic; }
+
+static ShearArgs shear_args(const float* psi, const c32* tau, int nsh, int niter, int iter, int op, int real_only)
+{
+    ShearArgs a{};
+    a.psi = psi; a.tau = tau; a.nsh = nsh; a.niter = niter; a.iter = iter; a.op = op; a.real_only = real_only;
+    return a;
+}
+
+int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int nsh)
+{
+    int rc = check_batch(p, nb * nsh);
+    if (rc) return rc;
+    RowArgs r = row_args(p, nb * nsh);
+    r.x = F;
+    r.work = p->work;
+    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0);
+    HIP_TRY(p->ops_row->row(ROW_SPREAD_INV, r, p->stream));
+    return P3D_OK;
+}
+
+int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only)
+{
+    int rc = check_batch(p, nb * nsh);
+    if (rc) return rc;
+    ColArgs c = col_args(p, nb * nsh);
+    c.in = p->work;
+    c.out = p->work;
+    c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only);
+    HIP_TRY(p->ops_col->col(COL_SHRINK, c, p->stream));
+    return P3D_OK;
+}
+
+int shearlet_gather_fwd(p3d_plan* p, const float* psi, c32* out, int nb, int nsh)
+{
+    int rc = check_batch(p, nb * nsh);
+    if (rc) return rc;
+    RowArgs r = row_args(p, nb);
+    r.work = p->work;
+    r.out = out;
+    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0);
+    HIP_TRY(p->ops_row->row(ROW_GATHER_FWD, r, p->stream));
+    return P3D_OK;
+}
+
 hipStream_t plan_stream(p3d_plan* plan) { return plan->stream; }
 int fft2_async(p3d_plan* plan, const c32* in, c32* out, int nslices, int inverse) { return fft2_enqueue(plan, in, out, nslices, inverse); }
 }  // namespace p3d

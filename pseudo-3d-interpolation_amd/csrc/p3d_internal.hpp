@@ -17,4 +17,16 @@ hipStream_t plan_stream(p3d_plan* plan);
 // numpy.fft conventions, in == out allowed; enqueued on plan_stream(plan)
 int fft2_async(p3d_plan* plan, const c32* in, c32* out, int nslices, int inverse);
 
+// ---- fused passes of one SHEARLET iteration on the plan's work buffer (batch entry b*nsh + s = shearlet s of slice b) ------------
+// available for the tuned (power-of-two) plans; psi: real spectra [nsh][nil][nxl] (row-major, FFT order); F / out: spectra
+// [nb][nil][nxl] row-major.  Together: out[b] = fft2( sum_s Psi_s-weighted analysis -> threshold -> synthesis ) without the
+// final inverse transform, i.e. out = sum_s Psi_s * fft2(T_s(ifft2(Psi_s * F))).
+bool shearlet_fused_supported(p3d_plan* plan);
+// work[b*nsh + s] = inverse row FFT of psi_s * F[b]
+int shearlet_spread_inv(p3d_plan* plan, const c32* F, const float* psi, int nb, int nsh);
+// per work slice: inverse column FFT, 1/(nil*nxl), real part if real_only, threshold with tau[b][iter][s], forward column FFT
+int shearlet_col_shrink(p3d_plan* plan, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only);
+// out[b] = sum_s psi_s * forward row FFT of work[b*nsh + s]
+int shearlet_gather_fwd(p3d_plan* plan, const float* psi, c32* out, int nb, int nsh);
+
 }  // namespace p3d

@@ -67,8 +67,19 @@
 
 namespace p3d {
 
-enum RowMode { ROW_FIRST = 0, ROW_MID = 1, ROW_LAST = 2 };
-enum ColMode { COL_ITER = 0, COL_STATS = 1, COL_FWD = 2, COL_INV = 3, COL_ITER_SOFT = 4, COL_ITER_GARROTE = 5 };  // COL_ITER = hard
+// ROW_SPREAD_INV / COL_SHRINK / ROW_GATHER_FWD: the three passes of one SHEARLET iteration (p3d_shearlet.hip).  The sum over
+// the shearlets sits in the row pass because that one has the registers for 16 more accumulators (80 vs 106 VGPRs).
+enum RowMode { ROW_FIRST = 0, ROW_MID = 1, ROW_LAST = 2, ROW_SPREAD_INV = 3, ROW_GATHER_FWD = 4 };
+enum ColMode { COL_ITER = 0, COL_STATS = 1, COL_FWD = 2, COL_INV = 3, COL_ITER_SOFT = 4, COL_ITER_GARROTE = 5,  // COL_ITER = hard
+               COL_SHRINK = 6 };
+
+// Shearlet frame: batch entry b*nsh + s of the work buffer holds shearlet s of slice b.  psi: real spectra [nsh][n1][N]
+// (row-major, FFT order); tau: [nb][niter][nsh].
+struct ShearArgs {
+    const float* psi;
+    const c32* tau;
+    int nsh, niter, iter, op, real_only;
+};
 
 constexpr int ROW_THREADS = P3D_ROW_THREADS;
 constexpr int STATS_PARTIAL = 8;  // floats per (slice, tile) written by COL_STATS
@@ -145,6 +156,7 @@ struct RowArgs {
     int plain;             // LAST: plain inverse transform (no re-insertion): fft2 hook
     float alpha;
     float scale;           // 1/(n1*N)
+    ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD
 };
 
 struct ColArgs {
@@ -161,6 +173,7 @@ struct ColArgs {
     int op;
     int in_std;         // `in` is row-major [nslices][N][n2] instead of column-blocked
     int out_std;        // same for `out`
+    ShearArgs sh;       // COL_SHRINK
 };
 
 // per-thread partial sums are float (16 terms); across the wave they are combined in double so that the
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
     c32 v[PPT];
 
     // observed data (every mode except a plain inverse transform) and the mask word of this thread
-    const bool need_obs = (MODE == ROW_FIRST) || !a.plain;
+    const bool need_obs = MODE < ROW_SPREAD_INV && ((MODE == ROW_FIRST) || !a.plain);
     unsigned mbits = 0;
     if (BITS && need_obs) mbits = valid ? a.bits[(size_t)vrow * TPL + tl] : 0u;
     auto obs_at = [&](int q) -> c32 {
@@ -283,6 +296,46 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
         if (CAN_COMPACT) {
             if (compact && bad && valid) atomicOr(a.violation, 1);
         }
+    } else if (MODE == ROW_SPREAD_INV) {
+        // work[b*nsh + s] = inverse row FFT of Psi_s * F[b]   (F = a.x: spectra of slice b, row-major; grid.y = b*nsh + s)
+        const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
+        const c32* const f = reinterpret_cast<const c32*>(a.x) + (size_t)b * a.n1 * N;
+        const float* const w = a.sh.psi + (size_t)s * a.n1 * N;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = valid ? f[off + TPL * q] * w[off + TPL * q] : c32{0.f, 0.f};
+        line_fft<N, INV, WAVE>(v, lds, tw, tl);
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] = v[q];
+        }
+        return;
+    } else if (MODE == ROW_GATHER_FWD) {
+        // out[b] = sum_s Psi_s * forward row FFT of work[b*nsh + s]   (out row-major spectra; grid.y = b)
+        c32 acc[PPT];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) acc[q] = c32{0.f, 0.f};
+        for (int s = 0; s < a.sh.nsh; ++s) {
+            const c32* const ws = a.work + ((size_t)slice * a.sh.nsh + s) * wk_slice_stride(a.n1, N);
+            const float* const w = a.sh.psi + (size_t)s * a.n1 * N;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(ws, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+            line_fft<N, FWD, WAVE>(v, lds, tw, tl);
+            // the weights are fetched after the transform, four at a time, to keep the register count of the transform
+#pragma unroll
+            for (int g = 0; g < PPT; g += 4) {
+                float wq[4];
+#pragma unroll
+                for (int i = 0; i < 4 && g + i < PPT; ++i) wq[i] = valid ? w[off + TPL * (g + i)] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4 && g + i < PPT; ++i) acc[g + i] = acc[g + i] + v[g + i] * wq[i];
+            }
+        }
+        if (valid) {
+            c32* const o = reinterpret_cast<c32*>(a.out) + sbase;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) o[off + TPL * q] = acc[q];
+        }
+        return;
     } else {
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
@@ -586,6 +639,28 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         return std_layout ? (unsigned)r * a.n2 + vcol : blk0 + (unsigned)r * 8;
     };
     c32 v[PPT];
+    if (MODE == COL_SHRINK) {
+        // coefficients of shearlet s of slice b (grid.y = b*nsh + s): back to the space domain, threshold (POCS.py:598 with a
+        // per-shearlet tau), forward again; in place on the work buffer
+        const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
+        const c32 tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
+        const float scale = 1.0f / ((float)N * (float)a.n2);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = inb[eoff(0, tl + TPL * q)];
+        line_fft<N, INV, false>(v, lds, tw, tl);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            c32 c = v[q] * scale;
+            if (a.sh.real_only) c.y = 0.f;   // FFST returns the real part for real data
+            v[q] = shrink(c, tau, a.sh.op);
+        }
+        line_fft<N, FWD, false>(v, lds, tw, tl);
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) outb[eoff(0, tl + TPL * q)] = v[q];
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < PPT; ++q) v[q] = inb[eoff(a.in_std, tl + TPL * q)];  // columns past the edge re-read column 0; never stored
 
@@ -745,6 +820,8 @@ hipError_t launch_row(int mode, const RowArgs& a, hipStream_t st)
         case ROW_FIRST: return bits ? launch_row_one<N, ROW_FIRST, true>(a, st) : launch_row_one<N, ROW_FIRST, false>(a, st);
         case ROW_MID: return bits ? launch_row_one<N, ROW_MID, true>(a, st) : launch_row_one<N, ROW_MID, false>(a, st);
         case ROW_LAST: return bits ? launch_row_one<N, ROW_LAST, true>(a, st) : launch_row_one<N, ROW_LAST, false>(a, st);
+        case ROW_SPREAD_INV: return launch_row_one<N, ROW_SPREAD_INV, false>(a, st);
+        case ROW_GATHER_FWD: return launch_row_one<N, ROW_GATHER_FWD, false>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -773,6 +850,7 @@ hipError_t launch_col(int mode, const ColArgs& a, hipStream_t st)
         case COL_STATS: return launch_col_one<N, COL_STATS>(a, st);
         case COL_FWD: return launch_col_one<N, COL_FWD>(a, st);
         case COL_INV: return launch_col_one<N, COL_INV>(a, st);
+        case COL_SHRINK: return launch_col_one<N, COL_SHRINK>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

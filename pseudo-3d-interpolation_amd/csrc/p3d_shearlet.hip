@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "p3d.h"
@@ -201,6 +202,7 @@ struct p3d_splan {
     p3d_plan* fft = nullptr;  // batched 2-D FFT of up to max_slices * nsh slices
     hipStream_t stream = nullptr;
     float* psi = nullptr;      // [nsh][nil][nxl]
+    bool fused = false;        // three fused passes per iteration (power-of-two extents); P3D_SHEARLET_UNFUSED=1 disables
     c32 *U = nullptr, *F = nullptr, *feed = nullptr, *tau = nullptr;
     size_t tau_cap = 0, sums_cap = 0;
     double* sums = nullptr;
@@ -257,6 +259,8 @@ extern "C" int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, in
     ALLOC(p->st_out, sizeof(c32) * per * S);
 #undef ALLOC
     if ((e = hipMemcpy(p->psi, psi, sizeof(float) * per * nsh, hipMemcpyHostToDevice)) != hipSuccess) return bail("upload of Psi", e);
+    const char* env = getenv("P3D_SHEARLET_UNFUSED");
+    p->fused = p3d::shearlet_fused_supported(p->fft) && !(env && env[0] == '1');
     *out = p;
     return P3D_OK;
 }
@@ -388,10 +392,20 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
                                                 p->done, 0);
     for (int k = 0; k < niter; ++k) {
         const bool last = k + 1 == niter;
-        S_RC(s_forward(p, nslices, real_only, p->done));
-        sthreshold_kernel<<<dim3(blocks_for(per, 64), nslices * nsh), 256, 0, p->stream>>>(p->U, per, nsh, p->tau, niter, k, prm->thresh_op, real_only ? 1 : 0,
-                                                                                      p->done);
-        S_RC(s_inverse(p, nslices, p->done));
+        if (p->fused) {
+            // three passes over the coefficients instead of twelve: spectra x Psi_s folded into the inverse row pass, the
+            // threshold into the column pass between its two transforms, x Psi_s and the sum over s into the forward row pass
+            S_RC(p3d::fft2_async(p->fft, p->feed, p->F, nslices, 0));
+            S_RC(p3d::shearlet_spread_inv(p->fft, p->F, p->psi, nslices, nsh));
+            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0));
+            S_RC(p3d::shearlet_gather_fwd(p->fft, p->psi, p->F, nslices, nsh));
+            S_RC(p3d::fft2_async(p->fft, p->F, p->F, nslices, 1));
+        } else {
+            S_RC(s_forward(p, nslices, real_only, p->done));
+            sthreshold_kernel<<<dim3(blocks_for(per, 64), nslices * nsh), 256, 0, p->stream>>>(p->U, per, nsh, p->tau, niter, k, prm->thresh_op,
+                                                                                          real_only ? 1 : 0, p->done);
+            S_RC(s_inverse(p, nslices, p->done));
+        }
         supdate_kernel<<<ugrid, 256, 0, p->stream>>>(p->F, p->feed, p->st_x, dtype, p->mask, p->st_out, p->sums + (size_t)(k + 1) * nslices, 1,
                                                     (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0, (float)prm->alpha, per, p->done, last ? 1 : 0);
         if (early) sconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
