@@ -227,6 +227,9 @@ def main():
 
     if rank == 0:
         its = K / seconds
+        shape = (nil, nxl, args.nslices, round(args.missing, 2))
+        baseline_tag = {(1024, 1024, 512, 0.8): " (BASELINE configs[2])", (512, 512, 256, 0.7): " (BASELINE configs[1])",
+                        (64, 64, 128, 0.5): " (BASELINE configs[0])"}.get(shape, "")
         line = {
             "metric": "POCS iterations/s on the 1024x1024x512 cube" if (nil, nxl, args.nslices) == (1024, 1024, 512)
             else f"POCS iterations/s on the {nil}x{nxl}x{args.nslices} cube",
@@ -243,7 +246,7 @@ def main():
             "data": "synthetic: 6 complex plane waves + 1% Gaussian noise per slice (seeded), random trace mask",
             "config": {
                 "workload": f"{nil}x{nxl}x{args.nslices} complex64 cube, {int(args.missing * 100)}% missing traces, FFT "
-                            f"transform, {args.thresh_op} threshold, exponential decay, {K} iterations (BASELINE configs[2])",
+                            f"transform, {args.thresh_op} threshold, exponential decay, {K} iterations" + baseline_tag,
                 "slices_per_gpu": n_local,
                 "parallelism": f"slice axis in {world} contiguous block(s), one rank per GPU, no collective in the loop",
             },
