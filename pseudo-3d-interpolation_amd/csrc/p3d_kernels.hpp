@@ -44,6 +44,9 @@
 #ifndef P3D_XO_EARLY
 #define P3D_XO_EARLY 0   // 1: prefetch all observed samples ahead of the inverse transform (32 VGPRs)
 #endif
+#ifndef P3D_XCD_PAIR
+#define P3D_XCD_PAIR 1   // narrow column tiles of one 64-byte block on the same XCD, back to back
+#endif
 #ifndef P3D_ABL
 #define P3D_ABL 0        // ablations for timing only (results wrong): 1 no transforms, 2 no forward, 4 no work store
 #endif
@@ -620,7 +623,18 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     const int tl = (tid / CW) % TPL;
     const int cbl = tid / (CW * TPL);  // column block of this thread inside the tile
     const int slice = blockIdx.y;
-    const int col = blockIdx.x * T + cbl * CW + c_lo;
+    // Tiles narrower than a 64-byte column block (long lines): the 8/T tiles of one block are given to workgroups g, g+8, ...,
+    // which the dispatcher places on the same XCD one after the other, so that the block's cache lines are fetched from HBM
+    // once and the other pieces hit that XCD's L2 (workgroup g of a 2-D grid runs on XCD g % 8 when gridDim.x % 8 == 0).
+    int tile = blockIdx.x;
+    if constexpr (T < 8) {
+        constexpr int G = 8 / T;
+        if (P3D_XCD_PAIR && (gridDim.x % (8 * G)) == 0) {
+            const int xcd = tile & 7, j = tile >> 3;
+            tile = ((j / G) * 8 + xcd) * G + (j % G);
+        }
+    }
+    const int col = tile * T + cbl * CW + c_lo;
     const bool valid = col < a.n2;
 
     if (a.done && a.done[slice] != 0) return;
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 template <int N>
 constexpr int col_tile()
 {
-    return N >= 4096 ? 2 : (N >= 1024 ? 8 : (N == 512 ? 16 : (N == 256 ? 32 : 64)));
+    return N >= 4096 ? 2 : (N >= 1024 ? 8 : (N == 512 ? 16 : (N == 256 ? 32 : 64)));  // N = 2048: 4-column tiles (2 WG/CU) measured slower (3.4 vs 2.6 ms)
 }
 
 template <int N>
