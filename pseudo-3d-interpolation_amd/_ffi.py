@@ -142,6 +142,13 @@ class DeviceBuffer:
         check(lib().p3d_memcpy_d2h(self.plan.handle, _ptr(out), self.ptr, out.nbytes))
         return out
 
+    def download_into(self, arr):
+        """Copy the first ``arr.nbytes`` bytes into a C-contiguous host array (e.g. a slab of the result cube)."""
+        if not arr.flags.c_contiguous or arr.nbytes > self.nbytes:
+            raise ValueError("destination must be C-contiguous and no larger than the buffer")
+        check(lib().p3d_memcpy_d2h(self.plan.handle, _ptr(arr), self.ptr, arr.nbytes))
+        return arr
+
     def free(self):
         if self.ptr:
             check(lib().p3d_free(self.plan.handle, self.ptr))

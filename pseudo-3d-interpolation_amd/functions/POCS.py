@@ -192,8 +192,8 @@ def _schedule_from_stats(stats, size, thresh_model, niter, p_max, p_min, kind):
 _plans = {}
 
 
-def _get_plan(nil, nxl, nslices, device):
-    key = (nil, nxl, device)
+def _get_plan(nil, nxl, nslices, device, slot=0):
+    key = (nil, nxl, device, slot)
     plan = _plans.get(key)
     if plan is None or plan.max_slices < nslices:
         if plan is not None:
@@ -300,6 +300,55 @@ def _check_common(mask, transform_kind, thresh_op):
     return kind
 
 
+class _FFTWorker:
+    """One plan + device buffers for a chunk of slices; two of them alternate so that the PCIe transfers of one chunk run while
+    the other chunk iterates (ctypes releases the GIL; each plan has its own non-blocking stream)."""
+
+    def __init__(self, nil, nxl, step, device, slot, maskf):
+        self.plan = _get_plan(nil, nxl, step, device, slot)
+        per = nil * nxl * 8
+        self.x = self.plan.alloc(per * step)
+        self.o = self.plan.alloc(per * step)
+        self.m = self.plan.alloc(maskf.nbytes).upload(maskf)
+
+    def close(self):
+        for b in (self.x, self.o, self.m):
+            b.free()
+
+    def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha):
+        n = chunk.shape[0]
+        t0 = time.perf_counter()
+        xc, dt = self.plan._cube(chunk)
+        active = xc.reshape(n, -1).any(axis=1)        # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+        self.x.upload(xc)                              # one upload serves the statistics and the loop
+        stats = self.plan.stats_dev(self.x.ptr, dt, n)
+        stats[~active] = 1.0                           # keep NaNs of empty slices out of the (unused) schedule rows
+        tau = sched(stats)
+        done, sums, _ = self.plan.run_dev(self.x.ptr, dt, self.m.ptr, tau, niter, self.o.ptr, n, thresh_op=thresh_op,
+                                          version=version, eps=eps, alpha=alpha, active=active)
+        if dst.dtype == xc.dtype:
+            self.o.download_into(dst)
+        else:                                          # e.g. a float64 cube: results are cast on assignment, as before
+            dst[...] = self.o.download(xc.shape, xc.dtype)
+        return done, sums, time.perf_counter() - t0
+
+
+def _result_rows(done, sums, runtime):
+    n = done.shape[0]
+    with np.errstate(invalid='ignore', divide='ignore'):
+        costs = ((sums[1:] - sums[:-1]) / sums[1:]) ** 2  # POCS.py:622
+    rows = []
+    for s in range(n):
+        k = int(done[s])
+        rows.append({
+            'niterations': k,
+            'runtime': round(runtime / n, 3) if k else 0,
+            'cost': float(costs[k - 1, s]) if k else 0,
+            'costs': [float(c) for c in costs[:k, s]] if k else [0],
+        })
+    return rows
+
+
 def pocs_cube(
     cube,
     mask,
@@ -376,6 +425,37 @@ def pocs_cube(
             raise IndexError('list index out of range (decay_kind="factors" yields one tau per iteration, the WAVELET '
                              'thresholding needs one per level and detail)')
         plan = _get_wavelet_plan(nil, nxl, min(step, nslices), _wavelet_name(ignored.get('transform'), wavelet), device)
+    elif thresh_model != 'data-driven' and out.flags.c_contiguous:
+        # FFT, statistics-driven schedules: chunks go through device buffers, uploaded once each, two chunks in flight
+        slice_bytes = nil * nxl * (8 if np.iscomplexobj(cube) else 4)
+        if not batch_slices and nslices * slice_bytes >= (1 << 30):
+            step = max(1, (256 << 20) // slice_bytes)            # ~256 MiB per chunk
+        step = min(step, nslices)
+        starts = list(range(0, nslices, step))
+        workers = [_FFTWorker(nil, nxl, step, device, slot, maskf) for slot in range(min(2, len(starts)))]
+
+        def sched(stats):
+            tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
+            return np.sqrt(tau) if sqrt_decay else tau  # POCS.py:595
+
+        def lane(w):
+            return [(lo, workers[w].run(cube[lo:lo + step], out[lo:lo + step], sched, niter, thresh_op, version, eps, alpha))
+                    for lo in starts[w::len(workers)]]
+
+        try:
+            if len(workers) == 1:
+                done_rows = lane(0)
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(len(workers)) as pool:
+                    done_rows = [r for part in pool.map(lane, range(len(workers))) for r in part]
+        finally:
+            for w in workers:
+                w.close()
+        if results is not None:
+            for _, (done, sums, runtime) in sorted(done_rows, key=lambda r: r[0]):
+                results.extend(_result_rows(done, sums, runtime))
+        return out
     else:
         plan = _get_plan(nil, nxl, min(step, nslices), device)
 
@@ -410,16 +490,7 @@ def pocs_cube(
         runtime = time.perf_counter() - t0
         out[lo:lo + n] = res
         if results is not None:
-            with np.errstate(invalid='ignore', divide='ignore'):
-                costs = ((sums[1:] - sums[:-1]) / sums[1:]) ** 2  # POCS.py:622
-            for s in range(n):
-                k = int(done[s])
-                results.append({
-                    'niterations': k,
-                    'runtime': round(runtime / n, 3) if k else 0,
-                    'cost': float(costs[k - 1, s]) if k else 0,
-                    'costs': [float(c) for c in costs[:k, s]] if k else [0],
-                })
+            results.extend(_result_rows(done, sums, runtime))
     return out
 
 
