@@ -804,7 +804,12 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.done = any_off ? p->done : nullptr;
     r.dtype = dtype;
     r.adaptive = adaptive ? 1 : 0;
-    r.write_out = early ? 1 : 0;
+    // Early exit: a slice that converges at iteration k leaves the forward row transform of its iterate in the work buffer;
+    // a "finalize" launch after the convergence test turns that back into `out` for exactly those slices, so the steady
+    // state does not store every iterate of every slice (8 B/point per iteration).  APOCS feeds a mix of iterate and
+    // observation forward instead of the iterate: there the per-iteration store stays.
+    const bool finalize = early && !adaptive;
+    r.write_out = (early && !finalize) ? 1 : 0;
     r.alpha = (float)prm->alpha;
     r.sum_row = 0;
     // rows of finished / empty slices are skipped by the kernels: their partial sums must read as zero
@@ -845,6 +850,15 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             conv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
             // slices that just finished are skipped from now on: their rows must read as zero afterwards
             HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
+            if (finalize && k + 1 < niter) {
+                RowArgs f = r;
+                f.only_done = k + 1;
+                f.plain = 0;      // the observed samples are needed (exact hand-back at observed traces)
+                f.sums = nullptr;
+                f.done = p->done;
+                f.scale = (float)(1.0 / (double)p->nxl);   // one row transform to undo, not a 2-D one
+                HIP_TRY(p->ops_row->row(ROW_LAST, f, p->stream));
+            }
         }
     }
     HIP_TRY(hipGetLastError());

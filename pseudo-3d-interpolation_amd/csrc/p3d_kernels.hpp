@@ -157,6 +157,8 @@ struct RowArgs {
     int adaptive;          // APOCS input mix
     int write_out;         // MID: also store the iterate to `out` (needed only when eps > 0)
     int plain;             // LAST: plain inverse transform (no re-insertion): fft2 hook
+    int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done == only_done; their work
+                           // rows hold the forward row transform of the converged iterate, which is handed to `out`
     float alpha;
     float scale;           // 1/(n1*N)
     ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD
@@ -213,7 +215,9 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
     const bool valid = row < a.n1;
 
     const int dn = a.done ? a.done[slice] : 0;
-    if (MODE == ROW_LAST) {
+    if (MODE == ROW_LAST && a.only_done) {
+        if (dn != a.only_done) return;
+    } else if (MODE == ROW_LAST) {
         if (dn > 0) return;  // converged earlier: `out` already holds that iterate
         if (dn < 0) {        // all-zero slice is handed back untouched (POCS.py:515-521)
             if (valid) {
@@ -360,7 +364,11 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
                 const int q = g + i;
                 c32 xn = v[q] * a.scale;
                 float m = 0.f;
-                if (!a.plain) {
+                if (MODE == ROW_LAST && a.only_done) {
+                    // xn = the converged iterate up to the round-off of one row-transform round trip; where a trace was
+                    // observed and alpha = 1 the iterate IS the observed sample (POCS.py:616-619): hand that back exactly
+                    if (a.alpha == 1.0f && mask_at(q) == 1.0f) xn = xo[i];
+                } else if (!a.plain) {
                     m = mask_at(q);
                     const float w = 1.0f - a.alpha * m;       // POCS.py:616
                     xn = axpby(xn, w, xo[i], a.alpha);        // POCS.py:619

@@ -468,3 +468,27 @@ def test_time2freq_closed_form_and_round_trip(ffi, nt, shape, up, real_only):
         lo = ffi.freq2time(Xw[keep], dt, t0, nfft=nfft, real_only=True, kidx=keep)
         want = np.fft.irfft(np.fft.rfft(x.astype(np.float64), n=nfft, axis=0) * win.reshape((-1,) + (1,) * len(shape)), n=nfft, axis=0)
         assert rel_l2(lo, want) < 5e-6
+
+
+def test_early_exit_hands_back_the_converged_iterate():
+    """eps > 0 on the tuned path: slices leave the loop at different iterations; the iterate of a finished slice is recovered from
+    the work buffer by the "finalize" launch (no per-iteration store).  It must be the oracle's iterate of that very iteration,
+    and observed traces must come back bit-exact (alpha = 1)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    nil = nxl = 64
+    mask = orc.synthetic_mask(nil, nxl, 0.3)
+    cube = np.stack([orc.synthetic_slice(nil, nxl, s) * (1.0 + 3.0 * s) for s in range(6)]) * mask
+    cube[4] = 0
+    kw = dict(niter=80, thresh_op="soft", thresh_model="exponential", eps=2e-7, p_max=0.99, p_min=1e-2)
+    res, infos = [], []
+    got = P.pocs_cube(cube.astype(np.complex64), mask, results=res, **kw)
+    want = orc.pocs_cube(cube.astype(np.complex128), mask, infos=infos, **kw)
+    its = [r["niterations"] for r in res]
+    assert its[4] == 0 and not got[4].any()
+    assert len({i for i in its if i}) >= 2 and max(its) < 80, its          # they really stop early, and not all together
+    for s in range(6):
+        assert its[s] == infos[s]["niterations"], (s, its[s], infos[s]["niterations"])
+        if its[s]:
+            assert rel_l2(got[s], want[s]) <= 1e-5
+            assert np.array_equal(got[s][mask == 1], cube[s].astype(np.complex64)[mask == 1])
