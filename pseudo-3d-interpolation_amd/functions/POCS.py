@@ -190,6 +190,7 @@ def _schedule_from_stats(stats, size, thresh_model, niter, p_max, p_min, kind):
 #                                      batched GPU entry point
 # =================================================================================================
 _plans = {}
+_workers = {}
 
 
 def _get_plan(nil, nxl, nslices, device, slot=0):
@@ -257,6 +258,9 @@ def _get_shearlet_plan(psi, nslices, device):
 
 def release_plans():
     """Free the cached GPU plans (work buffers) of this process."""
+    for w in _workers.values():
+        w.close()
+    _workers.clear()
     for cache in (_plans, _shearlet_plans):
         for plan in cache.values():
             plan.close()
@@ -302,18 +306,33 @@ def _check_common(mask, transform_kind, thresh_op):
 
 class _FFTWorker:
     """One plan + device buffers for a chunk of slices; two of them alternate so that the PCIe transfers of one chunk run while
-    the other chunk iterates (ctypes releases the GIL; each plan has its own non-blocking stream)."""
+    the other chunk iterates (ctypes releases the GIL; each plan has its own non-blocking stream).  Workers are cached like the
+    plans (per slice shape, device and slot): a per-slice caller (``POCS_algorithm`` under ``xr.apply_ufunc``) does not pay
+    for device allocations on every call."""
 
-    def __init__(self, nil, nxl, step, device, slot, maskf):
+    def __init__(self, nil, nxl, step, device, slot):
         self.plan = _get_plan(nil, nxl, step, device, slot)
+        self.capacity = self.plan.max_slices
         per = nil * nxl * 8
-        self.x = self.plan.alloc(per * step)
-        self.o = self.plan.alloc(per * step)
-        self.m = self.plan.alloc(maskf.nbytes).upload(maskf)
+        self.x = self.plan.alloc(per * self.capacity)
+        self.o = self.plan.alloc(per * self.capacity)
+        self.m = self.plan.alloc(nil * nxl * 4)
+
+    @classmethod
+    def get(cls, nil, nxl, step, device, slot, maskf):
+        key = (nil, nxl, device, slot)
+        w = _workers.get(key)
+        if w is None or w.capacity < step or w.plan.handle is None:
+            if w is not None:
+                w.close()
+            w = _workers[key] = cls(nil, nxl, step, device, slot)
+        w.m.upload(maskf)
+        return w
 
     def close(self):
-        for b in (self.x, self.o, self.m):
-            b.free()
+        if self.plan.handle is not None:   # buffers die with their plan otherwise
+            for b in (self.x, self.o, self.m):
+                b.free()
 
     def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha):
         n = chunk.shape[0]
@@ -432,7 +451,7 @@ def pocs_cube(
             step = max(1, (256 << 20) // slice_bytes)            # ~256 MiB per chunk
         step = min(step, nslices)
         starts = list(range(0, nslices, step))
-        workers = [_FFTWorker(nil, nxl, step, device, slot, maskf) for slot in range(min(2, len(starts)))]
+        workers = [_FFTWorker.get(nil, nxl, step, device, slot, maskf) for slot in range(min(2, len(starts)))]
 
         def sched(stats):
             tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
@@ -442,22 +461,18 @@ def pocs_cube(
             return [(lo, workers[w].run(cube[lo:lo + step], out[lo:lo + step], sched, niter, thresh_op, version, eps, alpha))
                     for lo in starts[w::len(workers)]]
 
-        try:
-            if len(workers) == 1:
-                done_rows = lane(0)
-            else:
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(len(workers)) as pool:
-                    done_rows = [r for part in pool.map(lane, range(len(workers))) for r in part]
-        finally:
-            for w in workers:
-                w.close()
+        if len(workers) == 1:
+            done_rows = lane(0)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(len(workers)) as pool:
+                done_rows = [r for part in pool.map(lane, range(len(workers))) for r in part]
         if results is not None:
             for _, (done, sums, runtime) in sorted(done_rows, key=lambda r: r[0]):
                 results.extend(_result_rows(done, sums, runtime))
         return out
     else:
-        plan = _get_plan(nil, nxl, min(step, nslices), device)
+        plan = _get_plan(nil, nxl, min(step, nslices), device, slot=2)   # slots 0 and 1 belong to the chunk workers
 
     for lo in range(0, nslices, step):
         chunk = cube[lo:lo + step]
