@@ -178,6 +178,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
 
+    # ---- the same job with the sparse-spectrum shortcut switched off (reported beside `value`, rank 0 only) ----
+    nz_fraction = plan.last_sparsity()
+    dense_its = None
+    if rank == 0 and nz_fraction >= 0:
+        os.environ["P3D_NO_SPARSE"] = "1"
+        torch.cuda.synchronize()
+        d0 = time.perf_counter()
+        job(K)
+        torch.cuda.synchronize()
+        dense_its = K / (time.perf_counter() - d0)   # the ranks run in parallel: rank 0's time for its block is the job's
+        del os.environ["P3D_NO_SPARSE"]
+
     # ---- the trivial gather of the blocks (outside the timed steps) -------------------------------
     gather_ms = 0.0
     if world > 1:
@@ -255,6 +267,13 @@ def main():
             "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / seconds,
             "device_ms_rank0": dev_ms,
             "gather_ms": gather_ms,
+            "sparse_spectrum": {
+                "nonzero_block_fraction": nz_fraction,
+                "note": "8-column blocks of the thresholded spectrum that kept a coefficient (rank 0, mean over slices and "
+                        "iterations); emptied blocks are not transformed back, stored or re-read -- exact. Data dependent: "
+                        "dense_path_iterations_per_s is the rate with the shortcut off (P3D_NO_SPARSE=1), from rank 0's block",
+                "dense_path_iterations_per_s": dense_its,
+            },
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -152,6 +152,12 @@ int p3d_time2freq(int device, const float* x, int nt, size_t ntraces, double dt,
 int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntraces, double dt, double t0, int nfft,
                   int real_only, float* out);
 
+/* Sparse-spectrum statistics of the last p3d_pocs_run[_dev] on this plan: fraction of 8-column blocks of the thresholded spectra
+ * that kept at least one coefficient, averaged over slices and iterations (blocks the threshold empties are neither transformed
+ * back, stored nor re-read -- exact, since they are zeros); -1 when the dense path ran (shape not eligible, P3D_NO_SPARSE=1,
+ * generic lengths). */
+int p3d_last_sparsity(p3d_plan* plan, double* nonzero_fraction);
+
 /* After a run with P3D_FLAG_PROFILE: average duration (ms) and launch count of the spectrum
  * (column) pass and of the space (row) pass kernels of the iteration loop. */
 int p3d_last_profile(p3d_plan* plan, double* colpass_ms, int* colpass_launches, double* rowpass_ms,

@@ -63,6 +63,7 @@ PROTOTYPES = {
                                 C.c_void_p]),
     "p3d_freq2time": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
                                 C.c_void_p]),
+    "p3d_last_sparsity": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_last_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),
     "p3d_wavelet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -274,6 +275,12 @@ class Plan:
                                      C.byref(prm), out_ptr, nslices, _ptr(done), None if sums is None else _ptr(sums),
                                      C.byref(ms)))
         return done, sums, ms.value
+
+    def last_sparsity(self):
+        """Fraction of 8-column spectrum blocks that kept a coefficient in the last run (-1: dense path)."""
+        v = C.c_double(-1.0)
+        check(lib().p3d_last_sparsity(self.handle, C.byref(v)))
+        return v.value
 
     def last_profile(self):
         cm, rm, cn, rn = C.c_double(), C.c_double(), C.c_int(), C.c_int()

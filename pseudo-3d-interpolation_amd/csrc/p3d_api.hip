@@ -64,6 +64,31 @@ static __global__ void rowbase_kernel(const uint16_t* bits, unsigned* rowbase, i
     for (int r = threadIdx.x; r <= n1; r += blockDim.x) rowbase[r] = cnt[r];
 }
 
+
+// Column-pass tile flags -> one 16-bit word per (slice, group of 8 row-pass threads): bit q = the column block that holds
+// element tl + tpl*q kept a coefficient.  col_t = columns per column-pass tile (a block spans 8/col_t tiles or a tile spans
+// col_t/8 blocks).  Also counts the kept blocks (statistics only).
+static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsigned long long* count, int nslices, int tiles, int col_t, int groups,
+                                      int nblocks, const int* done)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslices * groups) return;
+    const int s = i / groups, g = i - s * groups;
+    if (done && done[s] != 0) return;   // finished / empty slices: nobody reads their word
+    const uint8_t* f = flags + (size_t)s * tiles;
+    unsigned word = 0, kept = 0;
+    for (int q = 0; q < 16; ++q) {
+        const int b = g + groups * q;
+        if (b >= nblocks) continue;
+        unsigned any = 0;
+        if (col_t >= 8) any = f[b / (col_t / 8)];
+        else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
+        word |= (any ? 1u : 0u) << q;
+        kept += any ? 1u : 0u;
+    }
+    nzm[i] = (uint16_t)word;
+    if (kept) atomicAdd(count, (unsigned long long)kept);
+}
 // ---- per-slice sum of the per-row sums, fixed order (bitwise reproducible) ----------------------------------
 static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row, int n1)
 {
@@ -149,7 +174,12 @@ struct p3d_plan {
     const LineOps* ops_col = nullptr;  // length nil (transform along iline = down the columns)
     const LineOps* ops_row = nullptr;  // length nxl (transform along xline = along the rows)
     c32 *tw_col = nullptr, *tw_row = nullptr;  // padded twiddle tables of length nil / nxl
-    c32* work = nullptr;                        // column-blocked work buffer
+    c32* work = nullptr;                        // column-blocked work buffer (+ 64 zero bytes behind the last slice)
+    uint8_t* nzflag = nullptr;                  // [max_slices][tiles]: column-pass tile kept a coefficient (sparse skipping)
+    uint16_t* nzm = nullptr;                    // [max_slices][tpl/8] the same per row-pass thread group, one bit per register
+    unsigned long long* nzcount = nullptr;      // device counter: non-empty column blocks seen by nz_pack_kernel
+    bool sparse_ok = false;                     // shape supports skipping emptied tiles
+    double last_nonzero_fraction = -1.0;        // of the last p3d_pocs_run: kept column blocks / all (or -1: dense path)
     uint16_t* bits = nullptr;                   // packed binary trace mask [nil][tpl(nxl)]
     int* flag = nullptr;                        // device int[2]: mask not binary / x non-zero at a missing trace
     unsigned* rowbase = nullptr;                // [nil+1] observed positions before each row
@@ -216,7 +246,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
+    void* bufs[] = {p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -297,7 +327,17 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     } else {
         if ((rc = upload_table(p, oc, false, &p->tw_col)) != P3D_OK) return bail(rc);
         if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
-        TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * wk_slice_stride(nil, nxl) * max_slices));
+        const size_t welems = wk_slice_stride(nil, nxl) * max_slices;
+        TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * welems + 64));
+        TRY_OR_BAIL(hipMemset(p->work + welems, 0, 64));   // what the row pass reads for tiles the threshold emptied
+        // emptied tiles can be skipped when a row-pass thread's 16 elements sit in 16 whole column blocks (nxl >= 128) and
+        // 32-bit element offsets reach the zero pad
+        p->sparse_ok = orow->tpl % 8 == 0 && (double)welems + 8.0 < 4294967296.0;
+        if (p->sparse_ok) {
+            TRY_OR_BAIL(hipMalloc((void**)&p->nzflag, (size_t)p->tiles * max_slices));
+            TRY_OR_BAIL(hipMalloc((void**)&p->nzm, sizeof(uint16_t) * (size_t)(orow->tpl / 8) * max_slices));
+            TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
+        }
         TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
         TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
     }
@@ -830,11 +870,25 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     c.done = any_off ? p->done : nullptr;
     c.niter = niter;
     c.op = base_op;
+    // tiles of the spectrum that the threshold empties are neither transformed back, stored nor read again
+    const bool sparse = p->sparse_ok && !getenv("P3D_NO_SPARSE");
+    const int nblocks = (p->nxl + 7) / 8, groups = p->ops_row->tpl / 8;
+    if (sparse) {
+        c.nzflag = p->nzflag;
+        r.zero_off = (unsigned)(wk_slice_stride(p->nil, p->nxl) * (size_t)p->max_slices);
+        HIP_TRY(hipMemsetAsync(p->nzcount, 0, sizeof(unsigned long long), p->stream));
+    }
+    p->last_nonzero_fraction = -1.0;
 
     HIP_TRY(stamp());
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
+        if (sparse) {
+            nz_pack_kernel<<<(nslices * groups + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzm, p->nzcount, nslices, p->tiles, p->ops_col->col_tile,
+                                                                                groups, nblocks, c.done);
+            r.nzm = p->nzm;
+        }
         HIP_TRY(stamp());
         r.sum_row = k + 1;
         bool piped = false;
@@ -852,6 +906,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
             if (finalize && k + 1 < niter) {
                 RowArgs f = r;
+                f.nzm = nullptr;  // the rows it reads were written by the row pass: all there
                 f.only_done = k + 1;
                 f.plain = 0;      // the observed samples are needed (exact hand-back at observed traces)
                 f.sums = nullptr;
@@ -866,7 +921,10 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
 
     HIP_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) HIP_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
+    unsigned long long kept_blocks = 0;
+    if (sparse) HIP_TRY(hipMemcpyAsync(&kept_blocks, p->nzcount, sizeof kept_blocks, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (sparse) p->last_nonzero_fraction = (double)kept_blocks / ((double)niter * nslices * nblocks);
 
     if (niter_done)
         for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
@@ -1011,6 +1069,13 @@ int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, siz
     HIP_TRY(gen_launch_real_part(work, (float*)dout.p, (size_t)nfft * ntr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(float) * (size_t)nfft * ntr, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+int p3d_last_sparsity(p3d_plan* p, double* nonzero_fraction)
+{
+    if (!p || !nonzero_fraction) return fail(P3D_ERR_INVALID, "NULL argument");
+    *nonzero_fraction = p->last_nonzero_fraction;
     return P3D_OK;
 }
 

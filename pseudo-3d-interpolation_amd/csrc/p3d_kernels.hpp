@@ -157,6 +157,9 @@ struct RowArgs {
     int adaptive;          // APOCS input mix
     int write_out;         // MID: also store the iterate to `out` (needed only when eps > 0)
     int plain;             // LAST: plain inverse transform (no re-insertion): fft2 hook
+    const uint16_t* nzm;   // MID / LAST / pipe: per (slice, tl/8) one bit per register q, clear = the column block of element
+                           // tl + TPL*q was zeroed entirely by the threshold and NOT stored by the column pass (nullptr: dense)
+    unsigned zero_off;     // element index (from `work`) of a zero the loads of such blocks are pointed at
     int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done == only_done; their work
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
     float alpha;
@@ -179,6 +182,8 @@ struct ColArgs {
     int in_std;         // `in` is row-major [nslices][N][n2] instead of column-blocked
     int out_std;        // same for `out`
     ShearArgs sh;       // COL_SHRINK
+    uint8_t* nzflag;    // COL_ITER*: [nslices][tiles] 1 = the tile kept at least one coefficient; tiles that kept none are
+                        // neither transformed back nor stored (nullptr: always store)
 };
 
 // per-thread partial sums are float (16 terms); across the wave they are combined in double so that the
@@ -344,8 +349,23 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
         }
         return;
     } else {
+        if constexpr (TPL % 8 == 0) {
+            if (a.nzm != nullptr && !a.only_done) {   // blocks the column pass did not store read a zero instead
+                const unsigned nz = a.nzm[(size_t)slice * (TPL / 8) + (tl >> 3)];
+                const unsigned zbase = a.zero_off - (unsigned)slice * (unsigned)wk_slice_stride(a.n1, N);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+                for (int q = 0; q < PPT; ++q) {
+                    const unsigned o = ((nz >> q) & 1u) ? wlane : zbase - (unsigned)q * (TPL / 8) * wblk;
+                    v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[o] : c32{0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+        }
         if (!(P3D_ABL & 1)) line_fft<N, INV, WAVE>(v, lds, tw, tl);
         // The observed samples are fetched here, a few at a time, instead of being prefetched ahead of
         // the inverse transform: holding 16 of them across the transform costs 32 VGPRs and the 16
@@ -492,12 +512,21 @@ row_pipe_kernel(const RowArgs a)
     // (beyond the end, finished or empty slice) reads line 0 instead (locate() clamps) and its results are
     // simply not stored or summed.
     c32 v[PPT], bx[PPT], by[PPT];
-    auto load_work = [&](c32 (&dst)[PPT], const Where& w) {
+    // nz: bit q clear = the column block of register q was emptied by the threshold and not stored (see RowArgs::nzm)
+    constexpr bool CAN_SPARSE = TPL % 8 == 0;
+    const bool sparse = CAN_SPARSE && a.nzm != nullptr;
+    auto load_work = [&](c32 (&dst)[PPT], const Where& w, unsigned nz) {
         const unsigned wl = wlane(w);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q)
-            dst[q] = (P3D_ABL & 8) ? c32{(float)wl, (float)q} : wk_q_ptr<TPL>((const c32*)a.work, q, tl, wblk)[wl];
+        for (int q = 0; q < PPT; ++q) {
+            unsigned o = wl;
+            if (CAN_SPARSE) {
+                if (sparse) o = ((nz >> q) & 1u) ? wl : a.zero_off - (unsigned)q * (TPL / 8) * wblk;
+            }
+            dst[q] = (P3D_ABL & 8) ? c32{(float)wl, (float)q} : wk_q_ptr<TPL>((const c32*)a.work, q, tl, wblk)[o];
+        }
     };
+    auto nz_of = [&](const Where& w) -> unsigned { return sparse ? (unsigned)a.nzm[w.slice * (TPL / 8) + (tl >> 3)] : 0xffffu; };
     // (wbits, wbase): mask word / compact row base of the row being loaded (fetched a row earlier, see NOTE)
     auto load_obs = [&](c32 (&dst)[PPT], const Where& w, unsigned wbits, unsigned wbase) {
         if constexpr (COMPACT) {
@@ -526,7 +555,8 @@ row_pipe_kernel(const RowArgs a)
     unsigned mbits = 0, rbase = 0;
     if (BITS) mbits = a.bits[cur.row * TPL + tl];
     if (COMPACT) rbase = a.rowbase[cur.row];
-    load_work(by, cur);
+    unsigned nz_nxt = nz_of(nxt);   // consumed by the prefetch of the next row: fetched a row early like the mask word
+    load_work(by, cur, nz_of(cur));
     constexpr bool LATE = COMPACT && P3D_COMPACT_LATE;
     if (!LATE) load_obs(bx, cur, mbits, rbase);
 
@@ -543,9 +573,10 @@ row_pipe_kernel(const RowArgs a)
         unsigned mbits_nxt = 0, rbase_nxt = 0;
         if (BITS) mbits_nxt = a.bits[nxt.row * TPL + tl];
         if (COMPACT) rbase_nxt = a.rowbase[nxt.row];
+        const unsigned nz_nxt2 = nz_of(nxt2);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = by[q];
-        load_work(by, nxt);
+        load_work(by, nxt, nz_nxt);
         const unsigned off = (cur.slice * (unsigned)a.n1 + cur.row) * N + tl;
 
         __builtin_amdgcn_sched_barrier(0);
@@ -601,6 +632,7 @@ row_pipe_kernel(const RowArgs a)
         nxt = nxt2;
         mbits = mbits_nxt;
         rbase = rbase_nxt;
+        nz_nxt = nz_nxt2;
     }
 }
 
@@ -693,6 +725,16 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         const int op = MODE == COL_ITER ? 0 : (MODE == COL_ITER_SOFT ? 1 : (MODE == COL_ITER_GARROTE ? 2 : a.op));
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = shrink(v[q], tau, op);
+        if (ITER && a.nzflag != nullptr) {
+            // Sparse spectra (the premise of the method): a tile the threshold emptied is all zeros after the inverse
+            // transform too.  Say so instead of transforming and storing it; the row pass reads zeros for it.
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) any = any || (v[q].x != 0.0f) || (v[q].y != 0.0f);
+            const int kept = __syncthreads_or(any ? 1 : 0);
+            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
+            if (!kept) return;
+        }
     }
 
     if (MODE == COL_STATS) {
