@@ -64,6 +64,9 @@
 #ifndef P3D_PIPE_LOCKSTEP
 #define P3D_PIPE_LOCKSTEP 1
 #endif
+#ifndef P3D_PIPE_PREFETCH
+#define P3D_PIPE_PREFETCH 1  // 0 (experiment): no row-ahead prefetch of the work buffer (32 VGPRs less)
+#endif
 #ifndef P3D_ROW_WAVES_PER_EU
 #define P3D_ROW_WAVES_PER_EU (P3D_ROW_THREADS >= 512 ? 4 : 3)
 #endif
@@ -511,7 +514,10 @@ row_pipe_kernel(const RowArgs a)
     // consumed by the re-insertion of row r+1).  Loads are never predicated: a line that is switched off
     // (beyond the end, finished or empty slice) reads line 0 instead (locate() clamps) and its results are
     // simply not stored or summed.
-    c32 v[PPT], bx[PPT], by[PPT];
+    c32 v[PPT], bx[PPT];
+#if P3D_PIPE_PREFETCH
+    c32 by[PPT];
+#endif
     // nz: bit q clear = the column block of register q was emptied by the threshold and not stored (see RowArgs::nzm)
     constexpr bool CAN_SPARSE = TPL % 8 == 0;
     const bool sparse = CAN_SPARSE && a.nzm != nullptr;
@@ -556,7 +562,11 @@ row_pipe_kernel(const RowArgs a)
     if (BITS) mbits = a.bits[cur.row * TPL + tl];
     if (COMPACT) rbase = a.rowbase[cur.row];
     unsigned nz_nxt = nz_of(nxt);   // consumed by the prefetch of the next row: fetched a row early like the mask word
+#if P3D_PIPE_PREFETCH
     load_work(by, cur, nz_of(cur));
+#else
+    unsigned nz_cur = nz_of(cur);
+#endif
     constexpr bool LATE = COMPACT && P3D_COMPACT_LATE;
     if (!LATE) load_obs(bx, cur, mbits, rbase);
 
@@ -574,9 +584,13 @@ row_pipe_kernel(const RowArgs a)
         if (BITS) mbits_nxt = a.bits[nxt.row * TPL + tl];
         if (COMPACT) rbase_nxt = a.rowbase[nxt.row];
         const unsigned nz_nxt2 = nz_of(nxt2);
+#if P3D_PIPE_PREFETCH
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = by[q];
         load_work(by, nxt, nz_nxt);
+#else
+        load_work(v, cur, nz_cur);
+#endif
         const unsigned off = (cur.slice * (unsigned)a.n1 + cur.row) * N + tl;
 
         __builtin_amdgcn_sched_barrier(0);
@@ -632,6 +646,9 @@ row_pipe_kernel(const RowArgs a)
         nxt = nxt2;
         mbits = mbits_nxt;
         rbase = rbase_nxt;
+#if !P3D_PIPE_PREFETCH
+        nz_cur = nz_nxt;
+#endif
         nz_nxt = nz_nxt2;
     }
 }
