@@ -47,9 +47,6 @@
 #ifndef P3D_XCD_PAIR
 #define P3D_XCD_PAIR 1   // narrow column tiles of one 64-byte block on the same XCD, back to back
 #endif
-#ifndef P3D_ABL
-#define P3D_ABL 0        // ablations for timing only (results wrong): 1 no transforms, 2 no forward, 4 no work store
-#endif
 // persistent row pass, waves per SIMD: with the full-cube observed samples v[], bx[], by[] are live across both
 // transforms (~220 VGPRs -> 2); with compact samples, fetched after the inverse transform, 157 VGPRs -> 3
 #ifndef P3D_PIPE_WAVES_PER_EU
@@ -369,7 +366,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
 #pragma unroll
             for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
         }
-        if (!(P3D_ABL & 1)) line_fft<N, INV, WAVE>(v, lds, tw, tl);
+        line_fft<N, INV, WAVE>(v, lds, tw, tl);
         // The observed samples are fetched here, a few at a time, instead of being prefetched ahead of
         // the inverse transform: holding 16 of them across the transform costs 32 VGPRs and the 16
         // waves per CU this kernel is budgeted for (128 VGPRs) cover the latency instead.
@@ -439,8 +436,8 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
     }
 
     if (MODE != ROW_LAST) {
-        if (!(P3D_ABL & 3)) line_fft<N, FWD, WAVE>(v, lds, tw, tl);
-        if (valid && !(P3D_ABL & 4)) {
+        line_fft<N, FWD, WAVE>(v, lds, tw, tl);
+        if (valid) {
             for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] = v[q];
         }
     }
@@ -529,7 +526,7 @@ row_pipe_kernel(const RowArgs a)
             if (CAN_SPARSE) {
                 if (sparse) o = ((nz >> q) & 1u) ? wl : a.zero_off - (unsigned)q * (TPL / 8) * wblk;
             }
-            dst[q] = (P3D_ABL & 8) ? c32{(float)wl, (float)q} : wk_q_ptr<TPL>((const c32*)a.work, q, tl, wblk)[o];
+            dst[q] = wk_q_ptr<TPL>((const c32*)a.work, q, tl, wblk)[o];
         }
     };
     auto nz_of = [&](const Where& w) -> unsigned { return sparse ? (unsigned)a.nzm[w.slice * (TPL / 8) + (tl >> 3)] : 0xffffu; };
@@ -552,8 +549,7 @@ row_pipe_kernel(const RowArgs a)
             const unsigned off = (w.slice * (unsigned)a.n1 + w.row) * N + tl;
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
-                if (P3D_ABL & 8) dst[q] = c32{(float)off, 1.0f};
-                else if (DT == 0) dst[q] = (reinterpret_cast<const c32*>(a.x) + TPL * q)[off];
+                if (DT == 0) dst[q] = (reinterpret_cast<const c32*>(a.x) + TPL * q)[off];
                 else dst[q] = c32{(reinterpret_cast<const float*>(a.x) + TPL * q)[off], 0.f};
             }
         }
@@ -594,7 +590,7 @@ row_pipe_kernel(const RowArgs a)
         const unsigned off = (cur.slice * (unsigned)a.n1 + cur.row) * N + tl;
 
         __builtin_amdgcn_sched_barrier(0);
-        if (!(P3D_ABL & 1)) line_fft<N, INV, true>(v, lds, tw, tl);
+        line_fft<N, INV, true>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
         if (LATE) {
             load_obs(bx, cur, mbits, rbase);
@@ -633,10 +629,10 @@ row_pipe_kernel(const RowArgs a)
         }
 
         __builtin_amdgcn_sched_barrier(0);
-        if (!(P3D_ABL & 1)) line_fft<N, FWD, true>(v, lds, tw, tl);
+        line_fft<N, FWD, true>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
 
-        if (cur.on && (!(P3D_ABL & 8) || v[0].x == 1.2345e30f)) {
+        if (cur.on) {
             const unsigned wl = wlane(cur);
 #pragma unroll
             for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(a.work, q, tl, wblk)[wl] = v[q];
