@@ -513,7 +513,7 @@ int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
-    RowArgs r = row_args(p, nb * nsh);
+    RowArgs r = row_args(p, nb);   // one workgroup row-group per slice; the shearlets are looped over inside
     r.x = F;
     r.work = p->work;
     r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0);

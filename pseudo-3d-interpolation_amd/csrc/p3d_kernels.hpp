@@ -309,16 +309,23 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
             if (compact && bad && valid) atomicOr(a.violation, 1);
         }
     } else if (MODE == ROW_SPREAD_INV) {
-        // work[b*nsh + s] = inverse row FFT of Psi_s * F[b]   (F = a.x: spectra of slice b, row-major; grid.y = b*nsh + s)
-        const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
-        const c32* const f = reinterpret_cast<const c32*>(a.x) + (size_t)b * a.n1 * N;
-        const float* const w = a.sh.psi + (size_t)s * a.n1 * N;
+        // work[b*nsh + s] = inverse row FFT of Psi_s * F[b] for every s   (F = a.x: spectra of slice b, row-major; grid.y = b).
+        // The row of F is read once and kept in registers across the shearlets.
+        const c32* const f = reinterpret_cast<const c32*>(a.x) + sbase;
+        c32 fr[PPT];
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = valid ? f[off + TPL * q] * w[off + TPL * q] : c32{0.f, 0.f};
-        line_fft<N, INV, WAVE>(v, lds, tw, tl);
-        if (valid) {
+        for (int q = 0; q < PPT; ++q) fr[q] = valid ? f[off + TPL * q] : c32{0.f, 0.f};
+        for (int s = 0; s < a.sh.nsh; ++s) {
+            const float* const w = a.sh.psi + (size_t)s * a.n1 * N;
+            c32* const ws = a.work + ((size_t)slice * a.sh.nsh + s) * wk_slice_stride(a.n1, N);
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] = v[q];
+            for (int q = 0; q < PPT; ++q) v[q] = fr[q] * (valid ? w[off + TPL * q] : 0.f);
+            line_fft<N, INV, WAVE>(v, lds, tw, tl);
+            __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: store them together
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(ws, q, tl, wblk)[wlane] = v[q];
+            }
         }
         return;
     } else if (MODE == ROW_GATHER_FWD) {
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
 
     if (MODE != ROW_LAST) {
         line_fft<N, FWD, WAVE>(v, lds, tw, tl);
+        __syncthreads();   // the rows of a workgroup are adjacent and share 128-byte lines of the work buffer: store together
         if (valid) {
             for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] = v[q];
         }
