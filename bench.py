@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--nslices", type=int, default=512, help="slices of the whole cube (sharded over the GPUs)")
     ap.add_argument("--missing", type=float, default=0.8)
     ap.add_argument("--thresh-op", default="hard")
+    ap.add_argument("--alpha", type=float, default=1.0, help="re-insertion weight (the metric's setting: 1)")
+    ap.add_argument("--p-min", default="1e-3", help="final threshold factor or 'adaptive' (the metric's setting: 1e-3)")
     ap.add_argument("--eps", type=float, default=0.0, help="cost threshold of the early exit (0 = run all iterations, the metric's setting)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,9 +156,10 @@ def main():
         stats = plan.stats_dev(x_obs.data_ptr(), _ffi.P3D_C64, n_local)
         active = stats[:, 2] > 0
         stats[~active] = 1.0
-        tau = _schedule_from_stats(stats, nil * nxl, "exponential", niter, 0.99, 1e-3, "values")
+        p_min = args.p_min if args.p_min == "adaptive" else float(args.p_min)
+        tau = _schedule_from_stats(stats, nil * nxl, "exponential", niter, 0.99, p_min, "values")
         return plan.run_dev(x_obs.data_ptr(), _ffi.P3D_C64, mask_t.data_ptr(), tau, niter, out.data_ptr(), n_local,
-                            thresh_op=args.thresh_op, eps=args.eps, alpha=1.0, active=active, profile=profile,
+                            thresh_op=args.thresh_op, eps=args.eps, alpha=args.alpha, active=active, profile=profile,
                             want_sums=False)
 
     def fence():
