@@ -15,6 +15,7 @@
 #include "p3d.h"
 #include "p3d_generic.hpp"
 #include "p3d_internal.hpp"
+#include "p3d_flex.hpp"
 #include "p3d_kernels.hpp"
 
 namespace p3d {
@@ -38,9 +39,13 @@ static const LineOps* find_ops(int n)
         case 1024: return get_line_ops_1024();
         case 2048: return get_line_ops_2048();
         case 4096: return get_line_ops_4096();
-        default: return nullptr;
+        default: break;
     }
+    // any other length whose lines fit LDS: same two passes, LDS-resident mixed-radix transforms (p3d_flex.hip)
+    if (flex_supported(n) && !getenv("P3D_NO_FLEX")) return get_flex_ops();
+    return nullptr;
 }
+static bool is_flex(const LineOps* ops) { return ops && ops->tpl == 0; }
 }  // namespace p3d
 
 using namespace p3d;
@@ -208,10 +213,11 @@ struct p3d_plan {
     size_t slice_elems() const { return (size_t)nil * nxl; }
 };
 
-static int upload_table(p3d_plan* p, const LineOps* ops, bool for_rows, c32** dst)
+static int upload_table(p3d_plan* p, const LineOps* ops, bool for_rows, int n, c32** dst)
 {
-    std::vector<c32> host(for_rows ? ops->row_tw_slots : tw_slots(ops->n));
-    if (for_rows) ops->build_row_tw(host.data());
+    std::vector<c32> host(is_flex(ops) ? (size_t)n : (for_rows ? (size_t)ops->row_tw_slots : (size_t)tw_slots(ops->n)));
+    if (is_flex(ops)) gen_build_twiddles(n, host.data());   // plain table exp(-2 pi i k / n)
+    else if (for_rows) ops->build_row_tw(host.data());
     else build_twiddles(ops->n, host.data());
     HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * host.size()));
     HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
@@ -287,11 +293,12 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
         p->grow = gen_make_plan(nxl);
         p->tiles = p3d_plan::GEN_STAT_BLOCKS;
     } else {
-        p->tiles = (nxl + oc->col_tile - 1) / oc->col_tile;
+        const int ct = is_flex(oc) ? flex_col_tile(nil) : oc->col_tile;
+        p->tiles = (nxl + ct - 1) / ct;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         p->cus = prop.multiProcessorCount;
-        p->pipe_wgs = (orow->tpl <= 64 && !getenv("P3D_NO_PIPE")) ? p->cus : 0;  // the launcher sizes the grid per variant
+        p->pipe_wgs = (orow->tpl > 0 && orow->tpl <= 64 && !getenv("P3D_NO_PIPE")) ? p->cus : 0;  // the launcher sizes the grid per variant
     }
     int rc = P3D_OK;
     auto bail = [&](int code) {
@@ -325,20 +332,20 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
         TRY_OR_BAIL(hipMalloc((void**)&p->pct_hist, sizeof(unsigned) * 2048 * (size_t)max_slices));
         TRY_OR_BAIL(hipMalloc((void**)&p->pct_frac, sizeof(float) * (size_t)max_slices));
     } else {
-        if ((rc = upload_table(p, oc, false, &p->tw_col)) != P3D_OK) return bail(rc);
-        if ((rc = upload_table(p, orow, true, &p->tw_row)) != P3D_OK) return bail(rc);
+        if ((rc = upload_table(p, oc, false, nil, &p->tw_col)) != P3D_OK) return bail(rc);
+        if ((rc = upload_table(p, orow, true, nxl, &p->tw_row)) != P3D_OK) return bail(rc);
         const size_t welems = wk_slice_stride(nil, nxl) * max_slices;
         TRY_OR_BAIL(hipMalloc((void**)&p->work, sizeof(c32) * welems + 64));
         TRY_OR_BAIL(hipMemset(p->work + welems, 0, 64));   // what the row pass reads for tiles the threshold emptied
         // emptied tiles can be skipped when a row-pass thread's 16 elements sit in 16 whole column blocks (nxl >= 128) and
         // 32-bit element offsets reach the zero pad
-        p->sparse_ok = orow->tpl % 8 == 0 && (double)welems + 8.0 < 4294967296.0;
+        p->sparse_ok = orow->tpl > 0 && oc->tpl > 0 && orow->tpl % 8 == 0 && (double)welems + 8.0 < 4294967296.0;
         if (p->sparse_ok) {
             TRY_OR_BAIL(hipMalloc((void**)&p->nzflag, (size_t)p->tiles * max_slices));
             TRY_OR_BAIL(hipMalloc((void**)&p->nzm, sizeof(uint16_t) * (size_t)(orow->tpl / 8) * max_slices));
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
-        TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
+        if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
         TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
     }
     TRY_OR_BAIL(hipMalloc((void**)&p->flag, 2 * sizeof(int)));
@@ -401,6 +408,7 @@ static RowArgs row_args(p3d_plan* p, int nslices)
     r.nslices = nslices;
     r.alpha = 1.0f;
     r.scale = (float)(1.0 / ((double)p->nil * (double)p->nxl));
+    r.len = p->nxl;
     return r;
 }
 
@@ -410,6 +418,7 @@ static ColArgs col_args(p3d_plan* p, int nslices)
     c.tw = p->tw_col;
     c.n2 = p->nxl;
     c.nslices = nslices;
+    c.len = p->nil;
     return c;
 }
 
@@ -500,7 +509,7 @@ static int fft2_enqueue(p3d_plan* p, const void* in, void* out, int nslices, int
 
 namespace p3d {
 // ---- the three fused passes of one SHEARLET iteration (p3d_shearlet.hip); power-of-two plans only ----------------------------
-bool shearlet_fused_supported(p3d_plan* plan) { return plan && !plan->generic; }
+bool shearlet_fused_supported(p3d_plan* plan) { return plan && !plan->generic && plan->ops_row->tpl > 0 && plan->ops_col->tpl > 0; }
 
 static ShearArgs shear_args(const float* psi, const c32* tau, int nsh, int niter, int iter, int op, int real_only)
 {
@@ -798,19 +807,22 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
 
     // packed trace mask: binary masks (the workflow's fold-derived mask, cube_POCS_interpolation_3D.py:242-244)
     // travel as one 16-bit word per thread and row; anything else keeps the float weights
-    {
+    const bool flex_rows = is_flex(p->ops_row);   // the flexible row pass reads the float weights
+    HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
+    if (!flex_rows) {
         const int words = p->nil * p->ops_row->tpl;
-        HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
         pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl,
                                                                     p->ops_row->ppt);
         if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
         HIP_TRY(hipGetLastError());
     }
-    int nonbinary = 0;
+    int nonbinary = flex_rows ? 1 : 0;
     unsigned nobs = 0;
-    HIP_TRY(hipMemcpyAsync(&nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(&nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!flex_rows) {
+        HIP_TRY(hipMemcpyAsync(&nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(&nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     if (getenv("P3D_NO_MASK_BITS")) nonbinary = 1;  // experiments only
     // Compact observed samples for the steady-state row pass: only the observed positions of x are non-zero in
     // the workflow (x = stacked traces, mask = fold >= 1); ROW_FIRST verifies that and the full cube is used if not.

@@ -1,0 +1,367 @@
+// p3d_flex.hip -- the two-pass POCS pipeline for line lengths that are NOT powers of two.
+//
+// numpy.fft accepts every length and so does the reference (cube_POCS_interpolation_3D.py:255-257); survey grids are rarely
+// powers of two.  The register-resident engine of p3d_fft.hpp is specialised per power-of-two length at compile time; this file
+// provides the same two kernels -- column pass (forward transform, threshold, inverse transform) and row pass (inverse
+// transform, re-insertion, cost sums, forward transform) -- for any length whose lines fit LDS, behind the same LineOps /
+// RowArgs / ColArgs interface and on the same column-blocked work buffer, so that every caller in p3d_api.hip (POCS loop,
+// statistics, fft2 hooks, early exit, APOCS) runs unchanged and a slice may mix a tuned axis with a flexible one.
+//
+// Line FFT: mixed-radix Stockham autosort in LDS (ping-pong), factor list computed on the host (odd factors first: the
+// strided writes of a pass with small stride then have an odd stride in banks), radix 2 / 4 butterflies hard-wired, radix 3 / 5
+// / 7 as direct DFTs with constants from the twiddle table, larger primes as direct O(p^2) butterflies.  The twiddle table
+// exp(-2 pi i k / n) sits in LDS.
+//   column pass: a workgroup owns T columns (one 64-byte column block for T = 8); element i of column c lives at X[i*T + c],
+//                which is exactly the tile's layout in the work buffer: loads and stores are linear copies.
+//   row pass:    one wavefront per row (wave-level synchronisation only), LB rows per workgroup.
+// Arithmetic is float32 like the tuned path; results agree with it to rounding (different pass structure).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "p3d_flex.hpp"
+#include "p3d_kernels.hpp"
+
+namespace p3d {
+
+namespace {
+
+struct FlexFactors {
+    int n, nf;
+    int f[GEN_MAX_FACTORS];
+};
+
+FlexFactors flex_factors(int n)
+{
+    const GenPlan g = gen_make_plan(n);
+    FlexFactors p{};
+    p.n = n;
+    p.nf = g.nf;
+    int k = 0;
+    for (int i = 0; i < g.nf; ++i) if (g.f[i] % 2) p.f[k++] = g.f[i];   // odd first
+    for (int i = 0; i < g.nf; ++i) if (g.f[i] % 2 == 0) p.f[k++] = g.f[i];
+    return p;
+}
+
+constexpr size_t FLEX_LDS_MAX = 150 * 1024;
+constexpr size_t FLEX_LDS_TWO = 80 * 1024;   // two workgroups per CU
+
+size_t col_lds(int n, int T) { return sizeof(c32) * ((size_t)2 * T * n + n); }
+size_t row_lds(int n, int LB) { return sizeof(c32) * ((size_t)2 * LB * n + n); }
+
+int pick_col_tile(int n)
+{
+    if (col_lds(n, 8) <= FLEX_LDS_MAX) return 8;   // a whole 64-byte column block, even at one workgroup per CU
+    for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
+    return 0;
+}
+int pick_row_lines(int n)
+{
+    for (int LB : {4, 2, 1}) if (row_lds(n, LB) <= FLEX_LDS_TWO) return LB;
+    return row_lds(n, 1) <= FLEX_LDS_MAX ? 1 : 0;
+}
+
+// ---- butterflies --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ c32 conj_if(c32 w, int dir) { return dir > 0 ? c32{w.x, -w.y} : w; }
+__device__ __forceinline__ c32 mul_i(c32 a, int dir) { return dir > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x}; }   // a * (dir * i)
+
+// butterfly j of line c in pass (R, ns): inputs A[(j + t*m)*T + c] * w^(t*jm), outputs B[(j0 + k*ns)*T + c]
+template <int R>
+__device__ __forceinline__ void flex_bfly(const c32* A, c32* B, const c32* tw, int j, int c, int T, int m, int jm, int j0, int ns, int tstep, int rstep, int dir)
+{
+    c32 v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const c32 x = A[(j + t * m) * T + c];
+        v[t] = t == 0 ? x : x * conj_if(tw[t * jm * tstep], dir);
+    }
+    c32* o = B + j0 * T + c;
+    const int st = ns * T;
+    if constexpr (R == 2) {
+        o[0] = v[0] + v[1];
+        o[st] = v[0] - v[1];
+    } else if constexpr (R == 4) {
+        const c32 a = v[0] + v[2], b = v[0] - v[2], s = v[1] + v[3], d = mul_i(v[1] - v[3], dir);
+        o[0] = a + s;
+        o[st] = b + d;
+        o[2 * st] = a - s;
+        o[3 * st] = b - d;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            c32 acc = v[0];
+#pragma unroll
+            for (int t = 1; t < R; ++t) acc = acc + v[t] * conj_if(tw[((t * k) % R) * rstep], dir);
+            o[k * st] = acc;
+        }
+    }
+}
+
+// All passes of `lines` (= T) interleaved lines in LDS.  first/step: butterfly indices handled by this thread.  Returns the
+// buffer that holds the result.  SYNC: 0 = workgroup barrier, 1 = wavefront-level (one wave owns its lines).
+template <int SYNC>
+__device__ __forceinline__ void flex_sync()
+{
+    if constexpr (SYNC == 0) __syncthreads();
+    else exchange_sync<true>();
+}
+
+template <int SYNC>
+__device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, int dir, int tshift, int first, int step)
+{
+    const int n = pl.n, T = 1 << tshift;
+    int ns = 1;
+    for (int p = 0; p < pl.nf; ++p) {
+        const int R = pl.f[p];
+        const int m = n / R;
+        const int tstep = n / (ns * R), rstep = n / R;
+        for (int b = first; b < (m << tshift); b += step) {
+            const int c = b & (T - 1), j = b >> tshift;
+            const int jq = j / ns, jm = j - jq * ns;
+            const int j0 = jq * ns * R + jm;
+            switch (R) {
+                case 2: flex_bfly<2>(A, B, tw, j, c, T, m, jm, j0, ns, tstep, rstep, dir); break;
+                case 3: flex_bfly<3>(A, B, tw, j, c, T, m, jm, j0, ns, tstep, rstep, dir); break;
+                case 4: flex_bfly<4>(A, B, tw, j, c, T, m, jm, j0, ns, tstep, rstep, dir); break;
+                case 5: flex_bfly<5>(A, B, tw, j, c, T, m, jm, j0, ns, tstep, rstep, dir); break;
+                case 7: flex_bfly<7>(A, B, tw, j, c, T, m, jm, j0, ns, tstep, rstep, dir); break;
+                default:   // large prime factor: direct butterfly, inputs re-read from LDS
+                    for (int k = 0; k < R; ++k) {
+                        c32 acc{0.f, 0.f};
+                        for (int t = 0; t < R; ++t) {
+                            const long idx = ((long)t * jm * tstep + (long)((long)t * k % R) * rstep) % n;
+                            acc = acc + A[(j + t * m) * T + c] * conj_if(tw[idx], dir);
+                        }
+                        B[(j0 + k * ns) * T + c] = acc;
+                    }
+            }
+        }
+        flex_sync<SYNC>();
+        c32* t = A; A = B; B = t;
+        ns *= R;
+    }
+    return A;
+}
+
+// ---- column pass ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flex_col_kernel(const ColArgs a, const FlexFactors pl, int mode, int tshift)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = pl.n, T = 1 << tshift, tid = threadIdx.x;
+    c32* tw = reinterpret_cast<c32*>(smem_raw);
+    c32* A = tw + n;
+    c32* B = A + (size_t)n * T;
+    const int slice = blockIdx.y, col0 = blockIdx.x * T;
+    if (a.done && a.done[slice] != 0) return;
+    const bool iter = mode == COL_ITER || mode == COL_ITER_SOFT || mode == COL_ITER_GARROTE;
+
+    for (int i = tid; i < n; i += 256) tw[i] = a.tw[i];
+    const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
+    c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
+    auto goff = [&](int std_layout, int i, int col) -> size_t {
+        return std_layout ? (size_t)i * a.n2 + col : ((size_t)(col >> 3) * n + i) * 8 + (col & 7);
+    };
+    for (int e = tid; e < (n << tshift); e += 256) {
+        const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
+        A[e] = col < a.n2 ? inb[goff(a.in_std, i, col)] : c32{0.f, 0.f};
+    }
+    __syncthreads();
+
+    c32* X = A;
+    c32* Y = B;
+    if (mode != COL_INV) {
+        X = flex_fft<0>(A, B, tw, pl, FWD, tshift, tid, 256);
+        Y = X == A ? B : A;
+    }
+    if (iter || (mode == COL_FWD && a.tau != nullptr)) {
+        const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
+        const int op = mode == COL_ITER_SOFT ? 1 : (mode == COL_ITER_GARROTE ? 2 : a.op);   // callers pass COL_ITER + a.op
+        for (int e = tid; e < (n << tshift); e += 256) X[e] = shrink(X[e], tau, op);
+        __syncthreads();
+    }
+    if (mode == COL_STATS) {
+        // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
+        float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
+        for (int e = tid; e < (n << tshift); e += 256) {
+            if (col0 + (e & (T - 1)) >= a.n2) continue;
+            const c32 v = X[e];
+            const float p = v.x * v.x + v.y * v.y;
+            if (lex_greater(v.x, v.y, lr, li)) { lr = v.x; li = v.y; }
+            mx = fmaxf(mx, p);
+            mn = fminf(mn, p);
+            sq += p;
+        }
+        __shared__ float r[256 * 5];
+        r[tid * 5 + 0] = lr; r[tid * 5 + 1] = li; r[tid * 5 + 2] = mx; r[tid * 5 + 3] = mn; r[tid * 5 + 4] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            for (int t = 1; t < 256; ++t) {
+                const float* o = r + t * 5;
+                if (lex_greater(o[0], o[1], lr, li)) { lr = o[0]; li = o[1]; }
+                mx = fmaxf(mx, o[2]);
+                mn = fminf(mn, o[3]);
+                sq += o[4];
+            }
+            float* p = a.partials + ((size_t)slice * gridDim.x + blockIdx.x) * STATS_PARTIAL;
+            p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
+        }
+        return;
+    }
+    if (iter || mode == COL_INV) X = flex_fft<0>(X, Y, tw, pl, INV, tshift, tid, 256);
+    for (int e = tid; e < (n << tshift); e += 256) {
+        const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
+        if (col < a.n2) outb[goff(a.out_std, i, col)] = X[e];
+    }
+}
+
+// ---- row pass ------------------------------------------------------------------------------------------------------------------------
+// one wavefront per row, LB rows per workgroup; modes ROW_FIRST / ROW_MID / ROW_LAST as in row_kernel (p3d_kernels.hpp)
+__global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = pl.n, tid = threadIdx.x, lane = tid & 63, line = tid >> 6;
+    c32* tw = reinterpret_cast<c32*>(smem_raw);
+    c32* A = tw + n + (size_t)line * 2 * n;
+    c32* B = A + n;
+    const int slice = blockIdx.y, row = blockIdx.x * LB + line;
+    const bool valid = row < a.n1;
+    const int vrow = valid ? row : 0;
+    for (int i = tid; i < n; i += blockDim.x) tw[i] = a.tw[i];
+    __syncthreads();   // the only workgroup-wide barrier: from here on every wave is on its own
+
+    const int dn = a.done ? a.done[slice] : 0;
+    const size_t sbase = ((size_t)slice * a.n1 + vrow) * n;   // row-major cubes (x, out)
+    if (mode == ROW_LAST && a.only_done) {
+        if (dn != a.only_done) return;
+    } else if (mode == ROW_LAST) {
+        if (dn > 0) return;   // converged earlier: `out` already holds that iterate
+        if (dn < 0) {         // all-zero slice is handed back untouched (POCS.py:515-521)
+            if (valid)
+                for (int i = lane; i < n; i += 64) {
+                    if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = c32{0.f, 0.f};
+                    else reinterpret_cast<float*>(a.out)[sbase + i] = 0.f;
+                }
+            return;
+        }
+    } else if (dn != 0) {
+        return;
+    }
+    c32* const wrow = a.work + (size_t)slice * wk_slice_stride(a.n1, n) + (size_t)vrow * 8;   // + (i>>3)*n1*8 + (i&7)
+    const size_t wblk = (size_t)a.n1 * 8;
+    auto obs_at = [&](int i) -> c32 {
+        if (a.dtype == 0) return reinterpret_cast<const c32*>(a.x)[sbase + i];
+        return c32{reinterpret_cast<const float*>(a.x)[sbase + i], 0.f};
+    };
+    const float* const mrow = a.mask ? a.mask + (size_t)vrow * n : nullptr;
+
+    float acc = 0.f;
+    c32* X = A;
+    if (mode == ROW_FIRST) {
+        for (int i = lane; i < n; i += 64) {
+            const c32 x = valid ? obs_at(i) : c32{0.f, 0.f};
+            acc += sqrtf(x.x * x.x + x.y * x.y);
+            if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
+                const float m = mrow ? mrow[i] : 0.f;
+                const float w = 1.0f - a.alpha * m;
+                const c32 blend = x * a.alpha + x * w;
+                A[i] = blend + (x - x * m) * (1.0f - a.alpha);
+            } else {
+                A[i] = x;
+            }
+        }
+        exchange_sync<true>();
+    } else {
+        for (int i = lane; i < n; i += 64) A[i] = valid ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
+        exchange_sync<true>();
+        X = flex_fft<1>(A, B, tw, pl, INV, 0, lane, 64);
+        for (int i = lane; i < n; i += 64) {
+            c32 xn = X[i] * a.scale;
+            float m = 0.f;
+            c32 xo{0.f, 0.f};
+            if (!a.plain && valid) xo = obs_at(i);
+            if (mode == ROW_LAST && a.only_done) {
+                // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
+                if (a.alpha == 1.0f && mrow && mrow[i] == 1.0f) xn = xo;
+            } else if (!a.plain) {
+                m = mrow ? mrow[i] : 0.f;
+                const float w = 1.0f - a.alpha * m;        // POCS.py:616
+                xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
+            }
+            acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+            if ((mode == ROW_LAST || a.write_out) && valid) {
+                if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = xn;
+                else reinterpret_cast<float*>(a.out)[sbase + i] = xn.x;   // np.real(), POCS.py:656
+            }
+            if (mode == ROW_MID) {
+                if (a.adaptive) {   // x_input of the next iteration (POCS.py:574-575)
+                    const float w = 1.0f - a.alpha * m;
+                    const c32 blend = xo * a.alpha + xn * w;
+                    X[i] = blend + (xo - xn * m) * (1.0f - a.alpha);
+                } else {
+                    X[i] = xn;
+                }
+            }
+        }
+        exchange_sync<true>();
+    }
+    if (a.sums != nullptr) {
+        double ws = valid ? (double)acc : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
+        if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = ws;
+    }
+    if (mode != ROW_LAST) {
+        c32* Y = X == A ? B : A;
+        X = flex_fft<1>(X, Y, tw, pl, FWD, 0, lane, 64);
+        if (valid)
+            for (int i = lane; i < n; i += 64) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
+    }
+}
+
+hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
+{
+    if (mode != ROW_FIRST && mode != ROW_MID && mode != ROW_LAST) return hipErrorNotSupported;   // no shearlet passes here
+    if (a.bits != nullptr) return hipErrorInvalidValue;   // packed masks belong to the tuned row pass
+    const int n = a.len, LB = pick_row_lines(n);
+    if (LB == 0) return hipErrorNotSupported;
+    const FlexFactors pl = flex_factors(n);
+    const size_t lds = row_lds(n, LB);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
+    if (e != hipSuccess) return e;
+    flex_row_kernel<<<dim3((a.n1 + LB - 1) / LB, a.nslices), 64 * LB, lds, st>>>(a, pl, mode, LB);
+    return hipGetLastError();
+}
+
+hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
+{
+    if (mode == COL_SHRINK) return hipErrorNotSupported;
+    const int n = a.len, T = pick_col_tile(n);
+    if (T == 0) return hipErrorNotSupported;
+    int tshift = 0;
+    while ((1 << tshift) < T) ++tshift;
+    const FlexFactors pl = flex_factors(n);
+    const size_t lds = col_lds(n, T);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_col_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
+    if (e != hipSuccess) return e;
+    ColArgs b = a;
+    b.nzflag = nullptr;   // no sparse-tile skipping on this path
+    flex_col_kernel<<<dim3((a.n2 + T - 1) / T, a.nslices), 256, lds, st>>>(b, pl, mode, tshift);
+    return hipGetLastError();
+}
+
+hipError_t flex_no_pipe(const RowArgs&, int, hipStream_t) { return hipErrorNotSupported; }
+
+}  // namespace
+
+bool flex_supported(int n) { return n >= 2 && n <= GEN_MAX_N && gen_make_plan(n).nf > 0 && pick_col_tile(n) > 0 && pick_row_lines(n) > 0; }
+int flex_col_tile(int n) { return pick_col_tile(n); }
+
+const LineOps* get_flex_ops()
+{
+    // tpl = 0 marks the flexible implementation: no packed mask words, no persistent row pass, no sparse-tile flags
+    static const LineOps ops = {0, 0, 0, 0, &flex_row, &flex_col, &flex_no_pipe, 0, 0, nullptr};
+    return &ops;
+}
+
+}  // namespace p3d

@@ -164,6 +164,7 @@ struct RowArgs {
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
     float alpha;
     float scale;           // 1/(n1*N)
+    int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
     ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD
 };
 
@@ -182,6 +183,7 @@ struct ColArgs {
     int in_std;         // `in` is row-major [nslices][N][n2] instead of column-blocked
     int out_std;        // same for `out`
     ShearArgs sh;       // COL_SHRINK
+    int len;            // N, the column length (see RowArgs::len)
     uint8_t* nzflag;    // COL_ITER*: [nslices][tiles] 1 = the tile kept at least one coefficient; tiles that kept none are
                         // neither transformed back nor stored (nullptr: always store)
 };

@@ -1,0 +1,12 @@
+import sys, numpy as np
+sys.path.insert(0, '/root/repo')
+from pseudo_3d_interpolation_amd import _ffi
+rng = np.random.default_rng(0)
+for shape in [(31,17),(48,20),(20,48),(4,20),(20,4),(16,20),(20,16),(48,16),(16,48),(90,50),(12,12),(1000,960)]:
+    x = (rng.standard_normal((2,)+shape) + 1j*rng.standard_normal((2,)+shape)).astype(np.complex64)
+    with _ffi.Plan(shape[0], shape[1], 2) as p:
+        F = p.fft2(x); want = np.fft.fft2(x.astype(np.complex128))
+        e1 = np.linalg.norm(F-want)/np.linalg.norm(want)
+        I = p.fft2(x, inverse=True); want = np.fft.ifft2(x.astype(np.complex128))
+        e2 = np.linalg.norm(I-want)/np.linalg.norm(want)
+    print(shape, "fwd %.2e inv %.2e" % (e1, e2))
