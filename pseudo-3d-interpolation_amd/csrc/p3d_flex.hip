@@ -32,15 +32,23 @@ struct FlexFactors {
     int f[GEN_MAX_FACTORS];
 };
 
+// Radices of the passes.  Every pass is one trip through LDS and one barrier, so two prime factors are folded into one
+// in-register butterfly wherever a supported product exists (16 = 4x4 ... 6 = 2x3); primes above 7 stay direct O(p^2) passes.
+// Odd radices go first: the scattered writes of an early pass (small stride) then have an odd stride in LDS banks.
 FlexFactors flex_factors(int n)
 {
-    const GenPlan g = gen_make_plan(n);
     FlexFactors p{};
     p.n = n;
-    p.nf = g.nf;
-    int k = 0;
-    for (int i = 0; i < g.nf; ++i) if (g.f[i] % 2) p.f[k++] = g.f[i];   // odd first
-    for (int i = 0; i < g.nf; ++i) if (g.f[i] % 2 == 0) p.f[k++] = g.f[i];
+    if (gen_make_plan(n).nf <= 0) { p.nf = -1; return p; }
+    int rem = n, k = 0;
+    int radices[GEN_MAX_FACTORS];
+    for (int r : {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2})
+        while (rem % r == 0 && rem > 1) { radices[k++] = r; rem /= r; }
+    for (int q = 11; rem > 1; q += 2)
+        while (rem % q == 0) { radices[k++] = q; rem /= q; }
+    p.nf = 0;
+    for (int i = 0; i < k; ++i) if (radices[i] % 2) p.f[p.nf++] = radices[i];
+    for (int i = 0; i < k; ++i) if (radices[i] % 2 == 0) p.f[p.nf++] = radices[i];
     return p;
 }
 
@@ -56,53 +64,95 @@ int pick_col_tile(int n)
     for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
     return 0;
 }
-int pick_row_lines(int n)
+int pick_row_lines(int n)   // one wavefront per row; rows per workgroup
 {
-    if (row_lds(n, 1) > FLEX_LDS_MAX) return 0;
-    const int LB = n >= 768 ? 1 : (n >= 384 ? 2 : (n >= 192 ? 4 : 8));   // keep 256 threads busy in the narrowest pass (n/7 .. n/2 butterflies per line)
-    return LB;
+    for (int LB : {4, 2, 1}) if (row_lds(n, LB) <= FLEX_LDS_TWO) return LB;
+    return row_lds(n, 1) <= FLEX_LDS_MAX ? 1 : 0;
 }
 
 // ---- butterflies --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ c32 conj_if(c32 w, int dir) { return dir > 0 ? c32{w.x, -w.y} : w; }
 __device__ __forceinline__ c32 mul_i(c32 a, int dir) { return dir > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x}; }   // a * (dir * i)
 
-// butterfly j of a line in pass (R, ns): inputs in[t*mstride] * w^(t*jm), outputs out[k*ostride]; wk[q] = exp(-+2 pi i q / R)
+// ---- small DFTs on registers: X[k] = sum_t x[t] W^(t k), W = exp(dir * 2 pi i / R); w[q] = W^q ---------------------------------
 template <int R>
-__device__ __forceinline__ void flex_bfly(const c32* in, int mstride, c32* out, int ostride, const c32* tw, int twi, const c32 (&wk)[R], int dir)
+__device__ __forceinline__ void dft_small(c32 (&x)[R], const c32 (&w)[R], int dir)
 {
-    c32 v[R];
-    v[0] = in[0];
-#pragma unroll
-    for (int t = 1; t < R; ++t) v[t] = in[t * mstride] * conj_if(tw[t * twi], dir);
     if constexpr (R == 2) {
-        out[0] = v[0] + v[1];
-        out[ostride] = v[0] - v[1];
+        const c32 a = x[0] + x[1], b = x[0] - x[1];
+        x[0] = a; x[1] = b;
     } else if constexpr (R == 4) {
-        const c32 a = v[0] + v[2], b = v[0] - v[2], s = v[1] + v[3], d = mul_i(v[1] - v[3], dir);
-        out[0] = a + s;
-        out[ostride] = b + d;
-        out[2 * ostride] = a - s;
-        out[3 * ostride] = b - d;
+        const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], d = mul_i(x[1] - x[3], dir);
+        x[0] = a + s; x[1] = b + d; x[2] = a - s; x[3] = b - d;
     } else {
+        c32 y[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            c32 acc = v[0];
+            c32 acc = x[0];
 #pragma unroll
-            for (int t = 1; t < R; ++t) acc = acc + v[t] * wk[(t * k) % R];
-            out[k * ostride] = acc;
+            for (int t = 1; t < R; ++t) acc = acc + x[t] * w[(t * k) % R];
+            y[k] = acc;
         }
+#pragma unroll
+        for (int k = 0; k < R; ++k) x[k] = y[k];
     }
 }
 
-// one pass of radix R over `lines` lines of n points: line l, element i at X[i*istr + l*lstr]; threads first, first+step, ...
-template <int R>
+// R = R1 * R2 in registers: t = R2 t1 + t2, k = k1 + R1 k2:  X[k] = sum_t2 [ (sum_t1 x[t] W_R1^(t1 k1)) W_R^(t2 k1) ] W_R2^(t2 k2)
+template <int R1, int R2>
+struct Radix {
+    static constexpr int R = R1 * R2;
+    c32 wR[R];    // W_R^q   (only q = k1*t2 are used; R2 == 1: the DFT constants themselves)
+    c32 w1[R1];   // W_R1^q
+    c32 w2[R2];   // W_R2^q
+    __device__ __forceinline__ void load(const c32* tw, int n, int dir)
+    {
+#pragma unroll
+        for (int q = 0; q < R; ++q) wR[q] = conj_if(tw[q * (n / R)], dir);
+        if constexpr (R2 > 1) {
+#pragma unroll
+            for (int q = 0; q < R1; ++q) w1[q] = conj_if(tw[q * (n / R1)], dir);
+#pragma unroll
+            for (int q = 0; q < R2; ++q) w2[q] = conj_if(tw[q * (n / R2)], dir);
+        }
+    }
+    __device__ __forceinline__ void apply(c32 (&v)[R], int dir) const
+    {
+        if constexpr (R2 == 1) {
+            dft_small<R>(v, wR, dir);
+        } else {
+            c32 u[R];   // u[k1 * R2 + t2]
+#pragma unroll
+            for (int t2 = 0; t2 < R2; ++t2) {
+                c32 a[R1];
+#pragma unroll
+                for (int t1 = 0; t1 < R1; ++t1) a[t1] = v[R2 * t1 + t2];
+                dft_small<R1>(a, w1, dir);
+#pragma unroll
+                for (int k1 = 0; k1 < R1; ++k1) u[k1 * R2 + t2] = (k1 * t2) % R == 0 ? a[k1] : a[k1] * wR[(k1 * t2) % R];
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                c32 b[R2];
+#pragma unroll
+                for (int t2 = 0; t2 < R2; ++t2) b[t2] = u[k1 * R2 + t2];
+                dft_small<R2>(b, w2, dir);
+#pragma unroll
+                for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
+            }
+        }
+    }
+};
+
+// one pass of radix R = R1*R2 over `lines` lines of n points: line l, element i at X[i*istr + l*lstr]; this thread handles
+// butterflies first, first+step, ... ; butterfly j reads in[(j + t*m)], multiplies by w^(t*jm), writes out[j0 + k*ns]
+template <int R1, int R2>
 __device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, int n, int ns, int dir, int lines, int istr, int lstr, int first, int step)
 {
-    const int m = n / R, tstep = n / (ns * R), rstep = n / R;
-    c32 wk[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) wk[q] = conj_if(tw[q * rstep], dir);   // DFT constants: once per pass, not per butterfly
+    constexpr int R = R1 * R2;
+    const int m = n / R, tstep = n / (ns * R);
+    Radix<R1, R2> rx;
+    rx.load(tw, n, dir);   // constants: once per pass, not per butterfly
     const int total = m * lines;
     for (int b = first; b < total; b += step) {
         int l, j;
@@ -110,7 +160,16 @@ __device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, i
         else { l = b / m; j = b - l * m; }                     // separate lines (rows)
         const int jq = j / ns, jm = j - jq * ns;
         const int j0 = jq * ns * R + jm;
-        flex_bfly<R>(A + (size_t)j * istr + (size_t)l * lstr, m * istr, B + (size_t)j0 * istr + (size_t)l * lstr, ns * istr, tw, jm * tstep, wk, dir);
+        const c32* in = A + (size_t)j * istr + (size_t)l * lstr;
+        c32* out = B + (size_t)j0 * istr + (size_t)l * lstr;
+        const int mstride = m * istr, ostride = ns * istr, twi = jm * tstep;
+        c32 v[R];
+        v[0] = in[0];
+#pragma unroll
+        for (int t = 1; t < R; ++t) v[t] = in[t * mstride] * conj_if(tw[t * twi], dir);
+        rx.apply(v, dir);
+#pragma unroll
+        for (int k = 0; k < R; ++k) out[k * ostride] = v[k];
     }
 }
 
@@ -131,11 +190,21 @@ __device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, i
     for (int p = 0; p < pl.nf; ++p) {
         const int R = pl.f[p];
         switch (R) {
-            case 2: flex_pass<2>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break;
-            case 3: flex_pass<3>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break;
-            case 4: flex_pass<4>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break;
-            case 5: flex_pass<5>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break;
-            case 7: flex_pass<7>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break;
+#define P3D_FLEX_PASS(R1, R2) flex_pass<R1, R2>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break
+            case 2: P3D_FLEX_PASS(2, 1);
+            case 3: P3D_FLEX_PASS(3, 1);
+            case 4: P3D_FLEX_PASS(4, 1);
+            case 5: P3D_FLEX_PASS(5, 1);
+            case 6: P3D_FLEX_PASS(2, 3);
+            case 7: P3D_FLEX_PASS(7, 1);
+            case 8: P3D_FLEX_PASS(2, 4);
+            case 9: P3D_FLEX_PASS(3, 3);
+            case 10: P3D_FLEX_PASS(2, 5);
+            case 12: P3D_FLEX_PASS(3, 4);
+            case 14: P3D_FLEX_PASS(2, 7);
+            case 15: P3D_FLEX_PASS(3, 5);
+            case 16: P3D_FLEX_PASS(4, 4);
+#undef P3D_FLEX_PASS
             default: {   // large prime factor: direct butterfly, inputs re-read from LDS
                 const int m = n / R, tstep = n / (ns * R), rstep = n / R;
                 for (int b = first; b < m * lines; b += step) {
@@ -163,7 +232,7 @@ __device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, i
 }
 
 // ---- column pass ------------------------------------------------------------------------------------------------------------------
-constexpr int FLEX_COL_THREADS = 1024;   // 16 waves per CU even where the tile allows only one workgroup per CU
+constexpr int FLEX_COL_THREADS = 1024;   // 16 waves per CU although a tile of long columns allows one workgroup per CU only (512: 28.6 vs 31 Gpt/s)
 
 __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArgs a, const FlexFactors pl, int mode, int tshift)
 {
@@ -248,135 +317,106 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
 }
 
 // ---- row pass ------------------------------------------------------------------------------------------------------------------------
-// LB adjacent rows per workgroup (256 threads work on all of them together; line l, element i at X[l*n + i]); modes ROW_FIRST /
-// ROW_MID / ROW_LAST as in row_kernel (p3d_kernels.hpp)
-constexpr int FLEX_ROW_THREADS = 256;
-
-__global__ __launch_bounds__(FLEX_ROW_THREADS) void flex_row_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
+// one wavefront per row, LB rows per workgroup; modes ROW_FIRST / ROW_MID / ROW_LAST as in row_kernel (p3d_kernels.hpp)
+__global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ double rsum[FLEX_ROW_THREADS / 64];
-    const int n = pl.n, tid = threadIdx.x;
+    const int n = pl.n, tid = threadIdx.x, lane = tid & 63, line = tid >> 6;
     c32* tw = reinterpret_cast<c32*>(smem_raw);
-    c32* A = tw + n;
-    c32* B = A + (size_t)LB * n;
-    const int slice = blockIdx.y, row0 = blockIdx.x * LB;
-    const int nrows = min(LB, a.n1 - row0);   // >= 1
+    c32* A = tw + n + (size_t)line * 2 * n;
+    c32* B = A + n;
+    const int slice = blockIdx.y, row = blockIdx.x * LB + line;
+    const bool valid = row < a.n1;
+    const int vrow = valid ? row : 0;
+    for (int i = tid; i < n; i += blockDim.x) tw[i] = a.tw[i];
+    __syncthreads();   // the only workgroup-wide barrier: from here on every wave is on its own
 
-    const int dn = a.done ? a.done[slice] : 0;   // uniform over the workgroup
-    const size_t sbase0 = ((size_t)slice * a.n1 + row0) * n;   // row-major cubes (x, out): row l of the group at + l*n
+    const int dn = a.done ? a.done[slice] : 0;
+    const size_t sbase = ((size_t)slice * a.n1 + vrow) * n;   // row-major cubes (x, out)
     if (mode == ROW_LAST && a.only_done) {
         if (dn != a.only_done) return;
     } else if (mode == ROW_LAST) {
         if (dn > 0) return;   // converged earlier: `out` already holds that iterate
         if (dn < 0) {         // all-zero slice is handed back untouched (POCS.py:515-521)
-            for (int e = tid; e < nrows * n; e += FLEX_ROW_THREADS) {
-                if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase0 + e] = c32{0.f, 0.f};
-                else reinterpret_cast<float*>(a.out)[sbase0 + e] = 0.f;
-            }
+            if (valid)
+                for (int i = lane; i < n; i += 64) {
+                    if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = c32{0.f, 0.f};
+                    else reinterpret_cast<float*>(a.out)[sbase + i] = 0.f;
+                }
             return;
         }
     } else if (dn != 0) {
         return;
     }
-    for (int i = tid; i < n; i += FLEX_ROW_THREADS) tw[i] = a.tw[i];
-    c32* const wgrp = a.work + (size_t)slice * wk_slice_stride(a.n1, n) + (size_t)row0 * 8;   // row l, col i: + (i>>3)*n1*8 + l*8 + (i&7)
+    c32* const wrow = a.work + (size_t)slice * wk_slice_stride(a.n1, n) + (size_t)vrow * 8;   // + (i>>3)*n1*8 + (i&7)
     const size_t wblk = (size_t)a.n1 * 8;
-    auto obs_at = [&](size_t e) -> c32 {
-        if (a.dtype == 0) return reinterpret_cast<const c32*>(a.x)[sbase0 + e];
-        return c32{reinterpret_cast<const float*>(a.x)[sbase0 + e], 0.f};
+    auto obs_at = [&](int i) -> c32 {
+        if (a.dtype == 0) return reinterpret_cast<const c32*>(a.x)[sbase + i];
+        return c32{reinterpret_cast<const float*>(a.x)[sbase + i], 0.f};
     };
-    const float* const mgrp = a.mask ? a.mask + (size_t)row0 * n : nullptr;
-    const int total = LB * n, live = nrows * n;
+    const float* const mrow = a.mask ? a.mask + (size_t)vrow * n : nullptr;
 
+    float acc = 0.f;
     c32* X = A;
     if (mode == ROW_FIRST) {
-        for (int l = 0; l < LB; ++l) {
-            float acc = 0.f;
-            for (int i = tid; i < n; i += FLEX_ROW_THREADS) {
-                const int e = l * n + i;
-                const c32 x = l < nrows ? obs_at(e) : c32{0.f, 0.f};
-                acc += sqrtf(x.x * x.x + x.y * x.y);
-                if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
-                    const float m = (mgrp && l < nrows) ? mgrp[e] : 0.f;
-                    const float w = 1.0f - a.alpha * m;
-                    const c32 blend = x * a.alpha + x * w;
-                    A[e] = blend + (x - x * m) * (1.0f - a.alpha);
-                } else {
-                    A[e] = x;
-                }
-            }
-            if (a.sums != nullptr) {   // one sum per row (uniform control flow: every thread takes part)
-                double ws = (double)acc;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
-                __syncthreads();
-                if ((tid & 63) == 0) rsum[tid >> 6] = ws;
-                __syncthreads();
-                if (tid == 0 && l < nrows) a.sums[(size_t)slice * a.n1 + row0 + l] = rsum[0] + rsum[1] + rsum[2] + rsum[3];
+        for (int i = lane; i < n; i += 64) {
+            const c32 x = valid ? obs_at(i) : c32{0.f, 0.f};
+            acc += sqrtf(x.x * x.x + x.y * x.y);
+            if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
+                const float m = mrow ? mrow[i] : 0.f;
+                const float w = 1.0f - a.alpha * m;
+                const c32 blend = x * a.alpha + x * w;
+                A[i] = blend + (x - x * m) * (1.0f - a.alpha);
+            } else {
+                A[i] = x;
             }
         }
-        __syncthreads();
+        exchange_sync<true>();
     } else {
-        for (int e = tid; e < total; e += FLEX_ROW_THREADS) {
-            const int l = e / n, i = e - l * n;
-            A[e] = l < nrows ? wgrp[(size_t)(i >> 3) * wblk + (size_t)l * 8 + (i & 7)] : c32{0.f, 0.f};
-        }
-        __syncthreads();
-        X = flex_fft<0>(A, B, tw, pl, INV, LB, 1, n, tid, FLEX_ROW_THREADS);
-        for (int l = 0; l < LB; ++l) {
-            float acc = 0.f;
-            if (l < nrows) {
-                for (int i = tid; i < n; i += FLEX_ROW_THREADS) {
-                    const int e = l * n + i;
-                    c32 xn = X[e] * a.scale;
-                    float m = 0.f;
-                    c32 xo{0.f, 0.f};
-                    if (!a.plain) xo = obs_at(e);
-                    if (mode == ROW_LAST && a.only_done) {
-                        // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
-                        if (a.alpha == 1.0f && mgrp && mgrp[e] == 1.0f) xn = xo;
-                    } else if (!a.plain) {
-                        m = mgrp ? mgrp[e] : 0.f;
-                        const float w = 1.0f - a.alpha * m;        // POCS.py:616
-                        xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
-                    }
-                    acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
-                    if (mode == ROW_LAST || a.write_out) {
-                        if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase0 + e] = xn;
-                        else reinterpret_cast<float*>(a.out)[sbase0 + e] = xn.x;   // np.real(), POCS.py:656
-                    }
-                    if (mode == ROW_MID) {
-                        if (a.adaptive) {   // x_input of the next iteration (POCS.py:574-575)
-                            const float w = 1.0f - a.alpha * m;
-                            const c32 blend = xo * a.alpha + xn * w;
-                            X[e] = blend + (xo - xn * m) * (1.0f - a.alpha);
-                        } else {
-                            X[e] = xn;
-                        }
-                    }
+        for (int i = lane; i < n; i += 64) A[i] = valid ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
+        exchange_sync<true>();
+        X = flex_fft<1>(A, B, tw, pl, INV, 1, 1, n, lane, 64);
+        for (int i = lane; i < n; i += 64) {
+            c32 xn = X[i] * a.scale;
+            float m = 0.f;
+            c32 xo{0.f, 0.f};
+            if (!a.plain && valid) xo = obs_at(i);
+            if (mode == ROW_LAST && a.only_done) {
+                // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
+                if (a.alpha == 1.0f && mrow && mrow[i] == 1.0f) xn = xo;
+            } else if (!a.plain) {
+                m = mrow ? mrow[i] : 0.f;
+                const float w = 1.0f - a.alpha * m;        // POCS.py:616
+                xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
+            }
+            acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+            if ((mode == ROW_LAST || a.write_out) && valid) {
+                if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = xn;
+                else reinterpret_cast<float*>(a.out)[sbase + i] = xn.x;   // np.real(), POCS.py:656
+            }
+            if (mode == ROW_MID) {
+                if (a.adaptive) {   // x_input of the next iteration (POCS.py:574-575)
+                    const float w = 1.0f - a.alpha * m;
+                    const c32 blend = xo * a.alpha + xn * w;
+                    X[i] = blend + (xo - xn * m) * (1.0f - a.alpha);
+                } else {
+                    X[i] = xn;
                 }
             }
-            if (a.sums != nullptr) {
-                double ws = (double)acc;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
-                __syncthreads();
-                if ((tid & 63) == 0) rsum[tid >> 6] = ws;
-                __syncthreads();
-                if (tid == 0 && l < nrows) a.sums[(size_t)slice * a.n1 + row0 + l] = rsum[0] + rsum[1] + rsum[2] + rsum[3];
-            }
         }
-        __syncthreads();
+        exchange_sync<true>();
     }
-    (void)live;
+    if (a.sums != nullptr) {
+        double ws = valid ? (double)acc : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
+        if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = ws;
+    }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        X = flex_fft<0>(X, Y, tw, pl, FWD, LB, 1, n, tid, FLEX_ROW_THREADS);
-        for (int e = tid; e < total; e += FLEX_ROW_THREADS) {
-            const int l = e / n, i = e - l * n;
-            if (l < nrows) wgrp[(size_t)(i >> 3) * wblk + (size_t)l * 8 + (i & 7)] = X[e];
-        }
+        X = flex_fft<1>(X, Y, tw, pl, FWD, 1, 1, n, lane, 64);
+        if (valid)
+            for (int i = lane; i < n; i += 64) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
     }
 }
 
@@ -390,7 +430,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     const size_t lds = row_lds(n, LB);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
     if (e != hipSuccess) return e;
-    flex_row_kernel<<<dim3((a.n1 + LB - 1) / LB, a.nslices), FLEX_ROW_THREADS, lds, st>>>(a, pl, mode, LB);
+    flex_row_kernel<<<dim3((a.n1 + LB - 1) / LB, a.nslices), 64 * LB, lds, st>>>(a, pl, mode, LB);
     return hipGetLastError();
 }
 
