@@ -516,3 +516,29 @@ def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeyp
         assert P._get_plan(nil, nxl, 3, 0).last_sparsity() == -1.0
         assert 0.0 < frac < 1.0, frac          # some blocks were skipped, some kept
         assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120)])
+@pytest.mark.parametrize("kw", [
+    dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2),
+    dict(niter=8, thresh_op="soft", thresh_model="linear", eps=0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
+    dict(niter=30, thresh_op="soft", thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2),
+])
+def test_flexible_lengths_against_the_oracle(shape, kw):
+    """Line lengths that are not powers of two (one or both axes) run the LDS-resident passes of p3d_flex.hip, possibly mixed
+    with a tuned axis; same parity bar as the tuned path (soft threshold: continuous, 1e-5 end to end)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    nil, nxl = shape
+    mask = orc.synthetic_mask(nil, nxl, 0.5)
+    cube = (np.stack([orc.synthetic_slice(nil, nxl, 7 + s) for s in range(3)]) * mask).astype(np.complex64)
+    res, infos = [], []
+    got = P.pocs_cube(cube, mask, results=res, **kw)
+    want = orc.pocs_cube(cube.astype(np.complex128), mask, infos=infos, **kw)
+    for s in range(3):
+        assert res[s]["niterations"] == infos[s]["niterations"]
+        assert rel_l2(got[s], want[s]) <= 1e-5, (s, rel_l2(got[s], want[s]))
+    real = np.ascontiguousarray(cube.real)      # float32 cube through the same shapes
+    got = P.pocs_cube(real, mask, **kw)
+    want = orc.pocs_cube(real.astype(np.float64), mask, **kw)
+    assert got.dtype == np.float32 and rel_l2(got, want) <= 1e-5
