@@ -73,6 +73,19 @@ static __global__ void rowbase_kernel(const uint16_t* bits, unsigned* rowbase, i
 // Column-pass tile flags -> one 16-bit word per (slice, group of 8 row-pass threads): bit q = the column block that holds
 // element tl + tpl*q kept a coefficient.  col_t = columns per column-pass tile (a block spans 8/col_t tiles or a tile spans
 // col_t/8 blocks).  Also counts the kept blocks (statistics only).
+static __global__ void nz_count_kernel(const uint8_t* flags, unsigned long long* count, int nslices, int tiles, int col_t, int nblocks, const int* done)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslices * nblocks) return;
+    const int s = i / nblocks, b = i - s * nblocks;
+    if (done && done[s] != 0) return;
+    const uint8_t* f = flags + (size_t)s * tiles;
+    unsigned any = 0;
+    if (col_t >= 8) any = f[b / (col_t / 8)];
+    else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
+    if (any) atomicAdd(count, 1ull);
+}
+
 static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsigned long long* count, int nslices, int tiles, int col_t, int groups,
                                       int nblocks, const int* done)
 {
@@ -339,10 +352,11 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
         TRY_OR_BAIL(hipMemset(p->work + welems, 0, 64));   // what the row pass reads for tiles the threshold emptied
         // emptied tiles can be skipped when a row-pass thread's 16 elements sit in 16 whole column blocks (nxl >= 128) and
         // 32-bit element offsets reach the zero pad
-        p->sparse_ok = orow->tpl > 0 && oc->tpl > 0 && orow->tpl % 8 == 0 && (double)welems + 8.0 < 4294967296.0;
+        // the tuned row pass needs a thread's 16 elements in 16 whole column blocks (nxl >= 128); the flexible one reads tile flags
+        p->sparse_ok = (is_flex(orow) || orow->tpl % 8 == 0) && (double)welems + 8.0 < 4294967296.0;
         if (p->sparse_ok) {
             TRY_OR_BAIL(hipMalloc((void**)&p->nzflag, (size_t)p->tiles * max_slices));
-            TRY_OR_BAIL(hipMalloc((void**)&p->nzm, sizeof(uint16_t) * (size_t)(orow->tpl / 8) * max_slices));
+            TRY_OR_BAIL(hipMalloc((void**)&p->nzm, sizeof(uint16_t) * (size_t)(is_flex(orow) ? 1 : orow->tpl / 8) * max_slices));
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
         if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
@@ -884,7 +898,8 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     c.op = base_op;
     // tiles of the spectrum that the threshold empties are neither transformed back, stored nor read again
     const bool sparse = p->sparse_ok && !getenv("P3D_NO_SPARSE");
-    const int nblocks = (p->nxl + 7) / 8, groups = p->ops_row->tpl / 8;
+    const int nblocks = (p->nxl + 7) / 8, groups = flex_rows ? 1 : p->ops_row->tpl / 8;
+    const int col_t = is_flex(p->ops_col) ? flex_col_tile(p->nil) : p->ops_col->col_tile;
     if (sparse) {
         c.nzflag = p->nzflag;
         r.zero_off = (unsigned)(wk_slice_stride(p->nil, p->nxl) * (size_t)p->max_slices);
@@ -896,9 +911,14 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
-        if (sparse) {
-            nz_pack_kernel<<<(nslices * groups + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzm, p->nzcount, nslices, p->tiles, p->ops_col->col_tile,
-                                                                                groups, nblocks, c.done);
+        if (sparse && flex_rows) {   // the flexible row pass reads the tile flags themselves; count the kept blocks for the statistics
+            nz_count_kernel<<<(nslices * nblocks + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzcount, nslices, p->tiles, col_t, nblocks, c.done);
+            r.nzflag = p->nzflag;
+            r.nz_tiles = p->tiles;
+            r.nz_col_t = col_t;
+        } else if (sparse) {
+            nz_pack_kernel<<<(nslices * groups + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzm, p->nzcount, nslices, p->tiles, col_t, groups, nblocks,
+                                                                                c.done);
             r.nzm = p->nzm;
         }
         HIP_TRY(stamp());
@@ -919,6 +939,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             if (finalize && k + 1 < niter) {
                 RowArgs f = r;
                 f.nzm = nullptr;  // the rows it reads were written by the row pass: all there
+                f.nzflag = nullptr;
                 f.only_done = k + 1;
                 f.plain = 0;      // the observed samples are needed (exact hand-back at observed traces)
                 f.sums = nullptr;

@@ -266,8 +266,17 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
     if (iter || (mode == COL_FWD && a.tau != nullptr)) {
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
         const int op = mode == COL_ITER_SOFT ? 1 : (mode == COL_ITER_GARROTE ? 2 : a.op);   // callers pass COL_ITER + a.op
-        for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) X[e] = shrink(X[e], tau, op);
-        __syncthreads();
+        bool any = false;
+        for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
+            const c32 v = shrink(X[e], tau, op);
+            X[e] = v;
+            any = any || v.x != 0.0f || v.y != 0.0f;
+        }
+        const int kept = __syncthreads_or(any ? 1 : 0);
+        if (iter && a.nzflag != nullptr) {   // a tile the threshold emptied stays zeros: say so instead of transforming and storing it
+            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + blockIdx.x] = kept ? 1 : 0;
+            if (!kept) return;
+        }
     }
     if (mode == COL_STATS) {
         // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
@@ -373,7 +382,13 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
         }
         exchange_sync<true>();
     } else {
-        for (int i = lane; i < n; i += 64) A[i] = valid ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
+        // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros
+        const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
+        for (int i = lane; i < n; i += 64) {
+            bool kept = valid;
+            if (nzf) kept = kept && nzf[a.nz_col_t >= 8 ? (i >> 3) / (a.nz_col_t >> 3) : (i / a.nz_col_t)] != 0;
+            A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
+        }
         exchange_sync<true>();
         X = flex_fft<1>(A, B, tw, pl, INV, 1, 1, n, lane, 64);
         for (int i = lane; i < n; i += 64) {
@@ -445,9 +460,7 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
     const size_t lds = col_lds(n, T);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_col_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
     if (e != hipSuccess) return e;
-    ColArgs b = a;
-    b.nzflag = nullptr;   // no sparse-tile skipping on this path
-    flex_col_kernel<<<dim3((a.n2 + T - 1) / T, a.nslices), FLEX_COL_THREADS, lds, st>>>(b, pl, mode, tshift);
+    flex_col_kernel<<<dim3((a.n2 + T - 1) / T, a.nslices), FLEX_COL_THREADS, lds, st>>>(a, pl, mode, tshift);
     return hipGetLastError();
 }
 

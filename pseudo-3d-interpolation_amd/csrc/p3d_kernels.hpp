@@ -160,6 +160,9 @@ struct RowArgs {
     const uint16_t* nzm;   // MID / LAST / pipe: per (slice, tl/8) one bit per register q, clear = the column block of element
                            // tl + TPL*q was zeroed entirely by the threshold and NOT stored by the column pass (nullptr: dense)
     unsigned zero_off;     // element index (from `work`) of a zero the loads of such blocks are pointed at
+    const uint8_t* nzflag; // the flexible row pass (p3d_flex.hip) reads the column pass's tile flags directly: [nslices][nz_tiles],
+    int nz_tiles;          //   a tile spans nz_col_t columns
+    int nz_col_t;
     int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done == only_done; their work
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
     float alpha;

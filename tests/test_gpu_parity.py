@@ -494,7 +494,8 @@ def test_early_exit_hands_back_the_converged_iterate():
             assert np.array_equal(got[s][mask == 1], cube[s].astype(np.complex64)[mask == 1])
 
 
-@pytest.mark.parametrize("shape,missing", [((1024, 1024), 0.8), ((512, 256), 0.5), ((128, 2048), 0.6), ((256, 128), 0.3)])
+@pytest.mark.parametrize("shape,missing", [((1024, 1024), 0.8), ((512, 256), 0.5), ((128, 2048), 0.6), ((256, 128), 0.3),
+                                           ((120, 200), 0.5), ((128, 200), 0.6), ((200, 128), 0.6), ((1000, 40), 0.5)])
 def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeypatch):
     """Column blocks of the spectrum that the threshold empties are not transformed back, stored or re-read (sparse path).
     The result must equal the dense path's (P3D_NO_SPARSE=1) exactly, from the sparse early iterations to the dense late ones."""
