@@ -85,16 +85,32 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R], const c32 (&w)[R], int di
         const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], d = mul_i(x[1] - x[3], dir);
         x[0] = a + s; x[1] = b + d; x[2] = a - s; x[3] = b - d;
     } else {
-        c32 y[R];
+        // odd prime: pair x[q] with x[R-q].  W^(qk) = cos + i (dir sin) gives  X[k], X[R-k] = A_k +- i B_k  with
+        // A_k = x0 + sum_q cos(2 pi q k / R) (x[q] + x[R-q]),  B_k = sum_q (dir sin(2 pi q k / R)) (x[q] - x[R-q]):
+        // real coefficients only, a third of the multiplications of the direct form
+        constexpr int H = (R - 1) / 2;
+        c32 sp[H], dm[H];
+        c32 x0 = x[0];
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            c32 acc = x[0];
-#pragma unroll
-            for (int t = 1; t < R; ++t) acc = acc + x[t] * w[(t * k) % R];
-            y[k] = acc;
+        for (int q = 1; q <= H; ++q) {
+            sp[q - 1] = x[q] + x[R - q];
+            dm[q - 1] = x[q] - x[R - q];
+            x0 = x0 + sp[q - 1];
         }
+        const c32 xin = x[0];
+        x[0] = x0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) x[k] = y[k];
+        for (int k = 1; k <= H; ++k) {
+            c32 A = xin, B{0.f, 0.f};
+#pragma unroll
+            for (int q = 1; q <= H; ++q) {
+                const c32 wq = w[(q * k) % R];
+                A = A + sp[q - 1] * wq.x;
+                B = B + dm[q - 1] * wq.y;
+            }
+            x[k] = c32{A.x - B.y, A.y + B.x};
+            x[R - k] = c32{A.x + B.y, A.y - B.x};
+        }
     }
 }
 
