@@ -140,7 +140,7 @@ def main():
     mask_t = torch.from_numpy(mask.astype(np.float32)).to(device)
     n_cpu = 0
     cpu_slices = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is a single-GPU-run extra (rank 0, N = 1)
         n_cpu = max(1, min(os.cpu_count() or 1, 16, n_local))
         cpu_slices = np.stack([orc.synthetic_slice(nil, nxl, lo + s) for s in range(n_cpu)]) * mask
     x_obs = torch_slices(torch, nil, nxl, lo, n_local, device)
