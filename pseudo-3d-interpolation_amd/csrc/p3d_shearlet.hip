@@ -97,11 +97,6 @@ __global__ void sthreshold_kernel(c32* U, size_t per, int nsh, const c32* tau, i
     }
 }
 
-__global__ void real_part_kernel(c32* U, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) U[i].y = 0.f;
-}
-
 // per (slice, shearlet): lexicographic (real data: signed) maximum, max |c|, min |c|, sum |c|^2 -> stats[(b*nsh + s)*5 ..]
 __global__ void sstats_kernel(const c32* U, size_t per, int real_only, float* stats)
 {
