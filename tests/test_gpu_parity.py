@@ -543,3 +543,23 @@ def test_flexible_lengths_against_the_oracle(shape, kw):
     got = P.pocs_cube(real, mask, **kw)
     want = orc.pocs_cube(real.astype(np.float64), mask, **kw)
     assert got.dtype == np.float32 and rel_l2(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("switch", ["P3D_FORCE_GENERIC", "P3D_NO_FLEX", "P3D_NO_PIPE", "P3D_NO_COMPACT", "P3D_NO_MASK_BITS"])
+def test_slower_equivalent_paths_behind_the_switches(switch, monkeypatch):
+    """Every diagnostic switch selects a slower path that must give the same answer: the unfused generic loop (still the path for
+    lines longer than 6400), the non-persistent row pass, the full observed cube, the float mask."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    shape = (48, 20) if switch in ("P3D_FORCE_GENERIC", "P3D_NO_FLEX") else (64, 128)
+    mask = orc.synthetic_mask(*shape, 0.5)
+    cube = (np.stack([orc.synthetic_slice(*shape, 40 + s) for s in range(3)]) * mask).astype(np.complex64)
+    kw = dict(niter=10, thresh_op="soft", thresh_model="exponential", eps=1e-7, p_max=0.99, p_min=1e-2, alpha=0.9)
+    want = orc.pocs_cube(cube.astype(np.complex128), mask, **kw)
+    P.release_plans()                       # the switches are read when a plan is created / a job starts
+    monkeypatch.setenv(switch, "1")
+    try:
+        got = P.pocs_cube(cube, mask, **kw)
+    finally:
+        P.release_plans()
+    assert rel_l2(got, want) <= 1e-5
