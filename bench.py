@@ -211,6 +211,8 @@ def main():
         job(min(K, 20), profile=True)
         prof = plan.last_profile()
         it_ms = prof["colpass_ms"] + prof["rowpass_ms"]
+        kept = plan.last_sparsity()
+        kept = 1.0 if kept < 0 else kept
         alg_bytes = ALG_BYTES_PER_POINT * pts_local
         achieved = alg_bytes / (it_ms * 1e-3) / 1e9 if it_ms > 0 else 0.0
         traffic = None
@@ -230,8 +232,11 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "launch_ms": it_ms,
             "colpass_ms": prof["colpass_ms"], "rowpass_ms": prof["rowpass_ms"],
-            "colpass_moved_GBps": 16 * pts_local / (prof["colpass_ms"] * 1e-3) / 1e9 if prof["colpass_ms"] else 0.0,
-            "rowpass_moved_GBps": 28 * pts_local / (prof["rowpass_ms"] * 1e-3) / 1e9 if prof["rowpass_ms"] else 0.0,
+            # bytes the two passes move per point with a fraction f of the spectrum's column blocks kept: column pass 8 read +
+            # 8 f written; row pass 8 f read + 8 written + 8 (1 - missing) observed samples (compact)
+            "colpass_moved_GBps": (8 + 8 * kept) * pts_local / (prof["colpass_ms"] * 1e-3) / 1e9 if prof["colpass_ms"] else 0.0,
+            "rowpass_moved_GBps": (8 * kept + 8 + 8 * (1 - args.missing)) * pts_local / (prof["rowpass_ms"] * 1e-3) / 1e9
+            if prof["rowpass_ms"] else 0.0,
         }
 
     cpu = None
