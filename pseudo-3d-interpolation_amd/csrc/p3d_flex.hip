@@ -342,11 +342,16 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
 }
 
 // ---- row pass ------------------------------------------------------------------------------------------------------------------------
-// one wavefront per row, LB rows per workgroup; modes ROW_FIRST / ROW_MID / ROW_LAST as in row_kernel (p3d_kernels.hpp)
+// TPR threads per row (64: one wavefront, wave-level synchronisation only; 128: two wavefronts and workgroup barriers -- half the
+// rows per workgroup, half the LDS, twice the resident waves), LB rows per workgroup; modes ROW_FIRST / ROW_MID / ROW_LAST as in
+// row_kernel (p3d_kernels.hpp)
+template <int TPR>
 __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
 {
+    constexpr int SYNC = TPR == 64 ? 1 : 0;
+    __shared__ double rsum[4];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int n = pl.n, tid = threadIdx.x, lane = tid & 63, line = tid >> 6;
+    const int n = pl.n, tid = threadIdx.x, lane = tid % TPR, line = tid / TPR;
     c32* tw = reinterpret_cast<c32*>(smem_raw);
     c32* A = tw + n + (size_t)line * 2 * n;
     c32* B = A + n;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     const bool valid = row < a.n1;
     const int vrow = valid ? row : 0;
     for (int i = tid; i < n; i += blockDim.x) tw[i] = a.tw[i];
-    __syncthreads();   // the only workgroup-wide barrier: from here on every wave is on its own
+    __syncthreads();   // TPR = 64: the only workgroup-wide barrier, from here on every wave is on its own
 
     const int dn = a.done ? a.done[slice] : 0;
     const size_t sbase = ((size_t)slice * a.n1 + vrow) * n;   // row-major cubes (x, out)
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
         if (dn > 0) return;   // converged earlier: `out` already holds that iterate
         if (dn < 0) {         // all-zero slice is handed back untouched (POCS.py:515-521)
             if (valid)
-                for (int i = lane; i < n; i += 64) {
+                for (int i = lane; i < n; i += TPR) {
                     if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = c32{0.f, 0.f};
                     else reinterpret_cast<float*>(a.out)[sbase + i] = 0.f;
                 }
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     float acc = 0.f;
     c32* X = A;
     if (mode == ROW_FIRST) {
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += TPR) {
             const c32 x = valid ? obs_at(i) : c32{0.f, 0.f};
             acc += sqrtf(x.x * x.x + x.y * x.y);
             if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
@@ -396,18 +401,18 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
                 A[i] = x;
             }
         }
-        exchange_sync<true>();
+        flex_sync<SYNC>();
     } else {
         // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros
         const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += TPR) {
             bool kept = valid;
             if (nzf) kept = kept && nzf[a.nz_col_t >= 8 ? (i >> 3) / (a.nz_col_t >> 3) : (i / a.nz_col_t)] != 0;
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
-        exchange_sync<true>();
-        X = flex_fft<1>(A, B, tw, pl, INV, 1, 1, n, lane, 64);
-        for (int i = lane; i < n; i += 64) {
+        flex_sync<SYNC>();
+        X = flex_fft<SYNC>(A, B, tw, pl, INV, 1, 1, n, lane, TPR);
+        for (int i = lane; i < n; i += TPR) {
             c32 xn = X[i] * a.scale;
             float m = 0.f;
             c32 xo{0.f, 0.f};
@@ -435,19 +440,25 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
                 }
             }
         }
-        exchange_sync<true>();
+        flex_sync<SYNC>();
     }
     if (a.sums != nullptr) {
         double ws = valid ? (double)acc : 0.0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
-        if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = ws;
+        if constexpr (TPR == 64) {
+            if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = ws;
+        } else {   // two wavefronts per row
+            if ((tid & 63) == 0) rsum[tid >> 6] = ws;
+            __syncthreads();
+            if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = rsum[2 * line] + rsum[2 * line + 1];
+        }
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        X = flex_fft<1>(X, Y, tw, pl, FWD, 1, 1, n, lane, 64);
+        X = flex_fft<SYNC>(X, Y, tw, pl, FWD, 1, 1, n, lane, TPR);
         if (valid)
-            for (int i = lane; i < n; i += 64) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
+            for (int i = lane; i < n; i += TPR) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
     }
 }
 
@@ -458,10 +469,19 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     const int n = a.len, LB = pick_row_lines(n);
     if (LB == 0) return hipErrorNotSupported;
     const FlexFactors pl = flex_factors(n);
-    const size_t lds = row_lds(n, LB);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
+    // two wavefronts per row where the narrowest pass still has ~48 butterflies for them (measured: 500, 768, 1000 gain 20-25 %,
+    // 600 = 15*10*4 loses 8 %) and rows can be paired
+    int widest = 2;
+    for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
+    const bool two = LB >= 2 && n / widest >= 48;
+    const int lb = two ? LB / 2 : LB;
+    const size_t lds = row_lds(n, lb);
+    const void* kern = two ? reinterpret_cast<const void*>(flex_row_kernel<128>) : reinterpret_cast<const void*>(flex_row_kernel<64>);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
     if (e != hipSuccess) return e;
-    flex_row_kernel<<<dim3((a.n1 + LB - 1) / LB, a.nslices), 64 * LB, lds, st>>>(a, pl, mode, LB);
+    const dim3 grid((a.n1 + lb - 1) / lb, a.nslices);
+    if (two) flex_row_kernel<128><<<grid, 128 * lb, lds, st>>>(a, pl, mode, lb);
+    else flex_row_kernel<64><<<grid, 64 * lb, lds, st>>>(a, pl, mode, lb);
     return hipGetLastError();
 }
 
