@@ -228,10 +228,14 @@ struct p3d_plan {
 
 static int upload_table(p3d_plan* p, const LineOps* ops, bool for_rows, int n, c32** dst)
 {
-    std::vector<c32> host(is_flex(ops) ? (size_t)n : (for_rows ? (size_t)ops->row_tw_slots : (size_t)tw_slots(ops->n)));
-    if (is_flex(ops)) gen_build_twiddles(n, host.data());   // plain table exp(-2 pi i k / n)
-    else if (for_rows) ops->build_row_tw(host.data());
-    else build_twiddles(ops->n, host.data());
+    std::vector<c32> host;
+    if (is_flex(ops)) {
+        flex_build_table(n, host);   // plain table exp(-2 pi i k / n), or the chirp-z tables
+    } else {
+        host.resize(for_rows ? (size_t)ops->row_tw_slots : (size_t)tw_slots(ops->n));
+        if (for_rows) ops->build_row_tw(host.data());
+        else build_twiddles(ops->n, host.data());
+    }
     HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * host.size()));
     HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
     return P3D_OK;

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "p3d_flex.hpp"
@@ -28,19 +29,42 @@ namespace p3d {
 namespace {
 
 struct FlexFactors {
-    int n, nf;
-    int f[GEN_MAX_FACTORS];
+    int n;      // line length
+    int m;      // length of the transforms that are actually run: n, or the power of two M >= 2n-1 of the chirp-z form
+    int blue;   // 1: chirp-z (Bluestein) -- lines whose length has a large prime factor
+    int nf;
+    int f[GEN_MAX_FACTORS];   // radices of the passes of a length-m transform
 };
 
+int largest_prime_factor(int n)
+{
+    int best = 1;
+    for (int p = 2; (long)p * p <= n; ++p)
+        while (n % p == 0) { best = p; n /= p; }
+    return n > 1 ? n : best;
+}
+
+constexpr int FLEX_DIRECT_PRIME_MAX = 23;   // larger prime factors: chirp-z on a power of two instead of an O(p^2) pass
+constexpr int FLEX_BLUE_MAX_M = 4096;       // two LDS copies of a padded line: 2 * M * 8 B
+
 // Radices of the passes.  Every pass is one trip through LDS and one barrier, so two prime factors are folded into one
-// in-register butterfly wherever a supported product exists (16 = 4x4 ... 6 = 2x3); primes above 7 stay direct O(p^2) passes.
+// in-register butterfly wherever a supported product exists (16 = 4x4 ... 6 = 2x3); primes 11 .. 23 are direct O(p^2) passes.
 // Odd radices go first: the scattered writes of an early pass (small stride) then have an odd stride in LDS banks.
 FlexFactors flex_factors(int n)
 {
     FlexFactors p{};
-    p.n = n;
+    p.n = p.m = n;
     if (gen_make_plan(n).nf <= 0) { p.nf = -1; return p; }
-    int rem = n, k = 0;
+    const int lp = largest_prime_factor(n);
+    if (lp > 7) {
+        int M = 1;
+        while (M < 2 * n - 1) M *= 2;
+        // measured: up to M = 2048 (n <= 1024) the chirp-z form beats even radix-11 / 13 passes (1009 x 1013: 10.5 Gpt/s vs
+        // 1001 x 999 with direct 11- and 13-point passes: 2.5); M = 4096 leaves one column per workgroup and only pays for
+        // primes that would otherwise cost an O(p^2) pass of real weight
+        if (M <= 2048 || (lp > FLEX_DIRECT_PRIME_MAX && M <= FLEX_BLUE_MAX_M)) { p.blue = 1; p.m = M; }
+    }
+    int rem = p.m, k = 0;
     int radices[GEN_MAX_FACTORS];
     for (int r : {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2})
         while (rem % r == 0 && rem > 1) { radices[k++] = r; rem /= r; }
@@ -55,8 +79,8 @@ FlexFactors flex_factors(int n)
 constexpr size_t FLEX_LDS_MAX = 150 * 1024;
 constexpr size_t FLEX_LDS_TWO = 80 * 1024;   // two workgroups per CU
 
-size_t col_lds(int n, int T) { return sizeof(c32) * ((size_t)2 * T * n + n); }
-size_t row_lds(int n, int LB) { return sizeof(c32) * ((size_t)2 * LB * n + n); }
+size_t col_lds(int n, int T) { const size_t L = flex_factors(n).m; return sizeof(c32) * (2 * T * L + L); }
+size_t row_lds(int n, int LB) { const size_t L = flex_factors(n).m; return sizeof(c32) * (2 * LB * L + L); }
 
 int pick_col_tile(int n)
 {
@@ -64,7 +88,7 @@ int pick_col_tile(int n)
     for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
     return 0;
 }
-int pick_row_lines(int n)   // one wavefront per row; rows per workgroup
+int pick_row_lines(int n)   // rows per workgroup at one wavefront per row
 {
     for (int LB : {4, 2, 1}) if (row_lds(n, LB) <= FLEX_LDS_TWO) return LB;
     return row_lds(n, 1) <= FLEX_LDS_MAX ? 1 : 0;
@@ -201,7 +225,7 @@ __device__ __forceinline__ void flex_sync()
 template <int SYNC>
 __device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, int dir, int lines, int istr, int lstr, int first, int step)
 {
-    const int n = pl.n;
+    const int n = pl.m;
     int ns = 1;
     for (int p = 0; p < pl.nf; ++p) {
         const int R = pl.f[p];
@@ -247,21 +271,68 @@ __device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, i
     return A;
 }
 
+// DFT of `lines` lines of pl.n points (the first pl.n entries of buffers that hold pl.m).  Directly when the length factors into
+// small radices; otherwise in the chirp-z form on M = pl.m points:  X_k = c_k (a * conj c)_k with a_j = x_j c_j, c_k = exp(-i pi k^2 / n),
+// the convolution through two transforms of length M and the spectrum of conj c (gt: global table [tw_M | c | FFT_M(conj c)]).
+// The inverse transform is conj(DFT(conj x)).  Unnormalised like flex_fft; the result is returned in one of the two buffers.
+template <int SYNC>
+__device__ c32* flex_transform(c32* A, c32* B, const c32* tw, const c32* gt, const FlexFactors& pl, int dir, int lines, int istr, int lstr, int first, int step)
+{
+    if (!pl.blue) return flex_fft<SYNC>(A, B, tw, pl, dir, lines, istr, lstr, first, step);
+    const int n = pl.n, M = pl.m;
+    const c32* const chirp = gt + M;
+    const c32* const bhat = gt + M + n;
+    const float inv_m = 1.0f / (float)M;
+    const int total = lines * M;
+    auto split = [&](int e, int& l, int& i) {
+        if (lstr == 1) { i = e / lines; l = e - i * lines; }
+        else { l = e / M; i = e - l * M; }
+    };
+    for (int e = first; e < total; e += step) {
+        int l, i;
+        split(e, l, i);
+        c32* p = A + (size_t)i * istr + (size_t)l * lstr;
+        c32 v{0.f, 0.f};
+        if (i < n) v = conj_if(*p, dir) * chirp[i];
+        *p = v;
+    }
+    flex_sync<SYNC>();
+    c32* X = flex_fft<SYNC>(A, B, tw, pl, FWD, lines, istr, lstr, first, step);
+    c32* Y = X == A ? B : A;
+    for (int e = first; e < total; e += step) {
+        int l, i;
+        split(e, l, i);
+        c32* p = X + (size_t)i * istr + (size_t)l * lstr;
+        *p = *p * bhat[i];
+    }
+    flex_sync<SYNC>();
+    X = flex_fft<SYNC>(X, Y, tw, pl, INV, lines, istr, lstr, first, step);
+    for (int e = first; e < total; e += step) {
+        int l, i;
+        split(e, l, i);
+        if (i >= n) continue;
+        c32* p = X + (size_t)i * istr + (size_t)l * lstr;
+        *p = conj_if((*p * chirp[i]) * inv_m, dir);
+    }
+    flex_sync<SYNC>();
+    return X;
+}
+
 // ---- column pass ------------------------------------------------------------------------------------------------------------------
 constexpr int FLEX_COL_THREADS = 1024;   // 16 waves per CU although a tile of long columns allows one workgroup per CU only (512: 28.6 vs 31 Gpt/s)
 
 __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArgs a, const FlexFactors pl, int mode, int tshift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int n = pl.n, T = 1 << tshift, tid = threadIdx.x;
+    const int n = pl.n, L = pl.m, T = 1 << tshift, tid = threadIdx.x;
     c32* tw = reinterpret_cast<c32*>(smem_raw);
-    c32* A = tw + n;
-    c32* B = A + (size_t)n * T;
+    c32* A = tw + L;
+    c32* B = A + (size_t)L * T;
     const int slice = blockIdx.y, col0 = blockIdx.x * T;
     if (a.done && a.done[slice] != 0) return;
     const bool iter = mode == COL_ITER || mode == COL_ITER_SOFT || mode == COL_ITER_GARROTE;
 
-    for (int i = tid; i < n; i += FLEX_COL_THREADS) tw[i] = a.tw[i];
+    for (int i = tid; i < L; i += FLEX_COL_THREADS) tw[i] = a.tw[i];
     const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
     c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
     auto goff = [&](int std_layout, int i, int col) -> size_t {
@@ -276,7 +347,7 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
     c32* X = A;
     c32* Y = B;
     if (mode != COL_INV) {
-        X = flex_fft<0>(A, B, tw, pl, FWD, T, T, 1, tid, FLEX_COL_THREADS);
+        X = flex_transform<0>(A, B, tw, a.tw, pl, FWD, T, T, 1, tid, FLEX_COL_THREADS);
         Y = X == A ? B : A;
     }
     if (iter || (mode == COL_FWD && a.tau != nullptr)) {
@@ -334,7 +405,7 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
         }
         return;
     }
-    if (iter || mode == COL_INV) X = flex_fft<0>(X, Y, tw, pl, INV, T, T, 1, tid, FLEX_COL_THREADS);
+    if (iter || mode == COL_INV) X = flex_transform<0>(X, Y, tw, a.tw, pl, INV, T, T, 1, tid, FLEX_COL_THREADS);
     for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
         const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
         if (col < a.n2) outb[goff(a.out_std, i, col)] = X[e];
@@ -351,14 +422,14 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     constexpr int SYNC = TPR == 64 ? 1 : 0;
     __shared__ double rsum[4];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int n = pl.n, tid = threadIdx.x, lane = tid % TPR, line = tid / TPR;
+    const int n = pl.n, L = pl.m, tid = threadIdx.x, lane = tid % TPR, line = tid / TPR;
     c32* tw = reinterpret_cast<c32*>(smem_raw);
-    c32* A = tw + n + (size_t)line * 2 * n;
-    c32* B = A + n;
+    c32* A = tw + L + (size_t)line * 2 * L;
+    c32* B = A + L;
     const int slice = blockIdx.y, row = blockIdx.x * LB + line;
     const bool valid = row < a.n1;
     const int vrow = valid ? row : 0;
-    for (int i = tid; i < n; i += blockDim.x) tw[i] = a.tw[i];
+    for (int i = tid; i < L; i += blockDim.x) tw[i] = a.tw[i];
     __syncthreads();   // TPR = 64: the only workgroup-wide barrier, from here on every wave is on its own
 
     const int dn = a.done ? a.done[slice] : 0;
@@ -411,7 +482,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
         flex_sync<SYNC>();
-        X = flex_fft<SYNC>(A, B, tw, pl, INV, 1, 1, n, lane, TPR);
+        X = flex_transform<SYNC>(A, B, tw, a.tw, pl, INV, 1, 1, L, lane, TPR);
         for (int i = lane; i < n; i += TPR) {
             c32 xn = X[i] * a.scale;
             float m = 0.f;
@@ -456,7 +527,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        X = flex_fft<SYNC>(X, Y, tw, pl, FWD, 1, 1, n, lane, TPR);
+        X = flex_transform<SYNC>(X, Y, tw, a.tw, pl, FWD, 1, 1, L, lane, TPR);
         if (valid)
             for (int i = lane; i < n; i += TPR) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
     }
@@ -473,7 +544,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     // 600 = 15*10*4 loses 8 %) and rows can be paired
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
-    const bool two = LB >= 2 && n / widest >= 48;
+    const bool two = LB >= 2 && pl.m / widest >= 48;
     const int lb = two ? LB / 2 : LB;
     const size_t lds = row_lds(n, lb);
     const void* kern = two ? reinterpret_cast<const void*>(flex_row_kernel<128>) : reinterpret_cast<const void*>(flex_row_kernel<64>);
@@ -503,6 +574,50 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
 hipError_t flex_no_pipe(const RowArgs&, int, hipStream_t) { return hipErrorNotSupported; }
 
 }  // namespace
+
+// device table of a line length: exp(-2 pi i k / n), or for the chirp-z form [exp(-2 pi i k / M) | chirp c_k = exp(-i pi k^2 / n) |
+// FFT_M(conj c, wrapped)], computed in double precision and rounded once
+void flex_build_table(int n, std::vector<c32>& out)
+{
+    const FlexFactors pl = flex_factors(n);
+    if (!pl.blue) {
+        out.resize(n);
+        gen_build_twiddles(n, out.data());
+        return;
+    }
+    const int M = pl.m;
+    const double pi = 3.14159265358979323846;
+    out.resize((size_t)2 * M + n);
+    gen_build_twiddles(M, out.data());
+    std::vector<double> cr(n), ci(n), br(M, 0.0), bi(M, 0.0);
+    for (int k = 0; k < n; ++k) {
+        const long q = ((long)k * k) % (2L * n);   // k^2 mod 2n keeps the angle small
+        cr[k] = std::cos(pi * (double)q / n);
+        ci[k] = -std::sin(pi * (double)q / n);
+        out[(size_t)M + k] = c32{(float)cr[k], (float)ci[k]};
+        br[k] = cr[k]; bi[k] = -ci[k];
+        if (k) { br[M - k] = cr[k]; bi[M - k] = -ci[k]; }
+    }
+    // radix-2 transform of b in double precision (M is a power of two)
+    for (int i = 1, j = 0; i < M; ++i) {
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+        const double ang = -2.0 * pi / len;
+        for (int i = 0; i < M; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+                const int u = i + k, v = i + k + len / 2;
+                const double tr = br[v] * wr - bi[v] * wi, ti = br[v] * wi + bi[v] * wr;
+                br[v] = br[u] - tr; bi[v] = bi[u] - ti;
+                br[u] += tr; bi[u] += ti;
+            }
+    }
+    for (int k = 0; k < M; ++k) out[(size_t)M + n + k] = c32{(float)br[k], (float)bi[k]};
+}
 
 bool flex_supported(int n) { return n >= 2 && n <= GEN_MAX_N && gen_make_plan(n).nf > 0 && pick_col_tile(n) > 0 && pick_row_lines(n) > 0; }
 int flex_col_tile(int n) { return pick_col_tile(n); }
