@@ -519,7 +519,7 @@ def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeyp
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120)])
+@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143)])   # last two: chirp-z lengths
 @pytest.mark.parametrize("kw", [
     dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2),
     dict(niter=8, thresh_op="soft", thresh_model="linear", eps=0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
