@@ -84,7 +84,8 @@ size_t row_lds(int n, int LB) { const size_t L = flex_factors(n).m; return sizeo
 
 int pick_col_tile(int n)
 {
-    if (col_lds(n, 8) <= FLEX_LDS_MAX) return 8;   // a whole 64-byte column block, even at one workgroup per CU
+    if (col_lds(n, 8) <= FLEX_LDS_MAX) return 8;   // a whole 64-byte column block, even at one workgroup per CU (4-column tiles
+                                                   // with two workgroups per CU measured 10-18 % slower)
     for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
     return 0;
 }
@@ -328,7 +329,16 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
     c32* tw = reinterpret_cast<c32*>(smem_raw);
     c32* A = tw + L;
     c32* B = A + (size_t)L * T;
-    const int slice = blockIdx.y, col0 = blockIdx.x * T;
+    // tiles narrower than a 64-byte column block: the pieces of one block go to the same XCD back to back (see col_kernel)
+    int tile = blockIdx.x;
+    if (T < 8) {
+        const int G = 8 >> tshift;
+        if ((gridDim.x % (8 * G)) == 0) {
+            const int xcd = tile & 7, j = tile >> 3;
+            tile = ((j / G) * 8 + xcd) * G + (j % G);
+        }
+    }
+    const int slice = blockIdx.y, col0 = tile * T;
     if (a.done && a.done[slice] != 0) return;
     const bool iter = mode == COL_ITER || mode == COL_ITER_SOFT || mode == COL_ITER_GARROTE;
 
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
         }
         const int kept = __syncthreads_or(any ? 1 : 0);
         if (iter && a.nzflag != nullptr) {   // a tile the threshold emptied stays zeros: say so instead of transforming and storing it
-            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + blockIdx.x] = kept ? 1 : 0;
+            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
             if (!kept) return;
         }
     }
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
                 mn = fminf(mn, o[3]);
                 sq += o[4];
             }
-            float* p = a.partials + ((size_t)slice * gridDim.x + blockIdx.x) * STATS_PARTIAL;
+            float* p = a.partials + ((size_t)slice * gridDim.x + tile) * STATS_PARTIAL;
             p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
         }
         return;
