@@ -57,11 +57,14 @@ FlexFactors flex_factors(int n)
     if (gen_make_plan(n).nf <= 0) { p.nf = -1; return p; }
     const int lp = largest_prime_factor(n);
     if (lp > 7) {
-        int M = 1;
-        while (M < 2 * n - 1) M *= 2;
-        // measured: up to M = 2048 (n <= 1024) the chirp-z form beats even radix-11 / 13 passes (1009 x 1013: 10.5 Gpt/s vs
-        // 1001 x 999 with direct 11- and 13-point passes: 2.5); M = 4096 leaves one column per workgroup and only pays for
-        // primes that would otherwise cost an O(p^2) pass of real weight
+        int M = 2 * n - 1;   // the convolution length: the next 5-smooth number (radices 16 ... 2 cover it in three or four passes) ...
+        while (largest_prime_factor(M) > 5) ++M;
+        int P2 = 1;          // ... unless the next power of two is nearly as short: its radix-16 passes are the cheapest
+        while (P2 < 2 * n - 1) P2 *= 2;
+        if (4 * P2 <= 5 * M) M = P2;
+        // measured: up to M ~ 2048 (n <= 1024) the chirp-z form beats even radix-11 / 13 passes (1009 x 1013: 10.5 Gpt/s vs
+        // 1001 x 999 with direct 11- and 13-point passes: 2.5); longer padded lines leave one or two columns per workgroup and
+        // only pay for primes that would otherwise cost an O(p^2) pass of real weight
         if (M <= 2048 || (lp > FLEX_DIRECT_PRIME_MAX && M <= FLEX_BLUE_MAX_M)) { p.blue = 1; p.m = M; }
     }
     int rem = p.m, k = 0;
@@ -608,23 +611,34 @@ void flex_build_table(int n, std::vector<c32>& out)
         br[k] = cr[k]; bi[k] = -ci[k];
         if (k) { br[M - k] = cr[k]; bi[M - k] = -ci[k]; }
     }
-    // radix-2 transform of b in double precision (M is a power of two)
-    for (int i = 1, j = 0; i < M; ++i) {
-        int bit = M >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
-    }
-    for (int len = 2; len <= M; len <<= 1) {
-        const double ang = -2.0 * pi / len;
-        for (int i = 0; i < M; i += len)
-            for (int k = 0; k < len / 2; ++k) {
-                const double wr = std::cos(ang * k), wi = std::sin(ang * k);
-                const int u = i + k, v = i + k + len / 2;
-                const double tr = br[v] * wr - bi[v] * wi, ti = br[v] * wi + bi[v] * wr;
-                br[v] = br[u] - tr; bi[v] = bi[u] - ti;
-                br[u] += tr; bi[u] += ti;
+    // transform of b in double precision: the same mixed-radix Stockham passes as on the device, direct butterflies
+    {
+        std::vector<double> ar(br), ai(bi), cr2(M), ci2(M);
+        int ns = 1;
+        for (int pi_ = 0; pi_ < pl.nf; ++pi_) {
+            const int R = pl.f[pi_], m = M / R;
+            for (int j = 0; j < m; ++j) {
+                const int jq = j / ns, jm = j - jq * ns, j0 = jq * ns * R + jm;
+                for (int k = 0; k < R; ++k) {
+                    double sr = 0.0, si = 0.0;
+                    for (int t = 0; t < R; ++t) {
+                        // twiddle of the pass and of the butterfly: exp(-2 pi i (t jm / (ns R) + t k / R))
+                        const double ang = -2.0 * pi * ((double)t * jm / ((double)ns * R) + (double)((t * k) % R) / R);
+                        const double wr = std::cos(ang), wi = std::sin(ang);
+                        const double xr = ar[j + t * m], xi = ai[j + t * m];
+                        sr += xr * wr - xi * wi;
+                        si += xr * wi + xi * wr;
+                    }
+                    cr2[j0 + k * ns] = sr;
+                    ci2[j0 + k * ns] = si;
+                }
             }
+            ar.swap(cr2);
+            ai.swap(ci2);
+            ns *= R;
+        }
+        br = ar;
+        bi = ai;
     }
     for (int k = 0; k < M; ++k) out[(size_t)M + n + k] = c32{(float)br[k], (float)bi[k]};
 }
