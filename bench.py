@@ -125,10 +125,17 @@ def main():
     from pseudo_3d_interpolation_amd.functions.POCS import _schedule_from_stats
     from pseudo_3d_interpolation_amd.sharding import slice_block
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # P3D_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the multi-rank code path where no second GPU exists
+    # (the numbers mean nothing then).  The real thing: one rank per GPU over RCCL.
+    rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     nil, nxl, K, W = args.nil, args.nxl, args.steps, args.warmup
     lo, hi = slice_block(args.nslices, world, rank)
@@ -150,7 +157,7 @@ def main():
     out = torch.empty_like(x_obs)
     torch.cuda.synchronize()
 
-    plan = _ffi.Plan(nil, nxl, n_local, device=local_rank)
+    plan = _ffi.Plan(nil, nxl, n_local, device=dev_index)
 
     def job(niter, profile=False):
         stats = plan.stats_dev(x_obs.data_ptr(), _ffi.P3D_C64, n_local)
@@ -177,7 +184,7 @@ def main():
     seconds = time.perf_counter() - t0
     assert args.eps > 0 or (int(done.min()) == K and int(done.max()) == K)
     if world > 1:
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
 
@@ -196,11 +203,12 @@ def main():
     # ---- the trivial gather of the blocks (outside the timed steps) -------------------------------
     gather_ms = 0.0
     if world > 1:
-        blocks = [torch.empty_like(out) for _ in range(world)] if n_local * world == args.nslices else None
+        src = out.cpu() if rehearsal else out
+        blocks = [torch.empty_like(src) for _ in range(world)] if n_local * world == args.nslices else None
         if blocks is not None:
             fence()
             g0 = time.perf_counter()
-            dist.all_gather(blocks, out)
+            dist.all_gather(blocks, src)
             fence()
             gather_ms = (time.perf_counter() - g0) * 1e3
             del blocks
