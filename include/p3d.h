@@ -151,6 +151,12 @@ int p3d_time2freq(int device, const float* x, int nt, size_t ntraces, double dt,
                   const float* window, void* out);
 int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntraces, double dt, double t0, int nfft,
                   int real_only, float* out);
+/* the same transforms on DEVICE buffers (x / out of p3d_time2freq, X / out of p3d_freq2time), for callers that keep the cube in HBM
+ * across steps 12 -> 13 -> 14; window and kidx stay HOST arrays */
+int p3d_time2freq_dev(int device, const float* x_dev, int nt, size_t ntraces, double dt, double t0, int nfft, int real_only,
+                      const float* window, void* out_dev);
+int p3d_freq2time_dev(int device, const void* X_dev, int nfreq, const int32_t* kidx, size_t ntraces, double dt, double t0, int nfft,
+                      int real_only, float* out_dev);
 
 /* Sparse-spectrum statistics of the last p3d_pocs_run[_dev] on this plan: fraction of 8-column blocks of the thresholded spectra
  * that kept at least one coefficient, averaged over slices and iterations (blocks the threshold empties are neither transformed

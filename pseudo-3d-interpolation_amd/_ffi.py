@@ -63,6 +63,10 @@ PROTOTYPES = {
                                 C.c_void_p]),
     "p3d_freq2time": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
                                 C.c_void_p]),
+    "p3d_time2freq_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
+    "p3d_freq2time_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.c_void_p]),
     "p3d_last_sparsity": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_last_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),

@@ -1030,6 +1030,74 @@ static int helper_check(int device, size_t ntraces, int nfft)
 
 static double fft_freq(int k, int nfft, double dt) { return (k < (nfft + 1) / 2 ? k : k - nfft) / (nfft * dt); }  // np.fft.fftfreq
 
+// One transform along axis 0 of a row-major [nfft][ntr] complex matrix on the device, in place.  Lengths with tuned or flexible
+// column kernels run those (eight traces per workgroup, 64-byte pieces); longer ones the line-per-workgroup fallback.
+static int axis0_fft(int device, c32* work, int nfft, size_t ntr, int inverse)
+{
+    // (the column kernels address a row-major matrix with 32-bit element offsets)
+    const LineOps* ops = (double)nfft * (double)ntr < 4294967296.0 ? find_ops(nfft) : nullptr;
+    if (!ops) {
+        const GenPlan pl = gen_make_plan(nfft);
+        std::vector<c32> tw(nfft);
+        gen_build_twiddles(nfft, tw.data());
+        DevBuf dtw;
+        HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * nfft));
+        HIP_TRY(hipMemcpy(dtw.p, tw.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
+        HIP_TRY(gen_launch_line_fft(work, work, (const c32*)dtw.p, pl, inverse ? INV : FWD, 1.0f, 1, nfft, (int)ntr, false, nullptr, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        return P3D_OK;
+    }
+    std::vector<c32> host;
+    if (is_flex(ops)) {
+        flex_build_table(nfft, host);
+    } else {
+        host.resize(tw_slots(ops->n));
+        build_twiddles(ops->n, host.data());
+    }
+    DevBuf dtw;
+    HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * host.size()));
+    HIP_TRY(hipMemcpy(dtw.p, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
+    ColArgs c{};
+    c.tw = (const c32*)dtw.p;
+    c.in = work;
+    c.out = work;
+    c.n2 = (int)ntr;
+    c.nslices = 1;
+    c.len = nfft;
+    c.in_std = c.out_std = 1;
+    HIP_TRY(ops->col(inverse ? COL_INV : COL_FWD, c, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    (void)device;
+    return P3D_OK;
+}
+
+int p3d_time2freq_dev(int device, const float* x, int nt, size_t ntr, double dt, double t0, int nfft, int real_only, const float* window,
+                      void* out)
+{
+    if (!x || !out) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (nt < 1 || nfft < nt) return fail(P3D_ERR_INVALID, "need 1 <= nt <= nfft");
+    int rc = helper_check(device, ntr, nfft);
+    if (rc) return rc;
+    const int nfreq = real_only ? nfft / 2 + 1 : nfft;
+    std::vector<c32> fac(nfreq);
+    for (int k = 0; k < nfreq; ++k) {
+        // rfft bins are the non-negative frequencies k/(nfft*dt) (np.fft.rfftfreq), also for k = nfft/2
+        const double f = real_only ? k / (nfft * dt) : fft_freq(k, nfft, dt);
+        const double ang = -6.283185307179586476925286766559 * f * t0, w = window ? (double)window[k] : 1.0;
+        fac[k] = c32{(float)(dt * w * std::cos(ang)), (float)(dt * w * std::sin(ang))};
+    }
+    DevBuf dwork, dfac;
+    HIP_TRY(hipMalloc(&dwork.p, sizeof(c32) * (size_t)nfft * ntr));
+    HIP_TRY(hipMalloc(&dfac.p, sizeof(c32) * nfreq));
+    HIP_TRY(hipMemcpy(dfac.p, fac.data(), sizeof(c32) * nfreq, hipMemcpyHostToDevice));
+    c32* work = (c32*)dwork.p;
+    HIP_TRY(gen_launch_t2f_pad(x, work, nt, nfft, ntr, nullptr));
+    if ((rc = axis0_fft(device, work, nfft, ntr, 0))) return rc;
+    HIP_TRY(gen_launch_scale_rows(work, (c32*)out, (const c32*)dfac.p, nfreq, ntr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return P3D_OK;
+}
+
 int p3d_time2freq(int device, const float* x, int nt, size_t ntr, double dt, double t0, int nfft, int real_only, const float* window,
                   void* out)
 {
@@ -1038,43 +1106,24 @@ int p3d_time2freq(int device, const float* x, int nt, size_t ntr, double dt, dou
     int rc = helper_check(device, ntr, nfft);
     if (rc) return rc;
     const int nfreq = real_only ? nfft / 2 + 1 : nfft;
-    const GenPlan pl = gen_make_plan(nfft);
-    std::vector<c32> tw(nfft), fac(nfreq);
-    gen_build_twiddles(nfft, tw.data());
-    for (int k = 0; k < nfreq; ++k) {
-        // rfft bins are the non-negative frequencies k/(nfft*dt) (np.fft.rfftfreq), also for k = nfft/2
-        const double f = real_only ? k / (nfft * dt) : fft_freq(k, nfft, dt);
-        const double ang = -6.283185307179586476925286766559 * f * t0, w = window ? (double)window[k] : 1.0;
-        fac[k] = c32{(float)(dt * w * std::cos(ang)), (float)(dt * w * std::sin(ang))};
-    }
-    DevBuf dx, dwork, dtw, dfac;
+    DevBuf dx, dout;
     HIP_TRY(hipMalloc(&dx.p, sizeof(float) * (size_t)nt * ntr));
-    HIP_TRY(hipMalloc(&dwork.p, sizeof(c32) * (size_t)nfft * ntr));
-    HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * nfft));
-    HIP_TRY(hipMalloc(&dfac.p, sizeof(c32) * nfreq));
+    HIP_TRY(hipMalloc(&dout.p, sizeof(c32) * (size_t)nfreq * ntr));
     HIP_TRY(hipMemcpy(dx.p, x, sizeof(float) * (size_t)nt * ntr, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dtw.p, tw.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dfac.p, fac.data(), sizeof(c32) * nfreq, hipMemcpyHostToDevice));
-    c32* work = (c32*)dwork.p;
-    HIP_TRY(gen_launch_t2f_pad((const float*)dx.p, work, nt, nfft, ntr, nullptr));
-    HIP_TRY(gen_launch_line_fft(work, work, (const c32*)dtw.p, pl, FWD, 1.0f, 1, nfft, (int)ntr, false, nullptr, nullptr));
-    HIP_TRY(gen_launch_scale_rows(work, work, (const c32*)dfac.p, nfreq, ntr, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, work, sizeof(c32) * (size_t)nfreq * ntr, hipMemcpyDeviceToHost));
+    if ((rc = p3d_time2freq_dev(device, (const float*)dx.p, nt, ntr, dt, t0, nfft, real_only, window, dout.p))) return rc;
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(c32) * (size_t)nfreq * ntr, hipMemcpyDeviceToHost));
     return P3D_OK;
 }
 
-int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntr, double dt, double t0, int nfft, int real_only,
-                  float* out)
+int p3d_freq2time_dev(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntr, double dt, double t0, int nfft, int real_only,
+                      float* out)
 {
     if (!X || !out || !kidx) return fail(P3D_ERR_INVALID, "NULL buffer");
     if (nfreq < 1 || nfreq > nfft) return fail(P3D_ERR_INVALID, "need 1 <= nfreq <= nfft");
     int rc = helper_check(device, ntr, nfft);
     if (rc) return rc;
-    const GenPlan pl = gen_make_plan(nfft);
-    std::vector<c32> tw(nfft), fac(nfft, c32{0.f, 0.f});
+    std::vector<c32> fac(nfft, c32{0.f, 0.f});
     std::vector<int> src(nfft, INT_MIN);
-    gen_build_twiddles(nfft, tw.data());
     for (int r = 0; r < nfreq; ++r) {
         const int k = kidx[r];
         if (k < 0 || k >= nfft) return fail(P3D_ERR_INVALID, "kidx[%d] = %d outside 0..nfft-1", r, k);
@@ -1088,23 +1137,33 @@ int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, siz
         const double ang = 6.283185307179586476925286766559 * f * t0;
         fac[k] = c32{(float)std::cos(ang), (float)std::sin(ang)};
     }
-    DevBuf dX, dwork, dtw, dfac, dsrc, dout;
-    HIP_TRY(hipMalloc(&dX.p, sizeof(c32) * (size_t)nfreq * ntr));
+    DevBuf dwork, dfac, dsrc;
     HIP_TRY(hipMalloc(&dwork.p, sizeof(c32) * (size_t)nfft * ntr));
-    HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * nfft));
     HIP_TRY(hipMalloc(&dfac.p, sizeof(c32) * nfft));
     HIP_TRY(hipMalloc(&dsrc.p, sizeof(int) * nfft));
-    HIP_TRY(hipMalloc(&dout.p, sizeof(float) * (size_t)nfft * ntr));
-    HIP_TRY(hipMemcpy(dX.p, X, sizeof(c32) * (size_t)nfreq * ntr, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dtw.p, tw.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dfac.p, fac.data(), sizeof(c32) * nfft, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dsrc.p, src.data(), sizeof(int) * nfft, hipMemcpyHostToDevice));
     c32* work = (c32*)dwork.p;
-    HIP_TRY(gen_launch_f2t_fill((const c32*)dX.p, work, (const c32*)dfac.p, (const int*)dsrc.p, nfft, ntr, nullptr));
+    HIP_TRY(gen_launch_f2t_fill((const c32*)X, work, (const c32*)dfac.p, (const int*)dsrc.p, nfft, ntr, nullptr));
+    if ((rc = axis0_fft(device, work, nfft, ntr, 1))) return rc;
     // true_amplitude: the inverse carries 1/(nfft*dt)
-    HIP_TRY(gen_launch_line_fft(work, work, (const c32*)dtw.p, pl, INV, (float)(1.0 / (nfft * dt)), 1, nfft, (int)ntr, false, nullptr, nullptr));
-    HIP_TRY(gen_launch_real_part(work, (float*)dout.p, (size_t)nfft * ntr, nullptr));
+    HIP_TRY(gen_launch_real_part(work, out, (size_t)nfft * ntr, (float)(1.0 / (nfft * dt)), nullptr));
     HIP_TRY(hipDeviceSynchronize());
+    return P3D_OK;
+}
+
+int p3d_freq2time(int device, const void* X, int nfreq, const int32_t* kidx, size_t ntr, double dt, double t0, int nfft, int real_only,
+                  float* out)
+{
+    if (!X || !out || !kidx) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (nfreq < 1 || nfreq > nfft) return fail(P3D_ERR_INVALID, "need 1 <= nfreq <= nfft");
+    int rc = helper_check(device, ntr, nfft);
+    if (rc) return rc;
+    DevBuf dX, dout;
+    HIP_TRY(hipMalloc(&dX.p, sizeof(c32) * (size_t)nfreq * ntr));
+    HIP_TRY(hipMalloc(&dout.p, sizeof(float) * (size_t)nfft * ntr));
+    HIP_TRY(hipMemcpy(dX.p, X, sizeof(c32) * (size_t)nfreq * ntr, hipMemcpyHostToDevice));
+    if ((rc = p3d_freq2time_dev(device, dX.p, nfreq, kidx, ntr, dt, t0, nfft, real_only, (float*)dout.p))) return rc;
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(float) * (size_t)nfft * ntr, hipMemcpyDeviceToHost));
     return P3D_OK;
 }

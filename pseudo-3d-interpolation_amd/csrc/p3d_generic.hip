@@ -298,9 +298,9 @@ __global__ void f2t_fill_kernel(const c32* X, c32* work, const c32* factor, cons
         work[i] = v;
     }
 }
-__global__ void real_part_kernel(const c32* work, float* out, size_t total)
+__global__ void real_part_kernel(const c32* work, float* out, size_t total, float scale)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) out[i] = work[i].x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) out[i] = work[i].x * scale;
 }
 
 hipError_t gen_launch_t2f_pad(const float* x, c32* work, int nt, int nfft, size_t ntr, hipStream_t st)
@@ -318,9 +318,9 @@ hipError_t gen_launch_f2t_fill(const c32* X, c32* work, const c32* factor, const
     f2t_fill_kernel<<<4096, 256, 0, st>>>(X, work, factor, src, nfft, ntr);
     return hipGetLastError();
 }
-hipError_t gen_launch_real_part(const c32* work, float* out, size_t total, hipStream_t st)
+hipError_t gen_launch_real_part(const c32* work, float* out, size_t total, float scale, hipStream_t st)
 {
-    real_part_kernel<<<4096, 256, 0, st>>>(work, out, total);
+    real_part_kernel<<<4096, 256, 0, st>>>(work, out, total, scale);
     return hipGetLastError();
 }
 

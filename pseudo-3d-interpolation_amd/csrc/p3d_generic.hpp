@@ -39,6 +39,6 @@ hipError_t gen_launch_pct_tau(const unsigned* sel_lo, const unsigned* sel_hi, co
 hipError_t gen_launch_t2f_pad(const float* x, c32* work, int nt, int nfft, size_t ntr, hipStream_t st);
 hipError_t gen_launch_scale_rows(const c32* work, c32* out, const c32* factor, int nrows, size_t ntr, hipStream_t st);
 hipError_t gen_launch_f2t_fill(const c32* X, c32* work, const c32* factor, const int* src, int nfft, size_t ntr, hipStream_t st);
-hipError_t gen_launch_real_part(const c32* work, float* out, size_t total, hipStream_t st);
+hipError_t gen_launch_real_part(const c32* work, float* out, size_t total, float scale, hipStream_t st);
 
 }  // namespace p3d

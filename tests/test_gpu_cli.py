@@ -214,3 +214,22 @@ output_runtime_results: False
     # costs ~1e-4 on a 64 x 96 slice.  Most slices see none.
     assert max(errs) <= 2e-4, errs
     assert sorted(errs)[nf // 2] <= 1e-5, errs
+
+
+def test_device_resident_pipeline_matches_the_three_steps():
+    """pipeline.interpolate_time_cube (time -> frequency -> POCS -> time on device buffers) = the three host-level steps."""
+    from pseudo_3d_interpolation_amd import _ffi, pipeline
+    from pseudo_3d_interpolation_amd.functions import POCS as P
+    nt, nil, nxl, dt, t0 = 40, 64, 48, 0.004, 0.1
+    x, fold = _time_cube(nt, nil, nxl, 0.5, seed=11)
+    mask = np.where(fold <= 1, fold, 1)
+    kw = dict(niter=12, thresh_op='soft', thresh_model='exponential', eps=1e-9, alpha=0.9, p_max=0.99, p_min=1e-2)
+    for real_only, nfft in ((True, None), (False, None), (True, 48)):
+        F = _ffi.time2freq(x, dt, t0, nfft=nfft, real_only=real_only)
+        G = P.pocs_cube(F, mask, **kw)
+        want = _ffi.freq2time(G, dt, t0, nfft=nfft or nt, real_only=real_only)
+        res = []
+        got = pipeline.interpolate_time_cube(x, mask, dt, t0, nfft=nfft, real_only=real_only, results=res, batch_slices=7, **kw)
+        assert got.shape == want.shape and got.dtype == np.float32
+        assert rel_l2(got, want) <= 1e-6
+        assert len(res) == F.shape[0]
