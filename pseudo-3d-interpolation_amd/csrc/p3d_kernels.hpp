@@ -191,6 +191,10 @@ struct ColArgs {
                         // neither transformed back nor stored (nullptr: always store)
 };
 
+// |x| for the cost sums: the hardware square root (1 ulp) without the IEEE fix-up sequence the library call expands to (8 more
+// instructions per sample in a VALU-bound pass); the sums only feed the convergence test (POCS.py:622)
+__device__ __forceinline__ float abs_c32(c32 v) { return __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y); }
+
 // per-thread partial sums are float (16 terms); across the wave they are combined in double so that the
 // cost, a difference of two nearly equal sums (POCS.py:622), keeps its leading digits
 __device__ __forceinline__ double wave_sum(double v)
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
                     bad = bad || (!set && (x.x != 0.f || x.y != 0.f));
                 }
             }
-            acc += sqrtf(x.x * x.x + x.y * x.y);
+            acc += abs_c32(x);
             if (a.adaptive) {
                 // x_old = x at the first iteration (POCS.py:549, 574-575)
                 const float m = mask_at(q);
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
                     const float w = 1.0f - a.alpha * m;       // POCS.py:616
                     xn = axpby(xn, w, xo[i], a.alpha);        // POCS.py:619
                 }
-                acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+                acc += abs_c32(xn);
                 if (MODE == ROW_LAST || a.write_out) {
                     if (valid) {
                         if (a.dtype == 0) (reinterpret_cast<c32*>(a.out) + sbase)[off + TPL * q] = xn;
@@ -619,7 +623,7 @@ row_pipe_kernel(const RowArgs a)
             else m = (a.mask + TPL * q)[cur.row * N + tl];
             const float w = 1.0f - a.alpha * m;       // POCS.py:616
             xn = axpby(xn, w, bx[q], a.alpha);        // POCS.py:619
-            acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+            acc += abs_c32(xn);
             if (EXTRA && a.write_out && cur.on) {
                 if (DT == 0) (reinterpret_cast<c32*>(a.out) + TPL * q)[off] = xn;
                 else (reinterpret_cast<float*>(a.out) + TPL * q)[off] = xn.x;
