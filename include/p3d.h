@@ -213,6 +213,12 @@ int p3d_shearlet_run(p3d_splan* plan, const void* x, int dtype, const float* mas
                      const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
                      double* elapsed_ms);
 
+/* ---- step-15 slice smoothing (cube_postprocessing_3D.py:88-124 wraps scipy.ndimage.gaussian_filter / median_filter) ----------
+ * x/out HOST float32 [nslices][ny][nx]; boundary mode 'reflect'.  gaussian: separable, radius int(truncate * sigma + 0.5);
+ * median: size x size window, size in {3, 5, 7}. */
+int p3d_smooth_gaussian(int device, const float* x, size_t nslices, int ny, int nx, double sigma, double truncate, float* out);
+int p3d_smooth_median(int device, const float* x, size_t nslices, int ny, int nx, int size, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ and NumPy's FFT.  **Parity unpinned against the reference itself**: its module i
 image has, so no fixtures could be generated from it; what pins this file is SciPy / NumPy (the reference's own dependencies).
 """
 import numpy as np
-from scipy import signal
+from scipy import ndimage, signal
 
 
 def rescale(a, vmin=0, vmax=1):
@@ -96,3 +96,12 @@ def remove_acquisition_footprint(data, **kw):
 
 def spatial_antialiasing(data, direction, factors_upsampling, **kw):
     return apply_filter(data, antialias_filter(data.shape, direction, factors_upsampling, **kw))
+
+
+def smoothing_filter(x, filter_name=None, kwargs_filter=None, rescale_slice=False, kwargs_rescale=None):
+    """cube_postprocessing_3D.py:88-124 -- the same scipy.ndimage calls."""
+    func = {"gaussian": ndimage.gaussian_filter, "median": ndimage.median_filter}.get(filter_name)
+    if rescale_slice:
+        vmin, vmax = np.percentile(x, sorted(kwargs_rescale["vminmax"]))
+        return rescale(func(x, **kwargs_filter), vmin=vmin, vmax=vmax)
+    return func(x, **kwargs_filter)

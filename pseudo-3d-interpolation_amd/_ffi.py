@@ -68,6 +68,8 @@ PROTOTYPES = {
     "p3d_freq2time_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
                                     C.c_void_p]),
     "p3d_last_sparsity": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "p3d_smooth_gaussian": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "p3d_smooth_median": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "p3d_last_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),
     "p3d_wavelet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -523,4 +525,21 @@ def freq2time(X, dt, t0=0.0, nfft=None, real_only=False, kidx=None, device=0):
     out = np.empty((nfft,) + X.shape[1:], np.float32)
     check(lib().p3d_freq2time(int(device), _ptr(X), nfreq, _ptr(k), ntr, float(dt), float(t0), nfft, int(bool(real_only)),
                               _ptr(out)))
+    return out
+
+
+def smooth_slices(x, kind, device=0, **kw):
+    """scipy.ndimage.gaussian_filter / median_filter ('reflect' boundary) of every (ny, nx) slice of a float32 stack
+    (include/p3d.h, p3d_smooth_gaussian / p3d_smooth_median)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.ndim != 3:
+        raise ValueError("expected a stack of slices (n, ny, nx)")
+    out = np.empty_like(x)
+    n, ny, nx = x.shape
+    if kind == "gaussian":
+        check(lib().p3d_smooth_gaussian(int(device), _ptr(x), n, ny, nx, float(kw["sigma"]), float(kw.get("truncate", 4.0)), _ptr(out)))
+    elif kind == "median":
+        check(lib().p3d_smooth_median(int(device), _ptr(x), n, ny, nx, int(kw["size"]), _ptr(out)))
+    else:
+        raise ValueError(f"unknown smoothing filter {kind!r}")
     return out

@@ -4,13 +4,44 @@ Step 15 -- the kx-ky slice filters of ``pseudo_3D_interpolation/cube_postprocess
 Covered: ``remove_acquisition_footprint`` (:179-260) and ``spatial_antialiasing`` (:263-347) -- both are
 ``ifft2(ifftshift(filter) * fft2(slice)).real`` with a filter that depends on the slice shape only -- plus their helper
 ``gaussian_kernel_2d`` (:127-176).  The filter is built once on the host (NumPy; the reference uses scipy.signal.fftconvolve for the
-same convolution), the slices go through the 2-D FFT kernels of this package in batches.  Not covered: the scipy.ndimage
-smoothing filters, AGC, upsampling and the xarray/netCDF driver around them.
+same convolution), the slices go through the 2-D FFT kernels of this package in batches.  ``smoothing_filter`` (:88-124) runs
+scipy.ndimage's gaussian / median filter semantics in HIP gather kernels.  Not covered: AGC, upsampling and the xarray/netCDF
+driver around them.
 """
 import numpy as np
 
 from . import _ffi
 from .functions.utils import rescale
+
+
+def smoothing_filter(x, filter_name=None, kwargs_filter=None, rescale_slice=False, kwargs_rescale=None, device=0):
+    """Same arguments as the reference's wrapper of ``scipy.ndimage`` (cube_postprocessing_3D.py:88-124); ``x`` is one slice
+    ``(ny, nx)`` or a stack ``(n, ny, nx)`` (each slice filtered -- and rescaled -- on its own).  Supported: ``gaussian`` with a
+    scalar ``sigma`` (``truncate`` optional) and ``median`` with an odd ``size`` of 3, 5 or 7, both with SciPy's default
+    'reflect' boundary; the arithmetic is float32."""
+    kwargs_filter = dict(kwargs_filter or {})
+    if filter_name not in ('gaussian', 'median'):
+        raise TypeError(f'unknown filter {filter_name!r}')       # the reference calls None(...) here
+    if kwargs_filter.pop('mode', 'reflect') != 'reflect':
+        raise NotImplementedError("only the default boundary mode 'reflect' is implemented")
+    if filter_name == 'gaussian':
+        extra = set(kwargs_filter) - {'sigma', 'truncate'}
+        if extra or np.ndim(kwargs_filter.get('sigma')) != 0 or kwargs_filter.get('sigma') is None:
+            raise NotImplementedError(f'gaussian: scalar sigma (and truncate) only, got {sorted(kwargs_filter)}')
+    else:
+        extra = set(kwargs_filter) - {'size'}
+        if extra or kwargs_filter.get('size') not in (3, 5, 7):
+            raise NotImplementedError(f'median: size 3, 5 or 7 only, got {kwargs_filter}')
+    x = np.asarray(x)
+    squeeze = x.ndim == 2
+    stack = x[None] if squeeze else x
+    filt = _ffi.smooth_slices(stack, filter_name, device=device, **kwargs_filter)
+    if rescale_slice:
+        lo_hi = sorted(kwargs_rescale['vminmax'])
+        for i in range(stack.shape[0]):
+            vmin, vmax = np.percentile(stack[i], lo_hi)
+            filt[i] = rescale(filt[i], vmin=vmin, vmax=vmax)
+    return filt[0] if squeeze else filt
 
 
 def _gaussian_window(m, sigma):
