@@ -87,25 +87,42 @@ static __global__ void nz_count_kernel(const uint8_t* flags, unsigned long long*
 }
 
 static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsigned long long* count, int nslices, int tiles, int col_t, int groups,
-                                      int nblocks, const int* done)
+                                      int nblocks, const int* done, unsigned long long* nzl)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nslices * groups) return;
-    const int s = i / groups, g = i - s * groups;
-    if (done && done[s] != 0) return;   // finished / empty slices: nobody reads their word
-    const uint8_t* f = flags + (size_t)s * tiles;
+    const bool live = i < nslices * groups;
+    const int s = live ? i / groups : 0, g = live ? i - s * groups : 0;
+    const bool skip = !live || (done && done[s] != 0);   // finished / empty slices: nobody reads their word
     unsigned word = 0, kept = 0;
-    for (int q = 0; q < 16; ++q) {
-        const int b = g + groups * q;
-        if (b >= nblocks) continue;
-        unsigned any = 0;
-        if (col_t >= 8) any = f[b / (col_t / 8)];
-        else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
-        word |= (any ? 1u : 0u) << q;
-        kept += any ? 1u : 0u;
+    if (!skip) {
+        const uint8_t* f = flags + (size_t)s * tiles;
+        for (int q = 0; q < 16; ++q) {
+            const int b = g + groups * q;
+            if (b >= nblocks) continue;
+            unsigned any = 0;
+            if (col_t >= 8) any = f[b / (col_t / 8)];
+            else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
+            word |= (any ? 1u : 0u) << q;
+            kept += any ? 1u : 0u;
+        }
+        nzm[i] = (uint16_t)word;
+        if (kept) atomicAdd(count, (unsigned long long)kept);
     }
-    nzm[i] = (uint16_t)word;
-    if (kept) atomicAdd(count, (unsigned long long)kept);
+    // rows of one wavefront (groups == 8): the same flags as 64-bit lane masks per register q, nzl[s][q] bit l = word(l/8) bit q;
+    // the 8 threads of a slice are neighbours in the wave and build two words each
+    if (nzl != nullptr) {
+        const int base = (int)(threadIdx.x & 63u) & ~7;
+        unsigned long long m0 = 0, m1 = 0;
+        for (int k = 0; k < 8; ++k) {
+            const unsigned wk = (unsigned)__shfl((int)word, base + k, 64);
+            if ((wk >> (2 * g)) & 1u) m0 |= 0xFFull << (8 * k);
+            if ((wk >> (2 * g + 1)) & 1u) m1 |= 0xFFull << (8 * k);
+        }
+        if (!skip) {
+            nzl[(size_t)s * 16 + 2 * g] = m0;
+            nzl[(size_t)s * 16 + 2 * g + 1] = m1;
+        }
+    }
 }
 // ---- per-slice sum of the per-row sums, fixed order (bitwise reproducible) ----------------------------------
 static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row, int n1)
@@ -156,6 +173,18 @@ static __global__ void pack_mask_kernel(const float* mask, uint16_t* bits, int* 
 }
 
 
+// rows of one wavefront (tpl == 64): the same mask as lane masks, bits64[row][q] bit l = bits[row][l] bit q
+static __global__ void pack_mask64_kernel(const uint16_t* bits, unsigned long long* bits64, int n1, int ppt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1 * ppt) return;
+    const int row = i / ppt, q = i - row * ppt;
+    unsigned long long w = 0;
+    for (int l = 0; l < 64; ++l) w |= (unsigned long long)((bits[row * 64 + l] >> q) & 1u) << l;
+    bits64[i] = w;
+}
+
+
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...)
@@ -199,6 +228,8 @@ struct p3d_plan {
     bool sparse_ok = false;                     // shape supports skipping emptied tiles
     double last_nonzero_fraction = -1.0;        // of the last p3d_pocs_run: kept column blocks / all (or -1: dense path)
     uint16_t* bits = nullptr;                   // packed binary trace mask [nil][tpl(nxl)]
+    unsigned long long* bits64 = nullptr;       // tpl == 64: the same as lane masks [nil][ppt] (row_pipe64_kernel)
+    unsigned long long* nzl = nullptr;          // tpl == 64: nzm as lane masks [max_slices][16]
     int* flag = nullptr;                        // device int[2]: mask not binary / x non-zero at a missing trace
     unsigned* rowbase = nullptr;                // [nil+1] observed positions before each row
     void* xc = nullptr;                         // compact observed samples [nslices][nobs]
@@ -269,7 +300,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
+    void* bufs[] = {p->bits64, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -364,6 +395,10 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
         if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
+        if (orow->tpl == 64 && orow->ppt == 16 && !getenv("P3D_NO_PIPE64")) {
+            TRY_OR_BAIL(hipMalloc((void**)&p->bits64, sizeof(unsigned long long) * (size_t)nil * orow->ppt));
+            TRY_OR_BAIL(hipMalloc((void**)&p->nzl, sizeof(unsigned long long) * 16 * (size_t)max_slices));
+        }
         TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
     }
     TRY_OR_BAIL(hipMalloc((void**)&p->flag, 2 * sizeof(int)));
@@ -832,6 +867,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl,
                                                                     p->ops_row->ppt);
         if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
+        if (p->bits64) pack_mask64_kernel<<<(p->nil * p->ops_row->ppt + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, p->ops_row->ppt);
         HIP_TRY(hipGetLastError());
     }
     int nonbinary = flex_rows ? 1 : 0;
@@ -861,6 +897,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.x = x;
     r.mask = nonbinary ? mask : nullptr;
     r.bits = nonbinary ? nullptr : p->bits;
+    r.bits64 = nonbinary ? nullptr : p->bits64;
     r.xc = compact ? p->xc : nullptr;
     r.rowbase = p->rowbase;
     r.nobs = nobs;
@@ -922,8 +959,9 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             r.nz_col_t = col_t;
         } else if (sparse) {
             nz_pack_kernel<<<(nslices * groups + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzm, p->nzcount, nslices, p->tiles, col_t, groups, nblocks,
-                                                                                c.done);
+                                                                                c.done, groups == 8 ? p->nzl : nullptr);
             r.nzm = p->nzm;
+            r.nzl = groups == 8 ? p->nzl : nullptr;
         }
         HIP_TRY(stamp());
         r.sum_row = k + 1;
@@ -943,6 +981,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             if (finalize && k + 1 < niter) {
                 RowArgs f = r;
                 f.nzm = nullptr;  // the rows it reads were written by the row pass: all there
+                f.nzl = nullptr;
                 f.nzflag = nullptr;
                 f.only_done = k + 1;
                 f.plain = 0;      // the observed samples are needed (exact hand-back at observed traces)

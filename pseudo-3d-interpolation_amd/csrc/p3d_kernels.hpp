@@ -165,6 +165,8 @@ struct RowArgs {
     int nz_col_t;
     int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done == only_done; their work
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
+    const unsigned long long* bits64;  // TPL == 64 (a row = one wavefront): [n1][PPT] lane masks, bit l of word q = mask[row][l + 64*q]
+    const unsigned long long* nzl;     // TPL == 64: [nslices][PPT] lane masks of nzm (bit l of word q = nzm[slice][l/8] bit q); nullptr: dense
     float alpha;
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
@@ -667,6 +669,210 @@ row_pipe_kernel(const RowArgs a)
 }
 
 // =================================================================================================
+// persistent row pass for rows of exactly one wavefront (TPL == 64), binary mask, compact observed samples
+// =================================================================================================
+// Same arithmetic and schedule as row_pipe_kernel<N, true, DT, false, true> (bit for bit); what changes is WHERE the bookkeeping
+// runs.  A row is one wavefront, so slice, row, every base address, the trace mask of the row and the emptied-block flags of the
+// slice are wave-uniform: they live in scalar registers (s_load / SALU), predicates are 64-bit lane masks applied as EXEC or as
+// the selector of v_cndmask, the rank of a lane among the observed traces is v_mbcnt, and every access is "scalar base + one
+// 32-bit lane offset".  The generic kernel spends ~40 % of its vector instructions on exactly that bookkeeping.
+// Measured on the headline cube (profiles/r01_rowpass_wave_uniform.txt): sixteen rows per workgroup (1024 threads, one workgroup
+// of 154 KiB LDS per CU, 4 waves per SIMD inside the 128-VGPR budget) beats three 4-row workgroups; the row-ahead prefetch of the
+// work buffer buys nothing once most of its blocks are skipped, the early request of the observed samples a little.
+#ifndef P3D_PIPE64_WAVES_PER_EU
+#define P3D_PIPE64_WAVES_PER_EU 4
+#endif
+#ifndef P3D_PIPE64_THREADS
+#define P3D_PIPE64_THREADS 1024
+#endif
+#ifndef P3D_PIPE64_LOCKSTEP
+#define P3D_PIPE64_LOCKSTEP 1
+#endif
+#ifndef P3D_PIPE64_PREFETCH
+#define P3D_PIPE64_PREFETCH 0    // work-buffer loads of the next row in flight during this row (32 VGPRs)
+#endif
+#ifndef P3D_PIPE64_OBS_EARLY
+#define P3D_PIPE64_OBS_EARLY 1   // observed samples requested before the inverse transform instead of after it (32 VGPRs across it)
+#endif
+template <int N, int DT, bool SPARSE>
+__global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void row_pipe64_kernel(const RowArgs a)
+{
+    using PL = Plan<N>;
+    constexpr int TPL = PL::TPL, PPT = PL::PPT;
+    static_assert(TPL == 64, "one row per wavefront");
+    constexpr int LB = P3D_PIPE64_THREADS / TPL;
+    constexpr int LSTR = LdsRow::stride(N);
+    constexpr unsigned ES = DT == 0 ? 8u : 4u;   // bytes per observed sample
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + PassTables<N>::slots();
+    const TwOrdered tw{twl};
+
+    const int tid = threadIdx.x;
+    const int line = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = tid & 63;
+    for (int i = tid; i < PassTables<N>::slots(); i += P3D_PIPE64_THREADS) twl[i] = a.tw[i];
+    __syncthreads();
+    const LdsRow lds{data + line * LSTR};
+
+    const unsigned total = (unsigned)a.nslices * a.n1;
+    const unsigned step = gridDim.x * LB;
+    const unsigned wblk = (unsigned)a.n1 * 8;
+    const size_t wstride = wk_slice_stride(a.n1, N);
+    const unsigned lane_w = ((unsigned)(tl >> 3) * wblk + (unsigned)(tl & 7)) * 8u;   // byte offset of the lane inside a row, every q
+    const size_t qstride = (size_t)(TPL / 8) * wblk * 8u;                              // bytes from register q to q + 1
+
+    // The small tables (lane masks, row bases) are never written while this kernel runs: reading them through the constant
+    // address space lets the compiler use scalar loads although the loop also stores to the work buffer.
+    typedef const unsigned long long __attribute__((address_space(4))) * kmask_t;
+    typedef const unsigned __attribute__((address_space(4))) * kuint_t;
+    const kmask_t k_bits = (kmask_t)a.bits64, k_nzl = (kmask_t)a.nzl;
+    const kuint_t k_rowbase = (kuint_t)a.rowbase;
+    // "scalar base + 32-bit lane offset" addressing is matched per basic block: keep the zero-extension of the lane offset from
+    // being hoisted out of the predicated blocks (an empty asm, no instruction)
+    auto lane_off = [&]() -> unsigned { unsigned o = lane_w; asm volatile("" : "+v"(o)); return o; };
+
+    struct Where { unsigned slice, row; bool on; };
+    auto locate = [&](unsigned g) -> Where {
+        Where w;
+        w.on = g < total;
+        const unsigned gg = w.on ? g : 0u;
+        w.slice = gg / (unsigned)a.n1;
+        w.row = gg - w.slice * (unsigned)a.n1;
+        return w;
+    };
+    auto wbase = [&](const Where& w) -> char* { return reinterpret_cast<char*>(a.work) + (w.slice * wstride + (size_t)w.row * 8) * 8; };
+    // register q of a row sits q * qstride bytes further on: one running scalar pointer (the step is made opaque per call so
+    // that sixteen precomputed 64-bit multiples do not crowd the scalar registers)
+    auto qstep = [&]() -> size_t { size_t qs = qstride; asm volatile("" : "+s"(qs)); return qs; };
+    auto load_work = [&](c32 (&dst)[PPT], const Where& w) {
+        const char* b = wbase(w);
+        const size_t qs = qstep();
+        const kmask_t nz = k_nzl + (size_t)w.slice * PPT;
+        unsigned long long nzw[PPT];
+        if (SPARSE) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) nzw[q] = nz[q];   // all sixteen words in one go (s_load_dwordx16 twice)
+        }
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (SPARSE) {
+                c32 val{0.f, 0.f};
+                if (__builtin_amdgcn_inverse_ballot_w64(nzw[q])) val = *reinterpret_cast<const c32*>(b + lane_off());
+                dst[q] = val;
+            } else {
+                dst[q] = *reinterpret_cast<const c32*>(b + lane_off());
+            }
+            b += qs;
+        }
+    };
+    auto load_obs = [&](c32 (&dst)[PPT], unsigned long long (&mwords)[PPT], const Where& w) {
+        const kmask_t mrow = k_bits + (size_t)w.row * PPT;
+        const char* xb = reinterpret_cast<const char*>(a.xc) + ((size_t)w.slice * a.nobs + k_rowbase[w.row]) * ES;
+        unsigned running = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) mwords[q] = mrow[q];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const unsigned long long mw = mwords[q];
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mw, 0u));
+            const char* xq = xb + (size_t)running * ES;
+            c32 val{0.f, 0.f};
+            if (__builtin_amdgcn_inverse_ballot_w64(mw)) {
+                unsigned ro = rank * ES;
+                asm volatile("" : "+v"(ro));
+                if (DT == 0) val = *reinterpret_cast<const c32*>(xq + ro);
+                else val.x = *reinterpret_cast<const float*>(xq + ro);
+            }
+            dst[q] = val;
+            running += (unsigned)__builtin_popcountll(mw);
+        }
+    };
+
+    unsigned g = blockIdx.x * LB + line;
+    Where cur = locate(g);
+    Where nxt = locate(g + step);
+    c32 v[PPT], bx[PPT];
+#if P3D_PIPE64_PREFETCH
+    c32 by[PPT];
+    load_work(by, cur);
+    // Drain these loads HERE.  The loop's loads are predicated (their number is unknown at compile time), so a pending load on
+    // the entry path would turn into a full "s_waitcnt vmcnt(0)" in front of every row's inverse transform -- right behind the
+    // requests for the next row and for the observed samples, which are meant to be in flight during that transform.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
+    const float w_obs = 1.0f - a.alpha * 1.0f;   // POCS.py:616 at an observed trace
+
+    for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
+#if P3D_PIPE64_LOCKSTEP
+        __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
+#endif
+        const Where nxt2 = locate(g + 2 * step);
+#if P3D_PIPE64_PREFETCH
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = by[q];
+        load_work(by, nxt);
+#else
+        load_work(v, cur);
+#endif
+        unsigned long long mwords[PPT];   // the trace mask of this row as lane masks
+#if P3D_PIPE64_OBS_EARLY
+        // issued BEHIND the work-buffer loads (vmcnt retires in order: the transform below waits for those only) and in flight
+        // during the inverse transform
+        __builtin_amdgcn_sched_barrier(0);
+        load_obs(bx, mwords, cur);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        line_fft<N, INV, true>(v, lds, tw, tl);
+        __builtin_amdgcn_sched_barrier(0);
+#if !P3D_PIPE64_OBS_EARLY
+        load_obs(bx, mwords, cur);
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        // the samples are first touched HERE: without this the compiler starts on bx * alpha in the middle of the transform and
+        // waits for the loads there
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(bx[q].x), "+v"(bx[q].y));
+#endif
+
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            c32 xn = v[q] * a.scale;
+            const float w = __builtin_amdgcn_inverse_ballot_w64(mwords[q]) ? w_obs : 1.0f;
+            xn = axpby(xn, w, bx[q], a.alpha);        // POCS.py:616-619
+            acc += abs_c32(xn);
+            v[q] = xn;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (a.sums != nullptr) {
+            double ws = (double)acc;
+#pragma unroll
+            for (int o = TPL / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, TPL);
+            if (tl == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row] = ws;
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        line_fft<N, FWD, true>(v, lds, tw, tl);
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (cur.on) {
+            char* b = wbase(cur);
+            const size_t qs = qstep();
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                *reinterpret_cast<c32*>(b + lane_off()) = v[q];
+                b += qs;
+            }
+        }
+        g += step;
+        cur = nxt;
+        nxt = nxt2;
+    }
+}
+
+// =================================================================================================
 // spectrum (column) pass
 // =================================================================================================
 __device__ __forceinline__ bool lex_greater(float ar, float ai, float br, float bi)
@@ -892,6 +1098,27 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
         const bool bits = a.bits != nullptr;
         const bool extra = a.adaptive || a.write_out || a.done != nullptr;
         const bool compact = bits && a.xc != nullptr;
+        if constexpr (Plan<N>::TPL == 64) {
+            if (compact && !extra && a.bits64 != nullptr) {   // the wave-uniform variant
+                constexpr int LB64 = P3D_PIPE64_THREADS / 64;
+                constexpr size_t lds64 = sizeof(c32) * (PassTables<N>::slots() + LB64 * LdsRow::stride(N)) + 8 * sizeof(double);
+                const int fit_lds = (int)((160 * 1024) / lds64), fit_regs = (P3D_PIPE64_WAVES_PER_EU * 4 * 64) / P3D_PIPE64_THREADS;
+                const int per_cu64 = fit_lds < fit_regs ? fit_lds : fit_regs;
+                if (per_cu64 < 1) return hipErrorNotSupported;
+                const long wgs64 = (long)cus * per_cu64, groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;
+                const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));
+#define P3D_PIPE64(DT, SP)                                                                               \
+    do {                                                                                                \
+        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP>, lds64)) != hipSuccess) return e;               \
+        row_pipe64_kernel<N, DT, SP><<<grid64, P3D_PIPE64_THREADS, lds64, st>>>(a);                     \
+    } while (0)
+                const bool sp = a.nzl != nullptr;
+                if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true); else P3D_PIPE64(0, false); }
+                else { if (sp) P3D_PIPE64(1, true); else P3D_PIPE64(1, false); }
+#undef P3D_PIPE64
+                return hipGetLastError();
+            }
+        }
         if (a.dtype == 0) {
             if (compact) { if (extra) P3D_PIPE(true, 0, true, true); else P3D_PIPE(true, 0, false, true); }
             else if (bits) { if (extra) P3D_PIPE(true, 0, true, false); else P3D_PIPE(true, 0, false, false); }

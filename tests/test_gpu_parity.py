@@ -563,3 +563,36 @@ def test_slower_equivalent_paths_behind_the_switches(switch, monkeypatch):
     finally:
         P.release_plans()
     assert rel_l2(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("nil,dtype", [(64, np.complex64), (100, np.complex64), (256, np.float32), (1000, np.complex64)])
+def test_wave_uniform_row_pass_is_the_generic_one(nil, dtype, monkeypatch):
+    """Rows of 1024 samples are one wavefront each: their steady-state pass keeps slice / row / mask / emptied-block bookkeeping in
+    scalar registers (row_pipe64_kernel).  Same arithmetic as the generic persistent pass (P3D_NO_PIPE64=1): identical results,
+    with the sparse shortcut and without, for tuned and flexible column lengths, and both match the oracle."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    nxl = 1024
+    mask = orc.synthetic_mask(nil, nxl, 0.7)
+    cube = np.stack([orc.synthetic_slice(nil, nxl, 40 + s) for s in range(5)]) * mask     # 5 * nil rows: ragged last workgroup
+    cube = (cube.real if dtype == np.float32 else cube).astype(dtype)
+    # the soft operator is continuous: float32 rounding cannot flip a keep / drop decision (hard: a few coefficients per cube do)
+    kw = dict(niter=9, thresh_op="hard" if dtype == np.float32 else "soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
+    want = orc.pocs_cube(cube.astype(np.float64 if dtype == np.float32 else np.complex128), mask, **kw)
+    res = {}
+    for pipe64 in (True, False):
+        for sparse in (True, False):
+            P.release_plans()
+            for name, on in (("P3D_NO_PIPE64", not pipe64), ("P3D_NO_SPARSE", not sparse)):
+                monkeypatch.setenv(name, "1") if on else monkeypatch.delenv(name, raising=False)
+            try:
+                res[pipe64, sparse] = P.pocs_cube(cube, mask, **kw)
+            finally:
+                P.release_plans()
+    first = res[True, True]
+    # per slice: most sit at float32 rounding; a slice whose schedule passes through the noise floor of its spectrum is
+    # ill-conditioned for every float32 implementation (DESIGN.md section 4), on every path of this library alike
+    err = np.array([rel_l2(first[s], want[s]) for s in range(len(want))])
+    assert np.median(err) <= 1e-5 and err.max() <= 2e-3, err
+    for key, other in res.items():
+        assert np.array_equal(first, other), key
