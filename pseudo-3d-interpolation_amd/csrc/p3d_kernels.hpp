@@ -925,6 +925,10 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
     c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
     const unsigned blk0 = ((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7);  // column-blocked: + row*8
+    // element offset of (row r, this thread's column) = origin + r * pitch, both picked ONCE per layout (a select per element
+    // costs the sixteen loads and stores of a thread 60 vector instructions)
+    const unsigned in_org = a.in_std ? (unsigned)vcol : blk0, in_pitch = a.in_std ? (unsigned)a.n2 : 8u;
+    const unsigned out_org = a.out_std ? (unsigned)vcol : blk0, out_pitch = a.out_std ? (unsigned)a.n2 : 8u;
     auto eoff = [&](int std_layout, int r) -> unsigned {
         return std_layout ? (unsigned)r * a.n2 + vcol : blk0 + (unsigned)r * 8;
     };
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         return;
     }
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) v[q] = inb[eoff(a.in_std, tl + TPL * q)];  // columns past the edge re-read column 0; never stored
+    for (int q = 0; q < PPT; ++q) v[q] = inb[in_org + (unsigned)(tl + TPL * q) * in_pitch];  // columns past the edge re-read column 0; never stored
 
     if (MODE != COL_INV) line_fft<N, FWD, false>(v, lds, tw, tl);
 
@@ -964,10 +968,11 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         if (ITER && a.nzflag != nullptr) {
             // Sparse spectra (the premise of the method): a tile the threshold emptied is all zeros after the inverse
             // transform too.  Say so instead of transforming and storing it; the row pass reads zeros for it.
-            bool any = false;
+            // any bit set in any coefficient (a kept -0.0 counts as kept: harmless, the tile is then simply processed)
+            unsigned bits = 0;
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) any = any || (v[q].x != 0.0f) || (v[q].y != 0.0f);
-            const int kept = __syncthreads_or(any ? 1 : 0);
+            for (int q = 0; q < PPT; ++q) bits |= __float_as_uint(v[q].x) | __float_as_uint(v[q].y);
+            const int kept = __syncthreads_or(bits != 0u ? 1 : 0);
             if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
             if (!kept) return;
         }
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) outb[eoff(a.out_std, tl + TPL * q)] = v[q];
+        for (int q = 0; q < PPT; ++q) outb[out_org + (unsigned)(tl + TPL * q) * out_pitch] = v[q];
     }
 }
 

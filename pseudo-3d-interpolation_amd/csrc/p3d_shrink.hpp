@@ -12,11 +12,16 @@ namespace p3d {
 // max (POCS.py:288); comparisons and clipping against it are lexicographic as well.
 __device__ __forceinline__ c32 shrink(c32 X, c32 tau, int op)
 {
-    const float m = sqrtf(X.x * X.x + X.y * X.y);
+    const float p = X.x * X.x + X.y * X.y;
     if (op == 0) {  // hard: where(|X| < tau, 0, X)          threshold_operator.py:110-112
-        const bool below = (m < tau.x) || (m == tau.x && 0.0f < tau.y);
+        // |X| < Re tau  <=>  |X|^2 < (Re tau)^2 for Re tau > 0 (a negative Re tau keeps everything): no square root, whose
+        // IEEE fix-up sequence is a dozen instructions per coefficient of a pass that is bound by instruction issue.  Both forms
+        // place a coefficient within an ulp of the threshold arbitrarily; the tests treat that band as ties.
+        const float t2 = tau.x * tau.x;
+        const bool below = tau.x > 0.0f ? ((p < t2) || (p == t2 && 0.0f < tau.y)) : (tau.x == 0.0f && p == 0.0f && 0.0f < tau.y);
         return below ? c32{0.f, 0.f} : X;
     }
+    const float m = sqrtf(p);
     if (m == 0.0f) return c32{0.f, 0.f};  // 1 - tau/0 = -inf -> clipped to 0
     float gr, gi;
     if (op == 1) {  // soft: X * clip(1 - tau/|X|, 0)           threshold_operator.py:36-39
