@@ -263,9 +263,9 @@ static int upload_table(p3d_plan* p, const LineOps* ops, bool for_rows, int n, c
     if (is_flex(ops)) {
         flex_build_table(n, host);   // plain table exp(-2 pi i k / n), or the chirp-z tables
     } else {
-        host.resize(for_rows ? (size_t)ops->row_tw_slots : (size_t)tw_slots(ops->n));
+        host.resize(for_rows ? (size_t)ops->row_tw_slots : (size_t)ops->col_tw_slots);
         if (for_rows) ops->build_row_tw(host.data());
-        else build_twiddles(ops->n, host.data());
+        else ops->build_col_tw(host.data());
     }
     HIP_TRY(hipMalloc((void**)dst, sizeof(c32) * host.size()));
     HIP_TRY(hipMemcpy(*dst, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
@@ -1090,8 +1090,8 @@ static int axis0_fft(int device, c32* work, int nfft, size_t ntr, int inverse)
     if (is_flex(ops)) {
         flex_build_table(nfft, host);
     } else {
-        host.resize(tw_slots(ops->n));
-        build_twiddles(ops->n, host.data());
+        host.resize(ops->col_tw_slots);
+        ops->build_col_tw(host.data());
     }
     DevBuf dtw;
     HIP_TRY(hipMalloc(&dtw.p, sizeof(c32) * host.size()));

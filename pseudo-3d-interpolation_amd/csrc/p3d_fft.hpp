@@ -69,6 +69,17 @@ __device__ __forceinline__ c32 operator*(c32 a, c32 b)
         : "=v"(r) : "v"(as_f2(a)), "v"(as_f2(b)), "v"(t));
     return as_c32(r);
 }
+// a * conj(b): the same two instructions, the sign of b.y carried by the operand modifiers (bit-identical to conjugating first)
+__device__ __forceinline__ c32 mul_conj(c32 a, c32 b)
+{
+    p3d_f2 t, r;
+    // t = (a.y*b.y, a.y*b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(as_f2(a)), "v"(as_f2(b)));
+    // r = (a.x*b.x + t.x, -a.x*b.y + t.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(as_f2(a)), "v"(as_f2(b)), "v"(t));
+    return as_c32(r);
+}
 // a + i*b = (a.x - b.y, a.y + b.x);  a - i*b = (a.x + b.y, a.y - b.x)
 __device__ __forceinline__ c32 add_ib(c32 a, c32 b)
 {
@@ -87,6 +98,7 @@ P3D_HD c32 operator*(c32 a, c32 b)
 {
     return {__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
 }
+P3D_HD c32 mul_conj(c32 a, c32 b) { return a * c32{b.x, -b.y}; }
 P3D_HD c32 add_ib(c32 a, c32 b) { return {a.x - b.y, a.y + b.x}; }
 P3D_HD c32 sub_ib(c32 a, c32 b) { return {a.x + b.y, a.y - b.x}; }
 #endif
@@ -220,21 +232,7 @@ struct Plan {
 };
 
 // ---- twiddle tables ----------------------------------------------------------------------------
-// (a) master table: tw[tw_slot(k)] = exp(-2*pi*i*k/n); every pass of both directions indexes it with a
-//     computed slot (one multiply-add per twiddle).  Smallest LDS footprint: used by the column pass.
-constexpr int tw_slot(int k) { return k + (k >> 5); }       // padded position of entry k
-constexpr int tw_slots(int n) { return n + (n >> 5) + 1; }  // length of the padded table
-
-inline void build_twiddles(int n, c32* out)
-{
-    for (int i = 0; i < tw_slots(n); ++i) out[i] = c32{0.f, 0.f};
-    for (int k = 0; k < n; ++k) {
-        const double ang = -6.283185307179586476925286766559 * double(k) / double(n);
-        out[tw_slot(k)] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
-    }
-}
-
-// (b) per-pass ordered tables: for every pass p >= 1 of a direction, (R-1) rows of Ns entries, row t-1
+// (b) per-pass ordered tables (row pass): for every pass p >= 1 of a direction, (R-1) rows of Ns entries, row t-1
 //     holding exp(dir*2*pi*i*t*jm/(Ns*R)), jm = 0..Ns-1 -- the order in which neighbouring threads read
 //     them, at compile-time offsets from one per-thread base (no address arithmetic, no extra registers).
 //     Forward table first, inverse table at offset N.  Twice the LDS: used by the row pass, which is
@@ -264,24 +262,62 @@ struct PassTables {
     }
 };
 
-// twiddle access policies for pass_compute
-struct TwMaster {
+// (c) column-pass tables.  The LAST pass of a direction has entry k = t*jm of the plain table exp(-2*pi*i*k/N) (conjugated
+//     inside the multiply for the inverse): the lanes of a wave hold consecutive jm, so the strides t*8 B spread over the LDS
+//     banks without padding and the address is ONE multiply.  The MIDDLE pass of a three-pass plan (k = t*STEP*jm, STEP >= 2)
+//     would pile onto one bank there: it gets ordered rows like (b), (R-1)*NS entries per direction, with the very same
+//     values (built from the same expression).  ~10 KiB at N = 1024, so two column tiles still share a CU's 160 KiB.
+template <int N>
+struct ColTables {
+    using PL = Plan<N>;
+    static constexpr int master() { return N >= 16 ? N - N / 16 + 1 : N; }   // (R-1)*(N/R - 1) < N - N/16 for every radix
+    static constexpr bool has_mid() { return PL::NPASS == 3; }
+    static constexpr int mid_len(int dir) { return has_mid() ? (PL::radix(dir, 1) - 1) * PL::ns(dir, 1) : 0; }
+    static constexpr int mid_off(int dir) { return master() + (dir == FWD ? 0 : mid_len(FWD)); }
+    static constexpr int slots() { return master() + mid_len(FWD) + mid_len(INV); }
+    static c32 entry(int k)
+    {
+        const double ang = -6.283185307179586476925286766559 * double(k) / double(N);
+        return c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
+    }
+    static void build(c32* out)
+    {
+        for (int k = 0; k < master(); ++k) out[k] = entry(k);
+        if constexpr (PL::NPASS == 3) {
+            for (int dir = -1; dir <= 1; dir += 2) {
+                const int R = PL::radix(dir, 1), NS = PL::ns(dir, 1), STEP = N / (NS * R);
+                for (int t = 1; t < R; ++t)
+                    for (int jm = 0; jm < NS; ++jm) {
+                        c32 w = entry(t * STEP * jm);
+                        if (dir > 0) w.y = -w.y;
+                        out[mid_off(dir) + (t - 1) * NS + jm] = w;
+                    }
+            }
+        }
+    }
+};
+
+// twiddle policies for pass_compute: mul<N, DIR, P, T>(a, jm) = a * (twiddle t = T of pass P, position jm)
+struct TwCol {
     const c32* tw;
     template <int N, int DIR, int P, int T>
-    P3D_HD c32 get(int jm) const
+    P3D_HD c32 mul(c32 a, int jm) const
     {
-        constexpr int STEP = N / (Plan<N>::ns(DIR, P) * Plan<N>::radix(DIR, P));
-        c32 w = tw[tw_slot(T * STEP * jm)];
-        if (DIR > 0) w.y = -w.y;
-        return w;
+        using PL = Plan<N>;
+        if constexpr (P + 1 == PL::NPASS) {
+            const c32 w = tw[T * jm];
+            return DIR > 0 ? mul_conj(a, w) : a * w;
+        } else {
+            return a * (tw + (ColTables<N>::mid_off(DIR) + (T - 1) * PL::ns(DIR, P)))[jm];
+        }
     }
 };
 struct TwOrdered {
     const c32* tw;
     template <int N, int DIR, int P, int T>
-    P3D_HD c32 get(int jm) const
+    P3D_HD c32 mul(c32 a, int jm) const
     {
-        return (tw + (PassTables<N>::off(DIR, P) + (T - 1) * Plan<N>::ns(DIR, P)))[jm];
+        return a * (tw + (PassTables<N>::off(DIR, P) + (T - 1) * Plan<N>::ns(DIR, P)))[jm];
     }
 };
 
@@ -318,7 +354,7 @@ struct TwApply {  // a[t] = v[s + NB*t] * w_t for t = T..R-1 (compile-time t: ta
     static P3D_HD void run(c32* a, const c32* v, int s, TW tw, int jm)
     {
         if constexpr (T < R) {
-            a[T] = v[s + NB * T] * tw.template get<N, DIR, P, T>(jm);
+            a[T] = tw.template mul<N, DIR, P, T>(v[s + NB * T], jm);
             TwApply<N, DIR, P, T + 1, TW>::template run<R, NB>(a, v, s, tw, jm);
         }
     }

@@ -176,7 +176,7 @@ struct RowArgs {
 struct ColArgs {
     const c32* in;
     c32* out;           // may alias `in`
-    const c32* tw;      // padded twiddle table of length N (device)
+    const c32* tw;      // the column pass's twiddle tables (ColTables<N>, device)
     const c32* tau;     // [nslices][niter] (COL_ITER, optional for COL_FWD)
     const int* done;
     float* partials;    // [nslices][tiles][STATS_PARTIAL] (COL_STATS)
@@ -891,8 +891,8 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     using LDS = LdsColW<CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
-    c32* data = twl + tw_slots(N);
-    const TwMaster tw{twl};
+    c32* data = twl + ColTables<N>::slots();
+    const TwCol tw{twl};
 
     const int tid = threadIdx.x;
     const int c_lo = tid % CW;
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 
     if (a.done && a.done[slice] != 0) return;
 
-    for (int i = tid; i < tw_slots(N); i += THREADS) twl[i] = a.tw[i];
+    for (int i = tid; i < ColTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
 
     const LDS lds{data + cbl * LDS::stride(N) + c_lo};
@@ -1052,7 +1052,7 @@ constexpr size_t col_lds_bytes()
 {
     constexpr int T = col_tile<N>();
     constexpr int CW = T < 8 ? T : 8;
-    return sizeof(c32) * (tw_slots(N) + (size_t)(T / CW) * LdsColW<CW>::stride(N));
+    return sizeof(c32) * (ColTables<N>::slots() + (size_t)(T / CW) * LdsColW<CW>::stride(N));
 }
 
 template <class K>
@@ -1193,6 +1193,8 @@ struct LineOps {
     size_t row_lds;
     int row_tw_slots;                    // length of the row pass's twiddle tables ...
     void (*build_row_tw)(c32* out);      // ... and their builder
+    int col_tw_slots;                    // the same for the column pass (ColTables)
+    void (*build_col_tw)(c32* out);
 };
 
 }  // namespace p3d
