@@ -927,8 +927,11 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     const unsigned blk0 = ((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7);  // column-blocked: + row*8
     // element offset of (row r, this thread's column) = origin + r * pitch, both picked ONCE per layout (a select per element
     // costs the sixteen loads and stores of a thread 60 vector instructions)
-    const unsigned in_org = a.in_std ? (unsigned)vcol : blk0, in_pitch = a.in_std ? (unsigned)a.n2 : 8u;
-    const unsigned out_org = a.out_std ? (unsigned)vcol : blk0, out_pitch = a.out_std ? (unsigned)a.n2 : 8u;
+    // (the iteration itself always works on the column-blocked buffer: compile-time pitch, the q-dependent part of an address
+    // becomes an instruction immediate or one add)
+    const bool in_std = !ITER && a.in_std, out_std = !ITER && a.out_std;
+    const unsigned in_org = in_std ? (unsigned)vcol : blk0, in_pitch = in_std ? (unsigned)a.n2 : 8u;
+    const unsigned out_org = out_std ? (unsigned)vcol : blk0, out_pitch = out_std ? (unsigned)a.n2 : 8u;
     auto eoff = [&](int std_layout, int r) -> unsigned {
         return std_layout ? (unsigned)r * a.n2 + vcol : blk0 + (unsigned)r * 8;
     };
@@ -956,7 +959,8 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         return;
     }
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) v[q] = inb[in_org + (unsigned)(tl + TPL * q) * in_pitch];  // columns past the edge re-read column 0; never stored
+    for (int q = 0; q < PPT; ++q)   // scalar base + 32-bit byte offset (a slice is far below 4 GiB); columns past the edge re-read column 0
+        v[q] = *reinterpret_cast<const c32*>(reinterpret_cast<const char*>(inb) + (in_org + (unsigned)(tl + TPL * q) * in_pitch) * 8u);
 
     if (MODE != COL_INV) line_fft<N, FWD, false>(v, lds, tw, tl);
 
@@ -1030,7 +1034,11 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) outb[out_org + (unsigned)(tl + TPL * q) * out_pitch] = v[q];
+        for (int q = 0; q < PPT; ++q) {
+            unsigned o = (out_org + (unsigned)(tl + TPL * q) * out_pitch) * 8u;
+            asm volatile("" : "+v"(o));   // keeps the zero-extension inside this block ("scalar base + 32-bit offset" is matched per block)
+            *reinterpret_cast<c32*>(reinterpret_cast<char*>(outb) + o) = v[q];
+        }
     }
 }
 

@@ -17,9 +17,12 @@ __device__ __forceinline__ c32 shrink(c32 X, c32 tau, int op)
         // |X| < Re tau  <=>  |X|^2 < (Re tau)^2 for Re tau > 0 (a negative Re tau keeps everything): no square root, whose
         // IEEE fix-up sequence is a dozen instructions per coefficient of a pass that is bound by instruction issue.  Both forms
         // place a coefficient within an ulp of the threshold arbitrarily; the tests treat that band as ties.
+        // Lexicographic "<": |X| == Re tau counts as below when Im tau > 0, i.e. p <= t2, i.e. p < next_float(t2).  The limit
+        // depends on tau alone (a handful of instructions per thread, not per coefficient).
         const float t2 = tau.x * tau.x;
-        const bool below = tau.x > 0.0f ? ((p < t2) || (p == t2 && 0.0f < tau.y)) : (tau.x == 0.0f && p == 0.0f && 0.0f < tau.y);
-        return below ? c32{0.f, 0.f} : X;
+        float lim = 0.0f;                                          // Re tau < 0: nothing is below
+        if (tau.x >= 0.0f) lim = (tau.y > 0.0f && t2 < __builtin_inff()) ? __uint_as_float(__float_as_uint(t2) + 1u) : t2;
+        return p < lim ? c32{0.f, 0.f} : X;
     }
     const float m = sqrtf(p);
     if (m == 0.0f) return c32{0.f, 0.f};  // 1 - tau/0 = -inf -> clipped to 0
