@@ -108,19 +108,20 @@ static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsig
         nzm[i] = (uint16_t)word;
         if (kept) atomicAdd(count, (unsigned long long)kept);
     }
-    // rows of one wavefront (groups == 8): the same flags as 64-bit lane masks per register q, nzl[s][q] bit l = word(l/8) bit q;
-    // the 8 threads of a slice are neighbours in the wave and build two words each
+    // rows of whole wavefronts (groups = 8, 16, 32): the same flags as 64-bit lane masks, word (slice, wavefront, q) bit l = the
+    // flag word of thread group 8 * wavefront + l / 8, bit q; those 8 threads are neighbours in the wave and build two words each
     if (nzl != nullptr) {
         const int base = (int)(threadIdx.x & 63u) & ~7;
         unsigned long long m0 = 0, m1 = 0;
         for (int k = 0; k < 8; ++k) {
             const unsigned wk = (unsigned)__shfl((int)word, base + k, 64);
-            if ((wk >> (2 * g)) & 1u) m0 |= 0xFFull << (8 * k);
-            if ((wk >> (2 * g + 1)) & 1u) m1 |= 0xFFull << (8 * k);
+            if ((wk >> (2 * (g % 8))) & 1u) m0 |= 0xFFull << (8 * k);
+            if ((wk >> (2 * (g % 8) + 1)) & 1u) m1 |= 0xFFull << (8 * k);
         }
-        if (!skip) {
-            nzl[(size_t)s * 16 + 2 * g] = m0;
-            nzl[(size_t)s * 16 + 2 * g + 1] = m1;
+        if (!skip) {   // groups = 8 * (wavefronts per row); thread g serves wavefront g / 8, registers 2 * (g % 8) and + 1
+            const size_t w0 = pipe64_word((size_t)s, groups / 8, g / 8, 2 * (g % 8));
+            nzl[w0] = m0;
+            nzl[w0 + 1] = m1;
         }
     }
 }
@@ -173,15 +174,29 @@ static __global__ void pack_mask_kernel(const float* mask, uint16_t* bits, int* 
 }
 
 
-// rows of one wavefront (tpl == 64): the same mask as lane masks, bits64[row][q] bit l = bits[row][l] bit q
-static __global__ void pack_mask64_kernel(const uint16_t* bits, unsigned long long* bits64, int n1, int ppt)
+// rows of whole wavefronts (tpl = 64 * wpl): the same mask as lane masks, word pipe64_word(row, wpl, wsub, q) bit l =
+// bits[row][64 * wsub + l] bit q
+static __global__ void pack_mask64_kernel(const uint16_t* bits, unsigned long long* bits64, int n1, int wpl)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n1 * ppt) return;
-    const int row = i / ppt, q = i - row * ppt;
+    if (i >= n1 * wpl * 16) return;
+    const int q = i & 15, wsub = (i >> 4) % wpl, row = (i >> 4) / wpl;
     unsigned long long w = 0;
-    for (int l = 0; l < 64; ++l) w |= (unsigned long long)((bits[row * 64 + l] >> q) & 1u) << l;
+    for (int l = 0; l < 64; ++l) w |= (unsigned long long)((bits[(size_t)row * 64 * wpl + 64 * wsub + l] >> q) & 1u) << l;
     bits64[i] = w;
+}
+// cbase[word] = observed traces of the slice before the first column of that word (rowbase + the words to its left in column
+// order; word (wsub, q) covers columns 64 * (wsub + wpl * q) ...)
+static __global__ void pack_cbase_kernel(const unsigned long long* bits64, const unsigned* rowbase, unsigned* cbase, int n1, int wpl)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n1) return;
+    unsigned run = rowbase[row];
+    for (int j = 0; j < 16 * wpl; ++j) {
+        const size_t w = pipe64_word((size_t)row, wpl, j % wpl, j / wpl);
+        cbase[w] = run;
+        run += (unsigned)__popcll(bits64[w]);
+    }
 }
 
 
@@ -228,8 +243,9 @@ struct p3d_plan {
     bool sparse_ok = false;                     // shape supports skipping emptied tiles
     double last_nonzero_fraction = -1.0;        // of the last p3d_pocs_run: kept column blocks / all (or -1: dense path)
     uint16_t* bits = nullptr;                   // packed binary trace mask [nil][tpl(nxl)]
-    unsigned long long* bits64 = nullptr;       // tpl == 64: the same as lane masks [nil][ppt] (row_pipe64_kernel)
-    unsigned long long* nzl = nullptr;          // tpl == 64: nzm as lane masks [max_slices][16]
+    unsigned long long* bits64 = nullptr;       // tpl = 64, 128, 256: the same as lane masks (row_pipe64_kernel, pipe64_word)
+    unsigned long long* nzl = nullptr;          // ... nzm as lane masks, per slice
+    unsigned* cbase = nullptr;                  // ... observed traces before each word of bits64
     int* flag = nullptr;                        // device int[2]: mask not binary / x non-zero at a missing trace
     unsigned* rowbase = nullptr;                // [nil+1] observed positions before each row
     void* xc = nullptr;                         // compact observed samples [nslices][nobs]
@@ -300,7 +316,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->bits64, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
+    void* bufs[] = {p->cbase, p->bits64, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -346,7 +362,7 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         p->cus = prop.multiProcessorCount;
-        p->pipe_wgs = (orow->tpl > 0 && orow->tpl <= 64 && !getenv("P3D_NO_PIPE")) ? p->cus : 0;  // the launcher sizes the grid per variant
+        p->pipe_wgs = (orow->tpl > 0 && orow->tpl <= 256 && !getenv("P3D_NO_PIPE")) ? p->cus : 0;  // the launcher sizes the grid per variant
     }
     int rc = P3D_OK;
     auto bail = [&](int code) {
@@ -395,9 +411,11 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
         if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
-        if (orow->tpl == 64 && orow->ppt == 16 && !getenv("P3D_NO_PIPE64")) {
-            TRY_OR_BAIL(hipMalloc((void**)&p->bits64, sizeof(unsigned long long) * (size_t)nil * orow->ppt));
-            TRY_OR_BAIL(hipMalloc((void**)&p->nzl, sizeof(unsigned long long) * 16 * (size_t)max_slices));
+        if (orow->tpl % 64 == 0 && orow->tpl <= 256 && orow->tpl > 0 && orow->ppt == 16 && !getenv("P3D_NO_PIPE64")) {
+            const size_t wpl = (size_t)orow->tpl / 64;
+            TRY_OR_BAIL(hipMalloc((void**)&p->bits64, sizeof(unsigned long long) * 16 * wpl * (size_t)nil));
+            TRY_OR_BAIL(hipMalloc((void**)&p->cbase, sizeof(unsigned) * 16 * wpl * (size_t)nil));
+            TRY_OR_BAIL(hipMalloc((void**)&p->nzl, sizeof(unsigned long long) * 16 * wpl * (size_t)max_slices));
         }
         TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
     }
@@ -867,7 +885,11 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl,
                                                                     p->ops_row->ppt);
         if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
-        if (p->bits64) pack_mask64_kernel<<<(p->nil * p->ops_row->ppt + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, p->ops_row->ppt);
+        if (p->bits64 && p->nil <= 4096) {
+            const int wpl = p->ops_row->tpl / 64;
+            pack_mask64_kernel<<<(p->nil * wpl * 16 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, wpl);
+            pack_cbase_kernel<<<(p->nil + 255) / 256, 256, 0, p->stream>>>(p->bits64, p->rowbase, p->cbase, p->nil, wpl);
+        }
         HIP_TRY(hipGetLastError());
     }
     int nonbinary = flex_rows ? 1 : 0;
@@ -898,6 +920,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.mask = nonbinary ? mask : nullptr;
     r.bits = nonbinary ? nullptr : p->bits;
     r.bits64 = nonbinary ? nullptr : p->bits64;
+    r.cbase = nonbinary ? nullptr : p->cbase;
     r.xc = compact ? p->xc : nullptr;
     r.rowbase = p->rowbase;
     r.nobs = nobs;
@@ -959,9 +982,9 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             r.nz_col_t = col_t;
         } else if (sparse) {
             nz_pack_kernel<<<(nslices * groups + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzm, p->nzcount, nslices, p->tiles, col_t, groups, nblocks,
-                                                                                c.done, groups == 8 ? p->nzl : nullptr);
+                                                                                c.done, p->nzl);
             r.nzm = p->nzm;
-            r.nzl = groups == 8 ? p->nzl : nullptr;
+            r.nzl = p->nzl;
         }
         HIP_TRY(stamp());
         r.sum_row = k + 1;

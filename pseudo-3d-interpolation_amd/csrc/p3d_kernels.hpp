@@ -134,6 +134,10 @@ struct CompactIndex {
     }
 };
 
+// lane-mask tables of the wave-uniform persistent row pass (row_pipe64_kernel): one 64-bit word per (row or slice, wavefront of
+// the row, register q)
+__host__ __device__ constexpr size_t pipe64_word(size_t row_or_slice, int wpl, int wsub, int q) { return (row_or_slice * wpl + wsub) * 16 + q; }
+
 struct RowArgs {
     const void* x;         // observed cube (c64 or f32), [nslices][n1][N]
     const float* mask;     // [n1][N] float weights (generic path) or nullptr
@@ -165,8 +169,10 @@ struct RowArgs {
     int nz_col_t;
     int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done == only_done; their work
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
-    const unsigned long long* bits64;  // TPL == 64 (a row = one wavefront): [n1][PPT] lane masks, bit l of word q = mask[row][l + 64*q]
-    const unsigned long long* nzl;     // TPL == 64: [nslices][PPT] lane masks of nzm (bit l of word q = nzm[slice][l/8] bit q); nullptr: dense
+    const unsigned long long* bits64;  // rows of whole wavefronts: the mask as lane masks, word pipe64_word(row, TPL/64, wsub, q) bit l =
+                                       // mask[row][64*wsub + l + TPL*q]
+    const unsigned long long* nzl;     // the same for nzm, per slice (pipe64_word); nullptr: dense
+    const unsigned* cbase;             // observed traces of the slice before the first column of each word (pipe64_word)
     float alpha;
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
@@ -287,8 +293,10 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
 
     float acc = 0.f;
     if (MODE == ROW_FIRST) {
-        constexpr bool CAN_COMPACT = BITS && TPL <= 64;  // ranks come from wave ballots: a line must not span waves
-        const bool compact = CAN_COMPACT && a.xc != nullptr;
+        // ranks come from wave ballots: a line inside one wave counts as it goes (CompactIndex); a line of several waves takes
+        // the number of observed traces before each of its 64-column words from the table of the persistent pass (RowArgs::cbase)
+        constexpr bool CAN_COMPACT = BITS && (TPL <= 64 || (TPL % 64 == 0 && PPT == 16));
+        const bool compact = CAN_COMPACT && a.xc != nullptr && (TPL <= 64 || a.cbase != nullptr);
         CompactIndex<(TPL <= 64 ? TPL : 64)> ci(tid & 63, compact ? a.rowbase[vrow] : 0u);
         bool bad = false;
 #pragma unroll
@@ -297,7 +305,14 @@ __global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(
             if (CAN_COMPACT) {
                 if (compact) {  // uniform
                     const bool set = ((mbits >> q) & 1u) != 0;
-                    const unsigned idx = ci.next(set);
+                    unsigned idx;
+                    if constexpr (TPL <= 64) {
+                        idx = ci.next(set);
+                    } else {
+                        const unsigned long long b = __ballot(set);
+                        idx = a.cbase[pipe64_word((size_t)vrow, TPL / 64, (tid >> 6) % (TPL / 64), q)] +
+                              (unsigned)__popcll(b & ((1ull << (tid & 63)) - 1ull));
+                    }
                     if (set && valid) {
                         if (a.dtype == 0) reinterpret_cast<c32*>(a.xc)[(size_t)slice * a.nobs + idx] = x;
                         else reinterpret_cast<float*>(a.xc)[(size_t)slice * a.nobs + idx] = x.x;
@@ -669,24 +684,23 @@ row_pipe_kernel(const RowArgs a)
 }
 
 // =================================================================================================
-// persistent row pass for rows of exactly one wavefront (TPL == 64), binary mask, compact observed samples
+// persistent row pass for rows of whole wavefronts (TPL = 64, 128, 256), binary mask, compact observed samples
 // =================================================================================================
-// Same arithmetic and schedule as row_pipe_kernel<N, true, DT, false, true> (bit for bit); what changes is WHERE the bookkeeping
-// runs.  A row is one wavefront, so slice, row, every base address, the trace mask of the row and the emptied-block flags of the
-// slice are wave-uniform: they live in scalar registers (s_load / SALU), predicates are 64-bit lane masks applied as EXEC or as
-// the selector of v_cndmask, the rank of a lane among the observed traces is v_mbcnt, and every access is "scalar base + one
-// 32-bit lane offset".  The generic kernel spends ~40 % of its vector instructions on exactly that bookkeeping.
+// Same arithmetic as row_kernel<N, ROW_MID, true> / row_pipe_kernel (bit for bit); what changes is WHERE the bookkeeping runs.
+// Every wavefront works on 64 consecutive columns per register q, so slice, row, every base address, the trace mask of those
+// columns and the emptied-block flags of the slice are wave-uniform: they live in scalar registers (s_load / SALU), predicates
+// are 64-bit lane masks applied as EXEC or as the selector of v_cndmask, the rank of a lane among the observed traces is
+// v_mbcnt, and every access is "scalar base + one 32-bit lane offset".  The generic kernel spends ~40 % of its vector
+// instructions on exactly that bookkeeping.  Rows of 2048 / 4096 samples (2 / 4 wavefronts, workgroup barriers inside the
+// transforms) had no persistent pass at all: each 2-row workgroup of row_kernel re-reads 32 / 64 KiB of twiddle tables.
 // Measured on the headline cube (profiles/r01_rowpass_wave_uniform.txt): sixteen rows per workgroup (1024 threads, one workgroup
 // of 154 KiB LDS per CU, 4 waves per SIMD inside the 128-VGPR budget) beats three 4-row workgroups; the row-ahead prefetch of the
 // work buffer buys nothing once most of its blocks are skipped, the early request of the observed samples a little.
-#ifndef P3D_PIPE64_WAVES_PER_EU
-#define P3D_PIPE64_WAVES_PER_EU 4
-#endif
-#ifndef P3D_PIPE64_THREADS
-#define P3D_PIPE64_THREADS 1024
-#endif
 #ifndef P3D_PIPE64_LOCKSTEP
 #define P3D_PIPE64_LOCKSTEP 1
+#endif
+#ifndef P3D_PIPE64_MAXROWS
+#define P3D_PIPE64_MAXROWS 2
 #endif
 #ifndef P3D_PIPE64_PREFETCH
 #define P3D_PIPE64_PREFETCH 0    // work-buffer loads of the next row in flight during this row (32 VGPRs)
@@ -694,40 +708,63 @@ row_pipe_kernel(const RowArgs a)
 #ifndef P3D_PIPE64_OBS_EARLY
 #define P3D_PIPE64_OBS_EARLY 1   // observed samples requested before the inverse transform instead of after it (32 VGPRs across it)
 #endif
+// rows per workgroup: as many as 160 KiB of LDS hold next to the twiddle tables, at most 1024 threads
+template <int N>
+constexpr int pipe64_rows()
+{
+    constexpr int TPL = Plan<N>::TPL;
+    // rows of several wavefronts synchronise the whole workgroup at every exchange of a transform: two rows per workgroup (the
+    // pair that shares 128-byte lines), several workgroups per CU (2048 samples: 2.19 ms against 2.83 with 7 rows, 5.87 before)
+    int rows = TPL > 64 ? P3D_PIPE64_MAXROWS : 1024 / TPL;
+    while (rows > 1 && sizeof(c32) * (PassTables<N>::slots() + (size_t)rows * LdsRow::stride(N)) + 16 * sizeof(double) > 160 * 1024) --rows;
+    return rows;
+}
+template <int N>
+constexpr size_t pipe64_lds_bytes() { return sizeof(c32) * (PassTables<N>::slots() + (size_t)pipe64_rows<N>() * LdsRow::stride(N)) + 16 * sizeof(double); }
+template <int N>
+constexpr int pipe64_threads() { return pipe64_rows<N>() * Plan<N>::TPL; }
+
 template <int N, int DT, bool SPARSE>
-__global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void row_pipe64_kernel(const RowArgs a)
+__global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3) / 4) void row_pipe64_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
-    static_assert(TPL == 64, "one row per wavefront");
-    constexpr int LB = P3D_PIPE64_THREADS / TPL;
+    static_assert(TPL % 64 == 0 && PPT == 16, "rows of whole wavefronts");
+    constexpr int WPL = TPL / 64;                 // wavefronts per row
+    constexpr int THREADS = pipe64_threads<N>();
+    constexpr int LB = THREADS / TPL;             // rows per workgroup
     constexpr int LSTR = LdsRow::stride(N);
-    constexpr unsigned ES = DT == 0 ? 8u : 4u;   // bytes per observed sample
+    constexpr bool WAVE = WPL == 1;
+    constexpr unsigned ES = DT == 0 ? 8u : 4u;    // bytes per observed sample
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
     c32* data = twl + PassTables<N>::slots();
     const TwOrdered tw{twl};
 
     const int tid = threadIdx.x;
-    const int line = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tl = tid & 63;
-    for (int i = tid; i < PassTables<N>::slots(); i += P3D_PIPE64_THREADS) twl[i] = a.tw[i];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int line = wave / WPL, wsub = wave % WPL;
+    const int lane = tid & 63;
+    const int tl = wsub * 64 + lane;
+    for (int i = tid; i < PassTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
     const LdsRow lds{data + line * LSTR};
+    double* red = reinterpret_cast<double*>(data + LB * LSTR);   // per-wave partial sums of rows that span waves
 
     const unsigned total = (unsigned)a.nslices * a.n1;
     const unsigned step = gridDim.x * LB;
     const unsigned wblk = (unsigned)a.n1 * 8;
     const size_t wstride = wk_slice_stride(a.n1, N);
-    const unsigned lane_w = ((unsigned)(tl >> 3) * wblk + (unsigned)(tl & 7)) * 8u;   // byte offset of the lane inside a row, every q
-    const size_t qstride = (size_t)(TPL / 8) * wblk * 8u;                              // bytes from register q to q + 1
+    // element tl + TPL*q = column 64*(wsub + WPL*q) + lane: eight column blocks per wavefront and register
+    const unsigned lane_w = ((unsigned)(lane >> 3) * wblk + (unsigned)(lane & 7)) * 8u;   // byte offset of the lane, every q
+    const size_t qs64 = (size_t)8 * wblk * 8u;                                            // bytes per 64 columns
 
-    // The small tables (lane masks, row bases) are never written while this kernel runs: reading them through the constant
+    // The small tables (lane masks, compact bases) are never written while this kernel runs: reading them through the constant
     // address space lets the compiler use scalar loads although the loop also stores to the work buffer.
     typedef const unsigned long long __attribute__((address_space(4))) * kmask_t;
     typedef const unsigned __attribute__((address_space(4))) * kuint_t;
     const kmask_t k_bits = (kmask_t)a.bits64, k_nzl = (kmask_t)a.nzl;
-    const kuint_t k_rowbase = (kuint_t)a.rowbase;
+    const kuint_t k_cbase = (kuint_t)a.cbase;
     // "scalar base + 32-bit lane offset" addressing is matched per basic block: keep the zero-extension of the lane offset from
     // being hoisted out of the predicated blocks (an empty asm, no instruction)
     auto lane_off = [&]() -> unsigned { unsigned o = lane_w; asm volatile("" : "+v"(o)); return o; };
@@ -741,14 +778,16 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
         w.row = gg - w.slice * (unsigned)a.n1;
         return w;
     };
-    auto wbase = [&](const Where& w) -> char* { return reinterpret_cast<char*>(a.work) + (w.slice * wstride + (size_t)w.row * 8) * 8; };
-    // register q of a row sits q * qstride bytes further on: one running scalar pointer (the step is made opaque per call so
-    // that sixteen precomputed 64-bit multiples do not crowd the scalar registers)
-    auto qstep = [&]() -> size_t { size_t qs = qstride; asm volatile("" : "+s"(qs)); return qs; };
+    auto wbase = [&](const Where& w) -> char* {
+        return reinterpret_cast<char*>(a.work) + (w.slice * wstride + (size_t)w.row * 8) * 8 + (size_t)wsub * qs64;
+    };
+    // register q sits WPL * 64 columns further on: one running scalar pointer (the step is made opaque per call so that sixteen
+    // precomputed 64-bit multiples do not crowd the scalar registers)
+    auto qstep = [&]() -> size_t { size_t qs = qs64 * WPL; asm volatile("" : "+s"(qs)); return qs; };
     auto load_work = [&](c32 (&dst)[PPT], const Where& w) {
         const char* b = wbase(w);
         const size_t qs = qstep();
-        const kmask_t nz = k_nzl + (size_t)w.slice * PPT;
+        const kmask_t nz = k_nzl + pipe64_word(w.slice, WPL, wsub, 0);
         unsigned long long nzw[PPT];
         if (SPARSE) {
 #pragma unroll
@@ -767,16 +806,17 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
         }
     };
     auto load_obs = [&](c32 (&dst)[PPT], unsigned long long (&mwords)[PPT], const Where& w) {
-        const kmask_t mrow = k_bits + (size_t)w.row * PPT;
-        const char* xb = reinterpret_cast<const char*>(a.xc) + ((size_t)w.slice * a.nobs + k_rowbase[w.row]) * ES;
-        unsigned running = 0;
+        const kmask_t mrow = k_bits + pipe64_word(w.row, WPL, wsub, 0);
+        const kuint_t cb = k_cbase + pipe64_word(w.row, WPL, wsub, 0);   // observed traces before this word, from the start of the slice
+        const char* xb = reinterpret_cast<const char*>(a.xc) + (size_t)w.slice * a.nobs * ES;
+        unsigned cbs[PPT];
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) mwords[q] = mrow[q];
+        for (int q = 0; q < PPT; ++q) { mwords[q] = mrow[q]; cbs[q] = cb[q]; }
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const unsigned long long mw = mwords[q];
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mw, 0u));
-            const char* xq = xb + (size_t)running * ES;
+            const char* xq = xb + (size_t)cbs[q] * ES;
             c32 val{0.f, 0.f};
             if (__builtin_amdgcn_inverse_ballot_w64(mw)) {
                 unsigned ro = rank * ES;
@@ -785,7 +825,6 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
                 else val.x = *reinterpret_cast<const float*>(xq + ro);
             }
             dst[q] = val;
-            running += (unsigned)__builtin_popcountll(mw);
         }
     };
 
@@ -805,7 +844,7 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
 
     for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
 #if P3D_PIPE64_LOCKSTEP
-        __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
+        if (WAVE) __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
 #endif
         const Where nxt2 = locate(g + 2 * step);
 #if P3D_PIPE64_PREFETCH
@@ -815,7 +854,7 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
 #else
         load_work(v, cur);
 #endif
-        unsigned long long mwords[PPT];   // the trace mask of this row as lane masks
+        unsigned long long mwords[PPT];   // the trace mask of this wavefront's columns as lane masks
 #if P3D_PIPE64_OBS_EARLY
         // issued BEHIND the work-buffer loads (vmcnt retires in order: the transform below waits for those only) and in flight
         // during the inverse transform
@@ -823,7 +862,7 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
         load_obs(bx, mwords, cur);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        line_fft<N, INV, true>(v, lds, tw, tl);
+        line_fft<N, INV, WAVE>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
 #if !P3D_PIPE64_OBS_EARLY
         load_obs(bx, mwords, cur);
@@ -849,12 +888,23 @@ __global__ __launch_bounds__(P3D_PIPE64_THREADS, P3D_PIPE64_WAVES_PER_EU) void r
         if (a.sums != nullptr) {
             double ws = (double)acc;
 #pragma unroll
-            for (int o = TPL / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, TPL);
-            if (tl == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row] = ws;
+            for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
+            if constexpr (WAVE) {
+                if (lane == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row] = ws;
+            } else {   // the wavefronts of a row in the order row_kernel adds them
+                __syncthreads();
+                if (lane == 0) red[wave] = ws;
+                __syncthreads();
+                if (wsub == 0 && lane == 0 && cur.on) {
+                    double t = 0.0;
+                    for (int w = 0; w < WPL; ++w) t += red[line * WPL + w];
+                    a.sums[(size_t)cur.slice * a.n1 + cur.row] = t;
+                }
+            }
         }
 
         __builtin_amdgcn_sched_barrier(0);
-        line_fft<N, FWD, true>(v, lds, tw, tl);
+        line_fft<N, FWD, WAVE>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
 
         if (cur.on) {
@@ -1086,15 +1136,41 @@ hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
 template <int N>
 hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
 {
+    if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0) return hipErrorNotSupported;  // 32-bit offsets
+    const bool bits = a.bits != nullptr;
+    const bool extra = a.adaptive || a.write_out || a.done != nullptr;
+    const bool compact = bits && a.xc != nullptr;
+    hipError_t e = hipSuccess;
+    if constexpr (Plan<N>::TPL % 64 == 0 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
+        if (compact && !extra && a.bits64 != nullptr && a.cbase != nullptr) {   // the wave-uniform variant: one workgroup per CU
+            constexpr int LB64 = pipe64_rows<N>();
+            constexpr size_t lds64 = pipe64_lds_bytes<N>();
+            const long groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;
+            int per_cu64 = (int)((160 * 1024) / lds64);                        // workgroups a CU holds: LDS ...
+            const int by_waves = 16 / (pipe64_threads<N>() / 64);              // ... and 4 waves per SIMD
+            if (per_cu64 > by_waves) per_cu64 = by_waves;
+            if (per_cu64 < 1) per_cu64 = 1;
+            const long wgs64 = (long)cus * per_cu64;
+            const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));
+#define P3D_PIPE64(DT, SP)                                                                               \
+    do {                                                                                                \
+        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP>, lds64)) != hipSuccess) return e;               \
+        row_pipe64_kernel<N, DT, SP><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);                    \
+    } while (0)
+            const bool sp = a.nzl != nullptr;
+            if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true); else P3D_PIPE64(0, false); }
+            else { if (sp) P3D_PIPE64(1, true); else P3D_PIPE64(1, false); }
+#undef P3D_PIPE64
+            return hipGetLastError();
+        }
+    }
     if constexpr (Plan<N>::TPL > 64) {
         return hipErrorNotSupported;
     } else {
         constexpr int LB = ROW_THREADS / Plan<N>::TPL;
-        if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0) return hipErrorNotSupported;  // 32-bit offsets
-        const bool compact_path = a.bits != nullptr && a.xc != nullptr;
         // resident workgroups per CU: LDS (160 KiB per CU) and the register budget of the variant
         const int by_lds = (int)((160 * 1024) / row_lds_bytes<N>());
-        const int wpe = (compact_path && P3D_COMPACT_LATE) ? P3D_PIPE_WAVES_PER_EU_COMPACT : P3D_PIPE_WAVES_PER_EU;
+        const int wpe = (compact && P3D_COMPACT_LATE) ? P3D_PIPE_WAVES_PER_EU_COMPACT : P3D_PIPE_WAVES_PER_EU;
         const int by_regs = (wpe * 4 * 64) / ROW_THREADS;
         const int per_cu = by_lds < by_regs ? by_lds : by_regs;
         if (per_cu < 1) return hipErrorNotSupported;
@@ -1102,36 +1178,11 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
         const long groups = ((long)a.nslices * a.n1 + LB - 1) / LB;
         const dim3 grid((unsigned)(groups < wgs ? groups : wgs));
         constexpr size_t lds = row_lds_bytes<N>();
-        hipError_t e = hipSuccess;
 #define P3D_PIPE(BITS, DT, EXTRA, COMPACT)                                                                  \
     do {                                                                                                    \
         if ((e = allow_lds(row_pipe_kernel<N, BITS, DT, EXTRA, COMPACT>, lds)) != hipSuccess) return e;     \
         row_pipe_kernel<N, BITS, DT, EXTRA, COMPACT><<<grid, ROW_THREADS, lds, st>>>(a);                    \
     } while (0)
-        const bool bits = a.bits != nullptr;
-        const bool extra = a.adaptive || a.write_out || a.done != nullptr;
-        const bool compact = bits && a.xc != nullptr;
-        if constexpr (Plan<N>::TPL == 64) {
-            if (compact && !extra && a.bits64 != nullptr) {   // the wave-uniform variant
-                constexpr int LB64 = P3D_PIPE64_THREADS / 64;
-                constexpr size_t lds64 = sizeof(c32) * (PassTables<N>::slots() + LB64 * LdsRow::stride(N)) + 8 * sizeof(double);
-                const int fit_lds = (int)((160 * 1024) / lds64), fit_regs = (P3D_PIPE64_WAVES_PER_EU * 4 * 64) / P3D_PIPE64_THREADS;
-                const int per_cu64 = fit_lds < fit_regs ? fit_lds : fit_regs;
-                if (per_cu64 < 1) return hipErrorNotSupported;
-                const long wgs64 = (long)cus * per_cu64, groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;
-                const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));
-#define P3D_PIPE64(DT, SP)                                                                               \
-    do {                                                                                                \
-        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP>, lds64)) != hipSuccess) return e;               \
-        row_pipe64_kernel<N, DT, SP><<<grid64, P3D_PIPE64_THREADS, lds64, st>>>(a);                     \
-    } while (0)
-                const bool sp = a.nzl != nullptr;
-                if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true); else P3D_PIPE64(0, false); }
-                else { if (sp) P3D_PIPE64(1, true); else P3D_PIPE64(1, false); }
-#undef P3D_PIPE64
-                return hipGetLastError();
-            }
-        }
         if (a.dtype == 0) {
             if (compact) { if (extra) P3D_PIPE(true, 0, true, true); else P3D_PIPE(true, 0, false, true); }
             else if (bits) { if (extra) P3D_PIPE(true, 0, true, false); else P3D_PIPE(true, 0, false, false); }

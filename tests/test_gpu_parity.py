@@ -565,14 +565,16 @@ def test_slower_equivalent_paths_behind_the_switches(switch, monkeypatch):
     assert rel_l2(got, want) <= 1e-5
 
 
-@pytest.mark.parametrize("nil,dtype", [(64, np.complex64), (100, np.complex64), (256, np.float32), (1000, np.complex64)])
-def test_wave_uniform_row_pass_is_the_generic_one(nil, dtype, monkeypatch):
-    """Rows of 1024 samples are one wavefront each: their steady-state pass keeps slice / row / mask / emptied-block bookkeeping in
-    scalar registers (row_pipe64_kernel).  Same arithmetic as the generic persistent pass (P3D_NO_PIPE64=1): identical results,
-    with the sparse shortcut and without, for tuned and flexible column lengths, and both match the oracle."""
+@pytest.mark.parametrize("nil,nxl,dtype", [(64, 1024, np.complex64), (100, 1024, np.complex64), (256, 1024, np.float32),
+                                           (1000, 1024, np.complex64), (48, 2048, np.complex64), (50, 2048, np.float32),
+                                           (24, 4096, np.complex64)])
+def test_wave_uniform_row_pass_is_the_generic_one(nil, nxl, dtype, monkeypatch):
+    """Rows of 1024 / 2048 / 4096 samples are 1 / 2 / 4 whole wavefronts: their steady-state pass keeps slice / row / mask /
+    emptied-block bookkeeping in scalar registers (row_pipe64_kernel).  Same arithmetic as the generic passes (P3D_NO_PIPE64=1:
+    the generic persistent kernel for 1024, the one-launch-per-iteration row_kernel beyond): identical results, with the sparse
+    shortcut and without, for tuned and flexible column lengths, and both match the oracle."""
     import pseudo_3d_interpolation_amd.functions.POCS as P
     from oracle import pocs_oracle as orc
-    nxl = 1024
     mask = orc.synthetic_mask(nil, nxl, 0.7)
     cube = np.stack([orc.synthetic_slice(nil, nxl, 40 + s) for s in range(5)]) * mask     # 5 * nil rows: ragged last workgroup
     cube = (cube.real if dtype == np.float32 else cube).astype(dtype)
