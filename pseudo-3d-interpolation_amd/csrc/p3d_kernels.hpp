@@ -85,6 +85,11 @@ struct ShearArgs {
 };
 
 constexpr int ROW_THREADS = P3D_ROW_THREADS;
+// The one-launch-per-iteration row pass copies its twiddle tables (2N entries) into LDS once per workgroup: 16 KiB per four
+// 8-KiB rows at N = 1024.  Sixteen rows per workgroup (one 155-KiB workgroup per CU) take 1.8 ms off the first + last pass of a
+// job on the headline cube.  The SHEARLET modes keep their measured configuration.
+template <int N, int MODE>
+constexpr int row_threads() { return (N == 1024 && MODE <= 2 && P3D_ROW_THREADS < 1024) ? 1024 : P3D_ROW_THREADS; }
 constexpr int STATS_PARTIAL = 8;  // floats per (slice, tile) written by COL_STATS
 
 // ---- column-blocked work layout ------------------------------------------------------------------
@@ -217,10 +222,11 @@ __device__ __forceinline__ double wave_sum(double v)
 // =================================================================================================
 // BITS: the trace mask is binary and comes as one packed 16-bit word per thread and row.
 template <int N, int MODE, bool BITS>
-__global__ __launch_bounds__(ROW_THREADS, P3D_ROW_WAVES_PER_EU) void row_kernel(const RowArgs a)
+__global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >= 512 ? 4 : 3)) void row_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
+    constexpr int ROW_THREADS = row_threads<N, MODE>();   // shadows the global default
     constexpr int LB = ROW_THREADS / TPL;  // lines per workgroup
     constexpr int LSTR = LdsRow::stride(N);
     constexpr bool WAVE = TPL <= 64;       // a line never leaves its wavefront
@@ -1105,6 +1111,11 @@ constexpr size_t row_lds_bytes()
 {
     return sizeof(c32) * (PassTables<N>::slots() + (ROW_THREADS / Plan<N>::TPL) * LdsRow::stride(N)) + 8 * sizeof(double);
 }
+template <int N, int MODE>
+constexpr size_t row_lds_bytes_mode()
+{
+    return sizeof(c32) * (PassTables<N>::slots() + (row_threads<N, MODE>() / Plan<N>::TPL) * LdsRow::stride(N)) + 16 * sizeof(double);
+}
 template <int N>
 constexpr size_t col_lds_bytes()
 {
@@ -1123,12 +1134,12 @@ inline hipError_t allow_lds(K kernel, size_t bytes)
 template <int N, int MODE, bool BITS>
 hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
 {
-    constexpr int LB = ROW_THREADS / Plan<N>::TPL;
+    constexpr int LB = row_threads<N, MODE>() / Plan<N>::TPL;
     const dim3 grid((a.n1 + LB - 1) / LB, a.nslices);
-    constexpr size_t lds = row_lds_bytes<N>();
+    constexpr size_t lds = row_lds_bytes_mode<N, MODE>();
     hipError_t e = allow_lds(row_kernel<N, MODE, BITS>, lds);
     if (e != hipSuccess) return e;
-    row_kernel<N, MODE, BITS><<<grid, ROW_THREADS, lds, st>>>(a);
+    row_kernel<N, MODE, BITS><<<grid, row_threads<N, MODE>(), lds, st>>>(a);
     return hipGetLastError();
 }
 
