@@ -40,10 +40,10 @@ double check()
     using PL = Plan<N>;
     std::vector<cd> x(N);
     for (int i = 0; i < N; ++i) x[i] = cd(std::sin(0.37 * i * i + 0.1) + 0.25, std::cos(1.3 * i) - 0.5 * (i % 3));
-    std::vector<c32> tab(ORDERED ? PassTables<N>::slots() : tw_slots(N));
+    std::vector<c32> tab(ORDERED ? PassTables<N>::slots() : ColTables<N>::slots());
     if (ORDERED) PassTables<N>::build(tab.data());
-    else build_twiddles(N, tab.data());
-    using TW = std::conditional_t<ORDERED, TwOrdered, TwMaster>;
+    else ColTables<N>::build(tab.data());
+    using TW = std::conditional_t<ORDERED, TwOrdered, TwCol>;
     const TW tw{tab.data()};
     std::vector<std::vector<c32>> regs(PL::TPL, std::vector<c32>(PL::PPT));
     for (int tl = 0; tl < PL::TPL; ++tl)
