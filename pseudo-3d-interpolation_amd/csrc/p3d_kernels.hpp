@@ -776,12 +776,15 @@ __global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3)
     auto lane_off = [&]() -> unsigned { unsigned o = lane_w; asm volatile("" : "+v"(o)); return o; };
 
     struct Where { unsigned slice, row; bool on; };
+    typedef const int __attribute__((address_space(4))) * kint_t;
+    const kint_t k_done = (kint_t)a.done;   // early exit (eps > 0): set between launches, constant during one
     auto locate = [&](unsigned g) -> Where {
         Where w;
         w.on = g < total;
         const unsigned gg = w.on ? g : 0u;
         w.slice = gg / (unsigned)a.n1;
         w.row = gg - w.slice * (unsigned)a.n1;
+        if (k_done != nullptr && w.on && k_done[w.slice] != 0) w.on = false;   // finished / empty slice: leave it alone
         return w;
     };
     auto wbase = [&](const Where& w) -> char* {
@@ -1153,7 +1156,9 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
     const bool compact = bits && a.xc != nullptr;
     hipError_t e = hipSuccess;
     if constexpr (Plan<N>::TPL % 64 == 0 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
-        if (compact && !extra && a.bits64 != nullptr && a.cbase != nullptr) {   // the wave-uniform variant: one workgroup per CU
+        // the wave-uniform variant (it also honours the per-slice `done` flags of the early exit; APOCS and the per-iteration
+        // store stay with the generic kernels)
+        if (compact && !a.adaptive && !a.write_out && a.bits64 != nullptr && a.cbase != nullptr) {
             constexpr int LB64 = pipe64_rows<N>();
             constexpr size_t lds64 = pipe64_lds_bytes<N>();
             const long groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;

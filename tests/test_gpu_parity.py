@@ -470,13 +470,13 @@ def test_time2freq_closed_form_and_round_trip(ffi, nt, shape, up, real_only):
         assert rel_l2(lo, want) < 5e-6
 
 
-def test_early_exit_hands_back_the_converged_iterate():
+@pytest.mark.parametrize("nil,nxl", [(64, 64), (32, 1024), (16, 2048)])   # generic / wave-uniform (1 and 2 waves per row) row pass
+def test_early_exit_hands_back_the_converged_iterate(nil, nxl):
     """eps > 0 on the tuned path: slices leave the loop at different iterations; the iterate of a finished slice is recovered from
     the work buffer by the "finalize" launch (no per-iteration store).  It must be the oracle's iterate of that very iteration,
     and observed traces must come back bit-exact (alpha = 1)."""
     import pseudo_3d_interpolation_amd.functions.POCS as P
     from oracle import pocs_oracle as orc
-    nil = nxl = 64
     mask = orc.synthetic_mask(nil, nxl, 0.3)
     cube = np.stack([orc.synthetic_slice(nil, nxl, s) * (1.0 + 3.0 * s) for s in range(6)]) * mask
     cube[4] = 0
