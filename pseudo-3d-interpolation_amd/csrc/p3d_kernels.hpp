@@ -708,6 +708,7 @@ row_pipe_kernel(const RowArgs a)
 #ifndef P3D_PIPE64_MAXROWS
 #define P3D_PIPE64_MAXROWS 2
 #endif
+
 #ifndef P3D_PIPE64_PREFETCH
 #define P3D_PIPE64_PREFETCH 0    // work-buffer loads of the next row in flight during this row (32 VGPRs)
 #endif
@@ -730,8 +731,10 @@ constexpr size_t pipe64_lds_bytes() { return sizeof(c32) * (PassTables<N>::slots
 template <int N>
 constexpr int pipe64_threads() { return pipe64_rows<N>() * Plan<N>::TPL; }
 
+// (Tried and dropped: a wavefront that owns TWO adjacent rows and stores them together, so that the 64-byte halves of a line pair
+// up inside the wave and the lock-step barrier can go -- 12 waves per CU at 168 VGPRs: 2.03 ms against 1.92, niter = 10.)
 template <int N, int DT, bool SPARSE>
-__global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3) / 4) void row_pipe64_kernel(const RowArgs a)
+__global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
@@ -758,7 +761,6 @@ __global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3)
     double* red = reinterpret_cast<double*>(data + LB * LSTR);   // per-wave partial sums of rows that span waves
 
     const unsigned total = (unsigned)a.nslices * a.n1;
-    const unsigned step = gridDim.x * LB;
     const unsigned wblk = (unsigned)a.n1 * 8;
     const size_t wstride = wk_slice_stride(a.n1, N);
     // element tl + TPL*q = column 64*(wsub + WPL*q) + lane: eight column blocks per wavefront and register
@@ -769,15 +771,15 @@ __global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3)
     // address space lets the compiler use scalar loads although the loop also stores to the work buffer.
     typedef const unsigned long long __attribute__((address_space(4))) * kmask_t;
     typedef const unsigned __attribute__((address_space(4))) * kuint_t;
+    typedef const int __attribute__((address_space(4))) * kint_t;
     const kmask_t k_bits = (kmask_t)a.bits64, k_nzl = (kmask_t)a.nzl;
     const kuint_t k_cbase = (kuint_t)a.cbase;
+    const kint_t k_done = (kint_t)a.done;   // early exit (eps > 0): set between launches, constant during one
     // "scalar base + 32-bit lane offset" addressing is matched per basic block: keep the zero-extension of the lane offset from
     // being hoisted out of the predicated blocks (an empty asm, no instruction)
     auto lane_off = [&]() -> unsigned { unsigned o = lane_w; asm volatile("" : "+v"(o)); return o; };
 
     struct Where { unsigned slice, row; bool on; };
-    typedef const int __attribute__((address_space(4))) * kint_t;
-    const kint_t k_done = (kint_t)a.done;   // early exit (eps > 0): set between launches, constant during one
     auto locate = [&](unsigned g) -> Where {
         Where w;
         w.on = g < total;
@@ -836,33 +838,11 @@ __global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3)
             dst[q] = val;
         }
     };
-
-    unsigned g = blockIdx.x * LB + line;
-    Where cur = locate(g);
-    Where nxt = locate(g + step);
-    c32 v[PPT], bx[PPT];
-#if P3D_PIPE64_PREFETCH
-    c32 by[PPT];
-    load_work(by, cur);
-    // Drain these loads HERE.  The loop's loads are predicated (their number is unknown at compile time), so a pending load on
-    // the entry path would turn into a full "s_waitcnt vmcnt(0)" in front of every row's inverse transform -- right behind the
-    // requests for the next row and for the observed samples, which are meant to be in flight during that transform.
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#endif
     const float w_obs = 1.0f - a.alpha * 1.0f;   // POCS.py:616 at an observed trace
-
-    for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
-#if P3D_PIPE64_LOCKSTEP
-        if (WAVE) __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
-#endif
-        const Where nxt2 = locate(g + 2 * step);
-#if P3D_PIPE64_PREFETCH
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = by[q];
-        load_work(by, nxt);
-#else
+    // one row from the work buffer to the forward transform of the next iteration, left in v[]
+    auto process = [&](c32 (&v)[PPT], const Where& cur) {
+        c32 bx[PPT];
         load_work(v, cur);
-#endif
         unsigned long long mwords[PPT];   // the trace mask of this wavefront's columns as lane masks
 #if P3D_PIPE64_OBS_EARLY
         // issued BEHIND the work-buffer loads (vmcnt retires in order: the transform below waits for those only) and in flight
@@ -882,7 +862,6 @@ __global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3)
 #pragma unroll
         for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(bx[q].x), "+v"(bx[q].y));
 #endif
-
         float acc = 0.f;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -911,23 +890,36 @@ __global__ __launch_bounds__(pipe64_threads<N>(), (pipe64_threads<N>() / 64 + 3)
                 }
             }
         }
-
         __builtin_amdgcn_sched_barrier(0);
         line_fft<N, FWD, WAVE>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
+    };
 
-        if (cur.on) {
-            char* b = wbase(cur);
-            const size_t qs = qstep();
+    {
+        const unsigned step = gridDim.x * LB;
+        unsigned g = blockIdx.x * LB + line;
+        Where cur = locate(g);
+        Where nxt = locate(g + step);
+        for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
+#if P3D_PIPE64_LOCKSTEP
+            if (WAVE) __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
+#endif
+            const Where nxt2 = locate(g + 2 * step);
+            c32 v[PPT];
+            process(v, cur);
+            if (cur.on) {
+                char* b = wbase(cur);
+                const size_t qs = qstep();
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                *reinterpret_cast<c32*>(b + lane_off()) = v[q];
-                b += qs;
+                for (int q = 0; q < PPT; ++q) {
+                    *reinterpret_cast<c32*>(b + lane_off()) = v[q];
+                    b += qs;
+                }
             }
+            g += step;
+            cur = nxt;
+            nxt = nxt2;
         }
-        g += step;
-        cur = nxt;
-        nxt = nxt2;
     }
 }
 
@@ -1159,21 +1151,21 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
         // the wave-uniform variant (it also honours the per-slice `done` flags of the early exit; APOCS and the per-iteration
         // store stay with the generic kernels)
         if (compact && !a.adaptive && !a.write_out && a.bits64 != nullptr && a.cbase != nullptr) {
-            constexpr int LB64 = pipe64_rows<N>();
-            constexpr size_t lds64 = pipe64_lds_bytes<N>();
-            const long groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;
-            int per_cu64 = (int)((160 * 1024) / lds64);                        // workgroups a CU holds: LDS ...
-            const int by_waves = 16 / (pipe64_threads<N>() / 64);              // ... and 4 waves per SIMD
-            if (per_cu64 > by_waves) per_cu64 = by_waves;
-            if (per_cu64 < 1) per_cu64 = 1;
-            const long wgs64 = (long)cus * per_cu64;
-            const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));
-#define P3D_PIPE64(DT, SP)                                                                               \
-    do {                                                                                                \
-        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP>, lds64)) != hipSuccess) return e;               \
-        row_pipe64_kernel<N, DT, SP><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);                    \
-    } while (0)
             const bool sp = a.nzl != nullptr;
+#define P3D_PIPE64(DT, SP)                                                                                       \
+    do {                                                                                                        \
+        constexpr int LB64 = pipe64_rows<N>();                                                                  \
+        constexpr size_t lds64 = pipe64_lds_bytes<N>();                                                         \
+        const long groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;                                       \
+        int per_cu64 = (int)((160 * 1024) / lds64);            /* workgroups a CU holds: LDS ... */             \
+        const int by_waves = 16 / (pipe64_threads<N>() / 64);  /* ... and 4 waves per SIMD */                   \
+        if (per_cu64 > by_waves) per_cu64 = by_waves;                                                           \
+        if (per_cu64 < 1) per_cu64 = 1;                                                                         \
+        const long wgs64 = (long)cus * per_cu64;                                                                \
+        const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));                                     \
+        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP>, lds64)) != hipSuccess) return e;                       \
+        row_pipe64_kernel<N, DT, SP><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);                            \
+    } while (0)
             if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true); else P3D_PIPE64(0, false); }
             else { if (sp) P3D_PIPE64(1, true); else P3D_PIPE64(1, false); }
 #undef P3D_PIPE64
