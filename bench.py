@@ -120,7 +120,6 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from oracle import pocs_oracle as orc  # cpu_baseline leg + its input slices only
     from pseudo_3d_interpolation_amd import _ffi
     from pseudo_3d_interpolation_amd.functions.POCS import _schedule_from_stats
     from pseudo_3d_interpolation_amd.sharding import slice_block
@@ -143,11 +142,12 @@ def main():
     pts_local = n_local * nil * nxl
 
     # ---- inputs, resident in HBM before the clock starts -----------------------------------------
-    mask = orc.synthetic_mask(nil, nxl, args.missing)
+    mask = (np.random.default_rng(42).random((nil, nxl)) >= args.missing).astype(np.uint8)   # shared trace mask
     mask_t = torch.from_numpy(mask.astype(np.float32)).to(device)
     n_cpu = 0
     cpu_slices = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is a single-GPU-run extra (rank 0, N = 1)
+        from oracle import pocs_oracle as orc  # the cpu_baseline leg (and the slices it is fed) -- nothing else touches the oracle
         n_cpu = max(1, min(os.cpu_count() or 1, 16, n_local))
         cpu_slices = np.stack([orc.synthetic_slice(nil, nxl, lo + s) for s in range(n_cpu)]) * mask
     x_obs = torch_slices(torch, nil, nxl, lo, n_local, device)
