@@ -367,8 +367,9 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
         const int op = mode == COL_ITER_SOFT ? 1 : (mode == COL_ITER_GARROTE ? 2 : a.op);   // callers pass COL_ITER + a.op
         bool any = false;
+        const Shrink shr(tau, op);
         for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
-            const c32 v = shrink(X[e], tau, op);
+            const c32 v = shr(X[e]);
             X[e] = v;
             any = any || v.x != 0.0f || v.y != 0.0f;
         }

@@ -109,9 +109,9 @@ __global__ void gen_shrink_kernel(c32* w, const c32* tau, int niter, int iter, i
 {
     const int s = blockIdx.y;
     if (done && done[s] != 0) return;
-    const c32 t = tau[(size_t)s * niter + iter];
+    const Shrink shr(tau[(size_t)s * niter + iter], op);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x)
-        w[(size_t)s * per_slice + i] = shrink(w[(size_t)s * per_slice + i], t, op);
+        w[(size_t)s * per_slice + i] = shr(w[(size_t)s * per_slice + i]);
 }
 
 __device__ inline double block_sum(double v, double* sh)

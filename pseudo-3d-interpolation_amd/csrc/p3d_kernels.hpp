@@ -84,12 +84,15 @@ struct ShearArgs {
     int nsh, niter, iter, op, real_only;
 };
 
+#ifndef P3D_ROW1024_MAXMODE
+#define P3D_ROW1024_MAXMODE 2
+#endif
 constexpr int ROW_THREADS = P3D_ROW_THREADS;
 // The one-launch-per-iteration row pass copies its twiddle tables (2N entries) into LDS once per workgroup: 16 KiB per four
 // 8-KiB rows at N = 1024.  Sixteen rows per workgroup (one 155-KiB workgroup per CU) take 1.8 ms off the first + last pass of a
 // job on the headline cube.  The SHEARLET modes keep their measured configuration.
 template <int N, int MODE>
-constexpr int row_threads() { return (N == 1024 && MODE <= 2 && P3D_ROW_THREADS < 1024) ? 1024 : P3D_ROW_THREADS; }
+constexpr int row_threads() { return (N == 1024 && MODE <= P3D_ROW1024_MAXMODE && P3D_ROW_THREADS < 1024) ? 1024 : P3D_ROW_THREADS; }
 constexpr int STATS_PARTIAL = 8;  // floats per (slice, tile) written by COL_STATS
 
 // ---- column-blocked work layout ------------------------------------------------------------------
@@ -996,11 +999,12 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = inb[eoff(0, tl + TPL * q)];
         line_fft<N, INV, false>(v, lds, tw, tl);
+        const Shrink shr(tau, a.sh.op);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             c32 c = v[q] * scale;
             if (a.sh.real_only) c.y = 0.f;   // FFST returns the real part for real data
-            v[q] = shrink(c, tau, a.sh.op);
+            v[q] = shr(c);
         }
         line_fft<N, FWD, false>(v, lds, tw, tl);
         if (valid) {
@@ -1018,8 +1022,9 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     if (ITER || (MODE == COL_FWD && a.tau != nullptr)) {
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
         const int op = MODE == COL_ITER ? 0 : (MODE == COL_ITER_SOFT ? 1 : (MODE == COL_ITER_GARROTE ? 2 : a.op));
+        const Shrink shr(tau, op);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = shrink(v[q], tau, op);
+        for (int q = 0; q < PPT; ++q) v[q] = shr(v[q]);
         if (ITER && a.nzflag != nullptr) {
             // Sparse spectra (the premise of the method): a tile the threshold emptied is all zeros after the inverse
             // transform too.  Say so instead of transforming and storing it; the row pass reads zeros for it.

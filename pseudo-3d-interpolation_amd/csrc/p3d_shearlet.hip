@@ -91,9 +91,10 @@ __global__ void sthreshold_kernel(c32* U, size_t per, int nsh, const c32* tau, i
     if (done && done[b] != 0) return;
     const c32 t = tau[((size_t)b * niter + iter) * nsh + s];
     c32* p = U + (size_t)bs * per;
+    const p3d::Shrink shr(t, op);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
         const c32 v = p[i];
-        p[i] = real_only ? c32{p3d::shrink(v.x, t, op), 0.f} : p3d::shrink(v, t, op);
+        p[i] = real_only ? c32{p3d::shrink(v.x, t, op), 0.f} : shr(v);
     }
 }
 

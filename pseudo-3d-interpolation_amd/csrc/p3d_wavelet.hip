@@ -82,7 +82,20 @@ __device__ __forceinline__ float shrink_fast(float x, c32 tau, int op)
     const float g = op == 1 ? 1.0f - tau.x * r : 1.0f - (tau.x * tau.x) * (r * r);
     return (m > 0.0f && g > 0.0f) ? x * g : 0.f;
 }
-__device__ __forceinline__ c32 shrink_fast(c32 x, c32 tau, int op) { return p3d::shrink(x, tau, op); }
+// one threshold, many coefficients of a tile (what depends on tau alone is computed once: p3d::Shrink)
+template <typename T>
+struct ShrinkTile;
+template <>
+struct ShrinkTile<c32> : p3d::Shrink {
+    __device__ __forceinline__ ShrinkTile(c32 t, int o) : p3d::Shrink(t, o) {}
+};
+template <>
+struct ShrinkTile<float> {
+    c32 tau;
+    int op;
+    __device__ __forceinline__ ShrinkTile(c32 t, int o) : tau(t), op(o) {}
+    __device__ __forceinline__ float operator()(float x) const { return shrink_fast(x, tau, op); }
+};
 
 // sample k of a line of n samples at stride `st`, extended by straight lines through the edge pairs ('smooth')
 template <typename T>
@@ -113,6 +126,7 @@ __global__ void dwt_axis_kernel(const T* in, T* lo, T* hi, Filters f, int nlines
     c32 t_lo{0.f, 0.f}, t_hi{0.f, 0.f};
     if (th.z_lo >= 0) t_lo = th.tau[(((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3 + th.z_lo];
     if (th.z_hi >= 0) t_hi = th.tau[(((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3 + th.z_hi];
+    const p3d::ShrinkOf<T> sh_lo(t_lo, th.op), sh_hi(t_hi, th.op);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         // neighbouring threads walk along the contiguous direction of the data
         int line, o;
@@ -135,8 +149,8 @@ __global__ void dwt_axis_kernel(const T* in, T* lo, T* hi, Filters f, int nlines
                 acc_tap(d, f.dec_hi[j], v);
             }
         }
-        if (th.z_lo >= 0) a = p3d::shrink(a, t_lo, th.op);
-        if (th.z_hi >= 0) d = p3d::shrink(d, t_hi, th.op);
+        if (th.z_lo >= 0) a = sh_lo(a);
+        if (th.z_hi >= 0) d = sh_hi(d);
         const size_t dst = (size_t)line * out_lin + (size_t)o * out_el;
         lo[(size_t)s * lo_slice + dst] = a;
         hi[(size_t)s * hi_slice + dst] = d;
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
         const c32* t = th.tau + (((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3;
         t0 = t[0]; t1 = t[1]; t2 = t[2];
     }
+    const ShrinkTile<T> sh0(t0, th.op), sh1(t1, th.op), sh2(t2, th.op);
     const size_t cnt = (size_t)Ho * Wo;
     const int gc = oc0 + tx;
 #pragma unroll
@@ -328,9 +343,9 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
         if (go >= Ho || gc >= Wo) continue;
         T da = fl[q].second(), ad = fh[q].first(), dd = fh[q].second();
         if (th.tau) {   // threshold_wavelet: details only
-            da = shrink_fast(da, t0, th.op);
-            ad = shrink_fast(ad, t1, th.op);
-            dd = shrink_fast(dd, t2, th.op);
+            da = sh0(da);
+            ad = sh1(ad);
+            dd = sh2(dd);
         }
         const size_t o = (size_t)go * Wo + gc;
         cA[(size_t)s * cA_slice + o] = fl[q].first();

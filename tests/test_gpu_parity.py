@@ -86,6 +86,25 @@ def test_stats_match_numpy(ffi):
         assert abs(st[s, 4] - np.linalg.norm(X[s]) ** 2) < 1e-5 * np.linalg.norm(X[s]) ** 2
 
 
+@pytest.mark.parametrize("shape", [(64, 128), (1024, 1024), (60, 100), (16, 2048)])
+def test_a_coefficient_whose_modulus_is_the_threshold_is_kept(ffi, shape):
+    """`where(|X| < tau, 0, X)` with tau = max|X| (the first threshold of the inverse-proportional model, POCS.py:340-347) keeps
+    the largest coefficient: the hard operator compares squared moduli against a limit that reproduces `sqrtf(p) < tau` exactly,
+    not `p < tau*tau`.  With Im(tau) > 0 the lexicographic comparison counts the tie as below and nothing survives."""
+    x = _rand_c((3,) + shape, 11)
+    x[1] = x[1].real                       # a real slice: its largest coefficient is a Hermitian pair
+    with ffi.Plan(*shape, 3) as plan:
+        st = plan.stats(x)
+        tmax = st[:, 2]
+        kept = plan.fft2_shrink(x, tmax + 0j, "hard") != 0
+        none = plan.fft2_shrink(x, tmax + 1j, "hard") != 0
+        below = plan.fft2_shrink(x, tmax * (1 - 2e-7) + 0j, "hard") != 0
+    for s in range(3):
+        assert 1 <= kept[s].sum() <= 2, (s, int(kept[s].sum()))
+        assert none[s].sum() == 0
+        assert kept[s].sum() <= below[s].sum() <= 4
+
+
 # ------------------------------------------------------------------------------------------------
 # golden vectors of the reference (power-of-two cases; the others need the generic path)
 # ------------------------------------------------------------------------------------------------
