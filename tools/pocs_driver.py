@@ -21,6 +21,7 @@ ap.add_argument("--niter", type=int, default=3)
 ap.add_argument("--missing", type=float, default=0.8)
 ap.add_argument("--thresh-op", default="hard")
 ap.add_argument("--distinct", type=int, default=8)
+ap.add_argument("--real", action="store_true", help="float32 (time-domain) cube instead of complex64")
 a = ap.parse_args()
 
 rng = np.random.default_rng(0)
@@ -34,18 +35,19 @@ for s in range(a.distinct):
         k1, k2 = rng.integers(-(a.nil // 8), max(a.nil // 8, 1)), rng.integers(-(a.nxl // 8), max(a.nxl // 8, 1))
         acc += (rng.standard_normal() + 1j * rng.standard_normal()) * np.exp(2j * np.pi * (k1 * il + k2 * xl))
     acc += 0.01 * (rng.standard_normal(acc.shape) + 1j * rng.standard_normal(acc.shape))
-    base.append((acc * mask).astype(np.complex64))
+    base.append((acc.real * mask).astype(np.float32) if a.real else (acc * mask).astype(np.complex64))
 base = np.stack(base)
 
 plan = _ffi.Plan(a.nil, a.nxl, a.nslices)
-slice_bytes = a.nil * a.nxl * 8
+slice_bytes = a.nil * a.nxl * (4 if a.real else 8)
+DT = _ffi.P3D_F32 if a.real else _ffi.P3D_C64
 x = plan.alloc(slice_bytes * a.nslices)
 out = plan.alloc(slice_bytes * a.nslices)
 m = plan.alloc(mask.nbytes).upload(mask)
 for s in range(a.nslices):
     _ffi.check(_ffi.lib().p3d_memcpy_h2d(plan.handle, x.ptr + s * slice_bytes, base[s % a.distinct].ctypes.data, slice_bytes))
-stats = plan.stats_dev(x.ptr, _ffi.P3D_C64, a.nslices)
+stats = plan.stats_dev(x.ptr, DT, a.nslices)
 tau = _schedule_from_stats(stats, a.nil * a.nxl, "exponential", a.niter, 0.99, 1e-3, "values")
-done, _, ms = plan.run_dev(x.ptr, _ffi.P3D_C64, m.ptr, tau, a.niter, out.ptr, a.nslices, thresh_op=a.thresh_op,
+done, _, ms = plan.run_dev(x.ptr, DT, m.ptr, tau, a.niter, out.ptr, a.nslices, thresh_op=a.thresh_op,
                            profile=True, want_sums=False)
 print("niter", a.niter, "device ms", ms, plan.last_profile())
