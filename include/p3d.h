@@ -95,6 +95,10 @@ int p3d_malloc(p3d_plan* plan, void** dptr, size_t bytes);
 int p3d_free(p3d_plan* plan, void* dptr);
 int p3d_memcpy_h2d(p3d_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
 int p3d_memcpy_d2h(p3d_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
+/* page-locked host memory: copies to / from it run at the PCIe rate (pageable NumPy memory is staged by the runtime at a
+ * quarter of it); the chunk pipeline of pocs_cube keeps its staging buffers here */
+int p3d_host_alloc(void** hptr, size_t bytes);
+int p3d_host_free(void* hptr);
 
 /* Batched 2-D FFT of complex64 slices, numpy.fft.fft2 / ifft2 conventions (unnormalised forward,
  * 1/(nil*nxl) inverse).  Replaces the callables injected at cube_POCS_interpolation_3D.py:255-257;

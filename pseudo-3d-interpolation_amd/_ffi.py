@@ -46,6 +46,8 @@ PROTOTYPES = {
     "p3d_plan_destroy": (C.c_int, [C.c_void_p]),
     "p3d_malloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "p3d_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "p3d_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "p3d_host_free": (C.c_int, [C.c_void_p]),
     "p3d_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3d_fft2_c64_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -159,6 +161,29 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             check(lib().p3d_free(self.plan.handle, self.ptr))
+            self.ptr = None
+
+
+class PinnedBuffer:
+    """Page-locked host memory (p3d_host_alloc) viewed as NumPy arrays: the staging area of the chunk pipeline."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().p3d_host_alloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+        self._raw = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def view(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if n > self.nbytes:
+            raise ValueError("view larger than the buffer")
+        return self._raw[:n].view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self._raw = None
+            check(lib().p3d_host_free(self.ptr))
             self.ptr = None
 
 

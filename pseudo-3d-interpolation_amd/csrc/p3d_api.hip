@@ -444,6 +444,19 @@ int p3d_free(p3d_plan* p, void* dptr)
     return P3D_OK;
 }
 
+int p3d_host_alloc(void** hptr, size_t bytes)
+{
+    if (!hptr) return fail(P3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return P3D_OK;
+}
+
+int p3d_host_free(void* hptr)
+{
+    HIP_TRY(hipHostFree(hptr));
+    return P3D_OK;
+}
+
 int p3d_memcpy_h2d(p3d_plan* p, void* dst, const void* src, size_t bytes)
 {
     if (!p) return fail(P3D_ERR_INVALID, "NULL plan");

@@ -19,6 +19,7 @@ What runs where
 
 There is no CPU fallback for the loop: without the library or without a GPU these functions raise.
 """
+import os
 import time
 from functools import partial
 
@@ -304,11 +305,35 @@ def _check_common(mask, transform_kind, thresh_op):
     return kind
 
 
+_copy_pool = None
+
+
+def _slab_copy(dst, src):
+    """dst[...] = src (same shape, any dtypes) in parallel slabs along axis 0: NumPy releases the GIL in the copy loops, one
+    core moves ~10 GB/s, the PCIe link five times that."""
+    global _copy_pool
+    n = dst.shape[0]
+    parts = min(_COPY_THREADS, n)
+    if parts <= 1 or dst.nbytes < (32 << 20):
+        np.copyto(dst, src, casting='unsafe')
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(_COPY_THREADS)
+    cuts = [n * i // parts for i in range(parts + 1)]
+    list(_copy_pool.map(lambda i: np.copyto(dst[cuts[i]:cuts[i + 1]], src[cuts[i]:cuts[i + 1]], casting='unsafe'), range(parts)))
+
+
+_COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_CHUNK_WORKERS = int(os.environ.get('P3D_CHUNK_WORKERS', 4))   # chunks in flight (slots 0.. of the plan cache; slot 15 belongs to the unchunked path)
+
+
 class _FFTWorker:
-    """One plan + device buffers for a chunk of slices; two of them alternate so that the PCIe transfers of one chunk run while
-    the other chunk iterates (ctypes releases the GIL; each plan has its own non-blocking stream).  Workers are cached like the
-    plans (per slice shape, device and slot): a per-slice caller (``POCS_algorithm`` under ``xr.apply_ufunc``) does not pay
-    for device allocations on every call."""
+    """One plan + device buffers for a chunk of slices; four of them alternate so that the PCIe transfers (and, for float64 /
+    complex128 cubes, the dtype conversion through page-locked staging buffers) of one chunk run while another chunk iterates
+    (ctypes and NumPy's copy loops release the GIL; each plan has its own non-blocking stream).  Workers are cached like the plans
+    (per slice shape, device and slot): a per-slice caller (``POCS_algorithm`` under ``xr.apply_ufunc``) does not pay for
+    allocations on every call."""
 
     def __init__(self, nil, nxl, step, device, slot):
         self.plan = _get_plan(nil, nxl, step, device, slot)
@@ -317,6 +342,7 @@ class _FFTWorker:
         self.x = self.plan.alloc(per * self.capacity)
         self.o = self.plan.alloc(per * self.capacity)
         self.m = self.plan.alloc(nil * nxl * 4)
+        self.hx = self.ho = None     # page-locked staging, allocated when a cube needs a dtype conversion
 
     @classmethod
     def get(cls, nil, nxl, step, device, slot, maskf):
@@ -330,25 +356,43 @@ class _FFTWorker:
         return w
 
     def close(self):
-        if self.plan.handle is not None:   # buffers die with their plan otherwise
+        if self.plan.handle is not None:   # device buffers die with their plan otherwise
             for b in (self.x, self.o, self.m):
+                b.free()
+        for b in (self.hx, self.ho):
+            if b is not None:
                 b.free()
 
     def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha):
         n = chunk.shape[0]
         t0 = time.perf_counter()
-        xc, dt = self.plan._cube(chunk)
-        active = xc.reshape(n, -1).any(axis=1)        # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
-        self.x.upload(xc)                              # one upload serves the statistics and the loop
+        if n > self.capacity or chunk.shape[1:] != (self.plan.nil, self.plan.nxl):
+            raise ValueError(f'chunk {chunk.shape} does not fit the worker ({self.capacity}, {self.plan.nil}, {self.plan.nxl})')
+        dt, dtype = (_ffi.P3D_C64, np.complex64) if np.iscomplexobj(chunk) else (_ffi.P3D_F32, np.float32)
+        # cubes that already have the device dtype move straight between the caller's arrays and the device (the runtime reaches
+        # the PCIe rate from pageable memory here); others are converted through page-locked staging buffers in parallel slabs
+        direct = chunk.dtype == dtype and chunk.flags.c_contiguous and dst.dtype == dtype and dst.flags.c_contiguous
+        if direct:
+            self.x.upload(chunk)
+        else:
+            if self.hx is None:
+                per = self.plan.nil * self.plan.nxl * 8 * self.capacity
+                self.hx, self.ho = _ffi.PinnedBuffer(per), _ffi.PinnedBuffer(per)
+            xin = self.hx.view(chunk.shape, dtype)
+            _slab_copy(xin, chunk)
+            self.x.upload(xin)                         # one upload serves the statistics and the loop
         stats = self.plan.stats_dev(self.x.ptr, dt, n)
+        active = ~(stats[:, 2] == 0)                   # max|fft2(x)| == 0 <=> np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         stats[~active] = 1.0                           # keep NaNs of empty slices out of the (unused) schedule rows
         tau = sched(stats)
         done, sums, _ = self.plan.run_dev(self.x.ptr, dt, self.m.ptr, tau, niter, self.o.ptr, n, thresh_op=thresh_op,
                                           version=version, eps=eps, alpha=alpha, active=active)
-        if dst.dtype == xc.dtype:
+        if direct:
             self.o.download_into(dst)
-        else:                                          # e.g. a float64 cube: results are cast on assignment, as before
-            dst[...] = self.o.download(xc.shape, xc.dtype)
+        else:
+            xout = self.ho.view(chunk.shape, dtype)
+            self.o.download_into(xout)
+            _slab_copy(dst, xout)                      # e.g. a float64 cube: results are cast on assignment, as before
         return done, sums, time.perf_counter() - t0
 
 
@@ -448,10 +492,10 @@ def pocs_cube(
         # FFT, statistics-driven schedules: chunks go through device buffers, uploaded once each, two chunks in flight
         slice_bytes = nil * nxl * (8 if np.iscomplexobj(cube) else 4)
         if not batch_slices and nslices * slice_bytes >= (1 << 30):
-            step = max(1, (256 << 20) // slice_bytes)            # ~256 MiB per chunk
+            step = max(1, (int(os.environ.get('P3D_CHUNK_MIB', 128)) << 20) // slice_bytes)   # ~128 MiB per chunk, four in flight
         step = min(step, nslices)
         starts = list(range(0, nslices, step))
-        workers = [_FFTWorker.get(nil, nxl, step, device, slot, maskf) for slot in range(min(2, len(starts)))]
+        workers = [_FFTWorker.get(nil, nxl, step, device, slot, maskf) for slot in range(min(_CHUNK_WORKERS, len(starts)))]
 
         def sched(stats):
             tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
@@ -472,7 +516,7 @@ def pocs_cube(
                 results.extend(_result_rows(done, sums, runtime))
         return out
     else:
-        plan = _get_plan(nil, nxl, min(step, nslices), device, slot=2)   # slots 0 and 1 belong to the chunk workers
+        plan = _get_plan(nil, nxl, min(step, nslices), device, slot=15)   # the low slots belong to the chunk workers
 
     for lo in range(0, nslices, step):
         chunk = cube[lo:lo + step]

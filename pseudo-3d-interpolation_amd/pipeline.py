@@ -40,7 +40,7 @@ def interpolate_time_cube(x, mask, dt, t0=0.0, nfft=None, real_only=True, window
     if isinstance(p_min, str) and p_min != 'adaptive':
         p_min = float(p_min)
     step = int(batch_slices) if batch_slices else max(1, min(nfreq, (512 << 20) // (ntr * 8)))
-    plan = P._get_plan(nil, nxl, min(step, nfreq), device, slot=3)
+    plan = P._get_plan(nil, nxl, min(step, nfreq), device, slot=14)
     lib = _ffi.lib()
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
     win = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
