@@ -234,7 +234,8 @@ def main():
                 traffic = None
         roof = {
             "bound": "hbm",
-            "kernel": f"col_kernel<{nil}> + row_kernel<{nxl}> = one POCS iteration of {n_local} slices",
+            "kernel": f"col_kernel<{nil},COL_ITER> + the persistent row pass (row_pipe64_kernel<{nxl}> for rows of whole "
+                      f"wavefronts, row_pipe_kernel otherwise) = one POCS iteration of {n_local} slices",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
