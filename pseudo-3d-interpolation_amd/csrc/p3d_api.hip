@@ -110,7 +110,25 @@ static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsig
     }
     // rows of whole wavefronts (groups = 8, 16, 32): the same flags as 64-bit lane masks, word (slice, wavefront, q) bit l = the
     // flag word of thread group 8 * wavefront + l / 8, bit q; those 8 threads are neighbours in the wave and build two words each
-    if (nzl != nullptr) {
+    if (nzl != nullptr && groups < 8) {
+        // rows shorter than a wavefront (tpl = 8 * groups lanes per row, 64 / tpl rows per wave): lane l belongs to thread group
+        // (l % tpl) / 8 of its row; the `groups` threads of a slice are neighbours and build 16 / groups words each
+        const int base = (int)(threadIdx.x & 63u) - g, tpl = 8 * groups, per = 16 / groups;
+        unsigned long long pat[4] = {0, 0, 0, 0};
+        unsigned wg[4] = {0, 0, 0, 0};
+        for (int k = 0; k < groups; ++k) {
+            wg[k] = (unsigned)__shfl((int)word, base + k, 64);
+            for (int l0 = 0; l0 < 64; l0 += tpl) pat[k] |= 0xFFull << (l0 + 8 * k);
+        }
+        if (!skip) {
+            for (int qq = 0; qq < per; ++qq) {
+                const int q = g * per + qq;
+                unsigned long long m = 0;
+                for (int k = 0; k < groups; ++k) if ((wg[k] >> q) & 1u) m |= pat[k];
+                nzl[(size_t)s * 16 + q] = m;
+            }
+        }
+    } else if (nzl != nullptr) {
         const int base = (int)(threadIdx.x & 63u) & ~7;
         unsigned long long m0 = 0, m1 = 0;
         for (int k = 0; k < 8; ++k) {
@@ -174,31 +192,36 @@ static __global__ void pack_mask_kernel(const float* mask, uint16_t* bits, int* 
 }
 
 
-// rows of whole wavefronts (tpl = 64 * wpl): the same mask as lane masks, word pipe64_word(row, wpl, wsub, q) bit l =
-// bits[row][64 * wsub + l] bit q
-static __global__ void pack_mask64_kernel(const uint16_t* bits, unsigned long long* bits64, int n1, int wpl)
+// Lane-mask tables of the wave-uniform persistent row pass (row_pipe64_kernel).  A "unit" is what one wavefront (tpl <= 64: rpw =
+// 64 / tpl adjacent rows) or wpl = tpl / 64 wavefronts (one row) work on; word pipe64_word(unit, wpl, wsub, q) bit l = the mask of
+// the element lane l of wavefront wsub holds in register q.
+static __global__ void pack_mask64_kernel(const uint16_t* bits, unsigned long long* bits64, int n1, int tpl)
 {
+    const int wpl = tpl >= 64 ? tpl / 64 : 1, rpw = tpl >= 64 ? 1 : 64 / tpl;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n1 * wpl * 16) return;
-    const int q = i & 15, wsub = (i >> 4) % wpl, row = (i >> 4) / wpl;
+    if (i >= (n1 / rpw) * wpl * 16) return;
+    const int q = i & 15, wsub = (i >> 4) % wpl, unit = (i >> 4) / wpl;
     unsigned long long w = 0;
-    for (int l = 0; l < 64; ++l) w |= (unsigned long long)((bits[(size_t)row * 64 * wpl + 64 * wsub + l] >> q) & 1u) << l;
+    for (int l = 0; l < 64; ++l) {
+        const int row = unit * rpw + (tpl >= 64 ? 0 : l / tpl), tl = tpl >= 64 ? 64 * wsub + l : l % tpl;
+        w |= (unsigned long long)((bits[(size_t)row * tpl + tl] >> q) & 1u) << l;
+    }
     bits64[i] = w;
 }
-// cbase[word] = observed traces of the slice before the first column of that word (rowbase + the words to its left in column
-// order; word (wsub, q) covers columns 64 * (wsub + wpl * q) ...)
-static __global__ void pack_cbase_kernel(const unsigned long long* bits64, const unsigned* rowbase, unsigned* cbase, int n1, int wpl)
+// cbase[word] = position in the slice's compact array of the first observed sample of that word: the compact order is unit by
+// unit (rowbase of the unit's first row) and, inside a unit, word by word in table order
+static __global__ void pack_cbase_kernel(const unsigned long long* bits64, const unsigned* rowbase, unsigned* cbase, int n1, int tpl)
 {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n1) return;
-    unsigned run = rowbase[row];
+    const int wpl = tpl >= 64 ? tpl / 64 : 1, rpw = tpl >= 64 ? 1 : 64 / tpl;
+    const int unit = blockIdx.x * blockDim.x + threadIdx.x;
+    if (unit >= n1 / rpw) return;
+    unsigned run = rowbase[unit * rpw];
     for (int j = 0; j < 16 * wpl; ++j) {
-        const size_t w = pipe64_word((size_t)row, wpl, j % wpl, j / wpl);
+        const size_t w = (size_t)unit * wpl * 16 + j;
         cbase[w] = run;
         run += (unsigned)__popcll(bits64[w]);
     }
 }
-
 
 static thread_local std::string g_err;
 
@@ -411,8 +434,9 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
         if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
-        if (orow->tpl % 64 == 0 && orow->tpl <= 256 && orow->tpl > 0 && orow->ppt == 16 && !getenv("P3D_NO_PIPE64")) {
-            const size_t wpl = (size_t)orow->tpl / 64;
+        if (orow->tpl >= 8 && orow->tpl <= 256 && orow->ppt == 16 && nil % (orow->tpl >= 64 ? 1 : 64 / orow->tpl) == 0 &&
+            !getenv("P3D_NO_PIPE64")) {   // the wave-uniform persistent row pass: rows of 128 ... 4096 samples
+            const size_t wpl = orow->tpl >= 64 ? (size_t)orow->tpl / 64 : 1;
             TRY_OR_BAIL(hipMalloc((void**)&p->bits64, sizeof(unsigned long long) * 16 * wpl * (size_t)nil));
             TRY_OR_BAIL(hipMalloc((void**)&p->cbase, sizeof(unsigned) * 16 * wpl * (size_t)nil));
             TRY_OR_BAIL(hipMalloc((void**)&p->nzl, sizeof(unsigned long long) * 16 * wpl * (size_t)max_slices));
@@ -899,9 +923,9 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
                                                                     p->ops_row->ppt);
         if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
         if (p->bits64 && p->nil <= 4096) {
-            const int wpl = p->ops_row->tpl / 64;
-            pack_mask64_kernel<<<(p->nil * wpl * 16 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, wpl);
-            pack_cbase_kernel<<<(p->nil + 255) / 256, 256, 0, p->stream>>>(p->bits64, p->rowbase, p->cbase, p->nil, wpl);
+            const int tpl = p->ops_row->tpl, wpl = tpl >= 64 ? tpl / 64 : 1;
+            pack_mask64_kernel<<<(p->nil * wpl * 16 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, tpl);
+            pack_cbase_kernel<<<(p->nil + 255) / 256, 256, 0, p->stream>>>(p->bits64, p->rowbase, p->cbase, p->nil, tpl);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -932,8 +956,10 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.x = x;
     r.mask = nonbinary ? mask : nullptr;
     r.bits = nonbinary ? nullptr : p->bits;
-    r.bits64 = nonbinary ? nullptr : p->bits64;
-    r.cbase = nonbinary ? nullptr : p->cbase;
+    // APOCS runs the generic persistent pass, which counts the compact samples row by row: no word tables then (the first pass
+    // writes the compact array in the order its reader expects)
+    r.bits64 = (nonbinary || adaptive) ? nullptr : p->bits64;
+    r.cbase = (nonbinary || adaptive) ? nullptr : p->cbase;
     r.xc = compact ? p->xc : nullptr;
     r.rowbase = p->rowbase;
     r.nobs = nobs;

@@ -304,9 +304,17 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
     if (MODE == ROW_FIRST) {
         // ranks come from wave ballots: a line inside one wave counts as it goes (CompactIndex); a line of several waves takes
         // the number of observed traces before each of its 64-column words from the table of the persistent pass (RowArgs::cbase)
-        constexpr bool CAN_COMPACT = BITS && (TPL <= 64 || (TPL % 64 == 0 && PPT == 16));
-        const bool compact = CAN_COMPACT && a.xc != nullptr && (TPL <= 64 || a.cbase != nullptr);
-        CompactIndex<(TPL <= 64 ? TPL : 64)> ci(tid & 63, compact ? a.rowbase[vrow] : 0u);
+        // The order of the compact array is a convention between this kernel and the persistent passes.  Where the table of the
+        // wave-uniform pass exists (RowArgs::cbase: rows of 128 ... 4096 samples) a wavefront's samples of one register q are
+        // consecutive: index = cbase[word] + rank of the lane among the set lanes of the WAVE (for rows shorter than a wavefront
+        // the word spans the 64 / TPL adjacent rows the wave holds).  Otherwise: row-major, counted line by line.
+        constexpr bool WORDS = BITS && PPT == 16 && TPL >= 8 && TPL <= 256;
+        constexpr bool CAN_COMPACT = BITS && (TPL <= 64 || WORDS);
+        const bool by_words = WORDS && a.cbase != nullptr;
+        const bool compact = CAN_COMPACT && a.xc != nullptr && (TPL <= 64 || by_words);
+        CompactIndex<(TPL <= 64 ? TPL : 64)> ci(tid & 63, (compact && !by_words) ? a.rowbase[vrow] : 0u);
+        constexpr int RPW_ = TPL >= 64 ? 1 : 64 / TPL, WPL_ = TPL >= 64 ? TPL / 64 : 1;
+        const size_t word0 = pipe64_word((size_t)(vrow / RPW_), WPL_, (tid >> 6) % WPL_, 0);
         bool bad = false;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -315,12 +323,11 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
                 if (compact) {  // uniform
                     const bool set = ((mbits >> q) & 1u) != 0;
                     unsigned idx;
-                    if constexpr (TPL <= 64) {
-                        idx = ci.next(set);
+                    if (by_words) {   // uniform
+                        const unsigned long long b = __ballot(set && valid);
+                        idx = a.cbase[word0 + q] + (unsigned)__popcll(b & ((1ull << (tid & 63)) - 1ull));
                     } else {
-                        const unsigned long long b = __ballot(set);
-                        idx = a.cbase[pipe64_word((size_t)vrow, TPL / 64, (tid >> 6) % (TPL / 64), q)] +
-                              (unsigned)__popcll(b & ((1ull << (tid & 63)) - 1ull));
+                        idx = ci.next(set);
                     }
                     if (set && valid) {
                         if (a.dtype == 0) reinterpret_cast<c32*>(a.xc)[(size_t)slice * a.nobs + idx] = x;
@@ -741,10 +748,12 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
-    static_assert(TPL % 64 == 0 && PPT == 16, "rows of whole wavefronts");
-    constexpr int WPL = TPL / 64;                 // wavefronts per row
+    static_assert((TPL % 64 == 0 || 64 % TPL == 0) && TPL >= 8 && PPT == 16, "whole wavefronts per row or whole rows per wavefront");
+    constexpr int WPL = TPL >= 64 ? TPL / 64 : 1; // wavefronts per row
+    constexpr int RPW = TPL >= 64 ? 1 : 64 / TPL; // rows per wavefront: a "unit" = RPW adjacent rows of one slice (n1 % RPW == 0)
     constexpr int THREADS = pipe64_threads<N>();
     constexpr int LB = THREADS / TPL;             // rows per workgroup
+    constexpr int UPB = LB / RPW;                 // units per workgroup
     constexpr int LSTR = LdsRow::stride(N);
     constexpr bool WAVE = WPL == 1;
     constexpr unsigned ES = DT == 0 ? 8u : 4u;    // bytes per observed sample
@@ -755,20 +764,25 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int line = wave / WPL, wsub = wave % WPL;
+    const int uline = wave / WPL, wsub = wave % WPL;
     const int lane = tid & 63;
-    const int tl = wsub * 64 + lane;
+    const int sub = TPL >= 64 ? 0 : lane / TPL;                        // row of this lane inside its unit
+    const int tl = TPL >= 64 ? wsub * 64 + lane : lane % TPL;
+    const int line = uline * RPW + sub;
     for (int i = tid; i < PassTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
     const LdsRow lds{data + line * LSTR};
     double* red = reinterpret_cast<double*>(data + LB * LSTR);   // per-wave partial sums of rows that span waves
 
-    const unsigned total = (unsigned)a.nslices * a.n1;
+    const unsigned upslice = (unsigned)a.n1 / RPW;                      // units per slice
+    const unsigned total = (unsigned)a.nslices * upslice;
     const unsigned wblk = (unsigned)a.n1 * 8;
     const size_t wstride = wk_slice_stride(a.n1, N);
-    // element tl + TPL*q = column 64*(wsub + WPL*q) + lane: eight column blocks per wavefront and register
-    const unsigned lane_w = ((unsigned)(lane >> 3) * wblk + (unsigned)(lane & 7)) * 8u;   // byte offset of the lane, every q
-    const size_t qs64 = (size_t)8 * wblk * 8u;                                            // bytes per 64 columns
+    // element tl + TPL*q = column 64*(wsub + WPL*q) + lane (rows of whole wavefronts) or TPL*q + tl of row `sub` of the unit:
+    // min(TPL, 64) / 8 column blocks per wavefront and register, adjacent rows 64 bytes apart
+    const unsigned colpart = TPL >= 64 ? (unsigned)lane : (unsigned)tl;
+    const unsigned lane_w = ((colpart >> 3) * wblk + (colpart & 7) + (unsigned)sub * 8u) * 8u;   // byte offset of the lane, every q
+    const size_t qs64 = (size_t)8 * wblk * 8u;                                                   // bytes per 64 columns
 
     // The small tables (lane masks, compact bases) are never written while this kernel runs: reading them through the constant
     // address space lets the compiler use scalar loads although the loop also stores to the work buffer.
@@ -782,22 +796,22 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     // being hoisted out of the predicated blocks (an empty asm, no instruction)
     auto lane_off = [&]() -> unsigned { unsigned o = lane_w; asm volatile("" : "+v"(o)); return o; };
 
-    struct Where { unsigned slice, row; bool on; };
+    struct Where { unsigned slice, row; bool on; };   // row: the unit's index inside its slice (= the row itself when RPW == 1)
     auto locate = [&](unsigned g) -> Where {
         Where w;
         w.on = g < total;
         const unsigned gg = w.on ? g : 0u;
-        w.slice = gg / (unsigned)a.n1;
-        w.row = gg - w.slice * (unsigned)a.n1;
+        w.slice = gg / upslice;
+        w.row = gg - w.slice * upslice;
         if (k_done != nullptr && w.on && k_done[w.slice] != 0) w.on = false;   // finished / empty slice: leave it alone
         return w;
     };
     auto wbase = [&](const Where& w) -> char* {
-        return reinterpret_cast<char*>(a.work) + (w.slice * wstride + (size_t)w.row * 8) * 8 + (size_t)wsub * qs64;
+        return reinterpret_cast<char*>(a.work) + (w.slice * wstride + (size_t)w.row * RPW * 8) * 8 + (size_t)wsub * qs64;
     };
     // register q sits WPL * 64 columns further on: one running scalar pointer (the step is made opaque per call so that sixteen
     // precomputed 64-bit multiples do not crowd the scalar registers)
-    auto qstep = [&]() -> size_t { size_t qs = qs64 * WPL; asm volatile("" : "+s"(qs)); return qs; };
+    auto qstep = [&]() -> size_t { size_t qs = TPL >= 64 ? qs64 * WPL : qs64 / RPW; asm volatile("" : "+s"(qs)); return qs; };
     auto load_work = [&](c32 (&dst)[PPT], const Where& w) {
         const char* b = wbase(w);
         const size_t qs = qstep();
@@ -878,17 +892,18 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 
         if (a.sums != nullptr) {
             double ws = (double)acc;
+            constexpr int SEG = TPL >= 64 ? 64 : TPL;   // one row = SEG consecutive lanes: segmented reduction
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
+            for (int o = SEG / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, SEG);
             if constexpr (WAVE) {
-                if (lane == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row] = ws;
+                if ((lane & (SEG - 1)) == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row * RPW + sub] = ws;
             } else {   // the wavefronts of a row in the order row_kernel adds them
                 __syncthreads();
                 if (lane == 0) red[wave] = ws;
                 __syncthreads();
                 if (wsub == 0 && lane == 0 && cur.on) {
                     double t = 0.0;
-                    for (int w = 0; w < WPL; ++w) t += red[line * WPL + w];
+                    for (int w = 0; w < WPL; ++w) t += red[uline * WPL + w];
                     a.sums[(size_t)cur.slice * a.n1 + cur.row] = t;
                 }
             }
@@ -899,11 +914,11 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     };
 
     {
-        const unsigned step = gridDim.x * LB;
-        unsigned g = blockIdx.x * LB + line;
+        const unsigned step = gridDim.x * UPB;
+        unsigned g = blockIdx.x * UPB + uline;
         Where cur = locate(g);
         Where nxt = locate(g + step);
-        for (unsigned g0 = blockIdx.x * LB; g0 < total; g0 += step) {
+        for (unsigned g0 = blockIdx.x * UPB; g0 < total; g0 += step) {
 #if P3D_PIPE64_LOCKSTEP
             if (WAVE) __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
 #endif
@@ -1152,7 +1167,7 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
     const bool extra = a.adaptive || a.write_out || a.done != nullptr;
     const bool compact = bits && a.xc != nullptr;
     hipError_t e = hipSuccess;
-    if constexpr (Plan<N>::TPL % 64 == 0 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
+    if constexpr (Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
         // the wave-uniform variant (it also honours the per-slice `done` flags of the early exit; APOCS and the per-iteration
         // store stay with the generic kernels)
         if (compact && !a.adaptive && !a.write_out && a.bits64 != nullptr && a.cbase != nullptr) {
@@ -1161,7 +1176,8 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
     do {                                                                                                        \
         constexpr int LB64 = pipe64_rows<N>();                                                                  \
         constexpr size_t lds64 = pipe64_lds_bytes<N>();                                                         \
-        const long groups64 = ((long)a.nslices * a.n1 + LB64 - 1) / LB64;                                       \
+        constexpr int RPW64 = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL, UPB64 = LB64 / RPW64;                 \
+        const long groups64 = ((long)a.nslices * (a.n1 / RPW64) + UPB64 - 1) / UPB64;                           \
         int per_cu64 = (int)((160 * 1024) / lds64);            /* workgroups a CU holds: LDS ... */             \
         const int by_waves = 16 / (pipe64_threads<N>() / 64);  /* ... and 4 waves per SIMD */                   \
         if (per_cu64 > by_waves) per_cu64 = by_waves;                                                           \

@@ -489,7 +489,7 @@ def test_time2freq_closed_form_and_round_trip(ffi, nt, shape, up, real_only):
         assert rel_l2(lo, want) < 5e-6
 
 
-@pytest.mark.parametrize("nil,nxl", [(64, 64), (32, 1024), (16, 2048)])   # generic / wave-uniform (1 and 2 waves per row) row pass
+@pytest.mark.parametrize("nil,nxl", [(64, 64), (32, 1024), (16, 2048), (32, 512)])   # generic / wave-uniform row pass (1, 2 waves per row; 2 rows per wave)
 def test_early_exit_hands_back_the_converged_iterate(nil, nxl):
     """eps > 0 on the tuned path: slices leave the loop at different iterations; the iterate of a finished slice is recovered from
     the work buffer by the "finalize" launch (no per-iteration store).  It must be the oracle's iterate of that very iteration,
@@ -586,10 +586,12 @@ def test_slower_equivalent_paths_behind_the_switches(switch, monkeypatch):
 
 @pytest.mark.parametrize("nil,nxl,dtype", [(64, 1024, np.complex64), (100, 1024, np.complex64), (256, 1024, np.float32),
                                            (1000, 1024, np.complex64), (48, 2048, np.complex64), (50, 2048, np.float32),
-                                           (24, 4096, np.complex64)])
+                                           (24, 4096, np.complex64), (64, 512, np.complex64), (50, 256, np.complex64),
+                                           (100, 128, np.float32), (200, 512, np.float32), (33, 512, np.complex64)])
 def test_wave_uniform_row_pass_is_the_generic_one(nil, nxl, dtype, monkeypatch):
-    """Rows of 1024 / 2048 / 4096 samples are 1 / 2 / 4 whole wavefronts: their steady-state pass keeps slice / row / mask /
-    emptied-block bookkeeping in scalar registers (row_pipe64_kernel).  Same arithmetic as the generic passes (P3D_NO_PIPE64=1:
+    """Rows of 1024 / 2048 / 4096 samples are 1 / 2 / 4 whole wavefronts, rows of 512 / 256 / 128 samples sit 2 / 4 / 8 to a
+    wavefront (an odd number of rows -- the last case -- falls back to the generic pass): their steady-state pass keeps slice / row /
+    mask / emptied-block bookkeeping in scalar registers (row_pipe64_kernel).  Same arithmetic as the generic passes (P3D_NO_PIPE64=1:
     the generic persistent kernel for 1024, the one-launch-per-iteration row_kernel beyond): identical results, with the sparse
     shortcut and without, for tuned and flexible column lengths, and both match the oracle."""
     import pseudo_3d_interpolation_amd.functions.POCS as P
