@@ -700,18 +700,20 @@ row_pipe_kernel(const RowArgs a)
 }
 
 // =================================================================================================
-// persistent row pass for rows of whole wavefronts (TPL = 64, 128, 256), binary mask, compact observed samples
+// persistent row pass in units of wavefronts (rows of 128 ... 4096 samples), binary mask, compact observed samples
 // =================================================================================================
 // Same arithmetic as row_kernel<N, ROW_MID, true> / row_pipe_kernel (bit for bit); what changes is WHERE the bookkeeping runs.
-// Every wavefront works on 64 consecutive columns per register q, so slice, row, every base address, the trace mask of those
-// columns and the emptied-block flags of the slice are wave-uniform: they live in scalar registers (s_load / SALU), predicates
+// A wavefront works on 64 consecutive columns of one row per register q (rows of 1024 / 2048 / 4096 samples = 1 / 2 / 4
+// wavefronts) or on the same columns of 2 / 4 / 8 adjacent rows (512 / 256 / 128 samples), so slice, row, every base address,
+// the trace mask of those samples and the emptied-block flags of the slice are wave-uniform: they live in scalar registers (s_load / SALU), predicates
 // are 64-bit lane masks applied as EXEC or as the selector of v_cndmask, the rank of a lane among the observed traces is
 // v_mbcnt, and every access is "scalar base + one 32-bit lane offset".  The generic kernel spends ~40 % of its vector
 // instructions on exactly that bookkeeping.  Rows of 2048 / 4096 samples (2 / 4 wavefronts, workgroup barriers inside the
 // transforms) had no persistent pass at all: each 2-row workgroup of row_kernel re-reads 32 / 64 KiB of twiddle tables.
 // Measured on the headline cube (profiles/r01_rowpass_wave_uniform.txt): sixteen rows per workgroup (1024 threads, one workgroup
-// of 154 KiB LDS per CU, 4 waves per SIMD inside the 128-VGPR budget) beats three 4-row workgroups; the row-ahead prefetch of the
-// work buffer buys nothing once most of its blocks are skipped, the early request of the observed samples a little.
+// of 154 KiB LDS per CU, 4 waves per SIMD inside the 128-VGPR budget) beats three 4-row workgroups; a row-ahead prefetch of the
+// work buffer (tried: 32 more VGPRs) buys nothing once most of its blocks are skipped, the early request of the observed samples a
+// little.
 #ifndef P3D_PIPE64_LOCKSTEP
 #define P3D_PIPE64_LOCKSTEP 1
 #endif
@@ -719,9 +721,6 @@ row_pipe_kernel(const RowArgs a)
 #define P3D_PIPE64_MAXROWS 2
 #endif
 
-#ifndef P3D_PIPE64_PREFETCH
-#define P3D_PIPE64_PREFETCH 0    // work-buffer loads of the next row in flight during this row (32 VGPRs)
-#endif
 #ifndef P3D_PIPE64_OBS_EARLY
 #define P3D_PIPE64_OBS_EARLY 1   // observed samples requested before the inverse transform instead of after it (32 VGPRs across it)
 #endif
