@@ -422,6 +422,19 @@ def test_batching_is_transparent(P, orc):
     assert np.array_equal(a, b)
 
 
+def test_double_precision_cubes_are_converted_on_their_way_in(P, orc):
+    """complex128 / float64 cubes go through the page-locked staging buffers of the chunk pipeline (parallel slab copies with the
+    dtype conversion folded in); the result is the single-precision cube's, cast back, and keeps the caller's dtype."""
+    _, mask, obs = orc.synthetic_cube(1024, 512, 9, 0.6)          # 9 x 4 MiB: two slabs per copy, chunks of 4 slices
+    params = dict(niter=5, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2, batch_slices=4)
+    a = P.pocs_cube(obs, mask, **params)
+    b = P.pocs_cube(obs.astype(np.complex128), mask, **params)
+    assert b.dtype == np.complex128 and np.array_equal(b, a.astype(np.complex128))
+    r = P.pocs_cube(obs.real.astype(np.float64), mask, **dict(params, thresh_op="hard"))
+    r32 = P.pocs_cube(obs.real.astype(np.float32), mask, **dict(params, thresh_op="hard"))
+    assert r.dtype == np.float64 and np.array_equal(r, r32.astype(np.float64))
+
+
 def test_compact_observed_samples_path_is_exact(ffi, orc, monkeypatch):
     """The steady-state row pass reads the observed samples from a compact copy when x is zero at every
     missing trace; a cube that violates that (the API allows it: POCS.py:619 adds alpha*x everywhere) must take
