@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the extra run with the sparse-spectrum shortcut switched off")
     return ap.parse_args()
 
 
@@ -191,7 +192,7 @@ def main():
     # ---- the same job with the sparse-spectrum shortcut switched off (reported beside `value`, rank 0 only) ----
     nz_fraction = plan.last_sparsity()
     dense_its = None
-    if rank == 0 and nz_fraction >= 0:
+    if rank == 0 and nz_fraction >= 0 and not args.no_dense:
         os.environ["P3D_NO_SPARSE"] = "1"
         torch.cuda.synchronize()
         d0 = time.perf_counter()
@@ -216,7 +217,7 @@ def main():
     # ---- per-kernel durations of the same job, HIP events on the plan's stream --------------------
     roof = None
     if rank == 0 and not args.no_profile:
-        job(min(K, 20), profile=True)
+        job(K, profile=True)   # the same job once more with HIP events around every pass (same schedule, same sparsity as the timed one)
         prof = plan.last_profile()
         it_ms = prof["colpass_ms"] + prof["rowpass_ms"]
         kept = plan.last_sparsity()
