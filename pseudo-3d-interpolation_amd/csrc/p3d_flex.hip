@@ -92,6 +92,18 @@ int pick_col_tile(int n)
     for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
     return 0;
 }
+size_t row_lds_inplace(int n, int LB) { const size_t L = flex_factors(n).m; return sizeof(c32) * (LB * L + L); }
+// in-place passes (flex_pass_inplace): composite in-register radices only, at most one butterfly per thread in every pass
+bool flex_inplace_ok(const FlexFactors& pl, int tpr)
+{
+    if (pl.blue || pl.nf <= 0) return false;
+    for (int p = 0; p < pl.nf; ++p) {
+        const int R = pl.f[p];
+        if (R > 16 || R == 11 || R == 13) return false;
+        if (pl.m / R > tpr) return false;
+    }
+    return true;
+}
 int pick_row_lines(int n)   // rows per workgroup at one wavefront per row
 {
     for (int LB : {4, 2, 1}) if (row_lds(n, LB) <= FLEX_LDS_TWO) return LB;
@@ -217,14 +229,77 @@ __device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, i
     }
 }
 
-// All passes of `lines` (= T) interleaved lines in LDS.  first/step: butterfly indices handled by this thread.  Returns the
-// buffer that holds the result.  SYNC: 0 = workgroup barrier, 1 = wavefront-level (one wave owns its lines).
+// SYNC: 0 = workgroup barrier, 1 = wavefront-level (one wave owns its lines)
 template <int SYNC>
 __device__ __forceinline__ void flex_sync()
 {
     if constexpr (SYNC == 0) __syncthreads();
     else exchange_sync<true>();
 }
+
+// The same pass IN PLACE for one line with at most one butterfly per thread (m <= step): every thread reads the inputs of its
+// butterfly into registers, the line's threads synchronise, then the results overwrite the line.  No second buffer: half the
+// LDS per row, twice the resident waves of the row pass (which is latency-bound at 8 waves per CU).
+template <int R1, int R2, int SYNC>
+__device__ __forceinline__ void flex_pass_inplace(c32* A, const c32* tw, int n, int ns, int dir, int first, int step)
+{
+    constexpr int R = R1 * R2;
+    const int m = n / R, tstep = n / (ns * R);
+    Radix<R1, R2> rx;
+    rx.load(tw, n, dir);
+    c32 v[R];
+    const bool act = first < m;
+    const int jc = act ? first : 0;
+    const int jq = jc / ns, jm = jc - jq * ns;
+    const int j0 = jq * ns * R + jm;
+    {
+        const c32* in = A + jc;
+        const int twi = jm * tstep;
+        v[0] = in[0];
+#pragma unroll
+        for (int t = 1; t < R; ++t) v[t] = in[t * m] * conj_if(tw[t * twi], dir);
+    }
+    flex_sync<SYNC>();   // every input of the pass is in registers
+    if (act) {
+        rx.apply(v, dir);
+        c32* out = A + j0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) out[k * ns] = v[k];
+    }
+}
+
+template <int SYNC>
+__device__ void flex_fft_inplace(c32* A, const c32* tw, const FlexFactors& pl, int dir, int first, int step)
+{
+    const int n = pl.m;
+    int ns = 1;
+    for (int p = 0; p < pl.nf; ++p) {
+        const int R = pl.f[p];
+        switch (R) {
+#define P3D_FLEX_PASS(R1, R2) flex_pass_inplace<R1, R2, SYNC>(A, tw, n, ns, dir, first, step); break
+            case 2: P3D_FLEX_PASS(2, 1);
+            case 3: P3D_FLEX_PASS(3, 1);
+            case 4: P3D_FLEX_PASS(4, 1);
+            case 5: P3D_FLEX_PASS(5, 1);
+            case 6: P3D_FLEX_PASS(2, 3);
+            case 7: P3D_FLEX_PASS(7, 1);
+            case 8: P3D_FLEX_PASS(2, 4);
+            case 9: P3D_FLEX_PASS(3, 3);
+            case 10: P3D_FLEX_PASS(2, 5);
+            case 12: P3D_FLEX_PASS(3, 4);
+            case 14: P3D_FLEX_PASS(2, 7);
+            case 15: P3D_FLEX_PASS(3, 5);
+            case 16: P3D_FLEX_PASS(4, 4);
+#undef P3D_FLEX_PASS
+            default: break;   // never: flex_inplace_ok() admits the radices above only
+        }
+        flex_sync<SYNC>();
+        ns *= R;
+    }
+}
+
+// All passes of `lines` (= T) interleaved lines in LDS.  first/step: butterfly indices handled by this thread.  Returns the
+// buffer that holds the result.  SYNC: 0 = workgroup barrier, 1 = wavefront-level (one wave owns its lines).
 
 template <int SYNC>
 __device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, int dir, int lines, int istr, int lstr, int first, int step)
@@ -430,15 +505,16 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
 // TPR threads per row (64: one wavefront, wave-level synchronisation only; 128: two wavefronts and workgroup barriers -- half the
 // rows per workgroup, half the LDS, twice the resident waves), LB rows per workgroup; modes ROW_FIRST / ROW_MID / ROW_LAST as in
 // row_kernel (p3d_kernels.hpp)
-template <int TPR>
+template <int TPR, bool INPL>
 __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
 {
+    constexpr bool inpl = INPL;
     constexpr int SYNC = TPR == 64 ? 1 : 0;
     __shared__ double rsum[4];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int n = pl.n, L = pl.m, tid = threadIdx.x, lane = tid % TPR, line = tid / TPR;
     c32* tw = reinterpret_cast<c32*>(smem_raw);
-    c32* A = tw + L + (size_t)line * 2 * L;
+    c32* A = tw + L + (size_t)line * (inpl ? 1 : 2) * L;   // inpl: in-place passes, one buffer per row (flex_inplace_ok)
     c32* B = A + L;
     const int slice = blockIdx.y, row = blockIdx.x * LB + line;
     const bool valid = row < a.n1;
@@ -496,7 +572,8 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
         flex_sync<SYNC>();
-        X = flex_transform<SYNC>(A, B, tw, a.tw, pl, INV, 1, 1, L, lane, TPR);
+        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, INV, lane, TPR);
+        else X = flex_transform<SYNC>(A, B, tw, a.tw, pl, INV, 1, 1, L, lane, TPR);
         for (int i = lane; i < n; i += TPR) {
             c32 xn = X[i] * a.scale;
             float m = 0.f;
@@ -541,7 +618,8 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        X = flex_transform<SYNC>(X, Y, tw, a.tw, pl, FWD, 1, 1, L, lane, TPR);
+        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, FWD, lane, TPR);
+        else X = flex_transform<SYNC>(X, Y, tw, a.tw, pl, FWD, 1, 1, L, lane, TPR);
         if (valid)
             for (int i = lane; i < n; i += TPR) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
     }
@@ -559,14 +637,31 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;
-    const int lb = two ? LB / 2 : LB;
-    const size_t lds = row_lds(n, lb);
-    const void* kern = two ? reinterpret_cast<const void*>(flex_row_kernel<128>) : reinterpret_cast<const void*>(flex_row_kernel<64>);
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
-    if (e != hipSuccess) return e;
+    static const bool no_inplace = getenv("P3D_FLEX_NO_INPLACE") != nullptr;
+    bool two_ = two;
+    int inpl = 0;
+    if (!no_inplace) {
+        if (flex_inplace_ok(pl, two ? 128 : 64)) inpl = 1;
+        else if (!two && flex_inplace_ok(pl, 128)) { inpl = 1; two_ = true; }
+    }
+    int lb = two_ ? LB / 2 : LB;
+    if (lb < 1) lb = 1;
+    if (inpl) {   // 256 threads per workgroup; the single buffers let four of them share a CU
+        lb = two_ ? 2 : 4;
+        while (lb > 1 && row_lds_inplace(n, lb) > FLEX_LDS_MAX) lb /= 2;
+    }
+    const size_t lds = inpl ? row_lds_inplace(n, lb) : row_lds(n, lb);
     const dim3 grid((a.n1 + lb - 1) / lb, a.nslices);
-    if (two) flex_row_kernel<128><<<grid, 128 * lb, lds, st>>>(a, pl, mode, lb);
-    else flex_row_kernel<64><<<grid, 64 * lb, lds, st>>>(a, pl, mode, lb);
+#define P3D_FLEX_ROW(TPR, IP)                                                                                                  \
+    do {                                                                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_kernel<TPR, IP>),                            \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);                     \
+        if (e != hipSuccess) return e;                                                                                         \
+        flex_row_kernel<TPR, IP><<<grid, TPR * lb, lds, st>>>(a, pl, mode, lb);                                                \
+    } while (0)
+    if (two_) { if (inpl) P3D_FLEX_ROW(128, true); else P3D_FLEX_ROW(128, false); }
+    else { if (inpl) P3D_FLEX_ROW(64, true); else P3D_FLEX_ROW(64, false); }
+#undef P3D_FLEX_ROW
     return hipGetLastError();
 }
 
