@@ -114,9 +114,82 @@ int pick_row_lines(int n)   // rows per workgroup at one wavefront per row
 __device__ __forceinline__ c32 conj_if(c32 w, int dir) { return dir > 0 ? c32{w.x, -w.y} : w; }
 __device__ __forceinline__ c32 mul_i(c32 a, int dir) { return dir > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x}; }   // a * (dir * i)
 
-// ---- small DFTs on registers: X[k] = sum_t x[t] W^(t k), W = exp(dir * 2 pi i / R); w[q] = W^q ---------------------------------
+// exp(2 pi i q / R) for the in-register butterflies: compile-time constants (they used to be read from the twiddle table once per
+// pass: wave-uniform values that the compiler parked in scalar registers -- and spilled, one v_readlane per use)
 template <int R>
-__device__ __forceinline__ void dft_small(c32 (&x)[R], const c32 (&w)[R], int dir)
+struct Roots;
+template <>
+struct Roots<2> {
+    static constexpr float c[2] = {1.000000000e+00f, -1.000000000e+00f};
+    static constexpr float s[2] = {0.000000000e+00f, 1.224646800e-16f};
+};
+template <>
+struct Roots<3> {
+    static constexpr float c[3] = {1.000000000e+00f, -5.000000000e-01f, -5.000000000e-01f};
+    static constexpr float s[3] = {0.000000000e+00f, 8.660254040e-01f, -8.660254040e-01f};
+};
+template <>
+struct Roots<4> {
+    static constexpr float c[4] = {1.000000000e+00f, 6.123234000e-17f, -1.000000000e+00f, -1.836970200e-16f};
+    static constexpr float s[4] = {0.000000000e+00f, 1.000000000e+00f, 1.224646800e-16f, -1.000000000e+00f};
+};
+template <>
+struct Roots<5> {
+    static constexpr float c[5] = {1.000000000e+00f, 3.090169940e-01f, -8.090169940e-01f, -8.090169940e-01f, 3.090169940e-01f};
+    static constexpr float s[5] = {0.000000000e+00f, 9.510565160e-01f, 5.877852520e-01f, -5.877852520e-01f, -9.510565160e-01f};
+};
+template <>
+struct Roots<6> {
+    static constexpr float c[6] = {1.000000000e+00f, 5.000000000e-01f, -5.000000000e-01f, -1.000000000e+00f, -5.000000000e-01f, 5.000000000e-01f};
+    static constexpr float s[6] = {0.000000000e+00f, 8.660254040e-01f, 8.660254040e-01f, 1.224646800e-16f, -8.660254040e-01f, -8.660254040e-01f};
+};
+template <>
+struct Roots<7> {
+    static constexpr float c[7] = {1.000000000e+00f, 6.234898020e-01f, -2.225209340e-01f, -9.009688680e-01f, -9.009688680e-01f, -2.225209340e-01f, 6.234898020e-01f};
+    static constexpr float s[7] = {0.000000000e+00f, 7.818314820e-01f, 9.749279120e-01f, 4.338837390e-01f, -4.338837390e-01f, -9.749279120e-01f, -7.818314820e-01f};
+};
+template <>
+struct Roots<8> {
+    static constexpr float c[8] = {1.000000000e+00f, 7.071067810e-01f, 6.123234000e-17f, -7.071067810e-01f, -1.000000000e+00f, -7.071067810e-01f, -1.836970200e-16f, 7.071067810e-01f};
+    static constexpr float s[8] = {0.000000000e+00f, 7.071067810e-01f, 1.000000000e+00f, 7.071067810e-01f, 1.224646800e-16f, -7.071067810e-01f, -1.000000000e+00f, -7.071067810e-01f};
+};
+template <>
+struct Roots<9> {
+    static constexpr float c[9] = {1.000000000e+00f, 7.660444430e-01f, 1.736481780e-01f, -5.000000000e-01f, -9.396926210e-01f, -9.396926210e-01f, -5.000000000e-01f, 1.736481780e-01f, 7.660444430e-01f};
+    static constexpr float s[9] = {0.000000000e+00f, 6.427876100e-01f, 9.848077530e-01f, 8.660254040e-01f, 3.420201430e-01f, -3.420201430e-01f, -8.660254040e-01f, -9.848077530e-01f, -6.427876100e-01f};
+};
+template <>
+struct Roots<10> {
+    static constexpr float c[10] = {1.000000000e+00f, 8.090169940e-01f, 3.090169940e-01f, -3.090169940e-01f, -8.090169940e-01f, -1.000000000e+00f, -8.090169940e-01f, -3.090169940e-01f, 3.090169940e-01f, 8.090169940e-01f};
+    static constexpr float s[10] = {0.000000000e+00f, 5.877852520e-01f, 9.510565160e-01f, 9.510565160e-01f, 5.877852520e-01f, 1.224646800e-16f, -5.877852520e-01f, -9.510565160e-01f, -9.510565160e-01f, -5.877852520e-01f};
+};
+template <>
+struct Roots<12> {
+    static constexpr float c[12] = {1.000000000e+00f, 8.660254040e-01f, 5.000000000e-01f, 6.123234000e-17f, -5.000000000e-01f, -8.660254040e-01f, -1.000000000e+00f, -8.660254040e-01f, -5.000000000e-01f, -1.836970200e-16f, 5.000000000e-01f, 8.660254040e-01f};
+    static constexpr float s[12] = {0.000000000e+00f, 5.000000000e-01f, 8.660254040e-01f, 1.000000000e+00f, 8.660254040e-01f, 5.000000000e-01f, 1.224646800e-16f, -5.000000000e-01f, -8.660254040e-01f, -1.000000000e+00f, -8.660254040e-01f, -5.000000000e-01f};
+};
+template <>
+struct Roots<14> {
+    static constexpr float c[14] = {1.000000000e+00f, 9.009688680e-01f, 6.234898020e-01f, 2.225209340e-01f, -2.225209340e-01f, -6.234898020e-01f, -9.009688680e-01f, -1.000000000e+00f, -9.009688680e-01f, -6.234898020e-01f, -2.225209340e-01f, 2.225209340e-01f, 6.234898020e-01f, 9.009688680e-01f};
+    static constexpr float s[14] = {0.000000000e+00f, 4.338837390e-01f, 7.818314820e-01f, 9.749279120e-01f, 9.749279120e-01f, 7.818314820e-01f, 4.338837390e-01f, 1.224646800e-16f, -4.338837390e-01f, -7.818314820e-01f, -9.749279120e-01f, -9.749279120e-01f, -7.818314820e-01f, -4.338837390e-01f};
+};
+template <>
+struct Roots<15> {
+    static constexpr float c[15] = {1.000000000e+00f, 9.135454580e-01f, 6.691306060e-01f, 3.090169940e-01f, -1.045284630e-01f, -5.000000000e-01f, -8.090169940e-01f, -9.781476010e-01f, -9.781476010e-01f, -8.090169940e-01f, -5.000000000e-01f, -1.045284630e-01f, 3.090169940e-01f, 6.691306060e-01f, 9.135454580e-01f};
+    static constexpr float s[15] = {0.000000000e+00f, 4.067366430e-01f, 7.431448250e-01f, 9.510565160e-01f, 9.945218950e-01f, 8.660254040e-01f, 5.877852520e-01f, 2.079116910e-01f, -2.079116910e-01f, -5.877852520e-01f, -8.660254040e-01f, -9.945218950e-01f, -9.510565160e-01f, -7.431448250e-01f, -4.067366430e-01f};
+};
+template <>
+struct Roots<16> {
+    static constexpr float c[16] = {1.000000000e+00f, 9.238795330e-01f, 7.071067810e-01f, 3.826834320e-01f, 6.123234000e-17f, -3.826834320e-01f, -7.071067810e-01f, -9.238795330e-01f, -1.000000000e+00f, -9.238795330e-01f, -7.071067810e-01f, -3.826834320e-01f, -1.836970200e-16f, 3.826834320e-01f, 7.071067810e-01f, 9.238795330e-01f};
+    static constexpr float s[16] = {0.000000000e+00f, 3.826834320e-01f, 7.071067810e-01f, 9.238795330e-01f, 1.000000000e+00f, 9.238795330e-01f, 7.071067810e-01f, 3.826834320e-01f, 1.224646800e-16f, -3.826834320e-01f, -7.071067810e-01f, -9.238795330e-01f, -1.000000000e+00f, -9.238795330e-01f, -7.071067810e-01f, -3.826834320e-01f};
+};
+// W^q with W = exp(dir * 2 pi i / R)
+template <int R>
+__device__ __forceinline__ c32 root(int q, int dir) { return c32{Roots<R>::c[q], dir > 0 ? Roots<R>::s[q] : -Roots<R>::s[q]}; }
+
+// ---- small DFTs on registers: X[k] = sum_t x[t] W^(t k), W = exp(dir * 2 pi i / R) -------------------------------------------
+template <int R>
+__device__ __forceinline__ void dft_small(c32 (&x)[R], int dir)
 {
     if constexpr (R == 2) {
         const c32 a = x[0] + x[1], b = x[0] - x[1];
@@ -144,7 +217,7 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R], const c32 (&w)[R], int di
             c32 A = xin, B{0.f, 0.f};
 #pragma unroll
             for (int q = 1; q <= H; ++q) {
-                const c32 wq = w[(q * k) % R];
+                const c32 wq = root<R>((q * k) % R, dir);
                 A = A + sp[q - 1] * wq.x;
                 B = B + dm[q - 1] * wq.y;
             }
@@ -158,24 +231,10 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R], const c32 (&w)[R], int di
 template <int R1, int R2>
 struct Radix {
     static constexpr int R = R1 * R2;
-    c32 wR[R];    // W_R^q   (only q = k1*t2 are used; R2 == 1: the DFT constants themselves)
-    c32 w1[R1];   // W_R1^q
-    c32 w2[R2];   // W_R2^q
-    __device__ __forceinline__ void load(const c32* tw, int n, int dir)
-    {
-#pragma unroll
-        for (int q = 0; q < R; ++q) wR[q] = conj_if(tw[q * (n / R)], dir);
-        if constexpr (R2 > 1) {
-#pragma unroll
-            for (int q = 0; q < R1; ++q) w1[q] = conj_if(tw[q * (n / R1)], dir);
-#pragma unroll
-            for (int q = 0; q < R2; ++q) w2[q] = conj_if(tw[q * (n / R2)], dir);
-        }
-    }
     __device__ __forceinline__ void apply(c32 (&v)[R], int dir) const
     {
         if constexpr (R2 == 1) {
-            dft_small<R>(v, wR, dir);
+            dft_small<R>(v, dir);
         } else {
             c32 u[R];   // u[k1 * R2 + t2]
 #pragma unroll
@@ -183,16 +242,16 @@ struct Radix {
                 c32 a[R1];
 #pragma unroll
                 for (int t1 = 0; t1 < R1; ++t1) a[t1] = v[R2 * t1 + t2];
-                dft_small<R1>(a, w1, dir);
+                dft_small<R1>(a, dir);
 #pragma unroll
-                for (int k1 = 0; k1 < R1; ++k1) u[k1 * R2 + t2] = (k1 * t2) % R == 0 ? a[k1] : a[k1] * wR[(k1 * t2) % R];
+                for (int k1 = 0; k1 < R1; ++k1) u[k1 * R2 + t2] = (k1 * t2) % R == 0 ? a[k1] : a[k1] * root<R>((k1 * t2) % R, dir);
             }
 #pragma unroll
             for (int k1 = 0; k1 < R1; ++k1) {
                 c32 b[R2];
 #pragma unroll
                 for (int t2 = 0; t2 < R2; ++t2) b[t2] = u[k1 * R2 + t2];
-                dft_small<R2>(b, w2, dir);
+                dft_small<R2>(b, dir);
 #pragma unroll
                 for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
             }
@@ -208,7 +267,6 @@ __device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, i
     constexpr int R = R1 * R2;
     const int m = n / R, tstep = n / (ns * R);
     Radix<R1, R2> rx;
-    rx.load(tw, n, dir);   // constants: once per pass, not per butterfly
     const int total = m * lines;
     for (int b = first; b < total; b += step) {
         int l, j;
@@ -246,7 +304,6 @@ __device__ __forceinline__ void flex_pass_inplace(c32* A, const c32* tw, int n, 
     constexpr int R = R1 * R2;
     const int m = n / R, tstep = n / (ns * R);
     Radix<R1, R2> rx;
-    rx.load(tw, n, dir);
     c32 v[R];
     const bool act = first < m;
     const int jc = act ? first : 0;
