@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     if (mode == ROW_FIRST) {
         for (int i = lane; i < n; i += TPR) {
             const c32 x = valid ? obs_at(i) : c32{0.f, 0.f};
-            acc += sqrtf(x.x * x.x + x.y * x.y);
+            acc += abs_c32(x);
             if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
                 const float m = mrow ? mrow[i] : 0.f;
                 const float w = 1.0f - a.alpha * m;
@@ -623,9 +623,11 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     } else {
         // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros
         const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
+        const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);   // column tiles are 1, 2, 4 or 8 columns wide (pick_col_tile)
+#pragma unroll 4
         for (int i = lane; i < n; i += TPR) {
             bool kept = valid;
-            if (nzf) kept = kept && nzf[a.nz_col_t >= 8 ? (i >> 3) / (a.nz_col_t >> 3) : (i / a.nz_col_t)] != 0;
+            if (nzf) kept = kept && nzf[i >> tsh] != 0;
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
         flex_sync<SYNC>();
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
                 const float w = 1.0f - a.alpha * m;        // POCS.py:616
                 xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
             }
-            acc += sqrtf(xn.x * xn.x + xn.y * xn.y);
+            acc += abs_c32(xn);   // hardware square root: the sums only feed the convergence test
             if ((mode == ROW_LAST || a.write_out) && valid) {
                 if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = xn;
                 else reinterpret_cast<float*>(a.out)[sbase + i] = xn.x;   // np.real(), POCS.py:656
