@@ -137,6 +137,16 @@ int p3d_pocs_run(p3d_plan* plan, const void* x_host, int dtype, const float* mas
                  const uint8_t* active, const p3d_pocs_params* params, void* out_host, int nslices,
                  int32_t* niter_done, double* sums, double* elapsed_ms);
 
+/* The same two calls for a cube in HOST memory spread over several devices from ONE process: contiguous blocks of the slice axis
+ * (the split of sharding.slice_block) go to devices[0 .. ndev-1], one host thread and one plan per entry (a device may be listed
+ * more than once), chunks of ~256 MiB; every device copies its own block back, there is no collective.  The reference's
+ * counterpart is the dask worker farm over slices (cube_POCS_interpolation_3D.py:291-340).  Arguments as p3d_pocs_stats /
+ * p3d_pocs_run; tau is required. */
+int p3d_multi_stats(int ndev, const int* devices, int nil, int nxl, const void* x_host, int dtype, int nslices, double* stats_host);
+int p3d_multi_run(int ndev, const int* devices, int nil, int nxl, const void* x_host, int dtype, const float* mask_host,
+                  const double* tau, const uint8_t* active, const p3d_pocs_params* params, void* out_host, int nslices,
+                  int32_t* niter_done, double* sums);
+
 /* Steps 12 / 14 of the workflow: transform every trace of a (nt, ntraces) time-domain cube (ntraces = nil*nxl, the
  * slice-major layout: sample index slowest) to the frequency domain and back, with the conventions of
  *     xrft.fft(da, dim='twt', shift=False, true_phase=True, true_amplitude=True, shape={dim: nfft})

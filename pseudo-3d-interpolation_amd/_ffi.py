@@ -61,6 +61,9 @@ PROTOTYPES = {
     "p3d_pocs_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_double)]),
+    "p3d_multi_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_multi_run": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "p3d_time2freq": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p,
                                 C.c_void_p]),
     "p3d_freq2time": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int, C.c_int,
@@ -568,3 +571,42 @@ def smooth_slices(x, kind, device=0, **kw):
     else:
         raise ValueError(f"unknown smoothing filter {kind!r}")
     return out
+
+
+def _host_cube(x):
+    x = np.asarray(x)
+    if x.ndim != 3:
+        raise ValueError("expected a cube (nslices, nil, nxl)")
+    if np.iscomplexobj(x):
+        return np.ascontiguousarray(x, dtype=np.complex64), P3D_C64
+    return np.ascontiguousarray(x, dtype=np.float32), P3D_F32
+
+
+def multi_stats(x, devices):
+    """p3d_multi_stats: the statistics of every slice of a host cube, blocks of slices on the listed devices (one process)."""
+    xc, dt = _host_cube(x)
+    n, nil, nxl = xc.shape
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    st = np.empty((n, STATS_PER_SLICE), np.float64)
+    check(lib().p3d_multi_stats(len(dev), _ptr(dev), nil, nxl, _ptr(xc), dt, n, _ptr(st)))
+    return st
+
+
+def multi_run(x, mask, tau, niter, devices, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+    """p3d_multi_run: the POCS loop on a host cube, blocks of slices on the listed devices (one process, one thread and one plan
+    per entry).  Returns (out, niter_done, sums)."""
+    xc, dt = _host_cube(x)
+    n, nil, nxl = xc.shape
+    m = np.ascontiguousarray(mask, dtype=np.float32)
+    if m.shape != (nil, nxl):
+        raise ValueError(f"mask shape {m.shape} != {(nil, nxl)}")
+    t = Plan._tau(tau, n, niter)
+    act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+    prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    out = np.empty_like(xc)
+    done = np.zeros(n, np.int32)
+    sums = np.zeros((niter + 1, n), np.float64)
+    check(lib().p3d_multi_run(len(dev), _ptr(dev), nil, nxl, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act),
+                              C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums)))
+    return out, done, sums

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "p3d.h"
@@ -1284,6 +1285,92 @@ int p3d_last_profile(p3d_plan* p, double* col_ms, int* col_n, double* row_ms, in
     if (row_ms) *row_ms = p->prof_row_n ? p->prof_row_ms / p->prof_row_n : 0.0;
     if (row_n) *row_n = p->prof_row_n;
     return P3D_OK;
+}
+
+}  // extern "C"
+
+
+// ---- several devices from one process ----------------------------------------------------------------------------------------
+// Slices are independent (cube_POCS_interpolation_3D.py:314-340 hands them to a farm of workers): contiguous blocks of the slice
+// axis go to the listed devices, one host thread and one plan per entry, each block in chunks of ~256 MiB.  The blocks are host
+// arrays, so every device copies its own results back and no collective is needed.  (One process per GPU with torch.distributed
+// -- sharding.py, bench.py -- is the other way to shard; this entry point serves callers that stay in one process.)
+namespace {
+struct BlockJob { int dev, lo, hi; int rc = P3D_OK; std::string err; };
+
+template <class F>
+int run_blocks(int ndev, const int* devices, int nslices, F&& body)
+{
+    if (ndev < 1 || !devices) return fail(P3D_ERR_INVALID, "no devices");
+    if (nslices < 1) return fail(P3D_ERR_INVALID, "nslices = %d", nslices);
+    std::vector<BlockJob> jobs((size_t)ndev);
+    for (int d = 0; d < ndev; ++d) {   // the same split as sharding.slice_block
+        const int base = nslices / ndev, rem = nslices % ndev;
+        jobs[d].dev = devices[d];
+        jobs[d].lo = d * base + (d < rem ? d : rem);
+        jobs[d].hi = jobs[d].lo + base + (d < rem ? 1 : 0);
+    }
+    std::vector<std::thread> threads;
+    for (auto& j : jobs)
+        if (j.hi > j.lo) threads.emplace_back([&j, &body]() {
+            j.rc = body(j);
+            if (j.rc != P3D_OK) j.err = p3d_last_error();   // the message lives in this thread's storage
+        });
+    for (auto& t : threads) t.join();
+    for (const auto& j : jobs)
+        if (j.rc != P3D_OK) return fail(j.rc, "device %d, slices %d..%d: %s", j.dev, j.lo, j.hi - 1, j.err.c_str());
+    return P3D_OK;
+}
+int chunk_slices(int nil, int nxl, int block) { const long c = (256l << 20) / ((long)nil * nxl * 8); return (int)std::max(1l, std::min((long)block, c)); }
+}  // namespace
+
+extern "C" {
+
+int p3d_multi_stats(int ndev, const int* devices, int nil, int nxl, const void* x, int dtype, int nslices, double* stats)
+{
+    if (!x || !stats) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    const size_t per = (size_t)nil * nxl * (dtype == P3D_C64 ? sizeof(c32) : sizeof(float));
+    return run_blocks(ndev, devices, nslices, [&](BlockJob& j) -> int {
+        const int step = chunk_slices(nil, nxl, j.hi - j.lo);
+        p3d_plan* plan = nullptr;
+        int rc = p3d_plan_create(&plan, j.dev, nil, nxl, step);
+        for (int lo = j.lo; rc == P3D_OK && lo < j.hi; lo += step) {
+            const int n = std::min(step, j.hi - lo);
+            rc = p3d_pocs_stats(plan, (const char*)x + per * lo, dtype, n, stats + (size_t)P3D_STATS_PER_SLICE * lo);
+        }
+        const std::string keep = rc != P3D_OK ? std::string(p3d_last_error()) : std::string();
+        if (plan) p3d_plan_destroy(plan);
+        if (rc != P3D_OK) g_err = keep;
+        return rc;
+    });
+}
+
+int p3d_multi_run(int ndev, const int* devices, int nil, int nxl, const void* x, int dtype, const float* mask, const double* tau,
+                  const uint8_t* active, const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums)
+{
+    if (!x || !mask || !tau || !prm || !out) return fail(P3D_ERR_INVALID, "NULL argument");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    if (prm->niter < 1) return fail(P3D_ERR_INVALID, "niter = %d", prm->niter);
+    const size_t per = (size_t)nil * nxl * (dtype == P3D_C64 ? sizeof(c32) : sizeof(float));
+    const int niter = prm->niter;
+    return run_blocks(ndev, devices, nslices, [&](BlockJob& j) -> int {
+        const int step = chunk_slices(nil, nxl, j.hi - j.lo);
+        p3d_plan* plan = nullptr;
+        int rc = p3d_plan_create(&plan, j.dev, nil, nxl, step);
+        std::vector<double> part(sums ? (size_t)(niter + 1) * step : 0);
+        for (int lo = j.lo; rc == P3D_OK && lo < j.hi; lo += step) {
+            const int n = std::min(step, j.hi - lo);
+            rc = p3d_pocs_run(plan, (const char*)x + per * lo, dtype, mask, tau + (size_t)2 * niter * lo, active ? active + lo : nullptr, prm,
+                              (char*)out + per * lo, n, niter_done ? niter_done + lo : nullptr, sums ? part.data() : nullptr, nullptr);
+            if (rc == P3D_OK && sums)   // [(niter + 1)][n] of this chunk -> columns lo .. lo + n of [(niter + 1)][nslices]
+                for (int k = 0; k <= niter; ++k) std::memcpy(sums + (size_t)k * nslices + lo, part.data() + (size_t)k * n, sizeof(double) * n);
+        }
+        const std::string keep = rc != P3D_OK ? std::string(p3d_last_error()) : std::string();
+        if (plan) p3d_plan_destroy(plan);
+        if (rc != P3D_OK) g_err = keep;
+        return rc;
+    });
 }
 
 }  // extern "C"

@@ -632,3 +632,27 @@ def test_wave_uniform_row_pass_is_the_generic_one(nil, nxl, dtype, monkeypatch):
     assert np.median(err) <= 1e-5 and err.max() <= 2e-3, err
     for key, other in res.items():
         assert np.array_equal(first, other), key
+
+
+def test_one_process_several_devices_entry_point(ffi, orc):
+    """p3d_multi_stats / p3d_multi_run: blocks of slices on the listed devices, one host thread and one plan each (here the same
+    GPU twice and three times: the split, the threads, the chunking and the scatter of the per-iteration sums are what is tested).
+    Results are those of one plan over the whole cube, bit for bit; a bad device is reported, not swallowed."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    nil, nxl, n, niter = 64, 128, 7, 6
+    _, mask, obs = orc.synthetic_cube(nil, nxl, n, 0.5)
+    obs[3] = 0
+    with ffi.Plan(nil, nxl, n) as plan:
+        st = plan.stats(obs)
+        active = st[:, 2] > 0
+        st1 = st.copy()
+        st1[~active] = 1.0
+        tau = P._schedule_from_stats(st1, nil * nxl, "exponential", niter, 0.99, 1e-2, "values")
+        want, done, sums, _ = plan.run(obs, mask, tau, niter, thresh_op="soft", eps=1e-7, active=active)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        assert np.array_equal(ffi.multi_stats(obs, devices), st)
+        got, d2, s2 = ffi.multi_run(obs, mask, tau, niter, devices, thresh_op="soft", eps=1e-7, active=active)
+        assert np.array_equal(got, want) and np.array_equal(d2, done) and np.array_equal(s2, sums)
+    with pytest.raises(ffi.P3DError) as e:
+        ffi.multi_run(obs, mask, tau, niter, [0, 99])
+    assert "device 99" in str(e.value)
