@@ -144,6 +144,35 @@ static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsig
         }
     }
 }
+// Real cubes (row_real_kernel): lane masks over the HALF spectrum.  Register q < 8 of lane l holds column l + 64 q, register
+// q >= 8 reads the mirror column n2 - l - 64 q (n2 = 1024): word (slice, q) bit l = that column's 8-column block kept something.
+static __global__ void nz_real_kernel(const uint8_t* flags, unsigned long long* nzl, unsigned long long* count, int nslices, int tiles, int col_t,
+                                      int n2, const int* done)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslices * 16) return;
+    const int s = i >> 4, q = i & 15;
+    if (done && done[s] != 0) return;
+    const uint8_t* f = flags + (size_t)s * tiles;
+    auto block_kept = [&](int b) -> unsigned {
+        unsigned any = 0;
+        if (col_t >= 8) any = f[b / (col_t / 8)];
+        else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
+        return any ? 1u : 0u;
+    };
+    unsigned long long w = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int e = l + 64 * q, k = q < 8 ? e : n2 - e;
+        w |= (unsigned long long)block_kept(k >> 3) << l;
+    }
+    nzl[i] = w;
+    if (q == 0) {   // statistics: kept blocks of this slice's half spectrum
+        unsigned kept = 0;
+        for (int b = 0; b <= (n2 / 2) >> 3; ++b) kept += block_kept(b);
+        if (kept) atomicAdd(count, (unsigned long long)kept);
+    }
+}
+
 // ---- per-slice sum of the per-row sums, fixed order (bitwise reproducible) ----------------------------------
 static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row, int n1)
 {
@@ -984,14 +1013,30 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.sum_row = 0;
     // rows of finished / empty slices are skipped by the kernels: their partial sums must read as zero
     HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
-    HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
-    reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil);
+    // Real cubes with the hard operator: the spectrum stays Hermitian, so row pairs share one complex transform and the work
+    // buffer holds half the columns (row_real_kernel).  Needs the compact observed samples and the lane-mask tables.
+    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && compact && r.bits64 && r.cbase && !is_flex(p->ops_row) &&
+                     p->ops_row->row_real != nullptr && p->nil % 2 == 0 && p->pipe_wgs > 0 && !getenv("P3D_NO_REAL");
+    if (real_path) {
+        const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
+        if (re == hipErrorNotSupported) real_path = false;
+        else HIP_TRY(re);
+    }
+    if (!real_path) HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
     if (compact) {  // did every unobserved position hold a zero?
         int violation = 0;
         HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
-        if (violation) r.xc = nullptr;
+        if (violation) {
+            r.xc = nullptr;
+            if (real_path) {   // the row-pair passes live on the compact samples: take the complex path from the start
+                real_path = false;
+                HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
+                HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+            }
+        }
     }
+    reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil);
 
     ColArgs c = col_args(p, nslices);
     c.in = p->work;
@@ -1010,12 +1055,18 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         HIP_TRY(hipMemsetAsync(p->nzcount, 0, sizeof(unsigned long long), p->stream));
     }
     p->last_nonzero_fraction = -1.0;
+    const int n2_work = real_path ? p->nxl / 2 + 1 : p->nxl;   // columns of the work buffer
+    const int tiles_work = (n2_work + col_t - 1) / col_t;
+    c.n2 = n2_work;
 
     HIP_TRY(stamp());
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
-        if (sparse && flex_rows) {   // the flexible row pass reads the tile flags themselves; count the kept blocks for the statistics
+        if (sparse && real_path) {
+            nz_real_kernel<<<(nslices * 16 + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, c.done);
+            r.nzl = p->nzl;
+        } else if (sparse && flex_rows) {   // the flexible row pass reads the tile flags themselves; count the kept blocks for the statistics
             nz_count_kernel<<<(nslices * nblocks + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzcount, nslices, p->tiles, col_t, nblocks, c.done);
             r.nzflag = p->nzflag;
             r.nz_tiles = p->tiles;
@@ -1029,7 +1080,10 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         HIP_TRY(stamp());
         r.sum_row = k + 1;
         bool piped = false;
-        if (k + 1 < niter && p->pipe_wgs > 0) {  // steady state: persistent, software-pipelined row pass
+        if (real_path) {
+            HIP_TRY(p->ops_row->row_real(k + 1 < niter ? REAL_MID : REAL_LAST, r, p->pipe_wgs, p->stream));
+            piped = true;
+        } else if (k + 1 < niter && p->pipe_wgs > 0) {  // steady state: persistent, software-pipelined row pass
             const hipError_t pe = p->ops_row->row_pipe(r, p->pipe_wgs, p->stream);
             if (pe == hipSuccess) piped = true;
             else if (pe != hipErrorNotSupported) HIP_TRY(pe);
@@ -1051,7 +1105,8 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
                 f.sums = nullptr;
                 f.done = p->done;
                 f.scale = (float)(1.0 / (double)p->nxl);   // one row transform to undo, not a 2-D one
-                HIP_TRY(p->ops_row->row(ROW_LAST, f, p->stream));
+                if (real_path) HIP_TRY(p->ops_row->row_real(REAL_LAST, f, p->pipe_wgs, p->stream));
+                else HIP_TRY(p->ops_row->row(ROW_LAST, f, p->stream));
             }
         }
     }
@@ -1063,7 +1118,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     unsigned long long kept_blocks = 0;
     if (sparse) HIP_TRY(hipMemcpyAsync(&kept_blocks, p->nzcount, sizeof kept_blocks, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    if (sparse) p->last_nonzero_fraction = (double)kept_blocks / ((double)niter * nslices * nblocks);
+    if (sparse) p->last_nonzero_fraction = (double)kept_blocks / ((double)niter * nslices * (real_path ? (n2_work + 7) / 8 : nblocks));
 
     if (niter_done)
         for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);

@@ -804,7 +804,7 @@ int flex_col_tile(int n) { return pick_col_tile(n); }
 const LineOps* get_flex_ops()
 {
     // tpl = 0 marks the flexible implementation: no packed mask words, no persistent row pass, no sparse-tile flags
-    static const LineOps ops = {0, 0, 0, 0, &flex_row, &flex_col, &flex_no_pipe, 0, 0, nullptr};
+    static const LineOps ops = {0, 0, 0, 0, &flex_row, &flex_col, &flex_no_pipe, 0, 0, nullptr, 0, nullptr, nullptr};
     return &ops;
 }
 

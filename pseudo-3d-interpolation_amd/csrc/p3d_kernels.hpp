@@ -941,6 +941,221 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 }
 
 // =================================================================================================
+// real cubes (float32, time domain): two rows per complex transform, half-spectrum work buffer
+// =================================================================================================
+// x real => fft2(x) is Hermitian, and the hard threshold (a function of |X| alone) keeps it so: columns 0 ... N/2 of the row
+// transforms carry everything.  Rows 2p and 2p + 1 go through ONE complex transform, z = r_a + i r_b:
+//     R_a[k] = (Z[k] + conj Z[N-k]) / 2,   R_b[k] = (Z[k] - conj Z[N-k]) / (2 i),   k = 0 ... N/2,
+// and back: Z[k] = R_a[k] + i R_b[k], Z[N-k] = conj R_a[k] + i conj R_b[k].  The work buffer holds N/2 + 1 columns (the same
+// column-blocked layout, 65 blocks at N = 1024), the column pass is the complex one on half the columns, and a wavefront of this
+// pass owns a row pair: half the transforms, half the bytes of the complex path per row.  Z[N-k] sits in lane 64 - tl, register
+// 15 - q: one cross-lane read per stored element.  The element-wise work (scale, re-insertion, sums) is the arithmetic of the
+// complex path on the real parts; the imaginary part the reference carries along for a real cube is rounding noise (POCS.py:656
+// returns the real part) and is dropped here every iteration instead of once at the end.
+enum RealMode { REAL_FIRST = 0, REAL_MID = 1, REAL_LAST = 2 };
+
+template <int N, int MODE, bool SPARSE>
+__global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(const RowArgs a)
+{
+    using PL = Plan<N>;
+    constexpr int TPL = PL::TPL, PPT = PL::PPT;
+    static_assert(TPL == 64 && PPT == 16, "one wavefront per row pair");
+    constexpr int THREADS = pipe64_threads<N>();
+    constexpr int UPB = THREADS / 64;             // row pairs per workgroup
+    constexpr int LSTR = LdsRow::stride(N);
+    constexpr int HQ = PPT / 2;                   // registers 0 ... HQ-1 hold columns < N/2; register HQ of lane 0 holds column N/2
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + PassTables<N>::slots();
+    const TwOrdered tw{twl};
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    for (int i = tid; i < PassTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
+    __syncthreads();
+    const LdsRow lds{data + wave * LSTR};
+
+    const unsigned pps = (unsigned)a.n1 / 2;                   // row pairs per slice
+    const unsigned total = (unsigned)a.nslices * pps;
+    const unsigned wblk = (unsigned)a.n1 * 8;
+    const size_t wstride = wk_slice_stride(a.n1, N / 2 + 1);
+    const unsigned mlane = 64u - (unsigned)lane;               // column N - e sits (64 - lane) columns into register 15 - q's run
+    const unsigned lane_w = ((unsigned)(lane >> 3) * wblk + (unsigned)(lane & 7)) * 8u;
+    const unsigned lane_wm = ((mlane >> 3) * wblk + (mlane & 7)) * 8u;
+    const size_t qs64 = (size_t)8 * wblk * 8u;
+
+    typedef const unsigned long long __attribute__((address_space(4))) * kmask_t;
+    typedef const unsigned __attribute__((address_space(4))) * kuint_t;
+    typedef const int __attribute__((address_space(4))) * kint_t;
+    const kmask_t k_bits = (kmask_t)a.bits64, k_nzl = (kmask_t)a.nzl;
+    const kuint_t k_cbase = (kuint_t)a.cbase;
+    const kint_t k_done = (kint_t)a.done;
+    auto opaque = [](unsigned o) -> unsigned { asm volatile("" : "+v"(o)); return o; };
+    auto qstep = [&]() -> size_t { size_t qs = qs64; asm volatile("" : "+s"(qs)); return qs; };
+    const float w_obs = 1.0f - a.alpha * 1.0f;
+
+    const unsigned step = gridDim.x * UPB;
+    for (unsigned u = blockIdx.x * UPB + wave, u0 = blockIdx.x * UPB; u0 < total; u += step, u0 += step) {
+        if (MODE != REAL_FIRST) __syncthreads();   // lock-step: adjacent row pairs complete the 128-byte lines of a column block
+        const bool in_range = u < total;
+        const unsigned uu = in_range ? u : 0u;
+        const unsigned slice = uu / pps, pr = uu - slice * pps, ra = 2 * pr;
+        int dn = 0;
+        if (k_done != nullptr) dn = k_done[slice];
+        bool on = in_range;
+        if (MODE == REAL_MID) on = on && dn == 0;
+        if (MODE == REAL_LAST) on = on && (a.only_done ? dn == a.only_done : dn <= 0);
+        if (MODE == REAL_FIRST) on = on && dn == 0;
+        char* const wb = reinterpret_cast<char*>(a.work) + (slice * wstride + (size_t)ra * 8) * 8;   // row a; row b is 64 bytes on
+        const size_t xrow = ((size_t)slice * a.n1 + ra) * N;                                          // row-major cubes
+        // mask words and compact bases of the two rows (tables of the complex pass: one word per row and register)
+        unsigned long long ma[PPT], mb[PPT];
+        unsigned ca[PPT], cb[PPT];
+        {
+            const kmask_t m0 = k_bits + pipe64_word(ra, 1, 0, 0);
+            const kuint_t c0 = k_cbase + pipe64_word(ra, 1, 0, 0);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) { ma[q] = m0[q]; mb[q] = m0[PPT + q]; ca[q] = c0[q]; cb[q] = c0[PPT + q]; }
+        }
+        const char* const xcb = reinterpret_cast<const char*>(a.xc) + (size_t)slice * a.nobs * 4u;
+        c32 v[PPT];
+        float oa[PPT], ob[PPT];
+
+        if (MODE == REAL_FIRST) {
+            // ---- the observed rows themselves; their compact copy for the later passes ----
+            const float* const x = reinterpret_cast<const float*>(a.x) + xrow;
+            bool bad = false;
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const float xa = x[lane + 64 * q], xb = x[N + lane + 64 * q];
+                const bool seta = __builtin_amdgcn_inverse_ballot_w64(ma[q]), setb = __builtin_amdgcn_inverse_ballot_w64(mb[q]);
+                const unsigned rka = __builtin_amdgcn_mbcnt_hi((unsigned)(ma[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma[q], 0u));
+                const unsigned rkb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
+                if (on && a.xc != nullptr) {
+                    float* const xc = reinterpret_cast<float*>(a.xc) + (size_t)slice * a.nobs;
+                    if (seta) xc[ca[q] + rka] = xa;
+                    if (setb) xc[cb[q] + rkb] = xb;
+                }
+                bad = bad || (!seta && xa != 0.f) || (!setb && xb != 0.f);
+                sa += fabsf(xa);
+                sb += fabsf(xb);
+                v[q] = c32{xa, xb};
+            }
+            if (on && bad && a.violation != nullptr) atomicOr(a.violation, 1);
+            if (a.sums != nullptr) {
+                double da = (double)sa, db = (double)sb;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { da += __shfl_down(da, o, 64); db += __shfl_down(db, o, 64); }
+                if (lane == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + 1] = db; }
+            }
+        } else {
+            // ---- half spectra of the two rows -> Z = R_a + i R_b on all N columns ----
+            const kmask_t nz = k_nzl + (size_t)slice * PPT;
+            unsigned long long nzw[PPT];
+            if (SPARSE) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) nzw[q] = nz[q];
+            }
+            const size_t qs = qstep();
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const bool mirror = q >= HQ;
+                const char* const b = wb + (size_t)(mirror ? PPT - 1 - q : q) * qs;
+                c32 r0{0.f, 0.f}, r1{0.f, 0.f};
+                if (!SPARSE || __builtin_amdgcn_inverse_ballot_w64(nzw[q])) {
+                    const unsigned o = opaque(mirror ? lane_wm : lane_w);
+                    r0 = *reinterpret_cast<const c32*>(b + o);
+                    r1 = *reinterpret_cast<const c32*>(b + 64 + o);
+                }
+                if (mirror) { r0.y = -r0.y; r1.y = -r1.y; }
+                if ((q == 0 || q == HQ) && lane == 0) { r0.y = 0.f; r1.y = 0.f; }   // columns 0 and N/2 of a real row are real
+                v[q] = c32{r0.x - r1.y, r0.y + r1.x};
+            }
+            // observed samples of both rows (compact, float), requested before the transform
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const unsigned rka = __builtin_amdgcn_mbcnt_hi((unsigned)(ma[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma[q], 0u));
+                const unsigned rkb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
+                float fa = 0.f, fb = 0.f;
+                if (__builtin_amdgcn_inverse_ballot_w64(ma[q])) fa = *reinterpret_cast<const float*>(xcb + (size_t)ca[q] * 4u + opaque(rka * 4u));
+                if (__builtin_amdgcn_inverse_ballot_w64(mb[q])) fb = *reinterpret_cast<const float*>(xcb + (size_t)cb[q] * 4u + opaque(rkb * 4u));
+                oa[q] = fa;
+                ob[q] = fb;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            line_fft<N, INV, true>(v, lds, tw, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(oa[q]), "+v"(ob[q]));
+            float sa = 0.f, sb = 0.f;
+            const bool handback = MODE == REAL_LAST && a.only_done != 0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const bool seta = __builtin_amdgcn_inverse_ballot_w64(ma[q]), setb = __builtin_amdgcn_inverse_ballot_w64(mb[q]);
+                float xa = v[q].x * a.scale, xb = v[q].y * a.scale;
+                if (handback) {   // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
+                    if (a.alpha == 1.0f && seta) xa = oa[q];
+                    if (a.alpha == 1.0f && setb) xb = ob[q];
+                } else {
+                    xa = __builtin_fmaf(xa, seta ? w_obs : 1.0f, oa[q] * a.alpha);   // POCS.py:616-619
+                    xb = __builtin_fmaf(xb, setb ? w_obs : 1.0f, ob[q] * a.alpha);
+                }
+                sa += fabsf(xa);
+                sb += fabsf(xb);
+                v[q] = c32{xa, xb};
+            }
+            if (a.sums != nullptr) {
+                double da = (double)sa, db = (double)sb;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { da += __shfl_down(da, o, 64); db += __shfl_down(db, o, 64); }
+                if (lane == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + 1] = db; }
+            }
+            if (MODE == REAL_LAST) {
+                if (on) {
+                    float* const o = reinterpret_cast<float*>(a.out) + xrow;
+                    if (dn < 0) {   // all-zero slice is handed back untouched (POCS.py:515-521)
+#pragma unroll
+                        for (int q = 0; q < PPT; ++q) { o[lane + 64 * q] = 0.f; o[N + lane + 64 * q] = 0.f; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PPT; ++q) { o[lane + 64 * q] = v[q].x; o[N + lane + 64 * q] = v[q].y; }
+                    }
+                }
+                continue;
+            }
+        }
+
+        // ---- forward transform of z = r_a + i r_b, split into the two half spectra, store ----
+        __builtin_amdgcn_sched_barrier(0);
+        line_fft<N, FWD, true>(v, lds, tw, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == REAL_FIRST) __syncthreads();   // (first pass: keep the stores of adjacent pairs together as well)
+        {
+            const size_t qs = qstep();
+            const int src = (64 - lane) & 63;
+            char* b = wb;
+#pragma unroll
+            for (int q = 0; q <= HQ; ++q) {
+                const c32 z = v[q];
+                const c32 far = v[q < HQ ? PPT - 1 - q : HQ - 1];      // lanes > 0: Z[N - e] is register 15 - q of lane 64 - tl
+                c32 pz{__shfl(far.x, src, 64), __shfl(far.y, src, 64)};
+                if (lane == 0) pz = q == 0 ? v[0] : v[PPT - q];        // lane 0: Z[N - 64 q] is its own register 16 - q (q = 0: Z[0])
+                const c32 Ra{0.5f * (z.x + pz.x), 0.5f * (z.y - pz.y)};
+                const c32 Rb{0.5f * (z.y + pz.y), -0.5f * (z.x - pz.x)};
+                if (on && (q < HQ || lane == 0)) {
+                    const unsigned o = opaque(lane_w);
+                    *reinterpret_cast<c32*>(b + o) = Ra;
+                    *reinterpret_cast<c32*>(b + 64 + o) = Rb;
+                }
+                b += qs;
+            }
+        }
+    }
+}
+
+// =================================================================================================
 // spectrum (column) pass
 // =================================================================================================
 __device__ __forceinline__ bool lex_greater(float ar, float ai, float br, float bi)
@@ -1225,6 +1440,37 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
     }
 }
 
+// real (float32) cubes, rows of one wavefront: the row-pair passes over the half-spectrum work buffer
+template <int N>
+hipError_t launch_row_real(int mode, const RowArgs& a, int cus, hipStream_t st)
+{
+    if constexpr (Plan<N>::TPL == 64 && Plan<N>::PPT == 16) {
+        if (a.n1 % 2 != 0 || a.bits64 == nullptr || a.cbase == nullptr || a.dtype != 1) return hipErrorNotSupported;
+        if ((double)a.nslices * (double)wk_slice_stride(a.n1, N / 2 + 1) >= 4294967296.0) return hipErrorNotSupported;
+        constexpr size_t lds = pipe64_lds_bytes<N>();
+        constexpr int UPB = pipe64_threads<N>() / 64;
+        const long groups = ((long)a.nslices * (a.n1 / 2) + UPB - 1) / UPB;
+        const dim3 grid((unsigned)(groups < (long)cus ? groups : (long)cus));
+        hipError_t e = hipSuccess;
+#define P3D_REAL(MODE, SP)                                                                      \
+    do {                                                                                        \
+        if ((e = allow_lds(row_real_kernel<N, MODE, SP>, lds)) != hipSuccess) return e;         \
+        row_real_kernel<N, MODE, SP><<<grid, pipe64_threads<N>(), lds, st>>>(a);                \
+    } while (0)
+        const bool sp = a.nzl != nullptr;
+        switch (mode) {
+            case REAL_FIRST: P3D_REAL(REAL_FIRST, false); break;
+            case REAL_MID: if (sp) P3D_REAL(REAL_MID, true); else P3D_REAL(REAL_MID, false); break;
+            case REAL_LAST: if (sp) P3D_REAL(REAL_LAST, true); else P3D_REAL(REAL_LAST, false); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef P3D_REAL
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <int N>
 hipError_t launch_row(int mode, const RowArgs& a, hipStream_t st)
 {
@@ -1282,6 +1528,7 @@ struct LineOps {
     void (*build_row_tw)(c32* out);      // ... and their builder
     int col_tw_slots;                    // the same for the column pass (ColTables)
     void (*build_col_tw)(c32* out);
+    hipError_t (*row_real)(int mode, const RowArgs&, int cus, hipStream_t);   // REAL_* passes (hipErrorNotSupported where absent)
 };
 
 }  // namespace p3d

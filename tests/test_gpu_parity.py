@@ -616,6 +616,7 @@ def test_wave_uniform_row_pass_is_the_generic_one(nil, nxl, dtype, monkeypatch):
     kw = dict(niter=9, thresh_op="hard" if dtype == np.float32 else "soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
     want = orc.pocs_cube(cube.astype(np.float64 if dtype == np.float32 else np.complex128), mask, **kw)
     res = {}
+    monkeypatch.setenv("P3D_NO_REAL", "1")   # float32 cubes: the row-pair path has its own test, this one compares the complex passes
     for pipe64 in (True, False):
         for sparse in (True, False):
             P.release_plans()
@@ -656,3 +657,49 @@ def test_one_process_several_devices_entry_point(ffi, orc):
     with pytest.raises(ffi.P3DError) as e:
         ffi.multi_run(obs, mask, tau, niter, [0, 99])
     assert "device 99" in str(e.value)
+
+
+@pytest.mark.parametrize("nil,kw", [
+    (64, dict(niter=9, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
+    (100, dict(niter=12, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),
+    (256, dict(niter=40, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),
+    (1000, dict(niter=5, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
+])
+def test_real_cubes_share_one_transform_per_row_pair(nil, kw, monkeypatch):
+    """float32 cubes with the hard operator: the spectrum is Hermitian, rows go through the row pass in pairs (one complex
+    transform per pair) and the work buffer holds columns 0 ... N/2 only (row_real_kernel).  Same answer as the complex path
+    (P3D_NO_REAL=1) up to rounding -- the imaginary rounding noise the complex path carries is dropped every iteration -- with the
+    sparse shortcut and without, through the early exit and an all-zero slice; observed traces come back exact for alpha = 1."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    nxl = 1024
+    mask = orc.synthetic_mask(nil, nxl, 0.6)
+    cube = np.stack([orc.synthetic_slice(nil, nxl, 40 + s, real=True) * (1.0 + s) for s in range(5)]) * mask
+    cube[3] = 0
+    cube = cube.astype(np.float32)
+    kw = dict(kw, thresh_op="hard")
+    res = {}
+    for real in (True, False):
+        for sparse in (True, False):
+            P.release_plans()
+            for name, on in (("P3D_NO_REAL", not real), ("P3D_NO_SPARSE", not sparse)):
+                monkeypatch.setenv(name, "1") if on else monkeypatch.delenv(name, raising=False)
+            info = []
+            try:
+                res[real, sparse] = (P.pocs_cube(cube, mask, results=info, **kw), [r["niterations"] for r in info])
+            finally:
+                P.release_plans()
+    got, its = res[True, True]
+    assert got.dtype == np.float32 and not got[3].any() and its[3] == 0
+    assert np.array_equal(got, res[True, False][0])                       # skipping emptied blocks changes nothing
+    ref, its_ref = res[False, True]
+    assert its == its_ref
+    infos = []
+    want = orc.pocs_cube(cube.astype(np.float64), mask, infos=infos, **kw)
+    for s in (0, 1, 2, 4):
+        assert rel_l2(got[s], ref[s]) < 2e-6, (s, rel_l2(got[s], ref[s]))
+        assert its[s] == infos[s]["niterations"]
+        if kw.get("alpha", 1.0) == 1.0:
+            assert np.array_equal(got[s][mask == 1], cube[s][mask == 1])
+    err = np.array([rel_l2(got[s], want[s]) for s in (0, 1, 2, 4)])
+    assert np.median(err) <= 1e-5 and err.max() <= 2e-3, err
