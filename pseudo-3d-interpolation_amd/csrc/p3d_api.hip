@@ -147,7 +147,7 @@ static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsig
 // Real cubes (row_real_kernel): lane masks over the HALF spectrum.  Register q < 8 of lane l holds column l + 64 q, register
 // q >= 8 reads the mirror column n2 - l - 64 q (n2 = 1024): word (slice, q) bit l = that column's 8-column block kept something.
 static __global__ void nz_real_kernel(const uint8_t* flags, unsigned long long* nzl, unsigned long long* count, int nslices, int tiles, int col_t,
-                                      int n2, const int* done)
+                                      int n2, int tpl, const int* done)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nslices * 16) return;
@@ -162,7 +162,7 @@ static __global__ void nz_real_kernel(const uint8_t* flags, unsigned long long* 
     };
     unsigned long long w = 0;
     for (int l = 0; l < 64; ++l) {
-        const int e = l + 64 * q, k = q < 8 ? e : n2 - e;
+        const int e = l % tpl + tpl * q, k = q < 8 ? e : n2 - e;
         w |= (unsigned long long)block_kept(k >> 3) << l;
     }
     nzl[i] = w;
@@ -1016,7 +1016,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // Real cubes with the hard operator: the spectrum stays Hermitian, so row pairs share one complex transform and the work
     // buffer holds half the columns (row_real_kernel).  Needs the compact observed samples and the lane-mask tables.
     bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && compact && r.bits64 && r.cbase && !is_flex(p->ops_row) &&
-                     p->ops_row->row_real != nullptr && p->nil % 2 == 0 && p->pipe_wgs > 0 && !getenv("P3D_NO_REAL");
+                     p->ops_row->row_real != nullptr && p->pipe_wgs > 0 && !getenv("P3D_NO_REAL");
     if (real_path) {
         const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
         if (re == hipErrorNotSupported) real_path = false;
@@ -1064,7 +1064,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         c.iter = k;
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
         if (sparse && real_path) {
-            nz_real_kernel<<<(nslices * 16 + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, c.done);
+            nz_real_kernel<<<(nslices * 16 + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, p->ops_row->tpl, c.done);
             r.nzl = p->nzl;
         } else if (sparse && flex_rows) {   // the flexible row pass reads the tile flags themselves; count the kept blocks for the statistics
             nz_count_kernel<<<(nslices * nblocks + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzcount, nslices, p->tiles, col_t, nblocks, c.done);

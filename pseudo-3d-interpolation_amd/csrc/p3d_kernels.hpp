@@ -959,9 +959,12 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
-    static_assert(TPL == 64 && PPT == 16, "one wavefront per row pair");
+    static_assert(64 % TPL == 0 && TPL >= 8 && PPT == 16, "whole row pairs per wavefront");
+    constexpr int PW = 64 / TPL;                  // row pairs per wavefront: lanes [sub * TPL, (sub + 1) * TPL) hold rows a = PW * 2u + sub
+                                                  // and b = a + PW (so that the a-rows and the b-rows of a wave are each one unit of the
+                                                  // lane-mask tables of the complex pass)
     constexpr int THREADS = pipe64_threads<N>();
-    constexpr int UPB = THREADS / 64;             // row pairs per workgroup
+    constexpr int UPB = THREADS / 64;             // units (2 * PW rows) per workgroup
     constexpr int LSTR = LdsRow::stride(N);
     constexpr int HQ = PPT / 2;                   // registers 0 ... HQ-1 hold columns < N/2; register HQ of lane 0 holds column N/2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -971,19 +974,20 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
+    const int lane = tid & 63, tl = lane % TPL, sub = lane / TPL;
     for (int i = tid; i < PassTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
-    const LdsRow lds{data + wave * LSTR};
+    const LdsRow lds{data + (wave * PW + sub) * LSTR};
 
-    const unsigned pps = (unsigned)a.n1 / 2;                   // row pairs per slice
+    const unsigned pps = (unsigned)a.n1 / (2 * PW);            // units per slice
     const unsigned total = (unsigned)a.nslices * pps;
     const unsigned wblk = (unsigned)a.n1 * 8;
     const size_t wstride = wk_slice_stride(a.n1, N / 2 + 1);
-    const unsigned mlane = 64u - (unsigned)lane;               // column N - e sits (64 - lane) columns into register 15 - q's run
-    const unsigned lane_w = ((unsigned)(lane >> 3) * wblk + (unsigned)(lane & 7)) * 8u;
-    const unsigned lane_wm = ((mlane >> 3) * wblk + (mlane & 7)) * 8u;
-    const size_t qs64 = (size_t)8 * wblk * 8u;
+    const unsigned mlane = (unsigned)(TPL - tl);               // column N - e sits (TPL - tl) columns into register 15 - q's run
+    const unsigned lane_w = ((unsigned)(tl >> 3) * wblk + (unsigned)(tl & 7) + (unsigned)sub * 8u) * 8u;
+    const unsigned lane_wm = ((mlane >> 3) * wblk + (mlane & 7) + (unsigned)sub * 8u) * 8u;
+    const size_t qs64 = (size_t)(TPL / 8) * wblk * 8u;         // bytes from register q to q + 1
+    constexpr unsigned BROW = PW * 64u;                        // row b = row a + PW: bytes inside a column block
 
     typedef const unsigned long long __attribute__((address_space(4))) * kmask_t;
     typedef const unsigned __attribute__((address_space(4))) * kuint_t;
@@ -1000,21 +1004,22 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
         if (MODE != REAL_FIRST) __syncthreads();   // lock-step: adjacent row pairs complete the 128-byte lines of a column block
         const bool in_range = u < total;
         const unsigned uu = in_range ? u : 0u;
-        const unsigned slice = uu / pps, pr = uu - slice * pps, ra = 2 * pr;
+        const unsigned slice = uu / pps, pr = uu - slice * pps, ua = 2 * pr;   // ua, ua + 1: the table units of the a- and b-rows
+        const unsigned ra = ua * PW + (unsigned)sub;                           // this lane's row a
         int dn = 0;
         if (k_done != nullptr) dn = k_done[slice];
         bool on = in_range;
         if (MODE == REAL_MID) on = on && dn == 0;
         if (MODE == REAL_LAST) on = on && (a.only_done ? dn == a.only_done : dn <= 0);
         if (MODE == REAL_FIRST) on = on && dn == 0;
-        char* const wb = reinterpret_cast<char*>(a.work) + (slice * wstride + (size_t)ra * 8) * 8;   // row a; row b is 64 bytes on
-        const size_t xrow = ((size_t)slice * a.n1 + ra) * N;                                          // row-major cubes
+        char* const wb = reinterpret_cast<char*>(a.work) + (slice * wstride + (size_t)ua * PW * 8) * 8;   // the unit's first row
+        const size_t xrow = ((size_t)slice * a.n1 + ra) * N;                                               // row-major cubes, row a
         // mask words and compact bases of the two rows (tables of the complex pass: one word per row and register)
         unsigned long long ma[PPT], mb[PPT];
         unsigned ca[PPT], cb[PPT];
         {
-            const kmask_t m0 = k_bits + pipe64_word(ra, 1, 0, 0);
-            const kuint_t c0 = k_cbase + pipe64_word(ra, 1, 0, 0);
+            const kmask_t m0 = k_bits + pipe64_word(ua, 1, 0, 0);
+            const kuint_t c0 = k_cbase + pipe64_word(ua, 1, 0, 0);
 #pragma unroll
             for (int q = 0; q < PPT; ++q) { ma[q] = m0[q]; mb[q] = m0[PPT + q]; ca[q] = c0[q]; cb[q] = c0[PPT + q]; }
         }
@@ -1029,7 +1034,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             float sa = 0.f, sb = 0.f;
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
-                const float xa = x[lane + 64 * q], xb = x[N + lane + 64 * q];
+                const float xa = x[tl + TPL * q], xb = x[(size_t)PW * N + tl + TPL * q];
                 const bool seta = __builtin_amdgcn_inverse_ballot_w64(ma[q]), setb = __builtin_amdgcn_inverse_ballot_w64(mb[q]);
                 const unsigned rka = __builtin_amdgcn_mbcnt_hi((unsigned)(ma[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma[q], 0u));
                 const unsigned rkb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
@@ -1047,8 +1052,8 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             if (a.sums != nullptr) {
                 double da = (double)sa, db = (double)sb;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { da += __shfl_down(da, o, 64); db += __shfl_down(db, o, 64); }
-                if (lane == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + 1] = db; }
+                for (int o = TPL / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, TPL); db += __shfl_down(db, o, TPL); }
+                if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
             }
         } else {
             // ---- half spectra of the two rows -> Z = R_a + i R_b on all N columns ----
@@ -1067,10 +1072,10 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
                 if (!SPARSE || __builtin_amdgcn_inverse_ballot_w64(nzw[q])) {
                     const unsigned o = opaque(mirror ? lane_wm : lane_w);
                     r0 = *reinterpret_cast<const c32*>(b + o);
-                    r1 = *reinterpret_cast<const c32*>(b + 64 + o);
+                    r1 = *reinterpret_cast<const c32*>(b + BROW + o);
                 }
                 if (mirror) { r0.y = -r0.y; r1.y = -r1.y; }
-                if ((q == 0 || q == HQ) && lane == 0) { r0.y = 0.f; r1.y = 0.f; }   // columns 0 and N/2 of a real row are real
+                if ((q == 0 || q == HQ) && tl == 0) { r0.y = 0.f; r1.y = 0.f; }   // columns 0 and N/2 of a real row are real
                 v[q] = c32{r0.x - r1.y, r0.y + r1.x};
             }
             // observed samples of both rows (compact, float), requested before the transform
@@ -1085,7 +1090,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
                 ob[q] = fb;
             }
             __builtin_amdgcn_sched_barrier(0);
-            line_fft<N, INV, true>(v, lds, tw, lane);
+            line_fft<N, INV, true>(v, lds, tw, tl);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(oa[q]), "+v"(ob[q]));
@@ -1109,18 +1114,18 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             if (a.sums != nullptr) {
                 double da = (double)sa, db = (double)sb;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { da += __shfl_down(da, o, 64); db += __shfl_down(db, o, 64); }
-                if (lane == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + 1] = db; }
+                for (int o = TPL / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, TPL); db += __shfl_down(db, o, TPL); }
+                if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
             }
             if (MODE == REAL_LAST) {
                 if (on) {
                     float* const o = reinterpret_cast<float*>(a.out) + xrow;
                     if (dn < 0) {   // all-zero slice is handed back untouched (POCS.py:515-521)
 #pragma unroll
-                        for (int q = 0; q < PPT; ++q) { o[lane + 64 * q] = 0.f; o[N + lane + 64 * q] = 0.f; }
+                        for (int q = 0; q < PPT; ++q) { o[tl + TPL * q] = 0.f; o[(size_t)PW * N + tl + TPL * q] = 0.f; }
                     } else {
 #pragma unroll
-                        for (int q = 0; q < PPT; ++q) { o[lane + 64 * q] = v[q].x; o[N + lane + 64 * q] = v[q].y; }
+                        for (int q = 0; q < PPT; ++q) { o[tl + TPL * q] = v[q].x; o[(size_t)PW * N + tl + TPL * q] = v[q].y; }
                     }
                 }
                 continue;
@@ -1129,25 +1134,25 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
 
         // ---- forward transform of z = r_a + i r_b, split into the two half spectra, store ----
         __builtin_amdgcn_sched_barrier(0);
-        line_fft<N, FWD, true>(v, lds, tw, lane);
+        line_fft<N, FWD, true>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
         if (MODE == REAL_FIRST) __syncthreads();   // (first pass: keep the stores of adjacent pairs together as well)
         {
             const size_t qs = qstep();
-            const int src = (64 - lane) & 63;
+            const int src = sub * TPL + ((TPL - tl) % TPL);
             char* b = wb;
 #pragma unroll
             for (int q = 0; q <= HQ; ++q) {
                 const c32 z = v[q];
                 const c32 far = v[q < HQ ? PPT - 1 - q : HQ - 1];      // lanes > 0: Z[N - e] is register 15 - q of lane 64 - tl
                 c32 pz{__shfl(far.x, src, 64), __shfl(far.y, src, 64)};
-                if (lane == 0) pz = q == 0 ? v[0] : v[PPT - q];        // lane 0: Z[N - 64 q] is its own register 16 - q (q = 0: Z[0])
+                if (tl == 0) pz = q == 0 ? v[0] : v[PPT - q];          // tl = 0: Z[N - TPL q] is its own register 16 - q (q = 0: Z[0])
                 const c32 Ra{0.5f * (z.x + pz.x), 0.5f * (z.y - pz.y)};
                 const c32 Rb{0.5f * (z.y + pz.y), -0.5f * (z.x - pz.x)};
-                if (on && (q < HQ || lane == 0)) {
+                if (on && (q < HQ || tl == 0)) {
                     const unsigned o = opaque(lane_w);
                     *reinterpret_cast<c32*>(b + o) = Ra;
-                    *reinterpret_cast<c32*>(b + 64 + o) = Rb;
+                    *reinterpret_cast<c32*>(b + BROW + o) = Rb;
                 }
                 b += qs;
             }
@@ -1440,16 +1445,17 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
     }
 }
 
-// real (float32) cubes, rows of one wavefront: the row-pair passes over the half-spectrum work buffer
+// real (float32) cubes, rows of 128 ... 1024 samples: the row-pair passes over the half-spectrum work buffer
 template <int N>
 hipError_t launch_row_real(int mode, const RowArgs& a, int cus, hipStream_t st)
 {
-    if constexpr (Plan<N>::TPL == 64 && Plan<N>::PPT == 16) {
-        if (a.n1 % 2 != 0 || a.bits64 == nullptr || a.cbase == nullptr || a.dtype != 1) return hipErrorNotSupported;
+    if constexpr (64 % Plan<N>::TPL == 0 && Plan<N>::TPL >= 8 && Plan<N>::PPT == 16) {
+        constexpr int PW = 64 / Plan<N>::TPL;
+        if (a.n1 % (2 * PW) != 0 || a.bits64 == nullptr || a.cbase == nullptr || a.dtype != 1) return hipErrorNotSupported;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N / 2 + 1) >= 4294967296.0) return hipErrorNotSupported;
         constexpr size_t lds = pipe64_lds_bytes<N>();
         constexpr int UPB = pipe64_threads<N>() / 64;
-        const long groups = ((long)a.nslices * (a.n1 / 2) + UPB - 1) / UPB;
+        const long groups = ((long)a.nslices * (a.n1 / (2 * PW)) + UPB - 1) / UPB;
         const dim3 grid((unsigned)(groups < (long)cus ? groups : (long)cus));
         hipError_t e = hipSuccess;
 #define P3D_REAL(MODE, SP)                                                                      \

@@ -659,20 +659,24 @@ def test_one_process_several_devices_entry_point(ffi, orc):
     assert "device 99" in str(e.value)
 
 
-@pytest.mark.parametrize("nil,kw", [
-    (64, dict(niter=9, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
-    (100, dict(niter=12, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),
-    (256, dict(niter=40, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),
-    (1000, dict(niter=5, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
+@pytest.mark.parametrize("nil,nxl,kw", [
+    (64, 1024, dict(niter=9, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
+    (100, 1024, dict(niter=12, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),
+    (256, 1024, dict(niter=40, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),
+    (1000, 1024, dict(niter=5, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
+    (64, 512, dict(niter=9, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),          # two row pairs per wavefront
+    (200, 512, dict(niter=30, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),
+    (96, 256, dict(niter=8, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),       # four
+    (48, 128, dict(niter=8, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),           # eight
+    (100, 256, dict(niter=6, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),          # 100 rows are not a multiple of 8: complex path
 ])
-def test_real_cubes_share_one_transform_per_row_pair(nil, kw, monkeypatch):
+def test_real_cubes_share_one_transform_per_row_pair(nil, nxl, kw, monkeypatch):
     """float32 cubes with the hard operator: the spectrum is Hermitian, rows go through the row pass in pairs (one complex
     transform per pair) and the work buffer holds columns 0 ... N/2 only (row_real_kernel).  Same answer as the complex path
     (P3D_NO_REAL=1) up to rounding -- the imaginary rounding noise the complex path carries is dropped every iteration -- with the
     sparse shortcut and without, through the early exit and an all-zero slice; observed traces come back exact for alpha = 1."""
     import pseudo_3d_interpolation_amd.functions.POCS as P
     from oracle import pocs_oracle as orc
-    nxl = 1024
     mask = orc.synthetic_mask(nil, nxl, 0.6)
     cube = np.stack([orc.synthetic_slice(nil, nxl, 40 + s, real=True) * (1.0 + s) for s in range(5)]) * mask
     cube[3] = 0
