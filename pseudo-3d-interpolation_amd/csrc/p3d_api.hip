@@ -1015,8 +1015,9 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
     // Real cubes with the hard operator: the spectrum stays Hermitian, so row pairs share one complex transform and the work
     // buffer holds half the columns (row_real_kernel).  Needs the compact observed samples and the lane-mask tables.
-    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && compact && r.bits64 && r.cbase && !is_flex(p->ops_row) &&
-                     p->ops_row->row_real != nullptr && p->pipe_wgs > 0 && !getenv("P3D_NO_REAL");
+    // (The flexible-length row pass keeps the pair in LDS and takes any real mask: no compact samples, no tables needed there.)
+    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && p->ops_row->row_real != nullptr && !getenv("P3D_NO_REAL") &&
+                     (flex_rows ? p->nil % 2 == 0 : (compact && r.bits64 && r.cbase && p->pipe_wgs > 0));
     if (real_path) {
         const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
         if (re == hipErrorNotSupported) real_path = false;
@@ -1063,13 +1064,14 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
-        if (sparse && real_path) {
+        if (sparse && real_path && !flex_rows) {
             nz_real_kernel<<<(nslices * 16 + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, p->ops_row->tpl, c.done);
             r.nzl = p->nzl;
         } else if (sparse && flex_rows) {   // the flexible row pass reads the tile flags themselves; count the kept blocks for the statistics
-            nz_count_kernel<<<(nslices * nblocks + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzcount, nslices, p->tiles, col_t, nblocks, c.done);
+            const int nb_work = (n2_work + 7) / 8;   // the half spectrum of a real cube has its own tile count
+            nz_count_kernel<<<(nslices * nb_work + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzcount, nslices, tiles_work, col_t, nb_work, c.done);
             r.nzflag = p->nzflag;
-            r.nz_tiles = p->tiles;
+            r.nz_tiles = tiles_work;
             r.nz_col_t = col_t;
         } else if (sparse) {
             nz_pack_kernel<<<(nslices * groups + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzm, p->nzcount, nslices, p->tiles, col_t, groups, nblocks,

@@ -684,6 +684,165 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     }
 }
 
+// Real (float32) cubes with the hard operator (see row_real_kernel in p3d_kernels.hpp): rows 2p and 2p + 1 share one complex
+// transform, z = r_a + i r_b, and the work buffer holds columns 0 ... n/2 of the row spectra.  The line lives in LDS here, so the
+// partner Z[n - k] of the split is simply another element of the same buffer.  Any real mask (float weights), no compaction.
+template <int TPR, bool INPL>
+__global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
+{
+    constexpr int SYNC = TPR == 64 ? 1 : 0;
+    __shared__ double rsum[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = pl.n, L = pl.m, H = n / 2, tid = threadIdx.x, lane = tid % TPR, line = tid / TPR;
+    c32* tw = reinterpret_cast<c32*>(smem_raw);
+    c32* A = tw + L + (size_t)line * (INPL ? 1 : 2) * L;
+    c32* B = A + L;
+    const int slice = blockIdx.y, pair = blockIdx.x * LB + line;
+    const bool valid = 2 * pair + 1 < a.n1;
+    const int ra = valid ? 2 * pair : 0;
+    for (int i = tid; i < L; i += blockDim.x) tw[i] = a.tw[i];
+    __syncthreads();
+
+    const int dn = a.done ? a.done[slice] : 0;
+    const size_t sbase = ((size_t)slice * a.n1 + ra) * n;   // row a of the row-major cubes; row b follows
+    const float* const xa = reinterpret_cast<const float*>(a.x) + sbase;
+    float* const oa = reinterpret_cast<float*>(a.out) + sbase;
+    if (mode == ROW_LAST && a.only_done) {
+        if (dn != a.only_done) return;
+    } else if (mode == ROW_LAST) {
+        if (dn > 0) return;
+        if (dn < 0) {
+            if (valid)
+                for (int i = lane; i < n; i += TPR) { oa[i] = 0.f; oa[n + i] = 0.f; }
+            return;
+        }
+    } else if (dn != 0) {
+        return;
+    }
+    c32* const wrow = a.work + (size_t)slice * wk_slice_stride(a.n1, H + 1) + (size_t)ra * 8;   // row a; row b is 8 elements on
+    const size_t wblk = (size_t)a.n1 * 8;
+    const float* const ma = a.mask ? a.mask + (size_t)ra * n : nullptr;
+
+    float sa = 0.f, sb = 0.f;
+    c32* X = A;
+    if (mode == ROW_FIRST) {
+        for (int i = lane; i < n; i += TPR) {
+            const float va = valid ? xa[i] : 0.f, vb = valid ? xa[n + i] : 0.f;
+            sa += fabsf(va);
+            sb += fabsf(vb);
+            A[i] = c32{va, vb};
+        }
+        flex_sync<SYNC>();
+    } else {
+        const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
+        const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);
+#pragma unroll 4
+        for (int i = lane; i < n; i += TPR) {
+            const int k = i <= H ? i : n - i;
+            bool kept = valid;
+            if (nzf) kept = kept && nzf[k >> tsh] != 0;
+            c32 r0{0.f, 0.f}, r1{0.f, 0.f};
+            if (kept) {
+                const c32* w = wrow + (size_t)(k >> 3) * wblk + (k & 7);
+                r0 = w[0];
+                r1 = w[8];
+            }
+            if (i > H) { r0.y = -r0.y; r1.y = -r1.y; }
+            if (k == 0 || 2 * k == n) { r0.y = 0.f; r1.y = 0.f; }   // self-mirrored columns of a real row are real
+            A[i] = c32{r0.x - r1.y, r0.y + r1.x};
+        }
+        flex_sync<SYNC>();
+        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, INV, lane, TPR);
+        else X = flex_transform<SYNC>(A, B, tw, a.tw, pl, INV, 1, 1, L, lane, TPR);
+        const bool handback = mode == ROW_LAST && a.only_done != 0;
+        for (int i = lane; i < n; i += TPR) {
+            const c32 z = X[i] * a.scale;
+            float va = z.x, vb = z.y;
+            const float xoa = valid ? xa[i] : 0.f, xob = valid ? xa[n + i] : 0.f;
+            const float mka = ma ? ma[i] : 0.f, mkb = ma ? ma[n + i] : 0.f;
+            if (handback) {
+                if (a.alpha == 1.0f && mka == 1.0f) va = xoa;
+                if (a.alpha == 1.0f && mkb == 1.0f) vb = xob;
+            } else {
+                va = __builtin_fmaf(va, 1.0f - a.alpha * mka, xoa * a.alpha);   // POCS.py:616-619
+                vb = __builtin_fmaf(vb, 1.0f - a.alpha * mkb, xob * a.alpha);
+            }
+            sa += fabsf(va);
+            sb += fabsf(vb);
+            if (mode == ROW_LAST && valid) { oa[i] = va; oa[n + i] = vb; }
+            if (mode == ROW_MID) X[i] = c32{va, vb};
+        }
+        flex_sync<SYNC>();
+    }
+    if (a.sums != nullptr) {
+        double da = valid ? (double)sa : 0.0, db = valid ? (double)sb : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { da += __shfl_down(da, o, 64); db += __shfl_down(db, o, 64); }
+        if constexpr (TPR == 64) {
+            if (lane == 0 && valid) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + 1] = db; }
+        } else {   // two wavefronts per row pair
+            if ((tid & 63) == 0) { rsum[2 * (tid >> 6)] = da; rsum[2 * (tid >> 6) + 1] = db; }
+            __syncthreads();
+            if (lane == 0 && valid) {
+                a.sums[(size_t)slice * a.n1 + ra] = rsum[4 * line] + rsum[4 * line + 2];
+                a.sums[(size_t)slice * a.n1 + ra + 1] = rsum[4 * line + 1] + rsum[4 * line + 3];
+            }
+        }
+    }
+    if (mode != ROW_LAST) {
+        c32* Y = X == A ? B : A;
+        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, FWD, lane, TPR);
+        else X = flex_transform<SYNC>(X, Y, tw, a.tw, pl, FWD, 1, 1, L, lane, TPR);
+        if (valid)
+            for (int k = lane; k <= H; k += TPR) {
+                const c32 z = X[k], pz = X[k == 0 ? 0 : n - k];
+                c32* w = wrow + (size_t)(k >> 3) * wblk + (k & 7);
+                w[0] = c32{0.5f * (z.x + pz.x), 0.5f * (z.y - pz.y)};      // R_a = (Z[k] + conj Z[n-k]) / 2
+                w[8] = c32{0.5f * (z.y + pz.y), -0.5f * (z.x - pz.x)};     // R_b = (Z[k] - conj Z[n-k]) / 2i
+            }
+    }
+}
+
+// row-pair passes for float32 cubes (mode = ROW_FIRST / ROW_MID / ROW_LAST)
+hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
+{
+    if (mode != ROW_FIRST && mode != ROW_MID && mode != ROW_LAST) return hipErrorNotSupported;
+    if (a.dtype != 1 || a.n1 % 2 != 0 || a.adaptive || a.write_out) return hipErrorNotSupported;
+    const int n = a.len, LB = pick_row_lines(n);
+    if (LB == 0) return hipErrorNotSupported;
+    const FlexFactors pl = flex_factors(n);
+    int widest = 2;
+    for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
+    const bool two = LB >= 2 && pl.m / widest >= 48;
+    static const bool no_inplace = getenv("P3D_FLEX_NO_INPLACE") != nullptr;
+    bool two_ = two;
+    int inpl = 0;
+    if (!no_inplace) {
+        if (flex_inplace_ok(pl, two ? 128 : 64)) inpl = 1;
+        else if (!two && flex_inplace_ok(pl, 128)) { inpl = 1; two_ = true; }
+    }
+    int lb = two_ ? LB / 2 : LB;
+    if (lb < 1) lb = 1;
+    if (inpl) {
+        lb = two_ ? 2 : 4;
+        while (lb > 1 && row_lds_inplace(n, lb) > FLEX_LDS_MAX) lb /= 2;
+    }
+    const size_t lds = inpl ? row_lds_inplace(n, lb) : row_lds(n, lb);
+    const int pairs = a.n1 / 2;
+    const dim3 grid((pairs + lb - 1) / lb, a.nslices);
+#define P3D_FLEX_ROW(TPR, IP)                                                                                                  \
+    do {                                                                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_real_kernel<TPR, IP>),                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);                     \
+        if (e != hipSuccess) return e;                                                                                         \
+        flex_row_real_kernel<TPR, IP><<<grid, TPR * lb, lds, st>>>(a, pl, mode, lb);                                           \
+    } while (0)
+    if (two_) { if (inpl) P3D_FLEX_ROW(128, true); else P3D_FLEX_ROW(128, false); }
+    else { if (inpl) P3D_FLEX_ROW(64, true); else P3D_FLEX_ROW(64, false); }
+#undef P3D_FLEX_ROW
+    return hipGetLastError();
+}
+
 hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
 {
     if (mode != ROW_FIRST && mode != ROW_MID && mode != ROW_LAST) return hipErrorNotSupported;   // no shearlet passes here
@@ -804,7 +963,7 @@ int flex_col_tile(int n) { return pick_col_tile(n); }
 const LineOps* get_flex_ops()
 {
     // tpl = 0 marks the flexible implementation: no packed mask words, no persistent row pass, no sparse-tile flags
-    static const LineOps ops = {0, 0, 0, 0, &flex_row, &flex_col, &flex_no_pipe, 0, 0, nullptr, 0, nullptr, nullptr};
+    static const LineOps ops = {0, 0, 0, 0, &flex_row, &flex_col, &flex_no_pipe, 0, 0, nullptr, 0, nullptr, &flex_row_real};
     return &ops;
 }
 
