@@ -508,7 +508,16 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
         const int kept = __syncthreads_or(any ? 1 : 0);
         if (iter && a.nzflag != nullptr) {   // a tile the threshold emptied stays zeros: say so instead of transforming and storing it
             if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
-            if (!kept) return;
+            if (!kept) {
+                // the row pass skips whole 8-column blocks: an empty tile NARROWER than a block must still leave zeros behind for
+                // the case that a sibling tile of its block kept something (see col_kernel)
+                if (T < 8)
+                    for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
+                        const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
+                        if (col < a.n2) outb[goff(a.out_std, i, col)] = c32{0.f, 0.f};
+                    }
+                return;
+            }
         }
     }
     if (mode == COL_STATS) {

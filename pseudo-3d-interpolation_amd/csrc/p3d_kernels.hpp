@@ -1268,7 +1268,22 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
             for (int q = 0; q < PPT; ++q) bits |= __float_as_uint(v[q].x) | __float_as_uint(v[q].y);
             const int kept = __syncthreads_or(bits != 0u ? 1 : 0);
             if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
-            if (!kept) return;
+            if (!kept) {
+                // The row pass skips whole 8-column BLOCKS.  A tile narrower than a block may be empty next to a sibling that
+                // is not, and the row pass then reads this tile's columns too: they must hold the zeros, not last iteration's
+                // values (the transform is still skipped).
+                if constexpr (T < 8) {
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < PPT; ++q) {
+                            unsigned o = (out_org + (unsigned)(tl + TPL * q) * out_pitch) * 8u;
+                            asm volatile("" : "+v"(o));
+                            *reinterpret_cast<c32*>(reinterpret_cast<char*>(outb) + o) = c32{0.f, 0.f};
+                        }
+                    }
+                }
+                return;
+            }
         }
     }
 

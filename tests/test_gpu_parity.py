@@ -527,7 +527,11 @@ def test_early_exit_hands_back_the_converged_iterate(nil, nxl):
 
 
 @pytest.mark.parametrize("shape,missing", [((1024, 1024), 0.8), ((512, 256), 0.5), ((128, 2048), 0.6), ((256, 128), 0.3),
-                                           ((120, 200), 0.5), ((128, 200), 0.6), ((200, 128), 0.6), ((1000, 40), 0.5)])
+                                           ((120, 200), 0.5), ((128, 200), 0.6), ((200, 128), 0.6), ((1000, 40), 0.5),
+                                           # column tiles NARROWER than the 8-column blocks the row pass skips (4096-point tuned
+                                           # columns: 2 columns per tile; long flexible columns: 4): an emptied tile next to a
+                                           # kept sibling must read as zeros
+                                           ((4096, 256), 0.8), ((4096, 1024), 0.8), ((2000, 128), 0.6), ((2400, 200), 0.6)])
 def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeypatch):
     """Column blocks of the spectrum that the threshold empties are not transformed back, stored or re-read (sparse path).
     The result must equal the dense path's (P3D_NO_SPARSE=1) exactly, from the sparse early iterations to the dense late ones."""

@@ -47,6 +47,17 @@ for case in range(ncases):
         case, nil, nxl, ns, dtype.__name__, op, kw["thresh_model"], kw["niter"], kw["eps"], kw["alpha"], kw["version"], missing,
         np.median(err), err.max(), "" if its == its_ref else f"its {its} vs {its_ref} ", "<-- CHECK" if flag else ""), flush=True)
     bad += bool(flag)
+    if flag and os.environ.get("FUZZ_SWITCHES"):   # is a flagged case the same on the slower equivalent paths?
+        for sw in os.environ["FUZZ_SWITCHES"].split(","):
+            P.release_plans()
+            os.environ[sw] = "1"
+            try:
+                alt = P.pocs_cube(cube, mask, **kw)
+            finally:
+                del os.environ[sw]
+                P.release_plans()
+            d = np.array([np.linalg.norm(alt[s] - got[s]) / max(np.linalg.norm(got[s]), 1e-30) for s in range(ns)])
+            print("        with %s=1: rel diff to the default path max %.1e, equal: %s" % (sw, d.max(), bool(np.array_equal(alt, got))), flush=True)
 P.release_plans()
 print("flagged:", bad)
 sys.exit(1 if bad else 0)
