@@ -1014,15 +1014,11 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
         if (MODE == REAL_FIRST) on = on && dn == 0;
         char* const wb = reinterpret_cast<char*>(a.work) + (slice * wstride + (size_t)ua * PW * 8) * 8;   // the unit's first row
         const size_t xrow = ((size_t)slice * a.n1 + ra) * N;                                               // row-major cubes, row a
-        // mask words and compact bases of the two rows (tables of the complex pass: one word per row and register)
-        unsigned long long ma[PPT], mb[PPT];
-        unsigned ca[PPT], cb[PPT];
-        {
-            const kmask_t m0 = k_bits + pipe64_word(ua, 1, 0, 0);
-            const kuint_t c0 = k_cbase + pipe64_word(ua, 1, 0, 0);
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) { ma[q] = m0[q]; mb[q] = m0[PPT + q]; ca[q] = c0[q]; cb[q] = c0[PPT + q]; }
-        }
+        // Mask words and compact bases of the a-rows (unit ua) and the b-rows (unit ua + 1): tables of the complex pass.  They are
+        // (re)loaded where they are used, one unit at a time -- 16 x (64 + 32) bits per unit; all four sets at once do not fit the
+        // scalar registers and every use would then be a v_readlane from a spill lane.
+        auto words_of = [&](unsigned unit) -> kmask_t { kmask_t m = k_bits + pipe64_word(unit, 1, 0, 0); asm volatile("" : "+s"(m)); return m; };
+        auto bases_of = [&](unsigned unit) -> kuint_t { kuint_t c = k_cbase + pipe64_word(unit, 1, 0, 0); asm volatile("" : "+s"(c)); return c; };
         const char* const xcb = reinterpret_cast<const char*>(a.xc) + (size_t)slice * a.nobs * 4u;
         c32 v[PPT];
         float oa[PPT], ob[PPT];
@@ -1032,21 +1028,25 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             const float* const x = reinterpret_cast<const float*>(a.x) + xrow;
             bool bad = false;
             float sa = 0.f, sb = 0.f;
+            float* const xc = reinterpret_cast<float*>(a.xc) + (size_t)slice * a.nobs;
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                const float xa = x[tl + TPL * q], xb = x[(size_t)PW * N + tl + TPL * q];
-                const bool seta = __builtin_amdgcn_inverse_ballot_w64(ma[q]), setb = __builtin_amdgcn_inverse_ballot_w64(mb[q]);
-                const unsigned rka = __builtin_amdgcn_mbcnt_hi((unsigned)(ma[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma[q], 0u));
-                const unsigned rkb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
-                if (on && a.xc != nullptr) {
-                    float* const xc = reinterpret_cast<float*>(a.xc) + (size_t)slice * a.nobs;
-                    if (seta) xc[ca[q] + rka] = xa;
-                    if (setb) xc[cb[q] + rkb] = xb;
+            for (int h = 0; h < 2; ++h) {   // the a-rows, then the b-rows
+                const kmask_t mw = words_of(ua + h);
+                const kuint_t cw = bases_of(ua + h);
+                const float* const xr = x + (size_t)h * PW * N;
+                float sh = 0.f;
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    const unsigned long long m = mw[q];
+                    const float xv = xr[tl + TPL * q];
+                    const bool set = __builtin_amdgcn_inverse_ballot_w64(m);
+                    const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (on && a.xc != nullptr && set) xc[cw[q] + rk] = xv;
+                    bad = bad || (!set && xv != 0.f);
+                    sh += fabsf(xv);
+                    if (h == 0) v[q].x = xv; else v[q].y = xv;
                 }
-                bad = bad || (!seta && xa != 0.f) || (!setb && xb != 0.f);
-                sa += fabsf(xa);
-                sb += fabsf(xb);
-                v[q] = c32{xa, xb};
+                if (h == 0) sa = sh; else sb = sh;
             }
             if (on && bad && a.violation != nullptr) atomicOr(a.violation, 1);
             if (a.sums != nullptr) {
@@ -1080,14 +1080,18 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             }
             // observed samples of both rows (compact, float), requested before the transform
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                const unsigned rka = __builtin_amdgcn_mbcnt_hi((unsigned)(ma[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma[q], 0u));
-                const unsigned rkb = __builtin_amdgcn_mbcnt_hi((unsigned)(mb[q] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb[q], 0u));
-                float fa = 0.f, fb = 0.f;
-                if (__builtin_amdgcn_inverse_ballot_w64(ma[q])) fa = *reinterpret_cast<const float*>(xcb + (size_t)ca[q] * 4u + opaque(rka * 4u));
-                if (__builtin_amdgcn_inverse_ballot_w64(mb[q])) fb = *reinterpret_cast<const float*>(xcb + (size_t)cb[q] * 4u + opaque(rkb * 4u));
-                oa[q] = fa;
-                ob[q] = fb;
+            for (int h = 0; h < 2; ++h) {
+                const kmask_t mw = words_of(ua + h);
+                const kuint_t cw = bases_of(ua + h);
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    const unsigned long long m = mw[q];
+                    const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    float f = 0.f;
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) f = *reinterpret_cast<const float*>(xcb + (size_t)cw[q] * 4u + opaque(rk * 4u));
+                    if (h == 0) oa[q] = f; else ob[q] = f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             line_fft<N, INV, true>(v, lds, tw, tl);
@@ -1097,19 +1101,24 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             float sa = 0.f, sb = 0.f;
             const bool handback = MODE == REAL_LAST && a.only_done != 0;
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                const bool seta = __builtin_amdgcn_inverse_ballot_w64(ma[q]), setb = __builtin_amdgcn_inverse_ballot_w64(mb[q]);
-                float xa = v[q].x * a.scale, xb = v[q].y * a.scale;
-                if (handback) {   // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
-                    if (a.alpha == 1.0f && seta) xa = oa[q];
-                    if (a.alpha == 1.0f && setb) xb = ob[q];
-                } else {
-                    xa = __builtin_fmaf(xa, seta ? w_obs : 1.0f, oa[q] * a.alpha);   // POCS.py:616-619
-                    xb = __builtin_fmaf(xb, setb ? w_obs : 1.0f, ob[q] * a.alpha);
+            for (int h = 0; h < 2; ++h) {
+                const kmask_t mw = words_of(ua + h);
+                float sh = 0.f;
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    const bool set = __builtin_amdgcn_inverse_ballot_w64(mw[q]);
+                    const float xo = h == 0 ? oa[q] : ob[q];
+                    float xv = (h == 0 ? v[q].x : v[q].y) * a.scale;
+                    if (handback) {   // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
+                        if (a.alpha == 1.0f && set) xv = xo;
+                    } else {
+                        xv = __builtin_fmaf(xv, set ? w_obs : 1.0f, xo * a.alpha);   // POCS.py:616-619
+                    }
+                    sh += fabsf(xv);
+                    if (h == 0) v[q].x = xv; else v[q].y = xv;
                 }
-                sa += fabsf(xa);
-                sb += fabsf(xb);
-                v[q] = c32{xa, xb};
+                if (h == 0) sa = sh; else sb = sh;
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (a.sums != nullptr) {
                 double da = (double)sa, db = (double)sb;
