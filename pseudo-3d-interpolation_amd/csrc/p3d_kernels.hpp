@@ -832,10 +832,14 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
             b += qs;
         }
     };
-    auto load_obs = [&](c32 (&dst)[PPT], unsigned long long (&mwords)[PPT], const Where& w) {
-        const kmask_t mrow = k_bits + pipe64_word(w.row, WPL, wsub, 0);
+    // (the mask words are loaded again for the re-insertion instead of being kept across the transform: together with the compact
+    // bases and the emptied-block words they do not fit the scalar registers, and a spilled word costs a v_readlane per use)
+    auto words_of = [&](const Where& w) -> kmask_t { kmask_t m = k_bits + pipe64_word(w.row, WPL, wsub, 0); asm volatile("" : "+s"(m)); return m; };
+    auto load_obs = [&](c32 (&dst)[PPT], const Where& w) {
+        const kmask_t mrow = words_of(w);
         const kuint_t cb = k_cbase + pipe64_word(w.row, WPL, wsub, 0);   // observed traces before this word, from the start of the slice
         const char* xb = reinterpret_cast<const char*>(a.xc) + (size_t)w.slice * a.nobs * ES;
+        unsigned long long mwords[PPT];
         unsigned cbs[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) { mwords[q] = mrow[q]; cbs[q] = cb[q]; }
@@ -859,18 +863,17 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     auto process = [&](c32 (&v)[PPT], const Where& cur) {
         c32 bx[PPT];
         load_work(v, cur);
-        unsigned long long mwords[PPT];   // the trace mask of this wavefront's columns as lane masks
 #if P3D_PIPE64_OBS_EARLY
         // issued BEHIND the work-buffer loads (vmcnt retires in order: the transform below waits for those only) and in flight
         // during the inverse transform
         __builtin_amdgcn_sched_barrier(0);
-        load_obs(bx, mwords, cur);
+        load_obs(bx, cur);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         line_fft<N, INV, WAVE>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
 #if !P3D_PIPE64_OBS_EARLY
-        load_obs(bx, mwords, cur);
+        load_obs(bx, cur);
         __builtin_amdgcn_sched_barrier(0);
 #else
         // the samples are first touched HERE: without this the compiler starts on bx * alpha in the middle of the transform and
@@ -879,10 +882,11 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
         for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(bx[q].x), "+v"(bx[q].y));
 #endif
         float acc = 0.f;
+        const kmask_t mrow2 = words_of(cur);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             c32 xn = v[q] * a.scale;
-            const float w = __builtin_amdgcn_inverse_ballot_w64(mwords[q]) ? w_obs : 1.0f;
+            const float w = __builtin_amdgcn_inverse_ballot_w64(mrow2[q]) ? w_obs : 1.0f;
             xn = axpby(xn, w, bx[q], a.alpha);        // POCS.py:616-619
             acc += abs_c32(xn);
             v[q] = xn;
