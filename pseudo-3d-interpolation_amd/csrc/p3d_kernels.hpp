@@ -963,12 +963,14 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
-    static_assert(64 % TPL == 0 && TPL >= 8 && PPT == 16, "whole row pairs per wavefront");
-    constexpr int PW = 64 / TPL;                  // row pairs per wavefront: lanes [sub * TPL, (sub + 1) * TPL) hold rows a = PW * 2u + sub
+    static_assert((64 % TPL == 0 || TPL % 64 == 0) && TPL >= 8 && TPL <= 256 && PPT == 16, "whole row pairs per wavefront, or whole wavefronts per pair");
+    constexpr int WPL = TPL >= 64 ? TPL / 64 : 1; // wavefronts per row pair (rows of 2048 / 4096 samples: 2 / 4)
+    constexpr bool WAVE = WPL == 1;
+    constexpr int PW = TPL >= 64 ? 1 : 64 / TPL;  // row pairs per wavefront: lanes [sub * TPL, (sub + 1) * TPL) hold rows a = PW * 2u + sub
                                                   // and b = a + PW (so that the a-rows and the b-rows of a wave are each one unit of the
                                                   // lane-mask tables of the complex pass)
     constexpr int THREADS = pipe64_threads<N>();
-    constexpr int UPB = THREADS / 64;             // units (2 * PW rows) per workgroup
+    constexpr int UPB = THREADS / 64 / WPL;       // units (2 * PW rows) per workgroup
     constexpr int LSTR = LdsRow::stride(N);
     constexpr int HQ = PPT / 2;                   // registers 0 ... HQ-1 hold columns < N/2; register HQ of lane 0 holds column N/2
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -978,10 +980,12 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, tl = lane % TPL, sub = lane / TPL;
+    const int uline = wave / WPL, wsub = wave % WPL;
+    const int lane = tid & 63, tl = TPL >= 64 ? wsub * 64 + lane : lane % TPL, sub = TPL >= 64 ? 0 : lane / TPL;
     for (int i = tid; i < PassTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
-    const LdsRow lds{data + (wave * PW + sub) * LSTR};
+    const LdsRow lds{data + (uline * PW + sub) * LSTR};
+    double* red = reinterpret_cast<double*>(data + UPB * PW * LSTR);   // per-wave partial sums of pairs that span waves
 
     const unsigned pps = (unsigned)a.n1 / (2 * PW);            // units per slice
     const unsigned total = (unsigned)a.nslices * pps;
@@ -1004,7 +1008,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
     const float w_obs = 1.0f - a.alpha * 1.0f;
 
     const unsigned step = gridDim.x * UPB;
-    for (unsigned u = blockIdx.x * UPB + wave, u0 = blockIdx.x * UPB; u0 < total; u += step, u0 += step) {
+    for (unsigned u = blockIdx.x * UPB + uline, u0 = blockIdx.x * UPB; u0 < total; u += step, u0 += step) {
         if (MODE != REAL_FIRST) __syncthreads();   // lock-step: adjacent row pairs complete the 128-byte lines of a column block
         const bool in_range = u < total;
         const unsigned uu = in_range ? u : 0u;
@@ -1021,8 +1025,8 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
         // Mask words and compact bases of the a-rows (unit ua) and the b-rows (unit ua + 1): tables of the complex pass.  They are
         // (re)loaded where they are used, one unit at a time -- 16 x (64 + 32) bits per unit; all four sets at once do not fit the
         // scalar registers and every use would then be a v_readlane from a spill lane.
-        auto words_of = [&](unsigned unit) -> kmask_t { kmask_t m = k_bits + pipe64_word(unit, 1, 0, 0); asm volatile("" : "+s"(m)); return m; };
-        auto bases_of = [&](unsigned unit) -> kuint_t { kuint_t c = k_cbase + pipe64_word(unit, 1, 0, 0); asm volatile("" : "+s"(c)); return c; };
+        auto words_of = [&](unsigned unit) -> kmask_t { kmask_t m = k_bits + pipe64_word(unit, WPL, wsub, 0); asm volatile("" : "+s"(m)); return m; };
+        auto bases_of = [&](unsigned unit) -> kuint_t { kuint_t c = k_cbase + pipe64_word(unit, WPL, wsub, 0); asm volatile("" : "+s"(c)); return c; };
         const char* const xcb = reinterpret_cast<const char*>(a.xc) + (size_t)slice * a.nobs * 4u;
         c32 v[PPT];
         float oa[PPT], ob[PPT];
@@ -1055,13 +1059,26 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             if (on && bad && a.violation != nullptr) atomicOr(a.violation, 1);
             if (a.sums != nullptr) {
                 double da = (double)sa, db = (double)sb;
+                constexpr int SEG = TPL >= 64 ? 64 : TPL;
 #pragma unroll
-                for (int o = TPL / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, TPL); db += __shfl_down(db, o, TPL); }
-                if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
+                for (int o = SEG / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, SEG); db += __shfl_down(db, o, SEG); }
+                if constexpr (WAVE) {
+                    if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
+                } else {   // the wavefronts of a pair, in order
+                    __syncthreads();
+                    if (lane == 0) { red[2 * wave] = da; red[2 * wave + 1] = db; }
+                    __syncthreads();
+                    if (tl == 0 && on) {
+                        double ta = 0.0, tb = 0.0;
+                        for (int w = 0; w < WPL; ++w) { ta += red[2 * (uline * WPL + w)]; tb += red[2 * (uline * WPL + w) + 1]; }
+                        a.sums[(size_t)slice * a.n1 + ra] = ta;
+                        a.sums[(size_t)slice * a.n1 + ra + 1] = tb;
+                    }
+                }
             }
         } else {
             // ---- half spectra of the two rows -> Z = R_a + i R_b on all N columns ----
-            const kmask_t nz = k_nzl + (size_t)slice * PPT;
+            const kmask_t nz = k_nzl + pipe64_word(slice, WPL, wsub, 0);
             unsigned long long nzw[PPT];
             if (SPARSE) {
 #pragma unroll
@@ -1098,7 +1115,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            line_fft<N, INV, true>(v, lds, tw, tl);
+            line_fft<N, INV, WAVE>(v, lds, tw, tl);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(oa[q]), "+v"(ob[q]));
@@ -1126,9 +1143,22 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
             }
             if (a.sums != nullptr) {
                 double da = (double)sa, db = (double)sb;
+                constexpr int SEG = TPL >= 64 ? 64 : TPL;
 #pragma unroll
-                for (int o = TPL / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, TPL); db += __shfl_down(db, o, TPL); }
-                if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
+                for (int o = SEG / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, SEG); db += __shfl_down(db, o, SEG); }
+                if constexpr (WAVE) {
+                    if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
+                } else {   // the wavefronts of a pair, in order
+                    __syncthreads();
+                    if (lane == 0) { red[2 * wave] = da; red[2 * wave + 1] = db; }
+                    __syncthreads();
+                    if (tl == 0 && on) {
+                        double ta = 0.0, tb = 0.0;
+                        for (int w = 0; w < WPL; ++w) { ta += red[2 * (uline * WPL + w)]; tb += red[2 * (uline * WPL + w) + 1]; }
+                        a.sums[(size_t)slice * a.n1 + ra] = ta;
+                        a.sums[(size_t)slice * a.n1 + ra + 1] = tb;
+                    }
+                }
             }
             if (MODE == REAL_LAST) {
                 if (on) {
@@ -1147,18 +1177,26 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
 
         // ---- forward transform of z = r_a + i r_b, split into the two half spectra, store ----
         __builtin_amdgcn_sched_barrier(0);
-        line_fft<N, FWD, true>(v, lds, tw, tl);
+        line_fft<N, FWD, WAVE>(v, lds, tw, tl);
         __builtin_amdgcn_sched_barrier(0);
         if (MODE == REAL_FIRST) __syncthreads();   // (first pass: keep the stores of adjacent pairs together as well)
         {
             const size_t qs = qstep();
             const int src = sub * TPL + ((TPL - tl) % TPL);
+            if constexpr (!WAVE) {   // the partner may sit in another wavefront: the upper half of Z goes through the pair's LDS row
+                __syncthreads();
+#pragma unroll
+                for (int q = HQ; q < PPT; ++q) lds.at(tl + TPL * q) = v[q];
+                __syncthreads();
+            }
             char* b = wb;
 #pragma unroll
             for (int q = 0; q <= HQ; ++q) {
                 const c32 z = v[q];
                 const c32 far = v[q < HQ ? PPT - 1 - q : HQ - 1];      // lanes > 0: Z[N - e] is register 15 - q of lane 64 - tl
-                c32 pz{__shfl(far.x, src, 64), __shfl(far.y, src, 64)};
+                c32 pz;
+                if constexpr (WAVE) pz = c32{__shfl(far.x, src, 64), __shfl(far.y, src, 64)};
+                else pz = lds.at(tl == 0 ? N / 2 : N - (tl + TPL * q));   // (tl = 0 is overwritten below)
                 if (tl == 0) pz = q == 0 ? v[0] : v[PPT - q];          // tl = 0: Z[N - TPL q] is its own register 16 - q (q = 0: Z[0])
                 const c32 Ra{0.5f * (z.x + pz.x), 0.5f * (z.y - pz.y)};
                 const c32 Rb{0.5f * (z.y + pz.y), -0.5f * (z.x - pz.x)};
@@ -1477,14 +1515,22 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
 template <int N>
 hipError_t launch_row_real(int mode, const RowArgs& a, int cus, hipStream_t st)
 {
-    if constexpr (64 % Plan<N>::TPL == 0 && Plan<N>::TPL >= 8 && Plan<N>::PPT == 16) {
-        constexpr int PW = 64 / Plan<N>::TPL;
+    if constexpr ((64 % Plan<N>::TPL == 0 || Plan<N>::TPL % 64 == 0) && Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
+        constexpr int PW = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL, WPL = Plan<N>::TPL >= 64 ? Plan<N>::TPL / 64 : 1;
+        // Rows of 2048 samples (two wavefronts per pair: workgroup barriers around the split and the sums on top of those of the
+        // transforms, 8 waves per CU) lose what the half spectrum gains: 1024 x 2048 x 256 float32, 20 iterations, 71.3 ms against
+        // 68.4 on the complex path; 4096 samples: 37.1 against 43.0.  The kernel handles both; only the latter is switched on.
+        if (WPL == 2 && !getenv("P3D_REAL_2048")) return hipErrorNotSupported;
         if (a.n1 % (2 * PW) != 0 || a.bits64 == nullptr || a.cbase == nullptr || a.dtype != 1) return hipErrorNotSupported;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N / 2 + 1) >= 4294967296.0) return hipErrorNotSupported;
         constexpr size_t lds = pipe64_lds_bytes<N>();
-        constexpr int UPB = pipe64_threads<N>() / 64;
+        constexpr int UPB = pipe64_threads<N>() / 64 / WPL;
         const long groups = ((long)a.nslices * (a.n1 / (2 * PW)) + UPB - 1) / UPB;
-        const dim3 grid((unsigned)(groups < (long)cus ? groups : (long)cus));
+        int per_cu = (int)((160 * 1024) / lds);               // workgroups a CU holds: LDS and 4 waves per SIMD
+        if (per_cu > 16 / (pipe64_threads<N>() / 64)) per_cu = 16 / (pipe64_threads<N>() / 64);
+        if (per_cu < 1) per_cu = 1;
+        const long wgs = (long)cus * per_cu;
+        const dim3 grid((unsigned)(groups < wgs ? groups : wgs));
         hipError_t e = hipSuccess;
 #define P3D_REAL(MODE, SP)                                                                      \
     do {                                                                                        \

@@ -673,6 +673,9 @@ def test_one_process_several_devices_entry_point(ffi, orc):
     (96, 256, dict(niter=8, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),       # four
     (48, 128, dict(niter=8, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),           # eight
     (100, 256, dict(niter=6, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),          # 100 rows are not a multiple of 8: complex path
+    (48, 2048, dict(niter=9, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),          # two wavefronts per row pair
+    (64, 2048, dict(niter=30, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),
+    (24, 4096, dict(niter=6, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),      # four
     (64, 100, dict(niter=9, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),           # flexible row lengths: the pair lives in LDS
     (60, 75, dict(niter=8, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),        # odd length: no Nyquist column
     (128, 1000, dict(niter=30, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),     # two wavefronts per pair, in-place passes
@@ -692,6 +695,7 @@ def test_real_cubes_share_one_transform_per_row_pair(nil, nxl, kw, monkeypatch):
     cube = cube.astype(np.float32)
     kw = dict(kw, thresh_op="hard")
     res = {}
+    monkeypatch.setenv("P3D_REAL_2048", "1")   # rows of 2048 samples: implemented and tested, switched off by default (slower there)
     for real in (True, False):
         for sparse in (True, False):
             P.release_plans()
