@@ -149,8 +149,9 @@ static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsig
 static __global__ void nz_real_kernel(const uint8_t* flags, unsigned long long* nzl, unsigned long long* count, int nslices, int tiles, int col_t,
                                       int n2, int tpl, const int* done)
 {
+    // one wavefront per word: lane l decides its own bit, the word is the ballot
     const int wpl = tpl >= 64 ? tpl / 64 : 1;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
     if (i >= nslices * wpl * 16) return;
     const int q = i & 15, wsub = (i >> 4) % wpl, s = (i >> 4) / wpl;
     if (done && done[s] != 0) return;
@@ -161,16 +162,14 @@ static __global__ void nz_real_kernel(const uint8_t* flags, unsigned long long* 
         else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
         return any ? 1u : 0u;
     };
-    unsigned long long w = 0;
-    for (int l = 0; l < 64; ++l) {
-        const int e = (tpl >= 64 ? 64 * wsub + l : l % tpl) + tpl * q, k = q < 8 ? e : n2 - e;
-        w |= (unsigned long long)block_kept(k >> 3) << l;
-    }
-    nzl[i] = w;
+    const int e = (tpl >= 64 ? 64 * wsub + l : l % tpl) + tpl * q, k = q < 8 ? e : n2 - e;
+    const unsigned long long w = __ballot(block_kept(k >> 3) != 0u);
+    if (l == 0) nzl[i] = w;
     if (q == 0 && wsub == 0) {   // statistics: kept blocks of this slice's half spectrum
         unsigned kept = 0;
-        for (int b = 0; b <= (n2 / 2) >> 3; ++b) kept += block_kept(b);
-        if (kept) atomicAdd(count, (unsigned long long)kept);
+        for (int b = l; b <= (n2 / 2) >> 3; b += 64) kept += block_kept(b);
+        for (int o = 32; o > 0; o >>= 1) kept += __shfl_down(kept, o, 64);
+        if (l == 0 && kept) atomicAdd(count, (unsigned long long)kept);
     }
 }
 
@@ -1066,7 +1065,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         c.iter = k;
         HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
         if (sparse && real_path && !flex_rows) {
-            nz_real_kernel<<<(nslices * 16 * (p->ops_row->tpl >= 64 ? p->ops_row->tpl / 64 : 1) + 255) / 256, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, p->ops_row->tpl, c.done);
+            nz_real_kernel<<<(nslices * 16 * (p->ops_row->tpl >= 64 ? p->ops_row->tpl / 64 : 1) + 3) / 4, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, p->ops_row->tpl, c.done);
             r.nzl = p->nzl;
         } else if (sparse && flex_rows) {   // the flexible row pass reads the tile flags themselves; count the kept blocks for the statistics
             const int nb_work = (n2_work + 7) / 8;   // the half spectrum of a real cube has its own tile count
