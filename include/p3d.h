@@ -92,7 +92,7 @@ int p3d_plan_destroy(p3d_plan* plan);
 
 /* device-memory helpers so that a pure-ctypes caller needs no other GPU runtime */
 int p3d_malloc(p3d_plan* plan, void** dptr, size_t bytes);
-int p3d_free(p3d_plan* plan, void* dptr);
+int p3d_free(p3d_plan* plan, void* dptr);   /* `plan` may be NULL (the buffer outlived its plan) */
 int p3d_memcpy_h2d(p3d_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
 int p3d_memcpy_d2h(p3d_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
 /* page-locked host memory: copies to / from it run at the PCIe rate (pageable NumPy memory is staged by the runtime at a

@@ -381,7 +381,11 @@ int p3d_plan_destroy(p3d_plan* p)
     return P3D_OK;
 }
 
-int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices)
+// force_generic: the unfused any-length pipeline even where tuned kernels exist (the percentile operators rank the whole
+// spectrum, which the fused passes never materialise).  The experiment switch P3D_FORCE_GENERIC asks for the same from outside;
+// it is read here, once per plan -- nothing in this library ever WRITES the process environment (plans are created and run from
+// several host threads at once, and getenv racing a setenv is undefined behaviour).
+static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_slices, bool force_generic)
 {
     if (!out) return fail(P3D_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -389,7 +393,7 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     if (max_slices > 65535) return fail(P3D_ERR_INVALID, "max_slices > 65535: split the cube into batches");
     const LineOps* oc = find_ops(nil);
     const LineOps* orow = find_ops(nxl);
-    const bool generic = !oc || !orow || getenv("P3D_FORCE_GENERIC") != nullptr;
+    const bool generic = !oc || !orow || force_generic;
     if (generic && !(generic_ok(nil) && generic_ok(nxl)))
         return fail(P3D_ERR_UNSUPPORTED, "slice shape %d x %d: extents up to %d are supported", nil, nxl, GEN_MAX_N);
     int ndev = 0;
@@ -482,6 +486,11 @@ int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices
     return P3D_OK;
 }
 
+int p3d_plan_create(p3d_plan** out, int device, int nil, int nxl, int max_slices)
+{
+    return create_plan(out, device, nil, nxl, max_slices, getenv("P3D_FORCE_GENERIC") != nullptr);
+}
+
 int p3d_malloc(p3d_plan* p, void** dptr, size_t bytes)
 {
     if (!p || !dptr) return fail(P3D_ERR_INVALID, "NULL argument");
@@ -492,8 +501,9 @@ int p3d_malloc(p3d_plan* p, void** dptr, size_t bytes)
 
 int p3d_free(p3d_plan* p, void* dptr)
 {
-    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
-    HIP_TRY(hipSetDevice(p->device));
+    // p3d_malloc is a bare hipMalloc: the buffer does not die with its plan, so it can (and must) be freed after the plan is gone
+    // too -- `p` may be NULL then (hipFree finds the owning device from the pointer)
+    if (p) HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipFree(dptr));
     return P3D_OK;
 }
@@ -530,6 +540,20 @@ int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
 }  // extern "C"
 
 // ---- internal helpers ---------------------------------------------------------------------------
+// Diagnostic switches of one job: every one selects a slower, equivalent path.  Read once per call of
+// p3d_pocs_run_dev, on the calling thread, and handed down as plain values -- the launch paths never consult the environment.
+struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048; };
+static RunSwitches read_switches()
+{
+    RunSwitches s;
+    s.no_mask_bits = getenv("P3D_NO_MASK_BITS") != nullptr;
+    s.no_compact = getenv("P3D_NO_COMPACT") != nullptr;
+    s.no_real = getenv("P3D_NO_REAL") != nullptr;
+    s.no_sparse = getenv("P3D_NO_SPARSE") != nullptr;
+    s.real_2048 = getenv("P3D_REAL_2048") != nullptr;
+    return s;
+}
+
 static int check_batch(p3d_plan* p, int nslices)
 {
     if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
@@ -824,6 +848,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     HIP_TRY(hipSetDevice(p->device));
 
     const int niter = prm->niter;
+    const RunSwitches sw = read_switches();
     const bool profile = (prm->flags & P3D_FLAG_PROFILE) != 0;
     const bool early = prm->eps > 0.0;
     const bool adaptive = prm->version == P3D_VER_ADAPTIVE;
@@ -873,11 +898,8 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     if (percentile && !p->generic) {
         // the tuned kernels never materialise the spectrum; ranking it needs the unfused pipeline -> a second, generic plan
         if (!p->pct_plan) {
-            const int keep = p->device;
             p3d_plan* q = nullptr;
-            setenv("P3D_FORCE_GENERIC", "1", 1);
-            const int prc = p3d_plan_create(&q, keep, p->nil, p->nxl, p->max_slices);
-            unsetenv("P3D_FORCE_GENERIC");
+            const int prc = create_plan(&q, p->device, p->nil, p->nxl, p->max_slices, true);
             if (prc) return prc;
             p->pct_plan = q;
         }
@@ -966,10 +988,10 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(&nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
-    if (getenv("P3D_NO_MASK_BITS")) nonbinary = 1;  // experiments only
+    if (sw.no_mask_bits) nonbinary = 1;  // experiments only
     // Compact observed samples for the steady-state row pass: only the observed positions of x are non-zero in
     // the workflow (x = stacked traces, mask = fold >= 1); ROW_FIRST verifies that and the full cube is used if not.
-    bool compact = !nonbinary && p->pipe_wgs > 0 && p->nil <= 4096 && niter > 1 && !getenv("P3D_NO_COMPACT") &&
+    bool compact = !nonbinary && p->pipe_wgs > 0 && p->nil <= 4096 && niter > 1 && !sw.no_compact &&
                    nobs > 0 && (double)nobs < 0.75 * (double)p->slice_elems();
     if (compact) {
         const size_t need = (size_t)nslices * nobs * (dtype == P3D_C64 ? sizeof(c32) : sizeof(float));
@@ -1002,6 +1024,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.sums = p->rowsum;
     r.done = any_off ? p->done : nullptr;
     r.dtype = dtype;
+    r.real_2048 = sw.real_2048 ? 1 : 0;
     r.adaptive = adaptive ? 1 : 0;
     // Early exit: a slice that converges at iteration k leaves the forward row transform of its iterate in the work buffer;
     // a "finalize" launch after the convergence test turns that back into `out` for exactly those slices, so the steady
@@ -1016,7 +1039,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // Real cubes with the hard operator: the spectrum stays Hermitian, so row pairs share one complex transform and the work
     // buffer holds half the columns (row_real_kernel).  Needs the compact observed samples and the lane-mask tables.
     // (The flexible-length row pass keeps the pair in LDS and takes any real mask: no compact samples, no tables needed there.)
-    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && p->ops_row->row_real != nullptr && !getenv("P3D_NO_REAL") &&
+    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && p->ops_row->row_real != nullptr && !sw.no_real &&
                      (flex_rows ? p->nil % 2 == 0 : (compact && r.bits64 && r.cbase && p->pipe_wgs > 0));
     if (real_path) {
         const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
@@ -1047,7 +1070,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     c.niter = niter;
     c.op = base_op;
     // tiles of the spectrum that the threshold empties are neither transformed back, stored nor read again
-    const bool sparse = p->sparse_ok && !getenv("P3D_NO_SPARSE");
+    const bool sparse = p->sparse_ok && !sw.no_sparse;
     const int nblocks = (p->nxl + 7) / 8, groups = flex_rows ? 1 : p->ops_row->tpl / 8;
     const int col_t = is_flex(p->ops_col) ? flex_col_tile(p->nil) : p->ops_col->col_tile;
     if (sparse) {

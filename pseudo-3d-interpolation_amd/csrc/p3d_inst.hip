@@ -19,3 +19,14 @@ const LineOps* P3D_CAT(get_line_ops_, P3D_N)()
     return &ops;
 }
 }  // namespace p3d
+
+#if P3D_STAMPS && P3D_N == 1024
+// diagnostic build only: hand the stamps of the last row_pipe64_kernel<1024> launch to the host (tools/rowpass_stamps.py)
+extern "C" int p3d_debug_read_stamps(unsigned* out, int n)
+{
+    const size_t bytes = sizeof(unsigned) * (size_t)n;
+    if (bytes > sizeof(p3d::p3d_stamp_buf)) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(p3d::p3d_stamp_buf), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -184,6 +184,7 @@ struct RowArgs {
     float alpha;
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
+    int real_2048;         // host side only: the row-pair path for rows of 2048 samples is switched on (experiment switch P3D_REAL_2048)
     ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD
 };
 
@@ -721,8 +722,20 @@ row_pipe_kernel(const RowArgs a)
 #define P3D_PIPE64_MAXROWS 2
 #endif
 
-#ifndef P3D_PIPE64_OBS_EARLY
-#define P3D_PIPE64_OBS_EARLY 1   // observed samples requested before the inverse transform instead of after it (32 VGPRs across it)
+#ifndef P3D_ABL_NOSTORE   // ablations of the persistent row pass (timing experiments, results wrong): tools/rowpass_ablation.sh
+#define P3D_ABL_NOSTORE 0
+#endif
+#ifndef P3D_ABL_NOFFT
+#define P3D_ABL_NOFFT 0
+#endif
+#ifndef P3D_ABL_NOSUMS
+#define P3D_ABL_NOSUMS 0
+#endif
+#ifndef P3D_ABL_NOOBS
+#define P3D_ABL_NOOBS 0
+#endif
+#ifndef P3D_ABL_NOWORK
+#define P3D_ABL_NOWORK 0
 #endif
 // rows per workgroup: as many as 160 KiB of LDS hold next to the twiddle tables, at most 1024 threads
 template <int N>
@@ -740,8 +753,82 @@ constexpr size_t pipe64_lds_bytes() { return sizeof(c32) * (PassTables<N>::slots
 template <int N>
 constexpr int pipe64_threads() { return pipe64_rows<N>() * Plan<N>::TPL; }
 
-// (Tried and dropped: a wavefront that owns TWO adjacent rows and stores them together, so that the 64-byte halves of a line pair
-// up inside the wave and the lock-step barrier can go -- 12 waves per CU at 168 VGPRs: 2.03 ms against 1.92, niter = 10.)
+// ---- buffer addressing (wave-uniform descriptor + per-lane 32-bit byte offset) --------------------------------------------------
+// A predicated access is written as an UNCONDITIONAL buffer instruction whose switched-off lanes carry an offset beyond the
+// descriptor's range: the hardware range check returns zero for such a load lane / drops such a store lane without touching
+// memory.  That matters beyond the saved branch: `s_waitcnt vmcnt` counts in issue order, and hipcc can only count exactly through
+// straight-line code -- with one `s_cbranch_execz` per predicated global_load (what `if (lane_pred) x = *p;` compiles to) every
+// wait of the loop became vmcnt(0), i.e. each row waited for the write acknowledgements of the row before it
+// (profiles/r02_rowpass_*.txt).
+typedef unsigned p3d_u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_OOB = 0x80000000u;   // every descriptor below spans less than 2 GiB
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_srd(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// (loads whose results are carried around a loop travel as raw 64-bit integers: a loop-carried pair of floats invites the
+// vectoriser to keep it shuffled, and the copies that undo the shuffle sit -- with their wait -- in front of the back edge)
+typedef unsigned long long raw64;
+__device__ __forceinline__ raw64 buf_load_raw64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const p3d_u2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return (raw64)t.x | ((raw64)t.y << 32);
+}
+__device__ __forceinline__ c32 raw_c32(raw64 u) { return c32{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))}; }
+__device__ __forceinline__ c32 buf_load_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return raw_c32(buf_load_raw64(r, voff, soff)); }
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{(unsigned)u, (unsigned)(u >> 32)}, r, (int)voff, (int)soff, 0);
+}
+
+// In-kernel stamps (diagnostic build -DP3D_STAMPS=1 only, tools/rowpass_stamps.sh): cycles each wave of row_pipe64_kernel spends
+// between fixed points of a row, summed over its rows, in a buffer of their own that nothing else reads.
+#ifndef P3D_STAMPS
+#define P3D_STAMPS 0
+#endif
+#if P3D_STAMPS
+constexpr int STAMP_PHASES = 10;
+static __device__ unsigned p3d_stamp_buf[1024 * 16 * STAMP_PHASES];   // (one copy per translation unit; the reader sits next to the kernels)
+#define P3D_STAMP(i)                                                     \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        st_acc[i] += (unsigned)(t_ - st_prev);                           \
+        st_prev = t_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+#else
+#define P3D_STAMP(i) do { } while (0)
+#endif
+
+// (Tried and dropped in round 1: a wavefront that owns TWO adjacent rows and stores them together, so that the 64-byte halves of a
+// line pair up inside the wave and the lock-step barrier can go -- 12 waves per CU at 168 VGPRs: 2.03 ms against 1.92, niter = 10.)
+//
+// Schedule of one row (round 2).  Vector-memory operations retire in issue order, so a wave that waits for a load also waits for
+// every store it issued before that load.  The loop therefore never issues a load behind the stores it does not want to wait for:
+//
+//     top of row r:   v <- by            (work-buffer elements of row r, requested before the forward transform of row r-1)
+//                     inverse transform
+//                     re-insertion with bx (observed samples of row r, requested behind the forward transform of row r-1), sum |x|
+//                     scalar tables of row r+1; by <- work-buffer elements of row r+1     <- in flight during the forward transform
+//                     forward transform
+//                     bx <- observed samples of row r+1
+//                     lock-step barrier, stores of row r          <- a whole row of arithmetic passes before anything behind them
+//                                                                    is waited for
+// Every access is an unconditional buffer instruction (see above) except the work-buffer loads of emptied blocks, which are OLDER
+// than everything a later wait has to leave outstanding; the prologue issues the same number of (out-of-range) stores as the loop
+// body, so the compiler's wait counts at the loop header are exact: `vmcnt(32)` for the work-buffer elements (16 observed-sample
+// loads and 16 stores stay in flight), `vmcnt(31 ... 16)` for the samples, where round 1 had `vmcnt(0)` throughout.
+// What this bought, and what it did not: profiles/r02_rowpass_schedule.txt.
 template <int N, int DT, bool SPARSE>
 __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
 {
@@ -777,11 +864,13 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     const unsigned total = (unsigned)a.nslices * upslice;
     const unsigned wblk = (unsigned)a.n1 * 8;
     const size_t wstride = wk_slice_stride(a.n1, N);
+    const unsigned slice_bytes = (unsigned)(wstride * 8);               // one slice of the work buffer: at most 128 MiB
     // element tl + TPL*q = column 64*(wsub + WPL*q) + lane (rows of whole wavefronts) or TPL*q + tl of row `sub` of the unit:
     // min(TPL, 64) / 8 column blocks per wavefront and register, adjacent rows 64 bytes apart
     const unsigned colpart = TPL >= 64 ? (unsigned)lane : (unsigned)tl;
     const unsigned lane_w = ((colpart >> 3) * wblk + (colpart & 7) + (unsigned)sub * 8u) * 8u;   // byte offset of the lane, every q
-    const size_t qs64 = (size_t)8 * wblk * 8u;                                                   // bytes per 64 columns
+    const unsigned qs64 = 8u * wblk * 8u;                                                        // bytes per 64 columns
+    const unsigned qs = TPL >= 64 ? qs64 * WPL : qs64 / RPW;                                     // bytes from register q to q + 1
 
     // The small tables (lane masks, compact bases) are never written while this kernel runs: reading them through the constant
     // address space lets the compiler use scalar loads although the loop also stores to the work buffer.
@@ -791,9 +880,6 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     const kmask_t k_bits = (kmask_t)a.bits64, k_nzl = (kmask_t)a.nzl;
     const kuint_t k_cbase = (kuint_t)a.cbase;
     const kint_t k_done = (kint_t)a.done;   // early exit (eps > 0): set between launches, constant during one
-    // "scalar base + 32-bit lane offset" addressing is matched per basic block: keep the zero-extension of the lane offset from
-    // being hoisted out of the predicated blocks (an empty asm, no instruction)
-    auto lane_off = [&]() -> unsigned { unsigned o = lane_w; asm volatile("" : "+v"(o)); return o; };
 
     struct Where { unsigned slice, row; bool on; };   // row: the unit's index inside its slice (= the row itself when RPW == 1)
     auto locate = [&](unsigned g) -> Where {
@@ -805,15 +891,12 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
         if (k_done != nullptr && w.on && k_done[w.slice] != 0) w.on = false;   // finished / empty slice: leave it alone
         return w;
     };
-    auto wbase = [&](const Where& w) -> char* {
-        return reinterpret_cast<char*>(a.work) + (w.slice * wstride + (size_t)w.row * RPW * 8) * 8 + (size_t)wsub * qs64;
-    };
-    // register q sits WPL * 64 columns further on: one running scalar pointer (the step is made opaque per call so that sixteen
-    // precomputed 64-bit multiples do not crowd the scalar registers)
-    auto qstep = [&]() -> size_t { size_t qs = TPL >= 64 ? qs64 * WPL : qs64 / RPW; asm volatile("" : "+s"(qs)); return qs; };
-    auto load_work = [&](c32 (&dst)[PPT], const Where& w) {
-        const char* b = wbase(w);
-        const size_t qs = qstep();
+    auto work_srd = [&](const Where& w) { return buf_srd(reinterpret_cast<const char*>(a.work) + w.slice * wstride * 8, slice_bytes); };
+    auto work_soff = [&](const Where& w) -> unsigned { return w.row * (unsigned)(RPW * 64) + (unsigned)wsub * qs64; };
+    // by[] <- the unit's elements of the work buffer; emptied column blocks (SPARSE) read as zero without a memory access
+    auto issue_work = [&](raw64 (&dst)[PPT], const Where& w) {
+        const __amdgpu_buffer_rsrc_t srd = work_srd(w);
+        unsigned so = work_soff(w);
         const kmask_t nz = k_nzl + pipe64_word(w.slice, WPL, wsub, 0);
         unsigned long long nzw[PPT];
         if (SPARSE) {
@@ -823,125 +906,171 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             if (SPARSE) {
-                c32 val{0.f, 0.f};
-                if (__builtin_amdgcn_inverse_ballot_w64(nzw[q])) val = *reinterpret_cast<const c32*>(b + lane_off());
-                dst[q] = val;
+                // A register whose 64 columns were all emptied (most of them, late in a schedule) skips the instruction: an
+                // all-out-of-range load moves no data but still occupies the address unit (16 of them per row: +0.24 ms on
+                // the headline cube).  The branch is wave-uniform; it does not disturb the wait counts, because every
+                // operation whose count varies this way is OLDER than all those a later wait has to leave outstanding.
+                raw64 r = 0;
+                if (nzw[q] != 0 && !P3D_ABL_NOWORK) r = buf_load_raw64(srd, __builtin_amdgcn_inverse_ballot_w64(nzw[q]) ? lane_w : BUF_OOB, so);
+                dst[q] = r;
             } else {
-                dst[q] = *reinterpret_cast<const c32*>(b + lane_off());
+                dst[q] = buf_load_raw64(srd, P3D_ABL_NOWORK ? BUF_OOB : lane_w, so);
             }
-            b += qs;
+            so += qs;
         }
     };
     // (the mask words are loaded again for the re-insertion instead of being kept across the transform: together with the compact
     // bases and the emptied-block words they do not fit the scalar registers, and a spilled word costs a v_readlane per use)
     auto words_of = [&](const Where& w) -> kmask_t { kmask_t m = k_bits + pipe64_word(w.row, WPL, wsub, 0); asm volatile("" : "+s"(m)); return m; };
-    auto load_obs = [&](c32 (&dst)[PPT], const Where& w) {
+    // bx[] <- the unit's observed samples from the compact array (zero where the trace is missing)
+    auto obs_tables = [&](unsigned long long (&mwords)[PPT], unsigned (&cbs)[PPT], const Where& w) {
         const kmask_t mrow = words_of(w);
         const kuint_t cb = k_cbase + pipe64_word(w.row, WPL, wsub, 0);   // observed traces before this word, from the start of the slice
-        const char* xb = reinterpret_cast<const char*>(a.xc) + (size_t)w.slice * a.nobs * ES;
-        unsigned long long mwords[PPT];
-        unsigned cbs[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) { mwords[q] = mrow[q]; cbs[q] = cb[q]; }
+    };
+    auto issue_obs_with = [&](raw64 (&dst)[PPT], const Where& w, const unsigned long long (&mwords)[PPT], const unsigned (&cbs)[PPT]) {
+        const __amdgpu_buffer_rsrc_t srd = buf_srd(reinterpret_cast<const char*>(a.xc) + (size_t)w.slice * a.nobs * ES, a.nobs * ES);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const unsigned long long mw = mwords[q];
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mw, 0u));
-            const char* xq = xb + (size_t)cbs[q] * ES;
-            c32 val{0.f, 0.f};
-            if (__builtin_amdgcn_inverse_ballot_w64(mw)) {
-                unsigned ro = rank * ES;
-                asm volatile("" : "+v"(ro));
-                if (DT == 0) val = *reinterpret_cast<const c32*>(xq + ro);
-                else val.x = *reinterpret_cast<const float*>(xq + ro);
-            }
-            dst[q] = val;
+            const unsigned vo = (__builtin_amdgcn_inverse_ballot_w64(mw) && !P3D_ABL_NOOBS) ? rank * ES : BUF_OOB;
+            if (DT == 0) dst[q] = buf_load_raw64(srd, vo, cbs[q] * ES);
+            else dst[q] = (raw64)__builtin_amdgcn_raw_buffer_load_b32(srd, (int)vo, (int)(cbs[q] * ES), 0);   // (imaginary part: zero bits)
         }
     };
+    auto store_work = [&](const c32 (&src)[PPT], const Where& w, bool really) {
+        const __amdgpu_buffer_rsrc_t srd = work_srd(w);
+        unsigned so = work_soff(w);
+        const unsigned vo = (really && !P3D_ABL_NOSTORE) ? lane_w : BUF_OOB;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            buf_store_c32(srd, vo, so, src[q]);
+            so += qs;
+        }
+    };
+    // per-row sums of |x|: [nslices][n1] doubles (< 2 GiB: nslices <= 65535, n1 <= 4096); a null table swallows the stores
+    const __amdgpu_buffer_rsrc_t sums_srd = buf_srd(a.sums, a.sums != nullptr ? (unsigned)a.nslices * (unsigned)a.n1 * 8u : 0u);
     const float w_obs = 1.0f - a.alpha * 1.0f;   // POCS.py:616 at an observed trace
-    // one row from the work buffer to the forward transform of the next iteration, left in v[]
-    auto process = [&](c32 (&v)[PPT], const Where& cur) {
-        c32 bx[PPT];
-        load_work(v, cur);
-#if P3D_PIPE64_OBS_EARLY
-        // issued BEHIND the work-buffer loads (vmcnt retires in order: the transform below waits for those only) and in flight
-        // during the inverse transform
-        __builtin_amdgcn_sched_barrier(0);
-        load_obs(bx, cur);
+
+    const unsigned step = gridDim.x * UPB;
+    unsigned g = blockIdx.x * UPB + uline;
+    Where cur = locate(g);
+    c32 v[PPT];
+    raw64 bx[PPT], by[PPT];
+    unsigned long long mw_cur[PPT];   // the row's mask words stay in scalar registers from the request of its observed samples to its re-insertion
+    issue_work(by, cur);
+    {
+        unsigned cbs0[PPT];
+        obs_tables(mw_cur, cbs0, cur);
+        issue_obs_with(bx, cur, mw_cur, cbs0);
+    }
+    {   // as many stores as one trip of the loop issues, all out of range: the wait counts at the loop header are then the same
+        // along both edges into it (see the note above the kernel)
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = c32{0.f, 0.f};
+        store_work(v, cur, false);
+        buf_store_f64(sums_srd, BUF_OOB, 0u, 0.0);
+    }
+#if P3D_STAMPS
+    unsigned st_acc[STAMP_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
+    for (unsigned g0 = blockIdx.x * UPB; g0 < total; g0 += step) {
+        const Where nxt = locate(g + step);
         __builtin_amdgcn_sched_barrier(0);
-        line_fft<N, INV, WAVE>(v, lds, tw, tl);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = raw_c32(by[q]);
+#if P3D_STAMPS
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y));
+#endif
+        P3D_STAMP(0);   // wait for the row's elements of the work buffer
         __builtin_amdgcn_sched_barrier(0);
-#if !P3D_PIPE64_OBS_EARLY
-        load_obs(bx, cur);
+        // the LDS / twiddle addresses of the transforms are functions of tl alone; hoisted out of the loop they pin a dozen vector
+        // registers across it, which is what pushes the kernel over the 128 a 16-wave workgroup may use (and ONE spilled register is
+        // a scratch load, i.e. a vmcnt(0) in the middle of the transform).  Recomputed per row instead.
+        int tl_r = tl;
+        asm volatile("" : "+v"(tl_r));
+        if (!P3D_ABL_NOFFT) line_fft<N, INV, WAVE>(v, lds, tw, tl_r);
+        P3D_STAMP(1);   // inverse transform
         __builtin_amdgcn_sched_barrier(0);
-#else
         // the samples are first touched HERE: without this the compiler starts on bx * alpha in the middle of the transform and
         // waits for the loads there
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(bx[q].x), "+v"(bx[q].y));
-#endif
+        for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(bx[q]));
         float acc = 0.f;
-        const kmask_t mrow2 = words_of(cur);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             c32 xn = v[q] * a.scale;
-            const float w = __builtin_amdgcn_inverse_ballot_w64(mrow2[q]) ? w_obs : 1.0f;
-            xn = axpby(xn, w, bx[q], a.alpha);        // POCS.py:616-619
+            const float w = __builtin_amdgcn_inverse_ballot_w64(mw_cur[q]) ? w_obs : 1.0f;
+            xn = axpby(xn, w, raw_c32(bx[q]), a.alpha);        // POCS.py:616-619
             acc += abs_c32(xn);
             v[q] = xn;
         }
+#if P3D_STAMPS
+        asm volatile("" : "+v"(acc));
+#endif
+        P3D_STAMP(2);   // wait for the observed samples, re-insertion
         __builtin_amdgcn_sched_barrier(0);
-
-        if (a.sums != nullptr) {
+        if (!P3D_ABL_NOSUMS) {
             double ws = (double)acc;
             constexpr int SEG = TPL >= 64 ? 64 : TPL;   // one row = SEG consecutive lanes: segmented reduction
 #pragma unroll
             for (int o = SEG / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, SEG);
+            const unsigned so = (cur.slice * (unsigned)a.n1 + cur.row * RPW) * 8u;
             if constexpr (WAVE) {
-                if ((lane & (SEG - 1)) == 0 && cur.on) a.sums[(size_t)cur.slice * a.n1 + cur.row * RPW + sub] = ws;
+                buf_store_f64(sums_srd, ((lane & (SEG - 1)) == 0 && cur.on) ? (unsigned)sub * 8u : BUF_OOB, so, ws);
             } else {   // the wavefronts of a row in the order row_kernel adds them
                 __syncthreads();
                 if (lane == 0) red[wave] = ws;
                 __syncthreads();
-                if (wsub == 0 && lane == 0 && cur.on) {
-                    double t = 0.0;
-                    for (int w = 0; w < WPL; ++w) t += red[uline * WPL + w];
-                    a.sums[(size_t)cur.slice * a.n1 + cur.row] = t;
-                }
+                double t = 0.0;
+                for (int w = 0; w < WPL; ++w) t += red[uline * WPL + w];
+                buf_store_f64(sums_srd, (wsub == 0 && lane == 0 && cur.on) ? 0u : BUF_OOB, so, t);
             }
         }
+        P3D_STAMP(3);   // sum of |x|
         __builtin_amdgcn_sched_barrier(0);
-        line_fft<N, FWD, WAVE>(v, lds, tw, tl);
+        // The next row's elements of the work buffer, and the scalar tables its observed samples are found with, are requested
+        // BEFORE the forward transform: all waves of a workgroup run in step, so a latency nobody computes behind is a latency the
+        // whole CU waits for.
+        issue_work(by, nxt);
+        unsigned long long mw_nxt[PPT];
+        unsigned cbs_n[PPT];
+        obs_tables(mw_nxt, cbs_n, nxt);
+        P3D_STAMP(4);   // requests for the next row's work-buffer elements (scalar tables first)
         __builtin_amdgcn_sched_barrier(0);
-    };
-
-    {
-        const unsigned step = gridDim.x * UPB;
-        unsigned g = blockIdx.x * UPB + uline;
-        Where cur = locate(g);
-        Where nxt = locate(g + step);
-        for (unsigned g0 = blockIdx.x * UPB; g0 < total; g0 += step) {
+        if (!P3D_ABL_NOFFT) line_fft<N, FWD, WAVE>(v, lds, tw, tl_r);
+        P3D_STAMP(5);   // forward transform
+        __builtin_amdgcn_sched_barrier(0);
+        issue_obs_with(bx, nxt, mw_nxt, cbs_n);
+        P3D_STAMP(6);   // requests for the next row's observed samples
+        __builtin_amdgcn_sched_barrier(0);
+        // Adjacent rows share the 128-byte lines of the work buffer (64 bytes each), and sixteen adjacent rows make one contiguous
+        // KiB per column block: the waves of a workgroup store TOGETHER.  Measured on the headline cube (profiles/r02_rowpass_
+        // schedule.txt): barrier every row 1.60 ms, every 2nd / 4th / 8th / 32nd row 1.72 / 1.92 / 2.04 / 2.11 ms, never 2.36 ms;
+        // lock-step kept by groups of 2 / 4 / 8 waves only (counters in LDS) 1.74 / 1.80 / 1.71 ms.  A wavefront that holds two or
+        // more adjacent rows (RPW > 1) pairs their halves up by itself.
 #if P3D_PIPE64_LOCKSTEP
-            if (WAVE) __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: keep the waves of a workgroup in step
+        if (WAVE && RPW == 1) __builtin_amdgcn_s_barrier();
 #endif
-            const Where nxt2 = locate(g + 2 * step);
-            c32 v[PPT];
-            process(v, cur);
-            if (cur.on) {
-                char* b = wbase(cur);
-                const size_t qs = qstep();
+        P3D_STAMP(7);   // lock-step barrier
+        store_work(v, cur, cur.on);
+        P3D_STAMP(8);   // issue of the stores
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < PPT; ++q) {
-                    *reinterpret_cast<c32*>(b + lane_off()) = v[q];
-                    b += qs;
-                }
-            }
-            g += step;
-            cur = nxt;
-            nxt = nxt2;
-        }
+        for (int q = 0; q < PPT; ++q) mw_cur[q] = mw_nxt[q];
+        g += step;
+        cur = nxt;
     }
+#if P3D_STAMPS
+    if (lane == 0 && blockIdx.x < 1024 && wave < 16) {
+#pragma unroll
+        for (int i = 0; i < STAMP_PHASES; ++i) p3d_stamp_buf[((size_t)blockIdx.x * 16 + wave) * STAMP_PHASES + i] = st_acc[i];
+    }
+#endif
 }
 
 // =================================================================================================
@@ -1520,7 +1649,7 @@ hipError_t launch_row_real(int mode, const RowArgs& a, int cus, hipStream_t st)
         // Rows of 2048 samples (two wavefronts per pair: workgroup barriers around the split and the sums on top of those of the
         // transforms, 8 waves per CU) lose what the half spectrum gains: 1024 x 2048 x 256 float32, 20 iterations, 71.3 ms against
         // 68.4 on the complex path; 4096 samples: 37.1 against 43.0.  The kernel handles both; only the latter is switched on.
-        if (WPL == 2 && !getenv("P3D_REAL_2048")) return hipErrorNotSupported;
+        if (WPL == 2 && !a.real_2048) return hipErrorNotSupported;
         if (a.n1 % (2 * PW) != 0 || a.bits64 == nullptr || a.cbase == nullptr || a.dtype != 1) return hipErrorNotSupported;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N / 2 + 1) >= 4294967296.0) return hipErrorNotSupported;
         constexpr size_t lds = pipe64_lds_bytes<N>();

@@ -356,9 +356,8 @@ class _FFTWorker:
         return w
 
     def close(self):
-        if self.plan.handle is not None:   # device buffers die with their plan otherwise
-            for b in (self.x, self.o, self.m):
-                b.free()
+        for b in (self.x, self.o, self.m):   # p3d_malloc'ed: they outlive a closed plan, p3d_free takes a NULL plan then
+            b.free()
         for b in (self.hx, self.ho):
             if b is not None:
                 b.free()
@@ -556,6 +555,43 @@ def pocs_cube(
 # =================================================================================================
 #                                      per-slice contract
 # =================================================================================================
+_FFT_MODULES = ('numpy.fft', 'scipy.fft', 'scipy.fftpack', 'pyfftw.interfaces', 'mkl_fft')
+_FFT_BENIGN = {'s': (None,), 'axes': ((-2, -1), (0, 1), [-2, -1], [0, 1], None), 'norm': (None, 'backward')}
+
+
+def _unwrap_partial(func):
+    """(innermost callable, merged keywords) of nested functools.partial objects; keywords None when positional arguments are bound."""
+    kw = {}
+    while isinstance(func, partial):
+        if func.args:
+            return func.func, None
+        kw = {**(func.keywords or {}), **kw}
+        func = func.func
+    return func, kw
+
+
+def _check_transform_callables(kind, transform, itransform):
+    """The reference CALLS ``transform`` / ``itransform`` (POCS.py:535, 592, 613); here the HIP kernels are the transform, chosen by
+    ``transform_kind``.  A callable that is not the one the kind names would be ignored silently -- refuse it instead: FFT wants
+    ``fft2`` / ``ifft2`` of numpy.fft (or a drop-in: scipy.fft, pyfftw.interfaces, mkl_fft) over the last two axes, WAVELET
+    ``partial(pywt.wavedec2, ...)`` / ``partial(pywt.waverec2, ...)``, SHEARLET FFST's ``shearletTransformSpect`` /
+    ``inverseShearletTransformSpect`` (cube_POCS_interpolation_3D.py:255-274)."""
+    want = {'FFT': ('fft2', 'ifft2'), 'WAVELET': ('wavedec2', 'waverec2'),
+            'SHEARLET': ('shearletTransformSpect', 'inverseShearletTransformSpect')}[kind]
+    for func, name, role in ((transform, want[0], 'transform'), (itransform, want[1], 'itransform')):
+        inner, kw = _unwrap_partial(func)
+        fname = getattr(inner, '__name__', type(inner).__name__)
+        ok = kw is not None
+        if kind == 'FFT':
+            ok = ok and fname == name and str(getattr(inner, '__module__', '')).startswith(_FFT_MODULES)
+            ok = ok and all(k in _FFT_BENIGN and v in _FFT_BENIGN[k] for k, v in (kw or {}).items())
+        else:   # third-party functions (pywt / FFST need not be installed here): recognised by name
+            ok = ok and fname.endswith(name)
+        if not ok:
+            raise NotImplementedError(
+                f'{role}={func!r} is not the {name} that transform_kind={kind!r} names: the HIP kernels execute the transform '
+                f'themselves and cannot run an arbitrary callable (no CPU fallback)')
+
 def POCS_algorithm(
     x,
     mask,
@@ -586,9 +622,11 @@ def POCS_algorithm(
     ``niterations`` / ``runtime`` / ``cost``; one ``niter;runtime;cost_1;..`` line appended to
     ``path_results``; POCS.py:644-651) and return value (complex in -> complex out, real in -> real
     part; POCS.py:653-656) follow the reference.  Differences: ``transform`` / ``itransform`` must be
-    supplied but are not called (the transform is chosen by ``transform_kind``: ``'FFT'``, or ``'WAVELET'`` with the
-    wavelet name read from ``transform.keywords['wavelet']`` as set up by the step-13 driver, or ``'SHEARLET'`` with the
-    spectra in ``auxiliary_data``), and arithmetic is float32 on the GPU.
+    supplied and must be the functions ``transform_kind`` names (``np.fft.fft2`` / ``ifft2`` for ``'FFT'``; partials of
+    ``pywt.wavedec2`` / ``waverec2`` for ``'WAVELET'``, the wavelet name read from ``transform.keywords['wavelet']`` as set up by
+    the step-13 driver; FFST's ``shearletTransformSpect`` pair for ``'SHEARLET'`` with the spectra in ``auxiliary_data``) -- they
+    are not called, the HIP kernels are the transform, and any other callable raises ``NotImplementedError`` instead of being
+    ignored; arithmetic is float32 on the GPU.
     """
     if np.max(mask) > 1:
         raise ValueError(f'mask should be quasi-boolean (0 or 1) but has maximum of {np.max(mask)}')
@@ -599,6 +637,9 @@ def POCS_algorithm(
     transform_kind = transform_kind.upper()
     if transform_kind == 'SHEARLET' and auxiliary_data is None:
         raise ValueError(f'{transform_kind} requires pre-computed shearlets in Fourier domain (Psi)')
+
+    if transform_kind in _HIP_TRANSFORMS:
+        _check_transform_callables(transform_kind, transform, itransform)
 
     x = np.asarray(x)
     if x.ndim != 2:

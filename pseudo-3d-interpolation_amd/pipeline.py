@@ -47,11 +47,17 @@ def interpolate_time_cube(x, mask, dt, t0=0.0, nfft=None, real_only=True, window
     if win is not None and win.shape != (nfreq,):
         raise ValueError(f'window must have {nfreq} entries')
 
-    tbuf = plan.alloc(4 * max(nt, nfft) * ntr).upload(x)
-    fbuf = plan.alloc(8 * nfreq * ntr)
-    obuf = plan.alloc(8 * nfreq * ntr)
-    mbuf = plan.alloc(maskf.nbytes).upload(maskf)
+    bufs = []
+
+    def alloc(nbytes):
+        bufs.append(plan.alloc(nbytes))
+        return bufs[-1]
+
     try:
+        tbuf = alloc(4 * max(nt, nfft) * ntr).upload(x)
+        fbuf = alloc(8 * nfreq * ntr)
+        obuf = alloc(8 * nfreq * ntr)
+        mbuf = alloc(maskf.nbytes).upload(maskf)
         _ffi.check(lib.p3d_time2freq_dev(int(device), tbuf.ptr, nt, ntr, float(dt), float(t0), nfft, int(bool(real_only)),
                                          None if win is None else _ffi._ptr(win), fbuf.ptr))
         for lo in range(0, nfreq, step):
@@ -72,5 +78,5 @@ def interpolate_time_cube(x, mask, dt, t0=0.0, nfft=None, real_only=True, window
                                          int(bool(real_only)), tbuf.ptr))
         return tbuf.download((nfft, nil, nxl), np.float32)
     finally:
-        for b in (tbuf, fbuf, obuf, mbuf):
+        for b in bufs:
             b.free()

@@ -172,10 +172,13 @@ def test_wavelet_golden_runs():
         def fake_wavedec2(a, wavelet=None, mode=None):  # stands in for pywt.wavedec2: only its keywords are read
             raise AssertionError("the host transform must not be called")
 
+        def fake_waverec2(c, wavelet=None, mode=None):
+            raise AssertionError("the host transform must not be called")
+
         xin = x.astype(np.complex64 if np.iscomplexobj(x) else np.float32)
         res = {}
         got = P.POCS_algorithm(xin, mask, transform=partial(fake_wavedec2, wavelet=wavelet, mode="smooth"),
-                               itransform=partial(fake_wavedec2, wavelet=wavelet, mode="smooth"), transform_kind="WAVELET",
+                               itransform=partial(fake_waverec2, wavelet=wavelet, mode="smooth"), transform_kind="WAVELET",
                                results_dict=res, **prm)
         assert got.dtype == xin.dtype and got.shape == want.shape
         ok = np.isfinite(want) & np.isfinite(got)

@@ -92,12 +92,30 @@ def test_error_contract_matches_reference():
     # options the HIP build does not cover yet fail loudly instead of falling back to the CPU
     with pytest.raises(NotImplementedError):
         P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="CURVELET")
+    from functools import partial
+
+    def wavedec2(a, wavelet=None, mode=None):   # stand-ins for pywt's pair: recognised by name, never called
+        raise AssertionError("the host transform must not be called")
+
+    def waverec2(c, wavelet=None, mode=None):
+        raise AssertionError("the host transform must not be called")
+
+    wf, wi = partial(wavedec2, wavelet="db2", mode="smooth"), partial(waverec2, wavelet="db2", mode="smooth")
     with pytest.raises(NotImplementedError):
-        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET", thresh_op="soft-percentile")
+        P.POCS_algorithm(x, m, transform=wf, itransform=wi, transform_kind="WAVELET", thresh_op="soft-percentile")
     with pytest.raises(IndexError):  # the reference's threshold_wavelet indexes a (1, 1) tau per level (POCS.py:135-166)
-        P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="WAVELET", decay_kind="factors")
+        P.POCS_algorithm(x, m, transform=wf, itransform=wi, transform_kind="WAVELET", decay_kind="factors")
     with pytest.raises(ValueError):
         P.POCS_algorithm(x, m, transform=f, itransform=i, transform_kind="FFT", thresh_op="median")
+    # the reference calls the callables it is given (POCS.py:592, 613); the HIP path cannot, so anything that is not the transform
+    # `transform_kind` names is refused instead of being ignored
+    for bad_f, bad_i, kind in ((lambda a: a, lambda a: a, "FFT"), (np.fft.fft, np.fft.ifft, "FFT"), (i, f, "FFT"),
+                               (partial(f, s=(16, 16)), i, "FFT"), (f, i, "WAVELET"), (wf, wi, "FFT")):
+        with pytest.raises(NotImplementedError, match="cannot run an arbitrary callable"):
+            P.POCS_algorithm(x, m, transform=bad_f, itransform=bad_i, transform_kind=kind)
+    P._check_transform_callables("FFT", partial(np.fft.fft2, axes=(-2, -1)), partial(np.fft.ifft2, norm="backward"))
+    import scipy.fft
+    P._check_transform_callables("FFT", scipy.fft.fft2, scipy.fft.ifft2)
 
 
 def test_product_never_imports_oracle():

@@ -22,6 +22,7 @@ ap.add_argument("--missing", type=float, default=0.8)
 ap.add_argument("--thresh-op", default="hard")
 ap.add_argument("--distinct", type=int, default=8)
 ap.add_argument("--real", action="store_true", help="float32 (time-domain) cube instead of complex64")
+ap.add_argument("--stamps", action="store_true", help="print the in-kernel phase stamps of a -DP3D_STAMPS=1 build (last steady-state row pass)")
 a = ap.parse_args()
 
 rng = np.random.default_rng(0)
@@ -51,3 +52,20 @@ tau = _schedule_from_stats(stats, a.nil * a.nxl, "exponential", a.niter, 0.99, 1
 done, _, ms = plan.run_dev(x.ptr, DT, m.ptr, tau, a.niter, out.ptr, a.nslices, thresh_op=a.thresh_op,
                            profile=True, want_sums=False)
 print("niter", a.niter, "device ms", ms, plan.last_profile())
+
+if a.stamps:
+    import ctypes
+    NPH, names = 10, ["wait work loads", "inverse transform", "wait obs + re-insertion", "sum |x|", "request work (r+1)", "forward transform",
+                      "request obs (r+1)", "lock-step barrier", "issue stores", "-"]
+    buf = (ctypes.c_uint * (1024 * 16 * NPH))()
+    rc = _ffi.lib().p3d_debug_read_stamps(buf, len(buf))
+    assert rc == 0, rc
+    st = np.frombuffer(buf, dtype=np.uint32).reshape(1024, 16, NPH).astype(np.float64)
+    used = st.sum(axis=2) > 0
+    rows_per_wave = a.nslices * a.nil / max(int(used.sum()), 1)
+    per_row = st[used].mean(axis=0) / rows_per_wave
+    print(f"stamps: {int(used.sum())} waves, {rows_per_wave:.1f} rows per wave; mean shader cycles per row and wave:")
+    for n, c in zip(names, per_row):
+        if n != "-":
+            print(f"  {n:26s} {c:9.0f}  ({100 * c / per_row.sum():5.1f} %)")
+    print(f"  {'total':26s} {per_row.sum():9.0f}   spread over waves (total): min {st[used].sum(axis=1).min() / rows_per_wave:.0f} max {st[used].sum(axis=1).max() / rows_per_wave:.0f}")
