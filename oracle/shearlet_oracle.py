@@ -214,3 +214,40 @@ def pocs_cube_shearlet(cube, mask, Psi, infos=None, **params):
         if infos is not None:
             infos.append(info)
     return out
+
+
+# ---- the same loop for large REAL slices, evaluated with multi-threaded real transforms ------------------------------------------
+def pocs_slice_shearlet_real(x, mask, Psi, niter=50, thresh_op="hard", thresh_model="exponential", alpha=1.0, p_max=0.99,
+                             p_min=1e-5, workers=-1, info=None):
+    """`pocs_slice_shearlet(..., version='regular', eps=0)` for a REAL slice and real spectra with Psi_s(-k) = Psi_s(k) (what
+    `scales_shears_and_spectra` builds): ST_s = ifft2(Psi_s fft2(x)) is then real and equals irfft2 of the half spectrum, so the
+    loop runs on `scipy.fft.rfft2 / irfft2` with `workers` threads -- half the arithmetic of the complex transforms and all cores,
+    which is what makes BASELINE configs[4]'s slice (2048 x 1024, 125 shearlets: 250 two-million-point transforms per iteration)
+    checkable in a test.  Same arithmetic otherwise (float64, POCS.py:589-619); tests/test_gpu_shearlet.py holds it to
+    `pocs_slice_shearlet` on a small slice before using it."""
+    import scipy.fft as sf
+    x = np.asarray(x, dtype=np.float64)
+    if np.iscomplexobj(Psi) or x.ndim != 2:
+        raise ValueError("real 2-D slice and real spectra expected")
+    n1, n2 = x.shape
+    half = np.ascontiguousarray(np.moveaxis(np.asarray(Psi)[:, : n2 // 2 + 1, :], -1, 0), dtype=np.float64)   # [s][k1][k2 <= n2/2]
+
+    def fwd(v):
+        return sf.irfft2(half * sf.rfft2(v)[None], s=(n1, n2), axes=(1, 2), workers=workers)                    # [s][i][j]
+
+    def inv(st):
+        return sf.irfft2((sf.rfft2(st, axes=(1, 2), workers=workers) * half).sum(axis=0), s=(n1, n2))
+
+    st0 = fwd(x)
+    tau = shearlet_schedule(thresh_model, int(niter), float(p_max), p_min, np.moveaxis(st0, 0, -1), "values")  # (niter, nsh)
+    w = 1.0 - alpha * np.asarray(mask, dtype=np.float64)
+    cur, costs = x, []
+    for k in range(int(niter)):
+        st = st0 if k == 0 else fwd(cur)
+        shr = base.apply_threshold(st, tau[k][:, None, None], kind=thresh_op)
+        nxt = inv(shr) * w + x * alpha
+        costs.append(np.sum(np.abs(nxt) - np.abs(cur)) ** 2 / np.sum(np.abs(nxt)) ** 2)
+        cur = nxt
+    if isinstance(info, dict):
+        info.update(niterations=int(niter), costs=costs, tau=tau)
+    return cur
