@@ -189,7 +189,10 @@ int p3d_last_profile(p3d_plan* plan, double* colpass_ms, int* colpass_launches, 
  * threshold_wavelet (POCS.py:105-166).  The caller passes the four filters of the orthogonal / biorthogonal bank (doubles,
  * PyWavelets' dec_lo, dec_hi, rec_lo, rec_hi; 2..64 taps); `level` < 0 selects pywt.dwt_max_level(min(nil, nxl), flen).
  * Coefficients of one slice are a flat complex64 vector: cA, then (cH, cV, cD) of every level, coarsest first (PyWavelets'
- * list order); p3d_wavelet_info reports nlev, the vector length and the (rows, cols) of cA and of each level's details. */
+ * list order); p3d_wavelet_info reports nlev, the vector length and the (rows, cols) of cA and of each level's details.
+ * In p3d_wavelet_stats / p3d_wavelet_run (and p3d_shearlet_stats / p3d_shearlet_run below) the cube pointers `x`, `mask` and `out`
+ * may be host OR device pointers (the copy into the plan's staging area is a hipMemcpyDefault): a caller that keeps the cube in
+ * HBM pays a device-to-device copy instead of the PCIe transfer.  `elapsed_ms` is the device time of the loop alone. */
 typedef struct p3d_wplan p3d_wplan;
 int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int nxl, int max_slices, const double* dec_lo,
                             const double* dec_hi, const double* rec_lo, const double* rec_hi, int flen, int level);

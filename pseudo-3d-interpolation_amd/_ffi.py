@@ -237,6 +237,10 @@ class Plan:
         check(lib().p3d_fft2_c64(self.handle, _ptr(xc), _ptr(out), xc.shape[0], int(bool(inverse))))
         return out[0] if squeeze else out
 
+    def fft2_dev(self, in_ptr, out_ptr, nslices, inverse=False):
+        """fft2 / ifft2 (numpy conventions) of complex64 slices resident on the device; `out_ptr` may equal `in_ptr`."""
+        check(lib().p3d_fft2_c64_dev(self.handle, C.c_void_p(in_ptr), C.c_void_p(out_ptr), int(nslices), int(bool(inverse))))
+
     def fft2_shrink(self, x, tau, thresh_op="hard"):
         """threshold(fft2(x), tau, kind) on the device; ``tau`` scalar or one value per slice."""
         x = np.asarray(x)
@@ -440,6 +444,30 @@ class WaveletPlan:
                                     C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return out, done, sums, ms.value
 
+    def stats_dev(self, x_ptr, dtype, n):
+        """`stats` for a cube resident on the device (raw pointer, P3D_C64 / P3D_F32)."""
+        st = np.empty((n, self.nlev, 3, 4), np.float64)
+        check(lib().p3d_wavelet_stats(self.handle, C.c_void_p(x_ptr), dtype, n, _ptr(st)))
+        return st
+
+    def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, n, thresh_op="hard", version="regular", eps=0.0, alpha=1.0,
+                active=None):
+        """`run` on device-resident buffers (raw pointers; the library accepts host or device pointers for the cubes).  Returns
+        (niter_done, sums, device ms of the loop)."""
+        tau = np.broadcast_to(np.asarray(tau), (n, niter, self.nlev, 3))
+        t = np.empty(tau.shape + (2,), np.float64)
+        t[..., 0] = tau.real
+        t[..., 1] = tau.imag if np.iscomplexobj(tau) else 0.0
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_wavelet_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
+                                    C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return done, sums, ms.value
+
+
 # ---- SHEARLET variant ----------------------------------------------------------------------
 class ShearletPlan:
     """p3d_splan wrapper: frequency-domain shearlet frame with caller-supplied spectra ``psi`` (nil, nxl, nsh) -- the layout of
@@ -522,6 +550,28 @@ class ShearletPlan:
         check(lib().p3d_shearlet_run(self.handle, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act),
                                      C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return out, done, sums, ms.value
+
+    def stats_dev(self, x_ptr, dtype, n):
+        """`stats` for a cube resident on the device (raw pointer, P3D_C64 / P3D_F32)."""
+        st = np.empty((n, self.nsh, 5), np.float64)
+        check(lib().p3d_shearlet_stats(self.handle, C.c_void_p(x_ptr), dtype, n, _ptr(st)))
+        return st
+
+    def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, n, thresh_op="hard", version="regular", eps=0.0, alpha=1.0,
+                active=None):
+        """`run` on device-resident buffers (raw pointers).  Returns (niter_done, sums, device ms of the loop)."""
+        tau = np.broadcast_to(np.asarray(tau), (n, niter, self.nsh))
+        t = np.empty(tau.shape + (2,), np.float64)
+        t[..., 0] = tau.real
+        t[..., 1] = tau.imag if np.iscomplexobj(tau) else 0.0
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_shearlet_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
+                                     C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return done, sums, ms.value
 
 
 def time2freq(x, dt, t0=0.0, nfft=None, real_only=False, window=None, device=0):

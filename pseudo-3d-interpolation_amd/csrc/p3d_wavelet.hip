@@ -1024,7 +1024,7 @@ int p3d_wavelet_stats(p3d_wplan* p, const void* x, int dtype, int nslices, doubl
     if (rc) return rc;
     if (!x || !stats) return wfail(P3D_ERR_INVALID, "NULL buffer");
     const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
-    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyHostToDevice));
+    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));   // x: host or device pointer
     if (p->sums_cap < (size_t)nslices) {
         if (p->sums) hipFree(p->sums);
         p->sums = nullptr; p->sums_cap = 0;
@@ -1075,8 +1075,8 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     const bool real_path = dtype == P3D_F32 && real_tau;
     std::vector<int> done_h(nslices, 0);
     if (active) for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;
-    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyHostToDevice));
-    W_TRY(hipMemcpy(p->mask, mask, sizeof(float) * p->per(), hipMemcpyHostToDevice));
+    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));   // x: host or device pointer
+    W_TRY(hipMemcpy(p->mask, mask, sizeof(float) * p->per(), hipMemcpyDefault));
     W_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
@@ -1086,7 +1086,7 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     W_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) W_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
     W_TRY(hipStreamSynchronize(p->stream));
-    W_TRY(hipMemcpy(out, p->st_out, esz * p->per() * nslices, hipMemcpyDeviceToHost));
+    W_TRY(hipMemcpy(out, p->st_out, esz * p->per() * nslices, hipMemcpyDefault));
     if (niter_done) for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
     if (elapsed_ms) {
         float ms = 0.f;

@@ -42,3 +42,17 @@ def test_two_ranks_rehearsal():
     line = _last_json(res.stdout)
     assert line["n_gpus"] == 2 and line["config"]["slices_per_gpu"] == 8 and line["value"] > 0 and line["cpu_baseline"] is None
     assert line["gather_ms"] > 0
+
+
+@pytest.mark.parametrize("config,extra", [(0, []), (3, ["--nslices", "8", "--steps", "5"]), (4, ["--nil", "256", "--nxl", "128", "--nslices", "2", "--steps", "3"])])
+def test_other_configurations_emit_a_line(config, extra):
+    """bench.py --config i: every BASELINE configuration has a driver-runnable leg with its own roofline and CPU baseline (the
+    wavelet and shearlet legs on reduced sizes here; their full-size parity is in test_gpu_wavelet / test_gpu_shearlet)."""
+    res = subprocess.run([sys.executable, "bench.py", "--config", str(config), "--warmup", "1", "--cpu-seconds", "1", "--repeats", "2"] + extra,
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = _last_json(res.stdout)
+    assert REQUIRED <= set(line) and line["value"] > 0 and line["repeats"]["n"] == 2
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    assert line["steady_state_iterations_per_s"] > 0
