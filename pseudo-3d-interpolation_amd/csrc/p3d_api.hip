@@ -790,6 +790,17 @@ int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, 
     return P3D_OK;
 }
 
+// first / last row pass of a job on the complex path: the wave-uniform persistent kernel where the plan has its tables
+// (rows of 128 ... 4096 samples, P3D_NO_PIPE64 unset), the one-launch-per-pass kernels otherwise
+static hipError_t first_row_pass(p3d_plan* p, const RowArgs& r)
+{
+    if (p->pipe_wgs > 0 && p->bits64 != nullptr && p->ops_row->row_pipe64 != nullptr) {
+        const hipError_t e = p->ops_row->row_pipe64(PIPE_FIRST, r, p->pipe_wgs, p->stream);
+        if (e != hipErrorNotSupported) return e;
+    }
+    return p->ops_row->row(ROW_FIRST, r, p->stream);
+}
+
 int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, double* stats)
 {
     int rc = check_batch(p, nslices);
@@ -809,7 +820,7 @@ int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, doubl
     r.x = x;
     r.work = p->work;
     r.dtype = dtype;
-    HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+    HIP_TRY(first_row_pass(p, r));
     ColArgs c = col_args(p, nslices);
     c.in = p->work;
     c.partials = p->partials;
@@ -1046,7 +1057,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         if (re == hipErrorNotSupported) real_path = false;
         else HIP_TRY(re);
     }
-    if (!real_path) HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+    if (!real_path) HIP_TRY(first_row_pass(p, r));
     if (compact) {  // did every unobserved position hold a zero?
         int violation = 0;
         HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
@@ -1056,7 +1067,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             if (real_path) {   // the row-pair passes live on the compact samples: take the complex path from the start
                 real_path = false;
                 HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
-                HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+                HIP_TRY(first_row_pass(p, r));
             }
         }
     }
@@ -1112,6 +1123,11 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             const hipError_t pe = p->ops_row->row_pipe(r, p->pipe_wgs, p->stream);
             if (pe == hipSuccess) piped = true;
             else if (pe != hipErrorNotSupported) HIP_TRY(pe);
+        }
+        if (!piped && k + 1 == niter && p->pipe_wgs > 0 && p->bits64 != nullptr && p->ops_row->row_pipe64 != nullptr) {
+            const hipError_t le = p->ops_row->row_pipe64(PIPE_LAST, r, p->pipe_wgs, p->stream);   // last pass: compact samples in, whole rows out
+            if (le == hipSuccess) piped = true;
+            else if (le != hipErrorNotSupported) HIP_TRY(le);
         }
         if (!piped) HIP_TRY(p->ops_row->row(k + 1 < niter ? ROW_MID : ROW_LAST, r, p->stream));
         HIP_TRY(stamp());

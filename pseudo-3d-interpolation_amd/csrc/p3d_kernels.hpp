@@ -829,7 +829,13 @@ static __device__ unsigned p3d_stamp_buf[1024 * 16 * STAMP_PHASES];   // (one co
 // body, so the compiler's wait counts at the loop header are exact: `vmcnt(32)` for the work-buffer elements (16 observed-sample
 // loads and 16 stores stay in flight), `vmcnt(31 ... 16)` for the samples, where round 1 had `vmcnt(0)` throughout.
 // What this bought, and what it did not: profiles/r02_rowpass_schedule.txt.
-template <int N, int DT, bool SPARSE>
+// PM: which pass of a job.  PIPE_MID: the steady state described above.  PIPE_FIRST: observed cube -> compact copy of the observed
+// samples, sum |x_obs|, forward row transform -> work buffer (what row_kernel<ROW_FIRST> does, at 2.8 TB/s; without the lane-mask
+// tables -- the statistics pass has no mask yet -- only the transform).  PIPE_LAST: work buffer -> inverse row transform ->
+// re-insertion -> result cube (row_kernel<ROW_LAST> reads the FULL observed cube for that, zeros included: 8.6 GB where 5.2 do).
+enum PipeMode { PIPE_MID = 0, PIPE_FIRST = 1, PIPE_LAST = 2 };
+
+template <int N, int DT, bool SPARSE, int PM>
 __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
@@ -881,14 +887,25 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     const kuint_t k_cbase = (kuint_t)a.cbase;
     const kint_t k_done = (kint_t)a.done;   // early exit (eps > 0): set between launches, constant during one
 
-    struct Where { unsigned slice, row; bool on; };   // row: the unit's index inside its slice (= the row itself when RPW == 1)
+    // row: the unit's index inside its slice (= the row itself when RPW == 1); on: the unit is computed and stored; zero (PIPE_LAST):
+    // the unit belongs to an all-zero slice, which is handed back untouched (POCS.py:515-521)
+    struct Where { unsigned slice, row; bool on, zero; };
     auto locate = [&](unsigned g) -> Where {
         Where w;
         w.on = g < total;
+        w.zero = false;
         const unsigned gg = w.on ? g : 0u;
         w.slice = gg / upslice;
         w.row = gg - w.slice * upslice;
-        if (k_done != nullptr && w.on && k_done[w.slice] != 0) w.on = false;   // finished / empty slice: leave it alone
+        if (k_done != nullptr && w.on) {
+            const int dn = k_done[w.slice];
+            if (PM == PIPE_LAST) {   // converged earlier (dn > 0): `out` already holds that iterate
+                w.zero = dn < 0;
+                w.on = dn <= 0;
+            } else if (dn != 0) {
+                w.on = false;        // finished / empty slice: leave it alone
+            }
+        }
         return w;
     };
     auto work_srd = [&](const Where& w) { return buf_srd(reinterpret_cast<const char*>(a.work) + w.slice * wstride * 8, slice_bytes); };
@@ -950,6 +967,33 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
             so += qs;
         }
     };
+    // row-major cubes (observed cube `x`, result cube `out`; complex64 or float32): element tl + TPL*q of the unit's rows
+    const unsigned cube_slice_bytes = (unsigned)a.n1 * (unsigned)N * ES;                          // at most 128 MiB
+    const unsigned lane_c = ((unsigned)sub * (unsigned)N + colpart) * ES;
+    const unsigned qc = (TPL >= 64 ? 64u * WPL : (unsigned)TPL) * ES;
+    auto cube_soff = [&](const Where& w) -> unsigned { return (w.row * (unsigned)(RPW * N) + (unsigned)wsub * 64u) * ES; };
+    auto issue_cube = [&](raw64 (&dst)[PPT], const Where& w) {   // PIPE_FIRST: the unit's samples of the observed cube
+        const __amdgpu_buffer_rsrc_t srd = buf_srd(reinterpret_cast<const char*>(a.x) + (size_t)w.slice * cube_slice_bytes, cube_slice_bytes);
+        unsigned so = cube_soff(w);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            if (DT == 0) dst[q] = buf_load_raw64(srd, lane_c, so);
+            else dst[q] = (raw64)__builtin_amdgcn_raw_buffer_load_b32(srd, (int)lane_c, (int)so, 0);
+            so += qc;
+        }
+    };
+    auto store_cube = [&](const c32 (&src)[PPT], const Where& w) {   // PIPE_LAST: the unit's samples of the result (np.real for float32 cubes, POCS.py:656)
+        const __amdgpu_buffer_rsrc_t srd = buf_srd(reinterpret_cast<const char*>(a.out) + (size_t)w.slice * cube_slice_bytes, cube_slice_bytes);
+        unsigned so = cube_soff(w);
+        const unsigned vo = w.on ? lane_c : BUF_OOB;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const c32 val = w.zero ? c32{0.f, 0.f} : src[q];
+            if (DT == 0) buf_store_c32(srd, vo, so, val);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val.x), srd, (int)vo, (int)so, 0);
+            so += qc;
+        }
+    };
     // per-row sums of |x|: [nslices][n1] doubles (< 2 GiB: nslices <= 65535, n1 <= 4096); a null table swallows the stores
     const __amdgpu_buffer_rsrc_t sums_srd = buf_srd(a.sums, a.sums != nullptr ? (unsigned)a.nslices * (unsigned)a.n1 * 8u : 0u);
     const float w_obs = 1.0f - a.alpha * 1.0f;   // POCS.py:616 at an observed trace
@@ -960,6 +1004,97 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     c32 v[PPT];
     raw64 bx[PPT], by[PPT];
     unsigned long long mw_cur[PPT];   // the row's mask words stay in scalar registers from the request of its observed samples to its re-insertion
+    unsigned cbs_cur[PPT];            // PIPE_FIRST: where the row's observed samples go in the compact array
+    // per-row sum of |x| -> sums[slice][row] (one row = SEG consecutive lanes; the wavefronts of a long row in row_kernel's order)
+    auto store_row_sum = [&](float acc, const Where& w) {
+        double ws = (double)acc;
+        constexpr int SEG = TPL >= 64 ? 64 : TPL;
+#pragma unroll
+        for (int o = SEG / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, SEG);
+        const unsigned so = (w.slice * (unsigned)a.n1 + w.row * RPW) * 8u;
+        const bool wr = w.on && !w.zero;
+        if constexpr (WAVE) {
+            buf_store_f64(sums_srd, ((lane & (SEG - 1)) == 0 && wr) ? (unsigned)sub * 8u : BUF_OOB, so, ws);
+        } else {
+            __syncthreads();
+            if (lane == 0) red[wave] = ws;
+            __syncthreads();
+            double t = 0.0;
+            for (int i = 0; i < WPL; ++i) t += red[uline * WPL + i];
+            buf_store_f64(sums_srd, (wsub == 0 && lane == 0 && wr) ? 0u : BUF_OOB, so, t);
+        }
+    };
+    // the LDS / twiddle addresses of the transforms are functions of tl alone; hoisted out of the loop they pin a dozen vector
+    // registers across it, which is what pushes the kernel over the 128 a 16-wave workgroup may use (and ONE spilled register is
+    // a scratch load, i.e. a vmcnt(0) in the middle of the transform).  Recomputed per row instead.
+    auto fresh_tl = [&]() -> int { int t = tl; asm volatile("" : "+v"(t)); return t; };
+
+    if constexpr (PM == PIPE_FIRST) {
+        // ---- first pass of a job: observed cube -> (compact samples, sum |x_obs|) and forward row transform -> work buffer ----
+        const bool tables = k_bits != nullptr && k_cbase != nullptr && a.xc != nullptr;   // uniform for the launch
+        const __amdgpu_buffer_rsrc_t none = buf_srd(nullptr, 0u);
+        issue_cube(bx, cur);
+        if (tables) obs_tables(mw_cur, cbs_cur, cur);
+        {   // as many (dropped) stores as one trip of the loop issues: exact wait counts at the loop header
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) v[q] = c32{0.f, 0.f};
+            store_work(v, cur, false);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) buf_store_c32(none, BUF_OOB, 0u, v[q]);
+            buf_store_f64(sums_srd, BUF_OOB, 0u, 0.0);
+        }
+        for (unsigned g0 = blockIdx.x * UPB; g0 < total; g0 += step) {
+            const Where nxt = locate(g + step);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) v[q] = DT == 0 ? raw_c32(bx[q]) : c32{__uint_as_float((unsigned)bx[q]), 0.f};
+            __builtin_amdgcn_sched_barrier(0);
+            float acc = 0.f;
+            {   // compact copy of the observed samples (the order is a convention with the later passes: RowArgs::cbase + the rank
+                // of the lane among the set lanes of its word); a non-zero sample at a trace the mask calls missing raises `violation`
+                const __amdgpu_buffer_rsrc_t xsrd = tables ? buf_srd(reinterpret_cast<const char*>(a.xc) + (size_t)cur.slice * a.nobs * ES, a.nobs * ES) : none;
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    const unsigned long long mw = tables ? mw_cur[q] : 0ull;
+                    const bool set = __builtin_amdgcn_inverse_ballot_w64(mw);
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mw, 0u));
+                    const unsigned vo = (set && cur.on) ? rank * ES : BUF_OOB;
+                    const unsigned so = tables ? cbs_cur[q] * ES : 0u;
+                    if (DT == 0) buf_store_c32(xsrd, vo, so, v[q]);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), xsrd, (int)vo, (int)so, 0);
+                    bad = bad || (!set && (v[q].x != 0.f || v[q].y != 0.f));
+                    acc += abs_c32(v[q]);
+                }
+                if (tables && cur.on && __any(bad)) {   // (rare; an atomic older than every load a later wait covers)
+                    if (lane == 0) atomicOr(a.violation, 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            store_row_sum(acc, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_cube(bx, nxt);
+            unsigned long long mw_nxt[PPT];
+            unsigned cbs_nxt[PPT];
+            if (tables) obs_tables(mw_nxt, cbs_nxt, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            line_fft<N, FWD, WAVE>(v, lds, tw, fresh_tl());
+            __builtin_amdgcn_sched_barrier(0);
+#if P3D_PIPE64_LOCKSTEP
+            if (WAVE && RPW == 1) __builtin_amdgcn_s_barrier();
+#endif
+            store_work(v, cur, cur.on);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tables) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) { mw_cur[q] = mw_nxt[q]; cbs_cur[q] = cbs_nxt[q]; }
+            }
+            g += step;
+            cur = nxt;
+        }
+        return;
+    }
+
     issue_work(by, cur);
     {
         unsigned cbs0[PPT];
@@ -988,11 +1123,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 #endif
         P3D_STAMP(0);   // wait for the row's elements of the work buffer
         __builtin_amdgcn_sched_barrier(0);
-        // the LDS / twiddle addresses of the transforms are functions of tl alone; hoisted out of the loop they pin a dozen vector
-        // registers across it, which is what pushes the kernel over the 128 a 16-wave workgroup may use (and ONE spilled register is
-        // a scratch load, i.e. a vmcnt(0) in the middle of the transform).  Recomputed per row instead.
-        int tl_r = tl;
-        asm volatile("" : "+v"(tl_r));
+        const int tl_r = fresh_tl();
         if (!P3D_ABL_NOFFT) line_fft<N, INV, WAVE>(v, lds, tw, tl_r);
         P3D_STAMP(1);   // inverse transform
         __builtin_amdgcn_sched_barrier(0);
@@ -1014,23 +1145,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
 #endif
         P3D_STAMP(2);   // wait for the observed samples, re-insertion
         __builtin_amdgcn_sched_barrier(0);
-        if (!P3D_ABL_NOSUMS) {
-            double ws = (double)acc;
-            constexpr int SEG = TPL >= 64 ? 64 : TPL;   // one row = SEG consecutive lanes: segmented reduction
-#pragma unroll
-            for (int o = SEG / 2; o > 0; o >>= 1) ws += __shfl_down(ws, o, SEG);
-            const unsigned so = (cur.slice * (unsigned)a.n1 + cur.row * RPW) * 8u;
-            if constexpr (WAVE) {
-                buf_store_f64(sums_srd, ((lane & (SEG - 1)) == 0 && cur.on) ? (unsigned)sub * 8u : BUF_OOB, so, ws);
-            } else {   // the wavefronts of a row in the order row_kernel adds them
-                __syncthreads();
-                if (lane == 0) red[wave] = ws;
-                __syncthreads();
-                double t = 0.0;
-                for (int w = 0; w < WPL; ++w) t += red[uline * WPL + w];
-                buf_store_f64(sums_srd, (wsub == 0 && lane == 0 && cur.on) ? 0u : BUF_OOB, so, t);
-            }
-        }
+        if (!P3D_ABL_NOSUMS) store_row_sum(acc, cur);
         P3D_STAMP(3);   // sum of |x|
         __builtin_amdgcn_sched_barrier(0);
         // The next row's elements of the work buffer, and the scalar tables its observed samples are found with, are requested
@@ -1042,23 +1157,29 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
         obs_tables(mw_nxt, cbs_n, nxt);
         P3D_STAMP(4);   // requests for the next row's work-buffer elements (scalar tables first)
         __builtin_amdgcn_sched_barrier(0);
-        if (!P3D_ABL_NOFFT) line_fft<N, FWD, WAVE>(v, lds, tw, tl_r);
+        if constexpr (PM == PIPE_MID) {
+            if (!P3D_ABL_NOFFT) line_fft<N, FWD, WAVE>(v, lds, tw, tl_r);
+        }
         P3D_STAMP(5);   // forward transform
         __builtin_amdgcn_sched_barrier(0);
         issue_obs_with(bx, nxt, mw_nxt, cbs_n);
         P3D_STAMP(6);   // requests for the next row's observed samples
         __builtin_amdgcn_sched_barrier(0);
-        // Adjacent rows share the 128-byte lines of the work buffer (64 bytes each), and sixteen adjacent rows make one contiguous
-        // KiB per column block: the waves of a workgroup store TOGETHER.  Measured on the headline cube (profiles/r02_rowpass_
-        // schedule.txt): barrier every row 1.60 ms, every 2nd / 4th / 8th / 32nd row 1.72 / 1.92 / 2.04 / 2.11 ms, never 2.36 ms;
-        // lock-step kept by groups of 2 / 4 / 8 waves only (counters in LDS) 1.74 / 1.80 / 1.71 ms.  A wavefront that holds two or
-        // more adjacent rows (RPW > 1) pairs their halves up by itself.
+        if constexpr (PM == PIPE_MID) {
+            // Adjacent rows share the 128-byte lines of the work buffer (64 bytes each), and sixteen adjacent rows make one contiguous
+            // KiB per column block: the waves of a workgroup store TOGETHER.  Measured on the headline cube (profiles/r02_rowpass_
+            // schedule.txt): barrier every row 1.60 ms, every 2nd / 4th / 8th / 32nd row 1.72 / 1.92 / 2.04 / 2.11 ms, never 2.36 ms;
+            // lock-step kept by groups of 2 / 4 / 8 waves only (counters in LDS) 1.74 / 1.80 / 1.71 ms.  A wavefront that holds two or
+            // more adjacent rows (RPW > 1) pairs their halves up by itself.
 #if P3D_PIPE64_LOCKSTEP
-        if (WAVE && RPW == 1) __builtin_amdgcn_s_barrier();
+            if (WAVE && RPW == 1) __builtin_amdgcn_s_barrier();
 #endif
-        P3D_STAMP(7);   // lock-step barrier
-        store_work(v, cur, cur.on);
-        P3D_STAMP(8);   // issue of the stores
+            P3D_STAMP(7);   // lock-step barrier
+            store_work(v, cur, cur.on);
+            P3D_STAMP(8);   // issue of the stores
+        } else {
+            store_cube(v, cur);   // last pass of a job: whole rows of the result cube, no neighbour to wait for
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) mw_cur[q] = mw_nxt[q];
@@ -1572,6 +1693,56 @@ hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+// one launch of the wave-uniform persistent row pass (row_pipe64_kernel) in mode `pm` on a device with `cus` compute units;
+// hipErrorNotSupported where the kernel does not apply (the caller falls back to the generic kernels)
+template <int N>
+hipError_t launch_row_pipe64(int pm, const RowArgs& a, int cus, hipStream_t st)
+{
+    if constexpr (Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
+        constexpr int RPW64 = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL;
+        if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0 || a.n1 % RPW64 != 0 || cus < 1) return hipErrorNotSupported;
+        if (a.adaptive || a.write_out || a.only_done || a.plain) return hipErrorNotSupported;   // APOCS, per-iteration store, finalize, fft2 hook
+        const bool tables = a.bits64 != nullptr && a.cbase != nullptr;
+        if (pm == PIPE_FIRST) {
+            if (a.x == nullptr || (a.xc != nullptr && !tables)) return hipErrorNotSupported;   // (no tables: the transform only)
+        } else {
+            if (a.bits == nullptr || a.xc == nullptr || !tables) return hipErrorNotSupported;
+        }
+        constexpr int LB64 = pipe64_rows<N>();
+        constexpr size_t lds64 = pipe64_lds_bytes<N>();
+        constexpr int UPB64 = LB64 / RPW64;
+        const long groups64 = ((long)a.nslices * (a.n1 / RPW64) + UPB64 - 1) / UPB64;
+        int per_cu64 = (int)((160 * 1024) / lds64);            // workgroups a CU holds: LDS ...
+        const int by_waves = 16 / (pipe64_threads<N>() / 64);  // ... and 4 waves per SIMD
+        if (per_cu64 > by_waves) per_cu64 = by_waves;
+        if (per_cu64 < 1) per_cu64 = 1;
+        const long wgs64 = (long)cus * per_cu64;
+        const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));
+        hipError_t e = hipSuccess;
+#define P3D_PIPE64(DT, SP, PM)                                                                                  \
+    do {                                                                                                        \
+        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP, PM>, lds64)) != hipSuccess) return e;                   \
+        row_pipe64_kernel<N, DT, SP, PM><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);                        \
+    } while (0)
+        const bool sp = a.nzl != nullptr;
+        if (pm == PIPE_FIRST) {
+            if (a.dtype == 0) P3D_PIPE64(0, false, PIPE_FIRST); else P3D_PIPE64(1, false, PIPE_FIRST);
+        } else if (pm == PIPE_LAST) {
+            if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true, PIPE_LAST); else P3D_PIPE64(0, false, PIPE_LAST); }
+            else { if (sp) P3D_PIPE64(1, true, PIPE_LAST); else P3D_PIPE64(1, false, PIPE_LAST); }
+        } else if (pm == PIPE_MID) {
+            if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true, PIPE_MID); else P3D_PIPE64(0, false, PIPE_MID); }
+            else { if (sp) P3D_PIPE64(1, true, PIPE_MID); else P3D_PIPE64(1, false, PIPE_MID); }
+        } else {
+            return hipErrorInvalidValue;
+        }
+#undef P3D_PIPE64
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 // persistent steady-state row pass on a device with `cus` compute units
 template <int N>
 hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
@@ -1580,33 +1751,9 @@ hipError_t launch_row_pipe(const RowArgs& a, int cus, hipStream_t st)
     const bool bits = a.bits != nullptr;
     const bool extra = a.adaptive || a.write_out || a.done != nullptr;
     const bool compact = bits && a.xc != nullptr;
-    hipError_t e = hipSuccess;
-    if constexpr (Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
-        // the wave-uniform variant (it also honours the per-slice `done` flags of the early exit; APOCS and the per-iteration
-        // store stay with the generic kernels)
-        if (compact && !a.adaptive && !a.write_out && a.bits64 != nullptr && a.cbase != nullptr) {
-            const bool sp = a.nzl != nullptr;
-#define P3D_PIPE64(DT, SP)                                                                                       \
-    do {                                                                                                        \
-        constexpr int LB64 = pipe64_rows<N>();                                                                  \
-        constexpr size_t lds64 = pipe64_lds_bytes<N>();                                                         \
-        constexpr int RPW64 = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL, UPB64 = LB64 / RPW64;                 \
-        const long groups64 = ((long)a.nslices * (a.n1 / RPW64) + UPB64 - 1) / UPB64;                           \
-        int per_cu64 = (int)((160 * 1024) / lds64);            /* workgroups a CU holds: LDS ... */             \
-        const int by_waves = 16 / (pipe64_threads<N>() / 64);  /* ... and 4 waves per SIMD */                   \
-        if (per_cu64 > by_waves) per_cu64 = by_waves;                                                           \
-        if (per_cu64 < 1) per_cu64 = 1;                                                                         \
-        const long wgs64 = (long)cus * per_cu64;                                                                \
-        const dim3 grid64((unsigned)(groups64 < wgs64 ? groups64 : wgs64));                                     \
-        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP>, lds64)) != hipSuccess) return e;                       \
-        row_pipe64_kernel<N, DT, SP><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);                            \
-    } while (0)
-            if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true); else P3D_PIPE64(0, false); }
-            else { if (sp) P3D_PIPE64(1, true); else P3D_PIPE64(1, false); }
-#undef P3D_PIPE64
-            return hipGetLastError();
-        }
-    }
+    hipError_t e = launch_row_pipe64<N>(PIPE_MID, a, cus, st);   // the wave-uniform variant (it also honours the per-slice `done` flags)
+    if (e != hipErrorNotSupported) return e;
+    e = hipSuccess;
     if constexpr (Plan<N>::TPL > 64) {
         return hipErrorNotSupported;
     } else {
@@ -1738,6 +1885,7 @@ struct LineOps {
     int col_tw_slots;                    // the same for the column pass (ColTables)
     void (*build_col_tw)(c32* out);
     hipError_t (*row_real)(int mode, const RowArgs&, int cus, hipStream_t);   // REAL_* passes (hipErrorNotSupported where absent)
+    hipError_t (*row_pipe64)(int pm, const RowArgs&, int cus, hipStream_t);   // PIPE_FIRST / PIPE_MID / PIPE_LAST (hipErrorNotSupported where absent)
 };
 
 }  // namespace p3d
