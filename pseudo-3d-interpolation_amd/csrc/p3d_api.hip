@@ -17,6 +17,7 @@
 #include "p3d_generic.hpp"
 #include "p3d_internal.hpp"
 #include "p3d_flex.hpp"
+#include "p3d_resident.hpp"
 #include "p3d_kernels.hpp"
 
 namespace p3d {
@@ -47,6 +48,9 @@ static const LineOps* find_ops(int n)
     return nullptr;
 }
 static bool is_flex(const LineOps* ops) { return ops && ops->tpl == 0; }
+// largest slice the single-kernel path takes: 128 x 128 needs a 1024-thread workgroup, i.e. 128 registers per thread, and the
+// column transform through a 136-KiB LDS image does not fit them (350 B of scratch per thread) -- it stays with the two passes
+static const size_t RESIDENT_MAX_POINTS = 8192;
 }  // namespace p3d
 
 using namespace p3d;
@@ -542,7 +546,7 @@ int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
 // ---- internal helpers ---------------------------------------------------------------------------
 // Diagnostic switches of one job: every one selects a slower, equivalent path.  Read once per call of
 // p3d_pocs_run_dev, on the calling thread, and handed down as plain values -- the launch paths never consult the environment.
-struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048; };
+struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident; };
 static RunSwitches read_switches()
 {
     RunSwitches s;
@@ -551,6 +555,7 @@ static RunSwitches read_switches()
     s.no_real = getenv("P3D_NO_REAL") != nullptr;
     s.no_sparse = getenv("P3D_NO_SPARSE") != nullptr;
     s.real_2048 = getenv("P3D_REAL_2048") != nullptr;
+    s.no_resident = getenv("P3D_NO_RESIDENT") != nullptr;
     return s;
 }
 
@@ -1000,6 +1005,33 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     if (sw.no_mask_bits) nonbinary = 1;  // experiments only
+
+    // Small slices (32 ... 128 points per axis, at most 8192 per slice): the whole job in ONE kernel, a workgroup per slice, the
+    // slice in registers and LDS for all iterations (p3d_resident.hip).  Bit-identical to the passes below, which stay for the
+    // options it does not cover (APOCS, non-binary masks) and behind P3D_NO_RESIDENT=1.
+    if (!nonbinary && !adaptive && !sw.no_resident && !flex_rows && !is_flex(p->ops_col) && resident_supported(p->nil, p->nxl) &&
+        (size_t)p->nil * p->nxl <= RESIDENT_MAX_POINTS) {
+        ResidentArgs ra{};
+        ra.x = x; ra.out = out; ra.bits = p->bits; ra.tau = p->tau; ra.done = p->done; ra.sums = p->sums;
+        ra.tw_row = p->tw_row; ra.tw_col = p->tw_col;
+        ra.nslices = nslices; ra.niter = niter; ra.op = base_op; ra.dtype = dtype;
+        ra.alpha = (float)prm->alpha; ra.scale = (float)(1.0 / ((double)p->nil * (double)p->nxl)); ra.eps = prm->eps;
+        HIP_TRY(resident_launch(p->nil, p->nxl, ra, p->stream));
+        HIP_TRY(hipEventRecord(p->ev1, p->stream));
+        HIP_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
+        if (sums) HIP_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (niter_done)
+            for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
+        if (elapsed_ms) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+            *elapsed_ms = ms;
+        }
+        p->last_nonzero_fraction = -1.0;
+        p->prof_col_n = p->prof_row_n = 0;
+        return P3D_OK;
+    }
     // Compact observed samples for the steady-state row pass: only the observed positions of x are non-zero in
     // the workflow (x = stacked traces, mask = fold >= 1); ROW_FIRST verifies that and the full cube is used if not.
     bool compact = !nonbinary && p->pipe_wgs > 0 && p->nil <= 4096 && niter > 1 && !sw.no_compact &&

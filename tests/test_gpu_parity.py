@@ -409,6 +409,50 @@ def test_full_schedule_decision_replay(ffi, orc, nil, nxl, missing, K):
     assert flips <= max(8, 2e-5 * K * x.size)
 
 
+@pytest.mark.parametrize("shape", [(32, 32), (64, 64), (64, 128), (128, 64), (32, 128), (128, 32)])
+@pytest.mark.parametrize("op,real", [("hard", False), ("soft", False), ("garrote", False), ("hard", True), ("soft", True)])
+def test_resident_small_slices_equal_the_two_pass_path(P, orc, monkeypatch, shape, op, real):
+    """Slices of up to 8192 points run the whole job in ONE kernel (p3d_resident.hip: a workgroup per slice, the slice in registers
+    and LDS for all iterations).  Same templates, same tables, same order of operations and of the cost sums as the column / row
+    passes: results, iteration counts and cost histories must be BIT-identical to those (P3D_NO_RESIDENT=1; float32 cubes against
+    the complex passes, P3D_NO_REAL=1 -- the half-spectrum row-pair path drops the imaginary rounding noise and differs by 2e-6),
+    also with an all-zero slice in the batch; with the early exit on (slices leave the loop at different iterations) the iteration
+    counts and cost histories are identical and the results agree to the rounding of the passes' hand-back."""
+    nil, nxl = shape
+    _, mask, obs = orc.synthetic_cube(nil, nxl, 5, 0.5, real=real)
+    obs[3] = 0
+    monkeypatch.setenv("P3D_NO_REAL", "1")
+    for eps, niter in ((0.0, 9), (3e-4, 40)):
+        params = dict(niter=niter, thresh_op=op, thresh_model="exponential", eps=eps, p_max=0.99, p_min=1e-2 if op != "hard" else 1e-3)
+        monkeypatch.delenv("P3D_NO_RESIDENT", raising=False)
+        res_a = []
+        a = P.pocs_cube(obs, mask, results=res_a, **params)
+        monkeypatch.setenv("P3D_NO_RESIDENT", "1")
+        res_b = []
+        b = P.pocs_cube(obs, mask, results=res_b, **params)
+        monkeypatch.delenv("P3D_NO_RESIDENT")
+        assert a.dtype == obs.dtype
+        if eps == 0:
+            assert np.array_equal(a, b), (shape, op, real, eps, float(np.abs(a - b).max()))
+        else:
+            # the passes hand a converged slice back through one extra row-transform round trip (the "finalize" launch, DESIGN.md
+            # section 3 item 7); the single kernel stores the iterate itself
+            for s_ in range(a.shape[0]):
+                assert rel_l2(a[s_], b[s_]) < 2e-6 if b[s_].any() else not a[s_].any(), (shape, op, real, s_)
+        assert [r["niterations"] for r in res_a] == [r["niterations"] for r in res_b]
+        assert res_a[3]["niterations"] == 0 and not a[3].any()
+        for ra, rb in zip(res_a, res_b):
+            assert ra["costs"] == rb["costs"]
+        if eps > 0:
+            assert len({r["niterations"] for r in res_a}) >= 2   # the slices did leave at different iterations
+    # against the oracle as well (layer A, well-conditioned)
+    params = dict(niter=10, thresh_op=op, thresh_model="exponential", eps=0, p_max=0.99, p_min=0.08)
+    got = P.pocs_cube(obs, mask, **params)
+    want = orc.pocs_cube(obs.astype(np.float64 if real else np.complex128), mask, **params)
+    for s in (0, 1, 2, 4):
+        assert rel_l2(got[s], want[s]) < (TOL if op != "garrote" else 2e-4), (s, rel_l2(got[s], want[s]))
+
+
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at the full slice size
 # ------------------------------------------------------------------------------------------------
