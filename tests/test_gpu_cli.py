@@ -99,6 +99,60 @@ def test_fft_pocs_ifft_pipeline(tmp_path):
     release_plans()
 
 
+def test_netcdf_files_through_the_three_steps(tmp_path):
+    """SURVEY section 8f row N2 end to end: the same cube as netCDF-4 files -- written, read and merged by cube_io.py's h5py layer
+    under the image's interpreter that has h5py -- through steps 12, 13 and 14 on the GPU.  Every array of every product must
+    equal, bit for bit, what the .npz run of the same commands in this interpreter produces, and the per-batch files, the merged
+    cube, the parameter and the runtime files must all be there under their netCDF names."""
+    import subprocess
+    import sys
+    from test_cube_io_netcdf import CONDA, conda_has_h5py
+    if not conda_has_h5py():
+        pytest.skip("no interpreter with h5py in this image")
+    from pseudo_3d_interpolation_amd import cube_POCS_interpolation_3D as step13
+    from pseudo_3d_interpolation_amd import cube_apply_FFT as step12
+    from pseudo_3d_interpolation_amd import cube_apply_IFFT as step14
+    from pseudo_3d_interpolation_amd.cube_io import Cube, open_cube, save_cube
+    from pseudo_3d_interpolation_amd.functions.POCS import release_plans
+
+    nt, nil, nxl, dt, t0 = 24, 32, 64, 0.05, 7.0
+    x, fold = _time_cube(nt, nil, nxl, 0.5)
+    cube = Cube({'env': x, 'fold': fold}, {'env': ('twt', 'iline', 'xline'), 'fold': ('iline', 'xline')},
+                {'twt': t0 + dt * np.arange(nt), 'iline': np.arange(nil), 'xline': np.arange(nxl)},
+                {'long_name': 'test cube', 'description': 'synthetic', 'history': 'made;', 'text': ''}, {}, {'twt': {'units': 'ms'}})
+    path = save_cube(cube, str(tmp_path / 'cube_twt.npz'))
+    (tmp_path / 'netcdf.yml').write_text(yaml.safe_dump({'attrs_freq': {'data': {'units': 'amplitude'}, 'new_dim': {'units': 'kHz'}},
+                                                         'attrs_time': {'env': {'units': 'amplitude'}, 'twt': {'units': 'ms', 'spacing': dt}}}))
+    metadata = dict(transform_kind='fft', niter=8, eps=0, thresh_op='soft', thresh_model='exponential', decay_kind='values',
+                    p_max=0.99, p_min=0.1, alpha=1.0, sqrt_decay=False, version='regular', verbose=False)
+    (tmp_path / 'pocs.yml').write_text(yaml.safe_dump({'dim': 'freq_twt', 'var': 'freq_env', 'batch_chunk': 5, 'n_workers': 4, 'processes': True,
+                                                       'threads_per_worker': 1, 'memory_limit': '2GB', 'output_runtime_results': True,
+                                                       'metadata': metadata}))
+    prefix = 'cube_freq_FFT_soft_niter-8'
+    # the .npz run, here
+    step12.main(['12_cube_apply_FFT', path, '--params_netcdf', str(tmp_path / 'netcdf.yml'), '--compute_real'])
+    step13.main(['13_cube_interpolate_POCS', str(tmp_path / 'cube_freq.npz'), '--path_pocs_parameter', str(tmp_path / 'pocs.yml')])
+    step14.main(['14_cube_apply_IFFT', str(tmp_path / f'{prefix}.npz'), '--params_netcdf', str(tmp_path / 'netcdf.yml'), '--compute_real'])
+    release_plans()
+    # the netCDF run, in the interpreter that has h5py
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([CONDA, os.path.join(root, 'tests', 'helpers', 'nc_pipeline.py'), str(tmp_path), prefix], capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and 'NC PIPELINE OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    nc = tmp_path / 'nc'
+    batches = sorted(p for p in os.listdir(nc / prefix) if p.endswith('.nc'))
+    assert len(batches) == 3 and (nc / prefix / f'parameter_{prefix}.yml').exists() and (nc / prefix / f'runtimes_{prefix}.txt').exists()
+    for name in ('cube_freq', prefix, f'{prefix.replace("freq", "twt")}_interp-freq'):
+        a, b = open_cube(str(tmp_path / f'{name}.npz')), open_cube(str(nc / f'{name}.back.npz'))
+        assert set(a.data_vars) == set(b.data_vars) and a.dims == b.dims, name
+        for k in a.data_vars:
+            assert a.data_vars[k].dtype == b.data_vars[k].dtype and np.array_equal(a.data_vars[k], b.data_vars[k]), (name, k)
+        for k in a.coords:
+            assert np.array_equal(a.coords[k], b.coords[k]), (name, k)
+        for k in ('history', 'description'):
+            assert str(a.attrs.get(k)) == str(b.attrs.get(k)), (name, k)
+
+
 def test_wavelet_step13_time_domain(tmp_path):
     """transform_kind: wavelet on a time-domain cube (BASELINE configs[3] in miniature): file naming with the
     `_{wavelet}-smooth` suffix (cube_POCS_interpolation_3D.py:266) and results against the wavelet oracle."""
