@@ -546,7 +546,7 @@ int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
 // ---- internal helpers ---------------------------------------------------------------------------
 // Diagnostic switches of one job: every one selects a slower, equivalent path.  Read once per call of
 // p3d_pocs_run_dev, on the calling thread, and handed down as plain values -- the launch paths never consult the environment.
-struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident; };
+struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore; };
 static RunSwitches read_switches()
 {
     RunSwitches s;
@@ -556,6 +556,7 @@ static RunSwitches read_switches()
     s.no_sparse = getenv("P3D_NO_SPARSE") != nullptr;
     s.real_2048 = getenv("P3D_REAL_2048") != nullptr;
     s.no_resident = getenv("P3D_NO_RESIDENT") != nullptr;
+    s.no_tstore = getenv("P3D_NO_TSTORE") != nullptr;
     return s;
 }
 
@@ -1068,6 +1069,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.done = any_off ? p->done : nullptr;
     r.dtype = dtype;
     r.real_2048 = sw.real_2048 ? 1 : 0;
+    r.tstore = sw.no_tstore ? 0 : 1;
     r.adaptive = adaptive ? 1 : 0;
     // Early exit: a slice that converges at iteration k leaves the forward row transform of its iterate in the work buffer;
     // a "finalize" launch after the convergence test turns that back into `out` for exactly those slices, so the steady

@@ -185,6 +185,7 @@ struct RowArgs {
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
     int real_2048;         // host side only: the row-pair path for rows of 2048 samples is switched on (experiment switch P3D_REAL_2048)
+    int tstore;            // host side only: rows of one wavefront hand their transforms round through LDS and store 1-KiB runs (P3D_NO_TSTORE unset)
     ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD
 };
 
@@ -718,6 +719,9 @@ row_pipe_kernel(const RowArgs a)
 #ifndef P3D_PIPE64_LOCKSTEP
 #define P3D_PIPE64_LOCKSTEP 1
 #endif
+#ifndef P3D_PIPE64_XCD
+#define P3D_PIPE64_XCD 1
+#endif
 #ifndef P3D_PIPE64_MAXROWS
 #define P3D_PIPE64_MAXROWS 2
 #endif
@@ -745,11 +749,18 @@ constexpr int pipe64_rows()
     // rows of several wavefronts synchronise the whole workgroup at every exchange of a transform: two rows per workgroup (the
     // pair that shares 128-byte lines), several workgroups per CU (2048 samples: 2.19 ms against 2.83 with 7 rows, 5.87 before)
     int rows = TPL > 64 ? P3D_PIPE64_MAXROWS : 1024 / TPL;
-    while (rows > 1 && sizeof(c32) * (PassTables<N>::slots() + (size_t)rows * LdsRow::stride(N)) + 16 * sizeof(double) > 160 * 1024) --rows;
+    while (rows > 1 && sizeof(c32) * (PassTables<N>::slots() + (size_t)rows * (LdsRow::stride(N) + (TPL == 64 ? 4 : 0))) + 16 * sizeof(double) > 160 * 1024) --rows;
     return rows;
 }
+// Rows of ONE wavefront (N = 1024) can hand their forward transforms to each other through LDS before storing (TS, see
+// row_pipe64_kernel): the row buffers are then read ACROSS rows, and a row pitch of 8704 bytes = 0 mod 256 would put all sixteen
+// rows on the same banks; four more slots per row (32 bytes = 8 banks) spread them.
 template <int N>
-constexpr size_t pipe64_lds_bytes() { return sizeof(c32) * (PassTables<N>::slots() + (size_t)pipe64_rows<N>() * LdsRow::stride(N)) + 16 * sizeof(double); }
+constexpr bool pipe64_can_tstore() { return Plan<N>::TPL == 64; }
+template <int N>
+constexpr int pipe64_lstr() { return LdsRow::stride(N) + (pipe64_can_tstore<N>() ? 4 : 0); }
+template <int N>
+constexpr size_t pipe64_lds_bytes() { return sizeof(c32) * (PassTables<N>::slots() + (size_t)pipe64_rows<N>() * pipe64_lstr<N>()) + 16 * sizeof(double); }
 template <int N>
 constexpr int pipe64_threads() { return pipe64_rows<N>() * Plan<N>::TPL; }
 
@@ -783,6 +794,12 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned
 __device__ __forceinline__ void buf_store_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 v)
 {
     __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, (int)voff, (int)soff, 0);
+}
+typedef unsigned p3d_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store_2c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 a, c32 b)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(p3d_u4{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y)}, r,
+                                           (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
 {
@@ -835,7 +852,10 @@ static __device__ unsigned p3d_stamp_buf[1024 * 16 * STAMP_PHASES];   // (one co
 // re-insertion -> result cube (row_kernel<ROW_LAST> reads the FULL observed cube for that, zeros included: 8.6 GB where 5.2 do).
 enum PipeMode { PIPE_MID = 0, PIPE_FIRST = 1, PIPE_LAST = 2 };
 
-template <int N, int DT, bool SPARSE, int PM>
+// TS (PIPE_MID, rows of one wavefront, n1 a multiple of the 16 rows of a workgroup): the forward transforms are handed round through
+// LDS before they are stored, so that ONE dwordx4 instruction writes the 1-KiB run [16 rows][8 columns] of a column block -- whole
+// 128-byte lines, half the line accesses of sixteen rows' 64-byte pieces and half the store instructions (8 instead of 16).
+template <int N, int DT, bool SPARSE, int PM, bool TS = false>
 __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
@@ -846,8 +866,9 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     constexpr int THREADS = pipe64_threads<N>();
     constexpr int LB = THREADS / TPL;             // rows per workgroup
     constexpr int UPB = LB / RPW;                 // units per workgroup
-    constexpr int LSTR = LdsRow::stride(N);
+    constexpr int LSTR = pipe64_lstr<N>();
     constexpr bool WAVE = WPL == 1;
+    static_assert(!TS || (PM == PIPE_MID && pipe64_can_tstore<N>() && LB == 16), "transposed stores: sixteen one-wavefront rows per workgroup");
     constexpr unsigned ES = DT == 0 ? 8u : 4u;    // bytes per observed sample
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
@@ -999,7 +1020,13 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
     const float w_obs = 1.0f - a.alpha * 1.0f;   // POCS.py:616 at an observed trace
 
     const unsigned step = gridDim.x * UPB;
-    unsigned g = blockIdx.x * UPB + uline;
+    // Workgroups b, b + 8, b + 16 ... share an XCD (round-robin dispatch: speed only, never correctness).  Give the workgroups of one
+    // XCD ADJACENT row groups, so that what they store to a column block at about the same time is one contiguous run in one L2.
+    unsigned wg = blockIdx.x;
+#if P3D_PIPE64_XCD
+    if (gridDim.x % 8 == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    unsigned g = wg * UPB + uline;
     Where cur = locate(g);
     c32 v[PPT];
     raw64 bx[PPT], by[PPT];
@@ -1043,7 +1070,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
             for (int q = 0; q < PPT; ++q) buf_store_c32(none, BUF_OOB, 0u, v[q]);
             buf_store_f64(sums_srd, BUF_OOB, 0u, 0.0);
         }
-        for (unsigned g0 = blockIdx.x * UPB; g0 < total; g0 += step) {
+        for (unsigned g0 = wg * UPB; g0 < total; g0 += step) {
             const Where nxt = locate(g + step);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1101,18 +1128,54 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
         obs_tables(mw_cur, cbs0, cur);
         issue_obs_with(bx, cur, mw_cur, cbs0);
     }
+    // TS: after the lock-step barrier lane l of wave w reads, for j = 0 ... 7, the columns 8 (8 w + j) + 2 (l & 3), + 1 of row l >> 2
+    // from that row's buffer and stores them as bytes 16 l ... 16 l + 15 of the 1-KiB run of column block 8 w + j
+    const unsigned ts_row = (unsigned)lane >> 2;
+    const c32* const ts_src = data + ts_row * LSTR + (wave * 64 + 2 * (lane & 3)) + ((wave * 64) >> 4);   // + 8 j + (j >> 1): below
+    auto store_transposed = [&](const c32 (&src)[PPT], const Where& w, bool really) {
+        {   // own row -> its buffer, canonical positions
+            c32* const rowp = lds.ptr(lane);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) rowp[LdsRow::rel(64 * q)] = src[q];
+        }
+        __syncthreads();   // (all sixteen rows are in LDS)
+        c32 ta[8], tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // columns 8 j + 2 (l & 3) of the wave's 64: one padding slot per 16 columns
+            const c32* const sp = ts_src + 8 * j + (j >> 1);
+            ta[j] = sp[0];
+            tb[j] = sp[1];
+        }
+        __syncthreads();   // (everybody has what it needs: the buffers are free for the next row's transforms)
+        // the sixteen rows of a workgroup are g0 ... g0 + 15 of ONE slice (n1 % 16 == 0): row block and validity are workgroup-uniform
+        const __amdgpu_buffer_rsrc_t srd = work_srd(w);
+        const unsigned row0 = w.row - (unsigned)uline;
+        unsigned so = row0 * 64u + (unsigned)(wave * 8) * (wblk * 8u);
+        const unsigned vo = (really && !P3D_ABL_NOSTORE) ? (unsigned)lane * 16u : BUF_OOB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            buf_store_2c32(srd, vo, so, ta[j], tb[j]);
+            so += wblk * 8u;
+        }
+    };
     {   // as many stores as one trip of the loop issues, all out of range: the wait counts at the loop header are then the same
         // along both edges into it (see the note above the kernel)
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = c32{0.f, 0.f};
-        store_work(v, cur, false);
+        if constexpr (TS) {
+            const __amdgpu_buffer_rsrc_t none = buf_srd(nullptr, 0u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf_store_2c32(none, BUF_OOB, 0u, v[0], v[1]);
+        } else {
+            store_work(v, cur, false);
+        }
         buf_store_f64(sums_srd, BUF_OOB, 0u, 0.0);
     }
 #if P3D_STAMPS
     unsigned st_acc[STAMP_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
-    for (unsigned g0 = blockIdx.x * UPB; g0 < total; g0 += step) {
+    for (unsigned g0 = wg * UPB; g0 < total; g0 += step) {
         const Where nxt = locate(g + step);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1171,11 +1234,16 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
             // schedule.txt): barrier every row 1.60 ms, every 2nd / 4th / 8th / 32nd row 1.72 / 1.92 / 2.04 / 2.11 ms, never 2.36 ms;
             // lock-step kept by groups of 2 / 4 / 8 waves only (counters in LDS) 1.74 / 1.80 / 1.71 ms.  A wavefront that holds two or
             // more adjacent rows (RPW > 1) pairs their halves up by itself.
+            if constexpr (TS) {
+                P3D_STAMP(7);
+                store_transposed(v, cur, cur.on);   // (its two barriers keep the rows in step)
+            } else {
 #if P3D_PIPE64_LOCKSTEP
-            if (WAVE && RPW == 1) __builtin_amdgcn_s_barrier();
+                if (WAVE && RPW == 1) __builtin_amdgcn_s_barrier();
 #endif
-            P3D_STAMP(7);   // lock-step barrier
-            store_work(v, cur, cur.on);
+                P3D_STAMP(7);   // lock-step barrier
+                store_work(v, cur, cur.on);
+            }
             P3D_STAMP(8);   // issue of the stores
         } else {
             store_cube(v, cur);   // last pass of a job: whole rows of the result cube, no neighbour to wait for
@@ -1731,8 +1799,24 @@ hipError_t launch_row_pipe64(int pm, const RowArgs& a, int cus, hipStream_t st)
             if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true, PIPE_LAST); else P3D_PIPE64(0, false, PIPE_LAST); }
             else { if (sp) P3D_PIPE64(1, true, PIPE_LAST); else P3D_PIPE64(1, false, PIPE_LAST); }
         } else if (pm == PIPE_MID) {
-            if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true, PIPE_MID); else P3D_PIPE64(0, false, PIPE_MID); }
-            else { if (sp) P3D_PIPE64(1, true, PIPE_MID); else P3D_PIPE64(1, false, PIPE_MID); }
+            bool ts = false;
+            if constexpr (pipe64_can_tstore<N>() && LB64 == 16) {
+                ts = a.tstore && a.n1 % 16 == 0;
+                if (ts) {
+#define P3D_PIPE64_TS(DT, SP)                                                                                   \
+    do {                                                                                                        \
+        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP, PIPE_MID, true>, lds64)) != hipSuccess) return e;       \
+        row_pipe64_kernel<N, DT, SP, PIPE_MID, true><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);            \
+    } while (0)
+                    if (a.dtype == 0) { if (sp) P3D_PIPE64_TS(0, true); else P3D_PIPE64_TS(0, false); }
+                    else { if (sp) P3D_PIPE64_TS(1, true); else P3D_PIPE64_TS(1, false); }
+#undef P3D_PIPE64_TS
+                }
+            }
+            if (!ts) {
+                if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true, PIPE_MID); else P3D_PIPE64(0, false, PIPE_MID); }
+                else { if (sp) P3D_PIPE64(1, true, PIPE_MID); else P3D_PIPE64(1, false, PIPE_MID); }
+            }
         } else {
             return hipErrorInvalidValue;
         }
