@@ -152,8 +152,16 @@ int p3d_multi_run(int ndev, const int* devices, int nil, int nxl, const void* x_
  *     xrft.fft(da, dim='twt', shift=False, true_phase=True, true_amplitude=True, shape={dim: nfft})
  *                                                                                  cube_apply_FFT.py:240-254
  *     xrft.ifft(da, dim='freq_twt', true_phase=True, true_amplitude=True)          cube_apply_IFFT.py:83-94
- * i.e. F[k] = dt * exp(-2*pi*i*f_k*t0) * sum_n x[n] exp(-2*pi*i*k*n/nfft), f_k = fftfreq(nfft, dt)[k], and its exact
- * inverse.  (The xrft fork the reference pins is not available; this is upstream xrft's documented convention.)
+ * i.e. F[k] = dt * exp(-2*pi*i*f_k*t0) * sum_n x[n] exp(-2*pi*i*k*n/nfft) = dt * sum_n x[n] exp(-2*pi*i*f_k*(t0 + n*dt)),
+ * f_k = fftfreq(nfft, dt)[k], and its exact inverse.  (The xrft fork the reference pins is not available; this is upstream
+ * xrft's documented convention.)  For nfft == nt this is what xrft computes whichever way it gets there: its true_phase path
+ * rotates the trace by nt/2 samples (ifftshift) and refers the phase to the centre sample t[nt/2], and the two shifts cancel
+ * exactly.  For nfft > nt (--upsampling-factor; `shape=` exists only in the fork) the trace is zero-padded at its END here and
+ * every sample keeps its physical time t0 + n*dt; an implementation that rotates BEFORE padding would instead place the first
+ * half of the trace one record length later (phase exp(-2*pi*i*f_k*nt*dt) on those samples) and report direct_lag = t[nt/2].
+ * Which of the two the fork does cannot be established here (parity unpinned); step 14 inverts THIS
+ * convention exactly, so 12 -> 13 -> 14 round trips are unaffected, but spectra of an upsampled step 12 should not be mixed
+ * with spectra written by the reference's step 12.
  *   p3d_time2freq: x HOST float32 [nt][ntraces] -> out HOST complex64 [nfreq][ntraces]; the trace is zero-padded to
  *       nfft >= nt (--upsampling-factor); real_only != 0 keeps k = 0..nfft/2 (--compute_real, nfreq = nfft/2+1) else
  *       nfreq = nfft; window (HOST float32 [nfreq] or NULL) multiplies every frequency sample (cube_apply_FFT.py:273-278).
