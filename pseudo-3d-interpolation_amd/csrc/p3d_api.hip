@@ -546,7 +546,7 @@ int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
 // ---- internal helpers ---------------------------------------------------------------------------
 // Diagnostic switches of one job: every one selects a slower, equivalent path.  Read once per call of
 // p3d_pocs_run_dev, on the calling thread, and handed down as plain values -- the launch paths never consult the environment.
-struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore; };
+struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore, force_colpipe; };
 static RunSwitches read_switches()
 {
     RunSwitches s;
@@ -557,6 +557,7 @@ static RunSwitches read_switches()
     s.real_2048 = getenv("P3D_REAL_2048") != nullptr;
     s.no_resident = getenv("P3D_NO_RESIDENT") != nullptr;
     s.no_tstore = getenv("P3D_NO_TSTORE") != nullptr;
+    s.force_colpipe = getenv("P3D_FORCE_COLPIPE") != nullptr;
     return s;
 }
 
@@ -1123,6 +1124,11 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         r.zero_off = (unsigned)(wk_slice_stride(p->nil, p->nxl) * (size_t)p->max_slices);
         HIP_TRY(hipMemsetAsync(p->nzcount, 0, sizeof(unsigned long long), p->stream));
     }
+    // The persistent column pass (col_pipe_kernel) wins where nearly all tiles end at the threshold (-4 ... -12 % by shape at 4 % kept
+    // blocks) and loses as soon as a noticeable share is transformed back and stored (+14 % at the 6 % of a 20-iteration job, +9 % dense:
+    // profiles/r02_colpass_persistent.txt).  Which of the two a job is cannot be known before it has run, and choosing from the plan's
+    // previous job cost the 20-iteration bench line 7 %: it stays an experiment behind P3D_FORCE_COLPIPE=1, bit-identical and tested.
+    const bool colpipe = sparse && sw.force_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr;
     p->last_nonzero_fraction = -1.0;
     const int n2_work = real_path ? p->nxl / 2 + 1 : p->nxl;   // columns of the work buffer
     const int tiles_work = (n2_work + col_t - 1) / col_t;
@@ -1131,7 +1137,12 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     HIP_TRY(stamp());
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
-        HIP_TRY(p->ops_col->col(COL_ITER, c, p->stream));
+        {
+            hipError_t ce = hipErrorNotSupported;
+            if (colpipe) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
+            if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_ITER, c, p->stream);
+            HIP_TRY(ce);
+        }
         if (sparse && real_path && !flex_rows) {
             nz_real_kernel<<<(nslices * 16 * (p->ops_row->tpl >= 64 ? p->ops_row->tpl / 64 : 1) + 3) / 4, 256, 0, p->stream>>>(p->nzflag, p->nzl, p->nzcount, nslices, tiles_work, col_t, p->nxl, p->ops_row->tpl, c.done);
             r.nzl = p->nzl;

@@ -1716,6 +1716,133 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     }
 }
 
+// =================================================================================================
+// spectrum (column) pass, steady state: persistent, the next tile's loads in flight during the transforms
+// =================================================================================================
+// Same arithmetic as col_kernel<N, T, COL_ITER*> (bit for bit).  The one-launch form starts a workgroup per tile: every tile pays a
+// workgroup launch, a copy of the twiddle tables into LDS (10 KiB at N = 1024) and a full load latency before its first butterfly,
+// and 95 % of the tiles of a sparse spectrum end right after the threshold.  Here a workgroup stays on its CU (two per CU as
+// before), copies the tables once, and requests tile t + 1 BEFORE it transforms tile t (16 more registers pairs per thread; the
+// loads are issued ahead of the tile's stores, so waiting for them never waits for a store that is younger).
+#ifndef P3D_COLPIPE_WAVES_PER_EU
+#define P3D_COLPIPE_WAVES_PER_EU 4
+#endif
+template <int N, int T, int OP>
+__global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col_pipe_kernel(const ColArgs a)
+{
+    using PL = Plan<N>;
+    constexpr int TPL = PL::TPL, PPT = PL::PPT;
+    constexpr int THREADS = T * TPL;
+    static_assert(T % 8 == 0 && PPT == 16, "whole 64-byte column blocks per tile");
+    constexpr int CW = 8;
+    using LDS = LdsColW<CW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + ColTables<N>::slots();
+    const TwCol tw{twl};
+
+    const int tid = threadIdx.x;
+    const int c_lo = tid % CW;
+    const int tl = (tid / CW) % TPL;
+    const int cbl = tid / (CW * TPL);  // column block of this thread inside the tile
+    for (int i = tid; i < ColTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
+    __syncthreads();
+    const LDS lds{data + cbl * LDS::stride(N) + c_lo};
+
+    const unsigned tiles = (unsigned)(a.n2 + T - 1) / T;             // per slice
+    const unsigned total = (unsigned)a.nslices * tiles;
+    const size_t sstride = wk_slice_stride(N, a.n2);
+    const unsigned slice_bytes = (unsigned)(sstride * 8);
+    typedef const int __attribute__((address_space(4))) * kint_t;
+    const kint_t k_done = (kint_t)a.done;
+    typedef const unsigned long long __attribute__((address_space(4))) * ktau_t;
+    const ktau_t k_tau = (ktau_t)a.tau;   // [nslices][niter] float2, constant during the launch
+    struct Tile { unsigned slice, tile; bool on; };
+    auto locate = [&](unsigned g) -> Tile {
+        Tile t;
+        t.on = g < total;
+        const unsigned gg = t.on ? g : 0u;
+        t.slice = gg / tiles;
+        t.tile = gg - t.slice * tiles;
+        if (k_done != nullptr && t.on && k_done[t.slice] != 0) t.on = false;
+        return t;
+    };
+    // element (row tl + TPL q, this thread's column) of the tile: byte offset inside the slice
+    auto lane_off = [&](const Tile& t, bool& valid) -> unsigned {
+        const int col = (int)t.tile * T + cbl * CW + c_lo;
+        valid = col < a.n2;
+        const int vcol = valid ? col : 0;
+        return (((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7) + (unsigned)tl * 8) * 8u;
+    };
+    auto issue = [&](raw64 (&dst)[PPT], const Tile& t) {
+        bool valid;
+        const unsigned vo = lane_off(t, valid);
+        const __amdgpu_buffer_rsrc_t srd = buf_srd(reinterpret_cast<const char*>(a.in) + (size_t)t.slice * slice_bytes, slice_bytes);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) dst[q] = buf_load_raw64(srd, vo, (unsigned)(TPL * q) * 64u);
+    };
+
+    // Each workgroup takes a CONTIGUOUS run of tiles (on the headline cube: one whole slice, 8 MiB of consecutive addresses).  Handing
+    // the tiles out with a stride of gridDim.x instead -- tile b, b + 512, ... -- costs 40 % (1.37 against 0.94 ms): with 128 tiles per
+    // slice every workgroup then stays on ONE column block of every fourth slice, and the 512 concurrent streams sit 64 KiB apart.
+    const unsigned per = (total + gridDim.x - 1) / gridDim.x;
+    unsigned g = blockIdx.x * per;
+    const unsigned g_end = g + per < total ? g + per : total;
+    Tile cur = locate(g);
+    raw64 nx[PPT];
+    c32 v[PPT];
+    issue(nx, cur);
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) { v[q] = raw_c32(nx[q]); asm volatile("; first tile" : "+v"(v[q].x), "+v"(v[q].y)); }   // (nothing pending at the loop header)
+    for (unsigned i = 0; i < per; ++i) {   // (the same trip count for every workgroup: the loop holds workgroup barriers)
+        Tile nxt = locate(g + 1);
+        if (g + 1 >= g_end) nxt.on = false;
+        if (g >= g_end) cur.on = false;
+        __builtin_amdgcn_sched_barrier(0);
+        issue(nx, nxt);   // in flight during the transforms of this tile
+        __builtin_amdgcn_sched_barrier(0);
+        int tl_r = tl;
+        asm volatile("" : "+v"(tl_r));   // (the transforms' LDS / twiddle addresses are recomputed per tile instead of living in registers across the loop)
+        // (the threshold through the scalar path: a vector load here would sit BEHIND the sixteen loads of the next tile in the
+        // in-order vmcnt queue, and waiting for it would wait for them)
+        const unsigned long long tau_bits = k_tau[(size_t)cur.slice * a.niter + a.iter];
+        line_fft<N, FWD, false>(v, lds, tw, tl_r);
+        const Shrink shr(c32{__uint_as_float((unsigned)tau_bits), __uint_as_float((unsigned)(tau_bits >> 32))}, OP);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = shr(v[q]);
+        bool kept = true;
+        if (a.nzflag != nullptr) {   // a tile the threshold emptied is zeros after the inverse transform too: say so instead (see col_kernel)
+            unsigned bits = 0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) bits |= __float_as_uint(v[q].x) | __float_as_uint(v[q].y);
+            kept = __syncthreads_or(bits != 0u ? 1 : 0) != 0;
+            if (tid == 0 && cur.on) a.nzflag[(size_t)cur.slice * tiles + cur.tile] = kept ? 1 : 0;
+        }
+        // The hand-over of the next tile (v <- nx) is written out in BOTH arms, so that the compiler counts each arm by itself: behind
+        // the sixteen stores of a kept tile the wait for the loads is vmcnt(16) -- they were issued first --, not the vmcnt(0) a join
+        // of "stores or no stores" would force (dense spectra: 1.71 -> see profiles/r02_colpass_persistent.txt).
+        if (kept) {   // workgroup-uniform
+            line_fft<N, INV, false>(v, lds, tw, tl_r);
+            bool valid;
+            const unsigned vo = lane_off(cur, valid);
+            const __amdgpu_buffer_rsrc_t osrd = buf_srd(reinterpret_cast<char*>(a.out) + (size_t)cur.slice * slice_bytes, slice_bytes);
+            const unsigned so_v = (valid && cur.on) ? vo : BUF_OOB;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) buf_store_c32(osrd, so_v, (unsigned)(TPL * q) * 64u, v[q]);
+            // (the empty asm statements "use" the values HERE: without them the copies are renamed away and the wait moves to the
+            // first butterfly of the next trip -- behind the next issue of loads, where it covers the stores again)
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) { v[q] = raw_c32(nx[q]); asm volatile("; kept tile" : "+v"(v[q].x), "+v"(v[q].y)); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) { v[q] = raw_c32(nx[q]); asm volatile("; emptied tile" : "+v"(v[q].x), "+v"(v[q].y)); }
+        }
+        __syncthreads();   // the LDS image is free for the next tile
+        g += 1;
+        cur = nxt;
+    }
+}
+
 // ---- launch helpers, one instantiation set per line length --------------------------------------
 // columns per workgroup of the column pass: keep 512..1024 threads and <= ~80 KiB of LDS
 template <int N>
@@ -1938,6 +2065,36 @@ hipError_t launch_col_one(const ColArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+// persistent column pass of the iteration (column-blocked buffer in and out), `wgs` resident workgroups
+template <int N>
+hipError_t launch_col_pipe(const ColArgs& a, int cus, hipStream_t st)
+{
+    constexpr int T = col_tile<N>();
+    if constexpr (T % 8 == 0 && Plan<N>::PPT == 16) {
+        if (a.in_std || a.out_std || a.in != a.out || cus < 1) return hipErrorNotSupported;
+        if ((double)wk_slice_stride(N, a.n2) * 8.0 >= 2147483648.0) return hipErrorNotSupported;
+        constexpr size_t lds = col_lds_bytes<N>();
+        int per_cu = (int)((160 * 1024) / lds);
+        const int by_waves = (P3D_COLPIPE_WAVES_PER_EU * 4) / (T * Plan<N>::TPL / 64);
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        const long total = (long)a.nslices * ((a.n2 + T - 1) / T);
+        const long wgs = (long)cus * per_cu;
+        const dim3 grid((unsigned)(total < wgs ? total : wgs));
+        hipError_t e = hipSuccess;
+#define P3D_COLPIPE(OP)                                                                       \
+    do {                                                                                      \
+        if ((e = allow_lds(col_pipe_kernel<N, T, OP>, lds)) != hipSuccess) return e;          \
+        col_pipe_kernel<N, T, OP><<<grid, T * Plan<N>::TPL, lds, st>>>(a);                    \
+    } while (0)
+        if (a.op == 1) P3D_COLPIPE(1); else if (a.op == 2) P3D_COLPIPE(2); else P3D_COLPIPE(0);
+#undef P3D_COLPIPE
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <int N>
 hipError_t launch_col(int mode, const ColArgs& a, hipStream_t st)
 {
@@ -1970,6 +2127,7 @@ struct LineOps {
     void (*build_col_tw)(c32* out);
     hipError_t (*row_real)(int mode, const RowArgs&, int cus, hipStream_t);   // REAL_* passes (hipErrorNotSupported where absent)
     hipError_t (*row_pipe64)(int pm, const RowArgs&, int cus, hipStream_t);   // PIPE_FIRST / PIPE_MID / PIPE_LAST (hipErrorNotSupported where absent)
+    hipError_t (*col_pipe)(const ColArgs&, int cus, hipStream_t);             // persistent COL_ITER (hipErrorNotSupported where absent)
 };
 
 }  // namespace p3d

@@ -734,6 +734,16 @@ def test_wave_uniform_row_pass_is_the_generic_one(nil, nxl, dtype, monkeypatch):
     assert np.median(err) <= 1e-5 and err.max() <= 2e-3, err
     for key, other in res.items():
         assert np.array_equal(first, other), key
+    # the persistent column pass (an experiment behind P3D_FORCE_COLPIPE: faster only on very sparse spectra) against the one-launch one
+    monkeypatch.delenv("P3D_NO_PIPE64", raising=False)
+    monkeypatch.delenv("P3D_NO_SPARSE", raising=False)
+    monkeypatch.setenv("P3D_FORCE_COLPIPE", "1")
+    P.release_plans()
+    try:
+        assert np.array_equal(first, P.pocs_cube(cube, mask, **kw))
+    finally:
+        P.release_plans()
+        monkeypatch.delenv("P3D_FORCE_COLPIPE")
     if nxl == 1024:   # rows of one wavefront: with n1 a multiple of 16 the transforms go round through LDS and are stored as 1-KiB runs
         monkeypatch.delenv("P3D_NO_PIPE64", raising=False)
         monkeypatch.delenv("P3D_NO_SPARSE", raising=False)
