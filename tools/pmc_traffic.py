@@ -2,6 +2,7 @@
 of an iteration (FETCH_SIZE counts 64-byte requests where the L2 issues 128-byte ones on gfx950: MI355X_MICROARCH.md, HBM)."""
 import json
 import os
+import re
 import sys
 
 src, niter = sys.argv[1], int(sys.argv[2])
@@ -9,7 +10,8 @@ pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
 line = json.loads(open(os.path.join(src, "bench_line_under_trace.json")).read())
 parts = {}
 for k, cs in pmc.items():
-    if ("col_kernel" in k and k.endswith("mode0>")) or "row_pipe64_kernel" in k or "row_pipe_kernel" in k:
+    steady_row = re.search(r"row_pipe64_kernel<\d+, \d, (true|false), 0,", k) is not None   # PM = PIPE_MID only (first / last pass: once per job)
+    if ("col_kernel" in k and k.endswith("mode0>")) or steady_row or "row_pipe_kernel" in k:
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             parts[k] = {"read_bytes": 2 * cs["FETCH_SIZE"]["mean"] * 1024, "written_bytes": cs["WRITE_SIZE"]["mean"] * 1024,
                         "launches": cs["FETCH_SIZE"]["launches"], "tcc_miss_x128": cs.get("TCC_MISS_sum", {}).get("mean", 0) * 128}
