@@ -298,12 +298,13 @@ def main():
         plan = fft_plan
 
         def job(niter, profile=False):
-            stats = plan.stats_dev(x_obs.data_ptr(), DT, n_local)
+            # statistics of fft2(x_obs) with the mask at hand: the pass doubles as the first pass of the job (p3d_pocs_prime_dev)
+            stats = plan.prime_dev(x_obs.data_ptr(), DT, mask_t.data_ptr(), n_local)
             active = stats[:, 2] > 0
             stats[~active] = 1.0
             tau = P._schedule_from_stats(stats, nil * nxl, "exponential", niter, 0.99, p_min, "values")
             return plan.run_dev(x_obs.data_ptr(), DT, mask_t.data_ptr(), tau, niter, out.data_ptr(), n_local,
-                                thresh_op=op, eps=args.eps, alpha=args.alpha, active=active, profile=profile, want_sums=False)
+                                thresh_op=op, eps=args.eps, alpha=args.alpha, active=active, profile=profile, want_sums=False, primed=True)
     elif kind == "WAVELET":
         plan = _ffi.WaveletPlan(nil, nxl, n_local, wavelet=cfg["wavelet"], device=dev_index)
 

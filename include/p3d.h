@@ -60,6 +60,7 @@ extern "C" {
 
 /* p3d_pocs_params.flags */
 #define P3D_FLAG_PROFILE 1 /* bracket every kernel launch with HIP events; read with p3d_last_profile() */
+#define P3D_FLAG_PRIMED 2  /* p3d_pocs_prime_dev has just run on exactly this cube and mask: p3d_pocs_run_dev may skip its first pass */
 
 typedef struct p3d_plan p3d_plan;
 
@@ -115,6 +116,13 @@ int p3d_fft2_shrink_c64(p3d_plan* plan, const void* in_host, const double* tau, 
 /* Per-slice statistics of X0 = fft2(x) for the threshold schedule (replaces the device-independent
  * part of get_threshold_decay, POCS.py:535-546).  stats_host: [nslices][P3D_STATS_PER_SLICE]. */
 int p3d_pocs_stats_dev(p3d_plan* plan, const void* x_dev, int dtype, int nslices, double* stats_host);
+/* p3d_pocs_stats_dev for a caller that is about to run the job on the same cube: with the mask at hand the statistics pass IS the
+ * first pass of the job (forward row transform into the work buffer, compact copy of the observed samples, sum |x_obs|), so a
+ * following p3d_pocs_run_dev(..., flags | P3D_FLAG_PRIMED) on the same plan, pointers, dtype and batch skips it (one full pass over
+ * the cube per job).  The flag is a promise about the CONTENTS of x_dev and mask_dev (unchanged in between); the plan checks the
+ * rest and runs the ordinary first pass when anything else used it meanwhile, for APOCS and for float32 cubes that take the
+ * half-spectrum path.  Same statistics, same results, bit for bit. */
+int p3d_pocs_prime_dev(p3d_plan* plan, const void* x_dev, int dtype, const float* mask_dev, int nslices, double* stats_host);
 int p3d_pocs_stats(p3d_plan* plan, const void* x_host, int dtype, int nslices, double* stats_host);
 
 /* The POCS loop (POCS.py:549-632) for a batch of slices sharing one trace mask.

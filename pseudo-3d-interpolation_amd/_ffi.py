@@ -16,6 +16,7 @@ P3D_OP_PERCENTILE = 16
 P3D_OP.update({f"{k}-percentile": v | P3D_OP_PERCENTILE for k, v in list(P3D_OP.items())})
 P3D_VER = {"regular": 0, "fast": 1, "adaptive": 2}
 P3D_FLAG_PROFILE = 1
+P3D_FLAG_PRIMED = 2
 STATS_PER_SLICE = 6
 
 
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "p3d_fft2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "p3d_fft2_shrink_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_pocs_prime_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "p3d_pocs_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_pocs_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -267,11 +269,11 @@ class Plan:
         return st
 
     @staticmethod
-    def _params(niter, thresh_op, version, eps, alpha, profile):
+    def _params(niter, thresh_op, version, eps, alpha, profile, primed=False):
         if thresh_op not in P3D_OP:
             raise UnsupportedError(P3D_ERR_UNSUPPORTED, f"thresh_op {thresh_op!r} is not implemented by the HIP kernels")
-        return PocsParams(int(niter), P3D_OP[thresh_op], P3D_VER[version], P3D_FLAG_PROFILE if profile else 0,
-                          float(eps), float(alpha))
+        return PocsParams(int(niter), P3D_OP[thresh_op], P3D_VER[version],
+                          (P3D_FLAG_PROFILE if profile else 0) | (P3D_FLAG_PRIMED if primed else 0), float(eps), float(alpha))
 
     @staticmethod
     def _tau(tau, nslices, niter):
@@ -300,12 +302,19 @@ class Plan:
                                  C.byref(prm), _ptr(out), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return out, done, sums, ms.value
 
+    def prime_dev(self, x_ptr, dtype, mask_ptr, nslices):
+        """`stats_dev` that doubles as the first pass of the job: follow it with ``run_dev(..., primed=True)`` on the same
+        pointers and batch (include/p3d.h, p3d_pocs_prime_dev)."""
+        st = np.empty((nslices, STATS_PER_SLICE), np.float64)
+        check(lib().p3d_pocs_prime_dev(self.handle, x_ptr, dtype, mask_ptr, nslices, _ptr(st)))
+        return st
+
     def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, nslices, thresh_op="hard", version="regular",
-                eps=0.0, alpha=1.0, active=None, profile=False, want_sums=True):
+                eps=0.0, alpha=1.0, active=None, profile=False, want_sums=True, primed=False):
         """Device pointers in/out (cube stays resident in HBM).  Returns (niter_done, sums, elapsed_ms)."""
         t = self._tau(tau, nslices, niter)
         act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
-        prm = self._params(niter, thresh_op, version, eps, alpha, profile)
+        prm = self._params(niter, thresh_op, version, eps, alpha, profile, primed)
         done = np.zeros(nslices, np.int32)
         sums = np.zeros((niter + 1, nslices), np.float64) if want_sums else None
         ms = C.c_double(0.0)

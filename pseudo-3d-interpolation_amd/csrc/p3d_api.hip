@@ -322,6 +322,9 @@ struct p3d_plan {
     void* st_out = nullptr;
     float* st_mask = nullptr;
     size_t st_cap = 0;
+    // p3d_pocs_prime_dev: the first pass of a job run ahead of it (statistics + work buffer + compact samples of exactly this cube)
+    struct Primed { bool valid = false; const void* x = nullptr; const float* mask = nullptr; int dtype = 0, nslices = 0, nonbinary = 0, violation = 0; unsigned nobs = 0; } primed;
+    double* sum0 = nullptr;     // [max_slices] sum |x_obs| of the primed cube
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof_events;
     double prof_col_ms = 0, prof_row_ms = 0;
@@ -373,7 +376,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->cbase, p->bits64, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
+    void* bufs[] = {p->cbase, p->bits64, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->sum0, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -483,6 +486,7 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
     }
     TRY_OR_BAIL(hipMalloc((void**)&p->flag, 2 * sizeof(int)));
     TRY_OR_BAIL(hipMalloc((void**)&p->rowsum, sizeof(double) * (size_t)nil * max_slices));
+    TRY_OR_BAIL(hipMalloc((void**)&p->sum0, sizeof(double) * (size_t)max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
 #undef TRY_OR_BAIL
@@ -564,6 +568,7 @@ static RunSwitches read_switches()
 static int check_batch(p3d_plan* p, int nslices)
 {
     if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    p->primed.valid = false;   // whoever comes through here is about to use the work buffer (p3d_pocs_run_dev reads the state first)
     if (nslices < 1 || nslices > p->max_slices)
         return fail(P3D_ERR_INVALID, "nslices = %d outside 1..max_slices (%d)", nslices, p->max_slices);
     return P3D_OK;
@@ -808,6 +813,94 @@ static hipError_t first_row_pass(p3d_plan* p, const RowArgs& r)
     return p->ops_row->row(ROW_FIRST, r, p->stream);
 }
 
+// packed forms of a binary trace mask (16-bit words per thread and row, 64-bit lane masks, compact bases); nonbinary: the mask holds
+// other values than 0 / 1 (or the row pass is a flexible one, which reads the float weights); nobs: observed positions per slice
+static int pack_mask(p3d_plan* p, const float* mask, int* nonbinary, unsigned* nobs)
+{
+    const bool flex_rows = is_flex(p->ops_row);
+    HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
+    *nonbinary = flex_rows ? 1 : 0;
+    *nobs = 0;
+    if (flex_rows) return P3D_OK;
+    const int words = p->nil * p->ops_row->tpl;
+    pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl, p->ops_row->ppt);
+    if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
+    if (p->bits64 && p->nil <= 4096) {
+        const int tpl = p->ops_row->tpl, wpl = tpl >= 64 ? tpl / 64 : 1;
+        pack_mask64_kernel<<<(p->nil * wpl * 16 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, tpl);
+        pack_cbase_kernel<<<(p->nil + 255) / 256, 256, 0, p->stream>>>(p->bits64, p->rowbase, p->cbase, p->nil, tpl);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return P3D_OK;
+}
+
+// compact observed samples are worth their bookkeeping when the persistent row pass exists and less than 3/4 of the traces are there
+static bool want_compact(p3d_plan* p, int nonbinary, unsigned nobs, int niter, const RunSwitches& sw)
+{
+    return !nonbinary && p->pipe_wgs > 0 && p->nil <= 4096 && niter > 1 && !sw.no_compact && nobs > 0 &&
+           (double)nobs < 0.75 * (double)p->slice_elems();
+}
+
+static int ensure_xc(p3d_plan* p, int nslices, unsigned nobs, int dtype)
+{
+    const size_t need = (size_t)nslices * nobs * (dtype == P3D_C64 ? sizeof(c32) : sizeof(float));
+    if (p->xc_cap < need) {
+        if (p->xc) hipFree(p->xc);
+        p->xc = nullptr;
+        p->xc_cap = 0;
+        HIP_TRY(hipMalloc(&p->xc, need));
+        p->xc_cap = need;
+    }
+    return P3D_OK;
+}
+
+int p3d_pocs_prime_dev(p3d_plan* p, const void* x, int dtype, const float* mask, int nslices, double* stats)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!x || !mask || !stats) return fail(P3D_ERR_INVALID, "NULL buffer");
+    if (dtype != P3D_C64 && dtype != P3D_F32) return fail(P3D_ERR_INVALID, "unknown dtype %d", dtype);
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->generic || is_flex(p->ops_row) || is_flex(p->ops_col)) return p3d_pocs_stats_dev(p, x, dtype, nslices, stats);   // nothing to run ahead there
+    const RunSwitches sw = read_switches();
+    int nonbinary = 0;
+    unsigned nobs = 0;
+    if ((rc = pack_mask(p, mask, &nonbinary, &nobs))) return rc;
+    if (sw.no_mask_bits) nonbinary = 1;
+    const bool compact = want_compact(p, nonbinary, nobs, 2, sw);
+    if (compact && (rc = ensure_xc(p, nslices, nobs, dtype))) return rc;
+    RowArgs r = row_args(p, nslices);
+    r.x = x;
+    r.mask = nonbinary ? mask : nullptr;
+    r.bits = nonbinary ? nullptr : p->bits;
+    r.bits64 = nonbinary ? nullptr : p->bits64;
+    r.cbase = nonbinary ? nullptr : p->cbase;
+    r.xc = compact ? p->xc : nullptr;
+    r.rowbase = p->rowbase;
+    r.nobs = nobs;
+    r.violation = p->flag + 1;
+    r.work = p->work;
+    r.sums = p->rowsum;
+    r.dtype = dtype;
+    HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
+    HIP_TRY(first_row_pass(p, r));
+    reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sum0, p->nil);
+    ColArgs c = col_args(p, nslices);
+    c.in = p->work;
+    c.partials = p->partials;
+    HIP_TRY(p->ops_col->col(COL_STATS, c, p->stream));
+    int violation = 0;
+    if (compact) HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if ((rc = reduce_partials(p, nslices, stats))) return rc;   // (synchronises the stream)
+    p->primed.valid = true;
+    p->primed.x = x; p->primed.mask = mask; p->primed.dtype = dtype; p->primed.nslices = nslices;
+    p->primed.nonbinary = nonbinary; p->primed.nobs = nobs; p->primed.violation = violation;
+    return P3D_OK;
+}
+
 int p3d_pocs_stats_dev(p3d_plan* p, const void* x, int dtype, int nslices, double* stats)
 {
     int rc = check_batch(p, nslices);
@@ -852,6 +945,11 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
                      const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
                      double* elapsed_ms)
 {
+    // P3D_FLAG_PRIMED: the caller says p3d_pocs_prime_dev has just run on exactly this cube and mask -- believed only if the plan
+    // agrees (same pointers, type and batch, nothing else on the plan in between)
+    const bool primed_in = p && prm && (prm->flags & P3D_FLAG_PRIMED) && p->primed.valid && p->primed.x == x && p->primed.mask == mask &&
+                           p->primed.dtype == dtype && p->primed.nslices == nslices;
+    const p3d_plan::Primed primed_state = p ? p->primed : p3d_plan::Primed{};
     int rc = check_batch(p, nslices);
     if (rc) return rc;
     if (!x || !mask || !tau || !prm || !out) return fail(P3D_ERR_INVALID, "NULL argument");
@@ -986,25 +1084,14 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // packed trace mask: binary masks (the workflow's fold-derived mask, cube_POCS_interpolation_3D.py:242-244)
     // travel as one 16-bit word per thread and row; anything else keeps the float weights
     const bool flex_rows = is_flex(p->ops_row);   // the flexible row pass reads the float weights
-    HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
-    if (!flex_rows) {
-        const int words = p->nil * p->ops_row->tpl;
-        pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl,
-                                                                    p->ops_row->ppt);
-        if (p->nil <= 4096) rowbase_kernel<<<1, 1024, 0, p->stream>>>(p->bits, p->rowbase, p->nil, p->ops_row->tpl);
-        if (p->bits64 && p->nil <= 4096) {
-            const int tpl = p->ops_row->tpl, wpl = tpl >= 64 ? tpl / 64 : 1;
-            pack_mask64_kernel<<<(p->nil * wpl * 16 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, tpl);
-            pack_cbase_kernel<<<(p->nil + 255) / 256, 256, 0, p->stream>>>(p->bits64, p->rowbase, p->cbase, p->nil, tpl);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    int nonbinary = flex_rows ? 1 : 0;
+    int nonbinary = 0;
     unsigned nobs = 0;
-    if (!flex_rows) {
-        HIP_TRY(hipMemcpyAsync(&nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-        if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(&nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
+    if (primed_in) {   // packed by p3d_pocs_prime_dev, still in place
+        nonbinary = primed_state.nonbinary;
+        nobs = primed_state.nobs;
+        HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
+    } else if ((rc = pack_mask(p, mask, &nonbinary, &nobs))) {
+        return rc;
     }
     if (sw.no_mask_bits) nonbinary = 1;  // experiments only
 
@@ -1036,18 +1123,8 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     }
     // Compact observed samples for the steady-state row pass: only the observed positions of x are non-zero in
     // the workflow (x = stacked traces, mask = fold >= 1); ROW_FIRST verifies that and the full cube is used if not.
-    bool compact = !nonbinary && p->pipe_wgs > 0 && p->nil <= 4096 && niter > 1 && !sw.no_compact &&
-                   nobs > 0 && (double)nobs < 0.75 * (double)p->slice_elems();
-    if (compact) {
-        const size_t need = (size_t)nslices * nobs * (dtype == P3D_C64 ? sizeof(c32) : sizeof(float));
-        if (p->xc_cap < need) {
-            if (p->xc) hipFree(p->xc);
-            p->xc = nullptr;
-            p->xc_cap = 0;
-            HIP_TRY(hipMalloc(&p->xc, need));
-            p->xc_cap = need;
-        }
-    }
+    bool compact = want_compact(p, nonbinary, nobs, niter, sw);
+    if (compact && (rc = ensure_xc(p, nslices, nobs, dtype))) return rc;
 
     RowArgs r = row_args(p, nslices);
     r.x = x;
@@ -1092,8 +1169,15 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         if (re == hipErrorNotSupported) real_path = false;
         else HIP_TRY(re);
     }
-    if (!real_path) HIP_TRY(first_row_pass(p, r));
-    if (compact) {  // did every unobserved position hold a zero?
+    // The primed first pass is the complex one without the APOCS input mix: work buffer, compact samples and sum |x_obs| are there.
+    const bool primed = primed_in && !real_path && !adaptive;
+    if (primed) {
+        HIP_TRY(hipMemcpyAsync(p->sums, p->sum0, sizeof(double) * nslices, hipMemcpyDeviceToDevice, p->stream));
+        if (primed_state.violation) r.xc = nullptr;
+    } else if (!real_path) {
+        HIP_TRY(first_row_pass(p, r));
+    }
+    if (compact && !primed) {  // did every unobserved position hold a zero?
         int violation = 0;
         HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1106,7 +1190,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             }
         }
     }
-    reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil);
+    if (!primed) reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil);
 
     ColArgs c = col_args(p, nslices);
     c.in = p->work;

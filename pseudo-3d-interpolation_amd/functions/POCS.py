@@ -380,12 +380,12 @@ class _FFTWorker:
             xin = self.hx.view(chunk.shape, dtype)
             _slab_copy(xin, chunk)
             self.x.upload(xin)                         # one upload serves the statistics and the loop
-        stats = self.plan.stats_dev(self.x.ptr, dt, n)
+        stats = self.plan.prime_dev(self.x.ptr, dt, self.m.ptr, n)   # the statistics pass doubles as the first pass of the job
         active = ~(stats[:, 2] == 0)                   # max|fft2(x)| == 0 <=> np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         stats[~active] = 1.0                           # keep NaNs of empty slices out of the (unused) schedule rows
         tau = sched(stats)
         done, sums, _ = self.plan.run_dev(self.x.ptr, dt, self.m.ptr, tau, niter, self.o.ptr, n, thresh_op=thresh_op,
-                                          version=version, eps=eps, alpha=alpha, active=active)
+                                          version=version, eps=eps, alpha=alpha, active=active, primed=True)
         if direct:
             self.o.download_into(dst)
         else:

@@ -63,14 +63,14 @@ def interpolate_time_cube(x, mask, dt, t0=0.0, nfft=None, real_only=True, window
         for lo in range(0, nfreq, step):
             n = min(step, nfreq - lo)
             off = lo * ntr * 8
-            stats = plan.stats_dev(fbuf.ptr + off, _ffi.P3D_C64, n)
+            stats = plan.prime_dev(fbuf.ptr + off, _ffi.P3D_C64, mbuf.ptr, n)   # statistics = first pass of the job
             active = stats[:, 2] > 0                     # max |X0| = 0 <=> all-zero slice (POCS.py:515-521)
             stats[~active] = 1.0
             tau = P._schedule_from_stats(stats, ntr, thresh_model, niter, p_max, p_min, decay_kind)
             if sqrt_decay:
                 tau = np.sqrt(tau)
             done, sums, _ = plan.run_dev(fbuf.ptr + off, _ffi.P3D_C64, mbuf.ptr, tau, niter, obuf.ptr + off, n, thresh_op=thresh_op,
-                                         version=version, eps=eps, alpha=alpha, active=active)
+                                         version=version, eps=eps, alpha=alpha, active=active, primed=True)
             if results is not None:
                 results.extend(P._result_rows(done, sums, 0.0))
         kidx = np.arange(nfreq, dtype=np.int32)

@@ -484,6 +484,51 @@ def test_properties_full_size(P, orc):
     assert rel_l2(out[0], truth) < rel_l2(obs[0], truth)
 
 
+@pytest.mark.parametrize("shape,dtype,op,version", [((256, 1024), np.complex64, "hard", "regular"), ((64, 128), np.complex64, "soft", "regular"),
+                                                    ((256, 512), np.float32, "soft", "regular"), ((256, 512), np.float32, "hard", "regular"),
+                                                    ((128, 256), np.complex64, "hard", "adaptive"), ((90, 50), np.complex64, "hard", "regular"),
+                                                    ((64, 64), np.complex64, "hard", "regular")])
+def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
+    """p3d_pocs_prime_dev = the statistics pass that is also the first pass of the job (work buffer, compact samples, sum |x_obs|);
+    p3d_pocs_run_dev(P3D_FLAG_PRIMED) then skips its own.  Same statistics and bit-identical results, sums and iteration counts as
+    the plain pair -- also where the flag is only advisory (APOCS, float32 + hard = half-spectrum path, flexible lengths, the
+    single-kernel path of small slices) -- and a stale promise (something else used the plan in between) is not believed."""
+    nil, nxl = shape
+    n = 4
+    _, mask, obs = orc.synthetic_cube(nil, nxl, n, 0.6, real=dtype == np.float32)
+    obs[2] = 0
+    dt = ffi.P3D_F32 if dtype == np.float32 else ffi.P3D_C64
+    maskf = mask.astype(np.float32)
+    niter = 7
+    with ffi.Plan(nil, nxl, n) as plan:
+        x, o, m = plan.alloc(obs.nbytes).upload(obs), plan.alloc(obs.nbytes), plan.alloc(maskf.nbytes).upload(maskf)
+
+        def run(primed, spoil=False):
+            st = plan.prime_dev(x.ptr, dt, m.ptr, n) if primed else plan.stats_dev(x.ptr, dt, n)
+            active = st[:, 2] > 0
+            st[~active] = 1.0
+            tau = orc_schedule(st)
+            if spoil:
+                plan.fft2(obs[:1].astype(np.complex64))     # anything else on the plan: the primed state is gone
+            done, sums, _ = plan.run_dev(x.ptr, dt, m.ptr, tau, niter, o.ptr, n, thresh_op=op, version=version, alpha=0.9 if version == "adaptive" else 1.0,
+                                         eps=1e-6, active=active, primed=primed)
+            return st, o.download(obs.shape, dtype), done, sums
+
+        from pseudo_3d_interpolation_amd.functions.POCS import _schedule_from_stats
+
+        def orc_schedule(st):
+            return _schedule_from_stats(st, nil * nxl, "exponential", niter, 0.99, 1e-2, "values")
+
+        a = run(False)
+        b = run(True)
+        c = run(True, spoil=True)
+        for other in (b, c):
+            assert np.array_equal(a[0], other[0]) and np.array_equal(a[1], other[1]) and np.array_equal(a[2], other[2]) and np.array_equal(a[3], other[3])
+        assert not a[1][2].any() and a[2][2] == 0
+        for buf in (x, o, m):
+            buf.free()
+
+
 def test_generic_path_early_exit_and_zero_slice(P, orc):
     _, mask, obs = orc.synthetic_cube(45, 30, 3, 0.3)
     obs[1] = 0
