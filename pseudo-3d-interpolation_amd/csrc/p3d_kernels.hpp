@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 +
         cur = nxt;
     }
 #if P3D_STAMPS
-    if (lane == 0 && blockIdx.x < 1024 && wave < 16) {
+    if (PM == PIPE_MID && lane == 0 && blockIdx.x < 1024 && wave < 16) {   // (the steady state only: the last pass runs after it)
 #pragma unroll
         for (int i = 0; i < STAMP_PHASES; ++i) p3d_stamp_buf[((size_t)blockIdx.x * 16 + wave) * STAMP_PHASES + i] = st_acc[i];
     }
