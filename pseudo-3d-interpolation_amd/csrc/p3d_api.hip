@@ -550,7 +550,7 @@ int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
 // ---- internal helpers ---------------------------------------------------------------------------
 // Diagnostic switches of one job: every one selects a slower, equivalent path.  Read once per call of
 // p3d_pocs_run_dev, on the calling thread, and handed down as plain values -- the launch paths never consult the environment.
-struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore, force_colpipe; };
+struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore, force_colpipe, no_colpipe; };
 static RunSwitches read_switches()
 {
     RunSwitches s;
@@ -562,6 +562,7 @@ static RunSwitches read_switches()
     s.no_resident = getenv("P3D_NO_RESIDENT") != nullptr;
     s.no_tstore = getenv("P3D_NO_TSTORE") != nullptr;
     s.force_colpipe = getenv("P3D_FORCE_COLPIPE") != nullptr;
+    s.no_colpipe = getenv("P3D_NO_COLPIPE") != nullptr;
     return s;
 }
 
@@ -1211,8 +1212,12 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // The persistent column pass (col_pipe_kernel) wins where nearly all tiles end at the threshold (-4 ... -12 % by shape at 4 % kept
     // blocks) and loses as soon as a noticeable share is transformed back and stored (+14 % at the 6 % of a 20-iteration job, +9 % dense:
     // profiles/r02_colpass_persistent.txt).  Which of the two a job is cannot be known before it has run, and choosing from the plan's
-    // previous job cost the 20-iteration bench line 7 %: it stays an experiment behind P3D_FORCE_COLPIPE=1, bit-identical and tested.
-    const bool colpipe = sparse && sw.force_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr;
+    // previous job cost the 20-iteration bench line 7 %: there it stays an experiment behind P3D_FORCE_COLPIPE=1, bit-identical and tested.
+    // Columns of 2048 points are another matter: their 8-column tile takes a whole CU (1024 threads, 157 KiB of LDS), so the one-launch
+    // pass has nothing to overlap a tile's loads with, and the persistent pass wins at every density measured (-5 % at 8 iterations,
+    // -10 ... -12 % at 20 ... 60): the default there (P3D_NO_COLPIPE=1 switches it off).
+    const bool colpipe = sparse && p->cus > 0 && p->ops_col->col_pipe != nullptr &&
+                         (sw.force_colpipe || (p->ops_col->n >= 2048 && !sw.no_colpipe));
     p->last_nonzero_fraction = -1.0;
     const int n2_work = real_path ? p->nxl / 2 + 1 : p->nxl;   // columns of the work buffer
     const int tiles_work = (n2_work + col_t - 1) / col_t;

@@ -743,6 +743,27 @@ def test_slower_equivalent_paths_behind_the_switches(switch, monkeypatch):
     assert rel_l2(got, want) <= 1e-5
 
 
+def test_persistent_column_pass_of_2048_point_columns(monkeypatch):
+    """Columns of 2048 points: the persistent column pass (next tile's loads in flight during the transforms) is the default; it must
+    give the bits of the one-launch pass (P3D_NO_COLPIPE=1)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    nil, nxl = 2048, 128
+    mask = orc.synthetic_mask(nil, nxl, 0.7)
+    cube = (np.stack([orc.synthetic_slice(nil, nxl, 70 + s) for s in range(3)]) * mask).astype(np.complex64)
+    kw = dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
+    P.release_plans()
+    a = P.pocs_cube(cube, mask, **kw)
+    monkeypatch.setenv("P3D_NO_COLPIPE", "1")
+    try:
+        b = P.pocs_cube(cube, mask, **kw)
+    finally:
+        P.release_plans()
+    assert np.array_equal(a, b)
+    want = orc.pocs_cube(cube.astype(np.complex128), mask, **kw)
+    assert max(rel_l2(a[s], want[s]) for s in range(3)) <= 2e-3 and np.median([rel_l2(a[s], want[s]) for s in range(3)]) <= 1e-5
+
+
 @pytest.mark.parametrize("nil,nxl,dtype", [(64, 1024, np.complex64), (100, 1024, np.complex64), (256, 1024, np.float32),
                                            (1000, 1024, np.complex64), (48, 2048, np.complex64), (50, 2048, np.float32),
                                            (24, 4096, np.complex64), (64, 512, np.complex64), (50, 256, np.complex64),
