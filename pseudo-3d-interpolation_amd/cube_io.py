@@ -176,11 +176,9 @@ def _open_nc_h5py(path):
     import h5py
     data, dims, coords, var_attrs, coord_attrs = {}, {}, {}, {}, {}
     with h5py.File(path, 'r') as f:
-        scales = {}
-        for name, ds in f.items():
-            if isinstance(ds, h5py.Dataset) and _attr_in(ds.attrs.get('CLASS', b'')) == 'DIMENSION_SCALE':
-                scales[ds.id.__hash__()] = name
-        order = sorted((int(np.ravel(f[n].attrs.get('_Netcdf4Dimid', [1 << 30]))[0]), n) for n in scales.values())
+        scales = [name for name, ds in f.items()
+                  if isinstance(ds, h5py.Dataset) and _attr_in(ds.attrs.get('CLASS', b'')) == 'DIMENSION_SCALE']
+        order = sorted((int(np.ravel(f[n].attrs.get('_Netcdf4Dimid', [1 << 30]))[0]), n) for n in scales)
 
         def decode(ds):
             a = ds[()]
@@ -204,7 +202,7 @@ def _open_nc_h5py(path):
                 coords[name] = decode(ds)
                 coord_attrs[name] = {k: _attr_in(v) for k, v in ds.attrs.items() if k not in _NC_INTERNAL}
         for name, ds in f.items():
-            if not isinstance(ds, h5py.Dataset) or name in scales.values():
+            if not isinstance(ds, h5py.Dataset) or name in scales:
                 continue
             names = []
             for ax in range(ds.ndim):
