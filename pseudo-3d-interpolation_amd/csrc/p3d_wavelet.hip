@@ -229,8 +229,11 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     if (!xcd_decode(ntiles, ns, s, tile)) return;
     const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int or0 = by * TILE, oc0 = bx * TILE, r0 = 2 * or0 - L + 2, c0 = 2 * oc0 - L + 2;
+    // the last tile of an axis holds Ho mod TILE (Wo mod TILE) outputs -- 3 of 32 for a 512-point axis and db4 -- and needs
+    // that much of the input only: vh x vw valid outputs from IHv x IWv samples (the LDS pitch stays IW)
+    const int vh = min(TILE, Ho - or0), vw = min(TILE, Wo - oc0), IHv = 2 * vh + L - 2, IWv = 2 * vw + L - 2;
     const T* src = in + (size_t)s * in_slice;
-    const bool inside = r0 >= 0 && c0 >= 0 && r0 + IH <= H && c0 + IW <= W;
+    const bool inside = r0 >= 0 && c0 >= 0 && r0 + IHv <= H && c0 + IWv <= W;
     __shared__ float4 s_tap[MAXL / 2];
     if ((int)threadIdx.x < L / 2) {
         const int j = 2 * threadIdx.x;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     constexpr int KR = TILE == 32 ? 9 : 6, MC = (2 * TILE + MAXL - 2 + LX - 1) / LX;   // db4 .. coif2 at TILE 32: one batch
     if (inside) {
         const T* g = src + (size_t)r0 * W + c0;
-        for (int rb = ty; rb < IH; rb += KR * LY) {
+        for (int rb = ty; rb < IHv; rb += KR * LY) {
             T v[KR][MC];
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
 #pragma unroll
                 for (int m = 0; m < MC; ++m) {
                     v[k][m] = zero_of<T>();
-                    if (rb + k * LY < IH && tx + m * LX < IW) v[k][m] = g[ro + m * LX];
+                    if (rb + k * LY < IHv && tx + m * LX < IWv) v[k][m] = g[ro + m * LX];
                 }
             }
 #pragma unroll
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
                 T* d = s_in + (rb + k * LY) * IW + tx;
 #pragma unroll
                 for (int m = 0; m < MC; ++m)
-                    if (rb + k * LY < IH && tx + m * LX < IW) d[m * LX] = v[k][m];
+                    if (rb + k * LY < IHv && tx + m * LX < IWv) d[m * LX] = v[k][m];
             }
         }
     } else {
@@ -273,7 +276,10 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
             cn[m] = (unsigned)(c < 0 ? min(1, W - 1) : max(W - 2, 0));
             tc[m] = c < 0 ? (float)(-c) : (c >= W ? (float)(c - W + 1) : 0.f);
         }
-        for (int rb = ty; rb < IH; rb += KR * LY) {
+        // Only samples beyond an edge need their neighbours: x10 where the row is outside (uniform over a wavefront's two rows but
+        // for one wavefront at most), x01 where the column is, x11 where both are.  A sample that is not loaded is 0 and meets the
+        // weight 0: e + (e - 0) * 0 = e.
+        for (int rb = ty; rb < IHv; rb += KR * LY) {
             T v[KR][MC];
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
@@ -283,8 +289,16 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
 #pragma unroll
                 for (int m = 0; m < MC; ++m) {
                     v[k][m] = zero_of<T>();
-                    if (rb + k * LY < IH && tx + m * LX < IW)
-                        v[k][m] = extrapolate(extrapolate(src[rc + cc[m]], src[rn + cc[m]], tr), extrapolate(src[rc + cn[m]], src[rn + cn[m]], tr), tc[m]);
+                    if (rb + k * LY < IHv && tx + m * LX < IWv) {
+                        T x10 = zero_of<T>(), x01 = zero_of<T>(), x11 = zero_of<T>();
+                        const T x00 = src[rc + cc[m]];
+                        if (tr != 0.f) x10 = src[rn + cc[m]];
+                        if (tc[m] != 0.f) {
+                            x01 = src[rc + cn[m]];
+                            if (tr != 0.f) x11 = src[rn + cn[m]];
+                        }
+                        v[k][m] = extrapolate(extrapolate(x00, x10, tr), extrapolate(x01, x11, tr), tc[m]);
+                    }
                 }
             }
 #pragma unroll
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
                 T* d = s_in + (rb + k * LY) * IW + tx;
 #pragma unroll
                 for (int m = 0; m < MC; ++m)
-                    if (rb + k * LY < IH && tx + m * LX < IW) d[m * LX] = v[k][m];
+                    if (rb + k * LY < IHv && tx + m * LX < IWv) d[m * LX] = v[k][m];
             }
         }
     }
@@ -301,7 +315,8 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     // the wait counter with the LDS reads and serialise every step.
     // axis 1: row r, output tx: sum_j f[j] * row[2 tx + L - 1 - j], two taps = one aligned pair of samples at a time
     struct alignas(2 * sizeof(T)) Pair { T lo, hi; };
-    for (int r = ty; r < IH; r += LY) {
+    for (int r = ty; r < IHv; r += LY) {
+        if (tx >= vw) continue;
         const Pair* q = reinterpret_cast<const Pair*>(s_in + r * IW + 2 * tx + L - 2);
         Acc<T> ad;
         for (int jj = 0; jj < L / 2; ++jj) {
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
         s_hi[r * TILE + tx] = ad.second();
     }
     __syncthreads();
+    if (tx >= vw || ty * R >= vh) return;   // (no barrier below)
     // axis 0: column tx, outputs o = ty*R + q: sum_j f[j] * col[2o + L - 1 - j]
     Acc<T> fl[R], fh[R];   // (aa, da) from the low-pass rows, (ad, dd) from the high-pass rows
     const T* cl = s_lo + (2 * ty * R + L - 1) * TILE + tx;
@@ -413,8 +429,11 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
         const int j = L - 2 - 2 * threadIdx.x;
         s_tap[threadIdx.x] = float4{f.rec_lo[j], f.rec_hi[j], f.rec_lo[j + 1], f.rec_hi[j + 1]};
     }
+    // valid outputs of this tile (the last tile of an axis is mostly empty) and the coefficients they need
+    const int nvh = min(OH, (u.enabled ? u.n1 : RH) - m0), nvw = min(OW, (u.enabled ? u.n2 : RW) - n0);
+    const int KHv = (nvh + 1) / 2 + HL - 1, KWv = (nvw + 1) / 2 + HL - 1;
     constexpr int KR = TILE == 32 ? 5 : 3, MC = (TILE + MAXL / 2 - 1 + LX - 1) / LX;
-    for (int rb = ty; rb < KH; rb += KR * LY) {
+    for (int rb = ty; rb < KHv; rb += KR * LY) {
         T va[KR][MC], vh[KR][MC], vv[KR][MC], vd[KR][MC];
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
             for (int m = 0; m < MC; ++m) {
                 const int kc = tx + m * LX, gc = kc0 + kc;
                 va[k][m] = vh[k][m] = vv[k][m] = vd[k][m] = zero_of<T>();
-                if (kr < KH && kc < KW && gr < Ho && gc < Wo) {
+                if (kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
                     const size_t o = (size_t)gr * Wo + gc;
                     va[k][m] = pa[(size_t)gr * a_ld + gc];
                     vh[k][m] = pd[o];
@@ -438,14 +457,14 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
 #pragma unroll
             for (int m = 0; m < MC; ++m) {
                 const int kc = tx + m * LX, i = kr * KW + kc;
-                if (kr < KH && kc < KW) { s_a[i] = va[k][m]; s_h[i] = vh[k][m]; s_v[i] = vv[k][m]; s_d[i] = vd[k][m]; }
+                if (kr < KHv && kc < KWv) { s_a[i] = va[k][m]; s_h[i] = vh[k][m]; s_v[i] = vv[k][m]; s_d[i] = vd[k][m]; }
             }
         }
     }
     __syncthreads();
     // undo axis 0: out[m] = sum_t a[m/2 + t] rec_lo[(m&1) + L-2 - 2t] + d[...] rec_hi[...], t < L/2.  Column kc, output rows
     // ml = ty*R + q; rows 2i and 2i+1 read the same coefficients.  Taps from LDS, as in the analysis kernel.
-    for (int kc = tx; kc < KW; kc += LX) {
+    for (int kc = tx; kc < KWv && ty * R < nvh; kc += LX) {
         Acc<T> lo[R / 2], hi[R / 2];   // (even row, odd row) pairs
         const int i0 = (ty * R / 2) * KW + kc;
         for (int t = 0; t < HL; ++t) {
@@ -476,7 +495,7 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
         Acc<T> eo;
         const T* ql = s_lo + (ty + LY * i) * KW + tx;
         const T* qh = s_hi + (ty + LY * i) * KW + tx;
-        for (int t = 0; t < HL; ++t) {
+        for (int t = 0; t < HL && ty + LY * i < nvh && 2 * tx < nvw; ++t) {
             const float4 g = s_tap[t];
             eo.tap(g.x, g.z, ql[t]);
             eo.tap(g.y, g.w, qh[t]);
