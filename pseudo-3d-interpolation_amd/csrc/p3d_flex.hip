@@ -28,12 +28,20 @@ namespace p3d {
 
 namespace {
 
+constexpr int FLEX_MAX_PASSES = 12;   // radices are folded into 16 ... 2 where possible: lengths up to GEN_MAX_N need at most 6
+
 struct FlexFactors {
     int n;      // line length
     int m;      // length of the transforms that are actually run: n, or the power of two M >= 2n-1 of the chirp-z form
     int blue;   // 1: chirp-z (Bluestein) -- lines whose length has a large prime factor
     int nf;
-    int f[GEN_MAX_FACTORS];   // radices of the passes of a length-m transform
+    int f[FLEX_MAX_PASSES];     // radices of the passes of a length-m transform
+    // what a pass needs besides its radix R, computed once on the host (the device code used to divide for them in every pass,
+    // and the compiler hoisted the divisions of all thirteen radix cases in front of the dispatch):
+    int ns[FLEX_MAX_PASSES];    // product of the earlier radices = distance of a butterfly's outputs
+    int nb[FLEX_MAX_PASSES];    // butterflies per line, m / R = distance of a butterfly's inputs
+    int ts[FLEX_MAX_PASSES];    // twiddle step m / (ns R)
+    unsigned mg[FLEX_MAX_PASSES];   // j / ns = umulhi(j, mg) for j < 2^16 (ns > 1)
 };
 
 int largest_prime_factor(int n)
@@ -68,14 +76,24 @@ FlexFactors flex_factors(int n)
         if (M <= 2048 || (lp > FLEX_DIRECT_PRIME_MAX && M <= FLEX_BLUE_MAX_M)) { p.blue = 1; p.m = M; }
     }
     int rem = p.m, k = 0;
-    int radices[GEN_MAX_FACTORS];
+    int radices[32];
     for (int r : {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2})
         while (rem % r == 0 && rem > 1) { radices[k++] = r; rem /= r; }
     for (int q = 11; rem > 1; q += 2)
         while (rem % q == 0) { radices[k++] = q; rem /= q; }
+    if (k > FLEX_MAX_PASSES) { p.nf = -1; return p; }
     p.nf = 0;
     for (int i = 0; i < k; ++i) if (radices[i] % 2) p.f[p.nf++] = radices[i];
     for (int i = 0; i < k; ++i) if (radices[i] % 2 == 0) p.f[p.nf++] = radices[i];
+    int ns = 1;
+    for (int i = 0; i < p.nf; ++i) {
+        const int R = p.f[i];
+        p.ns[i] = ns;
+        p.nb[i] = p.m / R;
+        p.ts[i] = p.m / (ns * R);
+        p.mg[i] = ns > 1 ? (unsigned)((0x100000000ull + (unsigned)ns - 1) / (unsigned)ns) : 0u;   // ceil(2^32 / ns): exact for j ns < 2^32
+        ns *= R;
+    }
     return p;
 }
 
@@ -111,27 +129,19 @@ int pick_row_lines(int n)   // rows per workgroup at one wavefront per row
 }
 
 // ---- butterflies --------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ c32 conj_if(c32 w, int dir) { return dir > 0 ? c32{w.x, -w.y} : w; }
-__device__ __forceinline__ c32 mul_i(c32 a, int dir) { return dir > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x}; }   // a * (dir * i)
+// the direction of a transform is a template parameter (DIR = FWD: exp(-...), INV: exp(+...)): as a run-time value it cost a
+// select per twiddle and per butterfly constant
+template <int DIR> __device__ __forceinline__ c32 conj_if(c32 w) { return DIR > 0 ? c32{w.x, -w.y} : w; }
+template <int DIR> __device__ __forceinline__ c32 mul_di(c32 a) { return DIR > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x}; }   // a * (DIR * i)
 
 // exp(2 pi i q / R) for the in-register butterflies: compile-time constants (they used to be read from the twiddle table once per
 // pass: wave-uniform values that the compiler parked in scalar registers -- and spilled, one v_readlane per use)
 template <int R>
 struct Roots;
 template <>
-struct Roots<2> {
-    static constexpr float c[2] = {1.000000000e+00f, -1.000000000e+00f};
-    static constexpr float s[2] = {0.000000000e+00f, 1.224646800e-16f};
-};
-template <>
 struct Roots<3> {
     static constexpr float c[3] = {1.000000000e+00f, -5.000000000e-01f, -5.000000000e-01f};
     static constexpr float s[3] = {0.000000000e+00f, 8.660254040e-01f, -8.660254040e-01f};
-};
-template <>
-struct Roots<4> {
-    static constexpr float c[4] = {1.000000000e+00f, 6.123234000e-17f, -1.000000000e+00f, -1.836970200e-16f};
-    static constexpr float s[4] = {0.000000000e+00f, 1.000000000e+00f, 1.224646800e-16f, -1.000000000e+00f};
 };
 template <>
 struct Roots<5> {
@@ -183,23 +193,23 @@ struct Roots<16> {
     static constexpr float c[16] = {1.000000000e+00f, 9.238795330e-01f, 7.071067810e-01f, 3.826834320e-01f, 6.123234000e-17f, -3.826834320e-01f, -7.071067810e-01f, -9.238795330e-01f, -1.000000000e+00f, -9.238795330e-01f, -7.071067810e-01f, -3.826834320e-01f, -1.836970200e-16f, 3.826834320e-01f, 7.071067810e-01f, 9.238795330e-01f};
     static constexpr float s[16] = {0.000000000e+00f, 3.826834320e-01f, 7.071067810e-01f, 9.238795330e-01f, 1.000000000e+00f, 9.238795330e-01f, 7.071067810e-01f, 3.826834320e-01f, 1.224646800e-16f, -3.826834320e-01f, -7.071067810e-01f, -9.238795330e-01f, -1.000000000e+00f, -9.238795330e-01f, -7.071067810e-01f, -3.826834320e-01f};
 };
-// W^q with W = exp(dir * 2 pi i / R)
-template <int R>
-__device__ __forceinline__ c32 root(int q, int dir) { return c32{Roots<R>::c[q], dir > 0 ? Roots<R>::s[q] : -Roots<R>::s[q]}; }
+// W^q with W = exp(DIR * 2 pi i / R)
+template <int R, int DIR>
+__device__ __forceinline__ c32 root(int q) { return c32{Roots<R>::c[q], DIR > 0 ? Roots<R>::s[q] : -Roots<R>::s[q]}; }
 
-// ---- small DFTs on registers: X[k] = sum_t x[t] W^(t k), W = exp(dir * 2 pi i / R) -------------------------------------------
-template <int R>
-__device__ __forceinline__ void dft_small(c32 (&x)[R], int dir)
+// ---- small DFTs on registers: X[k] = sum_t x[t] W^(t k), W = exp(DIR * 2 pi i / R) -------------------------------------------
+template <int R, int DIR>
+__device__ __forceinline__ void dft_small(c32 (&x)[R])
 {
     if constexpr (R == 2) {
         const c32 a = x[0] + x[1], b = x[0] - x[1];
         x[0] = a; x[1] = b;
     } else if constexpr (R == 4) {
-        const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], d = mul_i(x[1] - x[3], dir);
+        const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], d = mul_di<DIR>(x[1] - x[3]);
         x[0] = a + s; x[1] = b + d; x[2] = a - s; x[3] = b - d;
     } else {
-        // odd prime: pair x[q] with x[R-q].  W^(qk) = cos + i (dir sin) gives  X[k], X[R-k] = A_k +- i B_k  with
-        // A_k = x0 + sum_q cos(2 pi q k / R) (x[q] + x[R-q]),  B_k = sum_q (dir sin(2 pi q k / R)) (x[q] - x[R-q]):
+        // odd prime: pair x[q] with x[R-q].  W^(qk) = cos + i (DIR sin) gives  X[k], X[R-k] = A_k +- i B_k  with
+        // A_k = x0 + sum_q cos(2 pi q k / R) (x[q] + x[R-q]),  B_k = sum_q (DIR sin(2 pi q k / R)) (x[q] - x[R-q]):
         // real coefficients only, a third of the multiplications of the direct form
         constexpr int H = (R - 1) / 2;
         c32 sp[H], dm[H];
@@ -217,7 +227,7 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R], int dir)
             c32 A = xin, B{0.f, 0.f};
 #pragma unroll
             for (int q = 1; q <= H; ++q) {
-                const c32 wq = root<R>((q * k) % R, dir);
+                const c32 wq = root<R, DIR>((q * k) % R);
                 A = A + sp[q - 1] * wq.x;
                 B = B + dm[q - 1] * wq.y;
             }
@@ -228,60 +238,82 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R], int dir)
 }
 
 // R = R1 * R2 in registers: t = R2 t1 + t2, k = k1 + R1 k2:  X[k] = sum_t2 [ (sum_t1 x[t] W_R1^(t1 k1)) W_R^(t2 k1) ] W_R2^(t2 k2)
-template <int R1, int R2>
-struct Radix {
-    static constexpr int R = R1 * R2;
-    __device__ __forceinline__ void apply(c32 (&v)[R], int dir) const
-    {
-        if constexpr (R2 == 1) {
-            dft_small<R>(v, dir);
-        } else {
-            c32 u[R];   // u[k1 * R2 + t2]
-#pragma unroll
-            for (int t2 = 0; t2 < R2; ++t2) {
-                c32 a[R1];
-#pragma unroll
-                for (int t1 = 0; t1 < R1; ++t1) a[t1] = v[R2 * t1 + t2];
-                dft_small<R1>(a, dir);
-#pragma unroll
-                for (int k1 = 0; k1 < R1; ++k1) u[k1 * R2 + t2] = (k1 * t2) % R == 0 ? a[k1] : a[k1] * root<R>((k1 * t2) % R, dir);
-            }
-#pragma unroll
-            for (int k1 = 0; k1 < R1; ++k1) {
-                c32 b[R2];
-#pragma unroll
-                for (int t2 = 0; t2 < R2; ++t2) b[t2] = u[k1 * R2 + t2];
-                dft_small<R2>(b, dir);
-#pragma unroll
-                for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
-            }
-        }
-    }
-};
-
-// one pass of radix R = R1*R2 over `lines` lines of n points: line l, element i at X[i*istr + l*lstr]; this thread handles
-// butterflies first, first+step, ... ; butterfly j reads in[(j + t*m)], multiplies by w^(t*jm), writes out[j0 + k*ns]
-template <int R1, int R2>
-__device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, int n, int ns, int dir, int lines, int istr, int lstr, int first, int step)
+template <int R1, int R2, int DIR>
+__device__ __forceinline__ void radix_apply(c32 (&v)[R1 * R2])
 {
     constexpr int R = R1 * R2;
-    const int m = n / R, tstep = n / (ns * R);
-    Radix<R1, R2> rx;
-    const int total = m * lines;
+    if constexpr (R2 == 1) {
+        dft_small<R, DIR>(v);
+    } else {
+        c32 u[R];   // u[k1 * R2 + t2]
+#pragma unroll
+        for (int t2 = 0; t2 < R2; ++t2) {
+            c32 a[R1];
+#pragma unroll
+            for (int t1 = 0; t1 < R1; ++t1) a[t1] = v[R2 * t1 + t2];
+            dft_small<R1, DIR>(a);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) u[k1 * R2 + t2] = (k1 * t2) % R == 0 ? a[k1] : a[k1] * root<R, DIR>((k1 * t2) % R);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            c32 b[R2];
+#pragma unroll
+            for (int t2 = 0; t2 < R2; ++t2) b[t2] = u[k1 * R2 + t2];
+            dft_small<R2, DIR>(b);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
+        }
+    }
+}
+
+// What a pass is told (FlexFactors, one entry per pass): output stride ns, butterflies per line nb, twiddle step ts, the
+// multiplier of the division by ns.  The values pass through an empty asm so that what is derived from them (R - 1 input
+// offsets, R output offsets ...) is computed where it is used and not, for all thirteen radix cases, in front of the dispatch.
+struct PassArgs {
+    int ns, nb, ts;
+    unsigned mg;
+};
+__device__ __forceinline__ PassArgs pass_args(const FlexFactors& pl, int p)
+{
+    PassArgs a{pl.ns[p], pl.nb[p], pl.ts[p], pl.mg[p]};
+    return a;
+}
+__device__ __forceinline__ void pin(PassArgs& a) { asm volatile("" : "+s"(a.ns), "+s"(a.nb), "+s"(a.ts), "+s"(a.mg)); }
+
+// Addressing of the lines a pass works on.  COLS: a column tile, 2^tsh interleaved lines (element i of line l at X[(i << tsh) + l]),
+// butterfly index b = (j << tsh) + l.  Otherwise ONE contiguous line (the caller's pointers are those of its line), b = j.
+// One pass of radix R = R1 R2: butterfly j reads in[j + t nb], multiplies by w^(t jm ts), writes out[j0 + k ns] with
+// jq = j / ns, jm = j mod ns, j0 = jq ns R + jm.  FIRST (ns = 1): jm = 0, all twiddles are 1.
+template <int R1, int R2, int DIR, bool FIRST, bool COLS>
+__device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, PassArgs pa, int tsh, int first, int step)
+{
+    constexpr int R = R1 * R2;
+    pin(pa);
+    const int total = COLS ? pa.nb << tsh : pa.nb;
+    const int istr = COLS ? 1 << tsh : 1;
     for (int b = first; b < total; b += step) {
-        int l, j;
-        if (lstr == 1) { j = b / lines; l = b - j * lines; }   // interleaved lines (column tile): line index fastest
-        else { l = b / m; j = b - l * m; }                     // separate lines (rows)
-        const int jq = j / ns, jm = j - jq * ns;
-        const int j0 = jq * ns * R + jm;
-        const c32* in = A + (size_t)j * istr + (size_t)l * lstr;
-        c32* out = B + (size_t)j0 * istr + (size_t)l * lstr;
-        const int mstride = m * istr, ostride = ns * istr, twi = jm * tstep;
+        const int j = COLS ? b >> tsh : b, l = COLS ? b & (istr - 1) : 0;
+        int j0 = j * R, jm = 0;
+        if (!FIRST) {
+            const int jq = (int)__umulhi((unsigned)j, pa.mg);
+            jm = j - jq * pa.ns;
+            j0 = jq * pa.ns * R + jm;
+        }
+        const c32* in = A + (COLS ? (j << tsh) + l : j);
+        c32* out = B + (COLS ? (j0 << tsh) + l : j0);
+        const int mstride = COLS ? pa.nb << tsh : pa.nb, ostride = COLS ? pa.ns << tsh : pa.ns;
         c32 v[R];
         v[0] = in[0];
+        if (FIRST) {
 #pragma unroll
-        for (int t = 1; t < R; ++t) v[t] = in[t * mstride] * conj_if(tw[t * twi], dir);
-        rx.apply(v, dir);
+            for (int t = 1; t < R; ++t) v[t] = in[t * mstride];
+        } else {
+            const int twi = jm * pa.ts;
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = in[t * mstride] * conj_if<DIR>(tw[t * twi]);
+        }
+        radix_apply<R1, R2, DIR>(v);
 #pragma unroll
         for (int k = 0; k < R; ++k) out[k * ostride] = v[k];
     }
@@ -295,160 +327,151 @@ __device__ __forceinline__ void flex_sync()
     else exchange_sync<true>();
 }
 
-// The same pass IN PLACE for one line with at most one butterfly per thread (m <= step): every thread reads the inputs of its
+// The same pass IN PLACE for one line with at most one butterfly per thread (nb <= step): every thread reads the inputs of its
 // butterfly into registers, the line's threads synchronise, then the results overwrite the line.  No second buffer: half the
 // LDS per row, twice the resident waves of the row pass (which is latency-bound at 8 waves per CU).
-template <int R1, int R2, int SYNC>
-__device__ __forceinline__ void flex_pass_inplace(c32* A, const c32* tw, int n, int ns, int dir, int first, int step)
+template <int R1, int R2, int DIR, bool FIRST, int SYNC>
+__device__ __forceinline__ void flex_pass_inplace(c32* A, const c32* tw, PassArgs pa, int first)
 {
     constexpr int R = R1 * R2;
-    const int m = n / R, tstep = n / (ns * R);
-    Radix<R1, R2> rx;
+    pin(pa);
     c32 v[R];
-    const bool act = first < m;
+    const bool act = first < pa.nb;
     const int jc = act ? first : 0;
-    const int jq = jc / ns, jm = jc - jq * ns;
-    const int j0 = jq * ns * R + jm;
+    int j0 = jc * R, jm = 0;
+    if (!FIRST) {
+        const int jq = (int)__umulhi((unsigned)jc, pa.mg);
+        jm = jc - jq * pa.ns;
+        j0 = jq * pa.ns * R + jm;
+    }
     {
         const c32* in = A + jc;
-        const int twi = jm * tstep;
         v[0] = in[0];
+        if (FIRST) {
 #pragma unroll
-        for (int t = 1; t < R; ++t) v[t] = in[t * m] * conj_if(tw[t * twi], dir);
+            for (int t = 1; t < R; ++t) v[t] = in[t * pa.nb];
+        } else {
+            const int twi = jm * pa.ts;
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = in[t * pa.nb] * conj_if<DIR>(tw[t * twi]);
+        }
     }
     flex_sync<SYNC>();   // every input of the pass is in registers
     if (act) {
-        rx.apply(v, dir);
+        radix_apply<R1, R2, DIR>(v);
         c32* out = A + j0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) out[k * ns] = v[k];
+        for (int k = 0; k < R; ++k) out[k * pa.ns] = v[k];
     }
 }
 
-template <int SYNC>
-__device__ void flex_fft_inplace(c32* A, const c32* tw, const FlexFactors& pl, int dir, int first, int step)
+// the in-register radices: R -> (R1, R2)
+#define P3D_FLEX_RADICES(X) X(2, 2, 1) X(3, 3, 1) X(4, 4, 1) X(5, 5, 1) X(6, 2, 3) X(7, 7, 1) X(8, 2, 4) X(9, 3, 3) X(10, 2, 5) X(12, 3, 4) X(14, 2, 7) X(15, 3, 5) X(16, 4, 4)
+
+template <int SYNC, int DIR>
+__device__ void flex_fft_inplace(c32* A, const c32* tw, const FlexFactors& pl, int first)
 {
-    const int n = pl.m;
-    int ns = 1;
-    for (int p = 0; p < pl.nf; ++p) {
-        const int R = pl.f[p];
-        switch (R) {
-#define P3D_FLEX_PASS(R1, R2) flex_pass_inplace<R1, R2, SYNC>(A, tw, n, ns, dir, first, step); break
-            case 2: P3D_FLEX_PASS(2, 1);
-            case 3: P3D_FLEX_PASS(3, 1);
-            case 4: P3D_FLEX_PASS(4, 1);
-            case 5: P3D_FLEX_PASS(5, 1);
-            case 6: P3D_FLEX_PASS(2, 3);
-            case 7: P3D_FLEX_PASS(7, 1);
-            case 8: P3D_FLEX_PASS(2, 4);
-            case 9: P3D_FLEX_PASS(3, 3);
-            case 10: P3D_FLEX_PASS(2, 5);
-            case 12: P3D_FLEX_PASS(3, 4);
-            case 14: P3D_FLEX_PASS(2, 7);
-            case 15: P3D_FLEX_PASS(3, 5);
-            case 16: P3D_FLEX_PASS(4, 4);
-#undef P3D_FLEX_PASS
-            default: break;   // never: flex_inplace_ok() admits the radices above only
+    // the first pass has no twiddles (ns = 1)
+    switch (pl.f[0]) {
+#define P3D_FLEX_CASE(R, R1, R2) case R: flex_pass_inplace<R1, R2, DIR, true, SYNC>(A, tw, pass_args(pl, 0), first); break;
+        P3D_FLEX_RADICES(P3D_FLEX_CASE)
+#undef P3D_FLEX_CASE
+        default: break;   // never: flex_inplace_ok() admits the radices above only
+    }
+    flex_sync<SYNC>();
+    for (int p = 1; p < pl.nf; ++p) {
+        switch (pl.f[p]) {
+#define P3D_FLEX_CASE(R, R1, R2) case R: flex_pass_inplace<R1, R2, DIR, false, SYNC>(A, tw, pass_args(pl, p), first); break;
+            P3D_FLEX_RADICES(P3D_FLEX_CASE)
+#undef P3D_FLEX_CASE
+            default: break;
         }
         flex_sync<SYNC>();
-        ns *= R;
     }
 }
 
-// All passes of `lines` (= T) interleaved lines in LDS.  first/step: butterfly indices handled by this thread.  Returns the
-// buffer that holds the result.  SYNC: 0 = workgroup barrier, 1 = wavefront-level (one wave owns its lines).
-
-template <int SYNC>
-__device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, int dir, int lines, int istr, int lstr, int first, int step)
+// large prime factor R: direct O(R^2) butterflies, inputs re-read from LDS
+template <int DIR, bool COLS>
+__device__ __forceinline__ void flex_pass_prime(const c32* A, c32* B, const c32* tw, int R, int n, PassArgs pa, int tsh, int first, int step)
 {
-    const int n = pl.m;
-    int ns = 1;
+    const int total = COLS ? pa.nb << tsh : pa.nb;
+    const int istr = COLS ? 1 << tsh : 1;
+    for (int b = first; b < total; b += step) {
+        const int j = COLS ? b >> tsh : b, l = COLS ? b & (istr - 1) : 0;
+        const int jq = pa.ns > 1 ? (int)__umulhi((unsigned)j, pa.mg) : j, jm = j - jq * pa.ns;
+        const int j0 = jq * pa.ns * R + jm;
+        for (int k = 0; k < R; ++k) {
+            c32 acc{0.f, 0.f};
+            for (int t = 0; t < R; ++t) {
+                const long idx = ((long)t * jm * pa.ts + (long)((long)t * k % R) * pa.nb) % n;
+                acc = acc + A[(size_t)(j + t * pa.nb) * istr + l] * conj_if<DIR>(tw[idx]);
+            }
+            B[(size_t)(j0 + k * pa.ns) * istr + l] = acc;
+        }
+    }
+}
+
+// All passes of one line or of a tile of interleaved lines in LDS (see flex_pass).  first/step: butterfly indices handled by this
+// thread.  Returns the buffer that holds the result.  SYNC: 0 = workgroup barrier, 1 = wavefront-level (one wave owns its line).
+template <int SYNC, int DIR, bool COLS>
+__device__ c32* flex_fft(c32* A, c32* B, const c32* tw, const FlexFactors& pl, int tsh, int first, int step)
+{
     for (int p = 0; p < pl.nf; ++p) {
         const int R = pl.f[p];
-        switch (R) {
-#define P3D_FLEX_PASS(R1, R2) flex_pass<R1, R2>(A, B, tw, n, ns, dir, lines, istr, lstr, first, step); break
-            case 2: P3D_FLEX_PASS(2, 1);
-            case 3: P3D_FLEX_PASS(3, 1);
-            case 4: P3D_FLEX_PASS(4, 1);
-            case 5: P3D_FLEX_PASS(5, 1);
-            case 6: P3D_FLEX_PASS(2, 3);
-            case 7: P3D_FLEX_PASS(7, 1);
-            case 8: P3D_FLEX_PASS(2, 4);
-            case 9: P3D_FLEX_PASS(3, 3);
-            case 10: P3D_FLEX_PASS(2, 5);
-            case 12: P3D_FLEX_PASS(3, 4);
-            case 14: P3D_FLEX_PASS(2, 7);
-            case 15: P3D_FLEX_PASS(3, 5);
-            case 16: P3D_FLEX_PASS(4, 4);
-#undef P3D_FLEX_PASS
-            default: {   // large prime factor: direct butterfly, inputs re-read from LDS
-                const int m = n / R, tstep = n / (ns * R), rstep = n / R;
-                for (int b = first; b < m * lines; b += step) {
-                    int l, j;
-                    if (lstr == 1) { j = b / lines; l = b - j * lines; }
-                    else { l = b / m; j = b - l * m; }
-                    const int jq = j / ns, jm = j - jq * ns;
-                    const int j0 = jq * ns * R + jm;
-                    for (int k = 0; k < R; ++k) {
-                        c32 acc{0.f, 0.f};
-                        for (int t = 0; t < R; ++t) {
-                            const long idx = ((long)t * jm * tstep + (long)((long)t * k % R) * rstep) % n;
-                            acc = acc + A[(size_t)(j + t * m) * istr + (size_t)l * lstr] * conj_if(tw[idx], dir);
-                        }
-                        B[(size_t)(j0 + k * ns) * istr + (size_t)l * lstr] = acc;
-                    }
-                }
+        if (p == 0) {
+            switch (R) {
+#define P3D_FLEX_CASE(R, R1, R2) case R: flex_pass<R1, R2, DIR, true, COLS>(A, B, tw, pass_args(pl, 0), tsh, first, step); break;
+                P3D_FLEX_RADICES(P3D_FLEX_CASE)
+#undef P3D_FLEX_CASE
+                default: flex_pass_prime<DIR, COLS>(A, B, tw, R, pl.m, pass_args(pl, 0), tsh, first, step);
+            }
+        } else {
+            switch (R) {
+#define P3D_FLEX_CASE(R, R1, R2) case R: flex_pass<R1, R2, DIR, false, COLS>(A, B, tw, pass_args(pl, p), tsh, first, step); break;
+                P3D_FLEX_RADICES(P3D_FLEX_CASE)
+#undef P3D_FLEX_CASE
+                default: flex_pass_prime<DIR, COLS>(A, B, tw, R, pl.m, pass_args(pl, p), tsh, first, step);
             }
         }
         flex_sync<SYNC>();
         c32* t = A; A = B; B = t;
-        ns *= R;
     }
     return A;
 }
 
-// DFT of `lines` lines of pl.n points (the first pl.n entries of buffers that hold pl.m).  Directly when the length factors into
-// small radices; otherwise in the chirp-z form on M = pl.m points:  X_k = c_k (a * conj c)_k with a_j = x_j c_j, c_k = exp(-i pi k^2 / n),
-// the convolution through two transforms of length M and the spectrum of conj c (gt: global table [tw_M | c | FFT_M(conj c)]).
-// The inverse transform is conj(DFT(conj x)).  Unnormalised like flex_fft; the result is returned in one of the two buffers.
-template <int SYNC>
-__device__ c32* flex_transform(c32* A, c32* B, const c32* tw, const c32* gt, const FlexFactors& pl, int dir, int lines, int istr, int lstr, int first, int step)
+// DFT of a line (or a tile of lines) of pl.n points (the first pl.n entries of buffers that hold pl.m).  Directly when the length
+// factors into small radices; otherwise in the chirp-z form on M = pl.m points:  X_k = c_k (a * conj c)_k with a_j = x_j c_j,
+// c_k = exp(-i pi k^2 / n), the convolution through two transforms of length M and the spectrum of conj c (gt: global table
+// [tw_M | c | FFT_M(conj c)]).  The inverse transform is conj(DFT(conj x)).  Unnormalised like flex_fft; the result is returned in
+// one of the two buffers.
+template <int SYNC, int DIR, bool COLS>
+__device__ c32* flex_transform(c32* A, c32* B, const c32* tw, const c32* gt, const FlexFactors& pl, int tsh, int first, int step)
 {
-    if (!pl.blue) return flex_fft<SYNC>(A, B, tw, pl, dir, lines, istr, lstr, first, step);
+    if (!pl.blue) return flex_fft<SYNC, DIR, COLS>(A, B, tw, pl, tsh, first, step);
     const int n = pl.n, M = pl.m;
     const c32* const chirp = gt + M;
     const c32* const bhat = gt + M + n;
     const float inv_m = 1.0f / (float)M;
-    const int total = lines * M;
-    auto split = [&](int e, int& l, int& i) {
-        if (lstr == 1) { i = e / lines; l = e - i * lines; }
-        else { l = e / M; i = e - l * M; }
-    };
-    for (int e = first; e < total; e += step) {
-        int l, i;
-        split(e, l, i);
-        c32* p = A + (size_t)i * istr + (size_t)l * lstr;
+    const int total = COLS ? M << tsh : M;
+    for (int e = first; e < total; e += step) {   // element e = (i << tsh) + l sits at A[e] in both layouts
+        const int i = COLS ? e >> tsh : e;
         c32 v{0.f, 0.f};
-        if (i < n) v = conj_if(*p, dir) * chirp[i];
-        *p = v;
+        if (i < n) v = conj_if<DIR>(A[e]) * chirp[i];
+        A[e] = v;
     }
     flex_sync<SYNC>();
-    c32* X = flex_fft<SYNC>(A, B, tw, pl, FWD, lines, istr, lstr, first, step);
+    c32* X = flex_fft<SYNC, FWD, COLS>(A, B, tw, pl, tsh, first, step);
     c32* Y = X == A ? B : A;
     for (int e = first; e < total; e += step) {
-        int l, i;
-        split(e, l, i);
-        c32* p = X + (size_t)i * istr + (size_t)l * lstr;
-        *p = *p * bhat[i];
+        const int i = COLS ? e >> tsh : e;
+        X[e] = X[e] * bhat[i];
     }
     flex_sync<SYNC>();
-    X = flex_fft<SYNC>(X, Y, tw, pl, INV, lines, istr, lstr, first, step);
+    X = flex_fft<SYNC, INV, COLS>(X, Y, tw, pl, tsh, first, step);
     for (int e = first; e < total; e += step) {
-        int l, i;
-        split(e, l, i);
+        const int i = COLS ? e >> tsh : e;
         if (i >= n) continue;
-        c32* p = X + (size_t)i * istr + (size_t)l * lstr;
-        *p = conj_if((*p * chirp[i]) * inv_m, dir);
+        X[e] = conj_if<DIR>((X[e] * chirp[i]) * inv_m);
     }
     flex_sync<SYNC>();
     return X;
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
     c32* X = A;
     c32* Y = B;
     if (mode != COL_INV) {
-        X = flex_transform<0>(A, B, tw, a.tw, pl, FWD, T, T, 1, tid, FLEX_COL_THREADS);
+        X = flex_transform<0, FWD, true>(A, B, tw, a.tw, pl, tshift, tid, FLEX_COL_THREADS);
         Y = X == A ? B : A;
     }
     if (iter || (mode == COL_FWD && a.tau != nullptr)) {
@@ -560,7 +583,7 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
         }
         return;
     }
-    if (iter || mode == COL_INV) X = flex_transform<0>(X, Y, tw, a.tw, pl, INV, T, T, 1, tid, FLEX_COL_THREADS);
+    if (iter || mode == COL_INV) X = flex_transform<0, INV, true>(X, Y, tw, a.tw, pl, tshift, tid, FLEX_COL_THREADS);
     for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
         const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
         if (col < a.n2) outb[goff(a.out_std, i, col)] = X[e];
@@ -640,8 +663,8 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
         flex_sync<SYNC>();
-        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, INV, lane, TPR);
-        else X = flex_transform<SYNC>(A, B, tw, a.tw, pl, INV, 1, 1, L, lane, TPR);
+        if constexpr (INPL) flex_fft_inplace<SYNC, INV>(A, tw, pl, lane);
+        else X = flex_transform<SYNC, INV, false>(A, B, tw, a.tw, pl, 0, lane, TPR);
         for (int i = lane; i < n; i += TPR) {
             c32 xn = X[i] * a.scale;
             float m = 0.f;
@@ -686,8 +709,8 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, FWD, lane, TPR);
-        else X = flex_transform<SYNC>(X, Y, tw, a.tw, pl, FWD, 1, 1, L, lane, TPR);
+        if constexpr (INPL) flex_fft_inplace<SYNC, FWD>(A, tw, pl, lane);
+        else X = flex_transform<SYNC, FWD, false>(X, Y, tw, a.tw, pl, 0, lane, TPR);
         if (valid)
             for (int i = lane; i < n; i += TPR) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
     }
@@ -761,8 +784,8 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
             A[i] = c32{r0.x - r1.y, r0.y + r1.x};
         }
         flex_sync<SYNC>();
-        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, INV, lane, TPR);
-        else X = flex_transform<SYNC>(A, B, tw, a.tw, pl, INV, 1, 1, L, lane, TPR);
+        if constexpr (INPL) flex_fft_inplace<SYNC, INV>(A, tw, pl, lane);
+        else X = flex_transform<SYNC, INV, false>(A, B, tw, a.tw, pl, 0, lane, TPR);
         const bool handback = mode == ROW_LAST && a.only_done != 0;
         for (int i = lane; i < n; i += TPR) {
             const c32 z = X[i] * a.scale;
@@ -800,8 +823,8 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        if constexpr (INPL) flex_fft_inplace<SYNC>(A, tw, pl, FWD, lane, TPR);
-        else X = flex_transform<SYNC>(X, Y, tw, a.tw, pl, FWD, 1, 1, L, lane, TPR);
+        if constexpr (INPL) flex_fft_inplace<SYNC, FWD>(A, tw, pl, lane);
+        else X = flex_transform<SYNC, FWD, false>(X, Y, tw, a.tw, pl, 0, lane, TPR);
         if (valid)
             for (int k = lane; k <= H; k += TPR) {
                 const c32 z = X[k], pz = X[k == 0 ? 0 : n - k];
@@ -966,7 +989,7 @@ void flex_build_table(int n, std::vector<c32>& out)
     for (int k = 0; k < M; ++k) out[(size_t)M + n + k] = c32{(float)br[k], (float)bi[k]};
 }
 
-bool flex_supported(int n) { return n >= 2 && n <= GEN_MAX_N && gen_make_plan(n).nf > 0 && pick_col_tile(n) > 0 && pick_row_lines(n) > 0; }
+bool flex_supported(int n) { return n >= 2 && n <= GEN_MAX_N && gen_make_plan(n).nf > 0 && flex_factors(n).nf > 0 && pick_col_tile(n) > 0 && pick_row_lines(n) > 0; }
 int flex_col_tile(int n) { return pick_col_tile(n); }
 
 const LineOps* get_flex_ops()
