@@ -480,113 +480,162 @@ __device__ c32* flex_transform(c32* A, c32* B, const c32* tw, const c32* gt, con
 // ---- column pass ------------------------------------------------------------------------------------------------------------------
 constexpr int FLEX_COL_THREADS = 1024;   // 16 waves per CU although a tile of long columns allows one workgroup per CU only (512: 28.6 vs 31 Gpt/s)
 
-__global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArgs a, const FlexFactors pl, int mode, int tshift)
+// Persistent: a workgroup owns a contiguous run of (slice, tile) pairs.  Long columns leave room for one workgroup per CU only
+// (two buffers of a tile: 128 KiB at 1000 x 8), so nothing else on the CU would cover a tile's load: the NEXT tile is requested
+// into registers (n T / 1024 <= FLEX_COL_PF samples per thread) before the current one is transformed.
+constexpr int FLEX_COL_PF = 10;   // 2 T L <= FLEX_LDS_MAX / 8  =>  n T / 1024 <= 9.4
+
+template <bool PERSIST>   // false: one tile per workgroup (per = 1), loaded straight into LDS
+__global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArgs a, const FlexFactors pl, int mode, int tshift, int ntiles, int per)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int n = pl.n, L = pl.m, T = 1 << tshift, tid = threadIdx.x;
+    __shared__ float r[(FLEX_COL_THREADS / 64) * 5];
+    const int n = pl.n, L = pl.m, T = 1 << tshift, tid_ = threadIdx.x;
     c32* tw = reinterpret_cast<c32*>(smem_raw);
     c32* A = tw + L;
     c32* B = A + (size_t)L * T;
-    // tiles narrower than a 64-byte column block: the pieces of one block go to the same XCD back to back (see col_kernel)
-    int tile = blockIdx.x;
-    if (T < 8) {
-        const int G = 8 >> tshift;
-        if ((gridDim.x % (8 * G)) == 0) {
-            const int xcd = tile & 7, j = tile >> 3;
-            tile = ((j / G) * 8 + xcd) * G + (j % G);
-        }
-    }
-    const int slice = blockIdx.y, col0 = tile * T;
-    if (a.done && a.done[slice] != 0) return;
     const bool iter = mode == COL_ITER || mode == COL_ITER_SOFT || mode == COL_ITER_GARROTE;
+    const int total = ntiles * a.nslices, nel = n << tshift;
+    const int begin = blockIdx.x * per, end = min(begin + per, total);
+    if (begin >= end) return;
+    for (int i = tid_; i < L; i += FLEX_COL_THREADS) tw[i] = a.tw[i];
 
-    for (int i = tid; i < L; i += FLEX_COL_THREADS) tw[i] = a.tw[i];
-    const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
-    c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
     auto goff = [&](int std_layout, int i, int col) -> size_t {
         return std_layout ? (size_t)i * a.n2 + col : ((size_t)(col >> 3) * n + i) * 8 + (col & 7);
     };
-    for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
-        const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
-        A[e] = col < a.n2 ? inb[goff(a.in_std, i, col)] : c32{0.f, 0.f};
-    }
-    __syncthreads();
-
-    c32* X = A;
-    c32* Y = B;
-    if (mode != COL_INV) {
-        X = flex_transform<0, FWD, true>(A, B, tw, a.tw, pl, tshift, tid, FLEX_COL_THREADS);
-        Y = X == A ? B : A;
-    }
-    if (iter || (mode == COL_FWD && a.tau != nullptr)) {
-        const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
-        const int op = mode == COL_ITER_SOFT ? 1 : (mode == COL_ITER_GARROTE ? 2 : a.op);   // callers pass COL_ITER + a.op
-        bool any = false;
-        const Shrink shr(tau, op);
-        for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
-            const c32 v = shr(X[e]);
-            X[e] = v;
-            any = any || v.x != 0.0f || v.y != 0.0f;
-        }
-        const int kept = __syncthreads_or(any ? 1 : 0);
-        if (iter && a.nzflag != nullptr) {   // a tile the threshold emptied stays zeros: say so instead of transforming and storing it
-            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
-            if (!kept) {
-                // the row pass skips whole 8-column blocks: an empty tile NARROWER than a block must still leave zeros behind for
-                // the case that a sibling tile of its block kept something (see col_kernel)
-                if (T < 8)
-                    for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
-                        const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
-                        if (col < a.n2) outb[goff(a.out_std, i, col)] = c32{0.f, 0.f};
-                    }
-                return;
-            }
-        }
-    }
-    if (mode == COL_STATS) {
-        // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
-        float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
-        for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
-            if (col0 + (e & (T - 1)) >= a.n2) continue;
-            const c32 v = X[e];
-            const float p = v.x * v.x + v.y * v.y;
-            if (lex_greater(v.x, v.y, lr, li)) { lr = v.x; li = v.y; }
-            mx = fmaxf(mx, p);
-            mn = fminf(mn, p);
-            sq += p;
-        }
-        __shared__ float r[(FLEX_COL_THREADS / 64) * 5];
+    // request tile `idx` into registers (nothing for a slice that is finished: its tile is skipped below).  A whole column block
+    // of the work buffer is one contiguous run of n * 8 samples.
+    c32 pre[FLEX_COL_PF];
+    auto request = [&](int idx) {
+        int t = tid_;
+        asm volatile("" : "+v"(t));   // (addresses are computed here, per tile: hoisted out of the tile loop they spilled)
+        const int slice = idx / ntiles, col0 = (idx - slice * ntiles) << tshift;
+        const bool live = idx < end && !(a.done && a.done[slice] != 0);
+        const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
+        if (!a.in_std && T == 8 && col0 + 8 <= a.n2) {
+            const c32* const src = inb + (size_t)(col0 >> 3) * n * 8 + t;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float orr = __shfl_down(lr, o, 64), oi = __shfl_down(li, o, 64);
-            const float omx = __shfl_down(mx, o, 64), omn = __shfl_down(mn, o, 64), osq = __shfl_down(sq, o, 64);
-            if (lex_greater(orr, oi, lr, li)) { lr = orr; li = oi; }
-            mx = fmaxf(mx, omx);
-            mn = fminf(mn, omn);
-            sq += osq;
-        }
-        if ((tid & 63) == 0) {
-            float* o = r + (tid >> 6) * 5;
-            o[0] = lr; o[1] = li; o[2] = mx; o[3] = mn; o[4] = sq;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int t = 1; t < FLEX_COL_THREADS / 64; ++t) {
-                const float* o = r + t * 5;
-                if (lex_greater(o[0], o[1], lr, li)) { lr = o[0]; li = o[1]; }
-                mx = fmaxf(mx, o[2]);
-                mn = fminf(mn, o[3]);
-                sq += o[4];
+            for (int k = 0; k < FLEX_COL_PF; ++k) {
+                pre[k] = c32{0.f, 0.f};
+                if (live && t + k * FLEX_COL_THREADS < nel) pre[k] = src[k * FLEX_COL_THREADS];
             }
-            float* p = a.partials + ((size_t)slice * gridDim.x + tile) * STATS_PARTIAL;
-            p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
+        } else {
+#pragma unroll
+            for (int k = 0; k < FLEX_COL_PF; ++k) {
+                const int e = t + k * FLEX_COL_THREADS, c = e & (T - 1), i = e >> tshift, col = col0 + c;
+                pre[k] = c32{0.f, 0.f};
+                if (live && e < nel && col < a.n2) pre[k] = inb[goff(a.in_std, i, col)];
+            }
         }
-        return;
-    }
-    if (iter || mode == COL_INV) X = flex_transform<0, INV, true>(X, Y, tw, a.tw, pl, tshift, tid, FLEX_COL_THREADS);
-    for (int e = tid; e < (n << tshift); e += FLEX_COL_THREADS) {
-        const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
-        if (col < a.n2) outb[goff(a.out_std, i, col)] = X[e];
+    };
+    if constexpr (PERSIST) request(begin);
+
+    // (one trip when not persistent: the compiler then sees straight-line code)
+    for (int idx = begin; idx < (PERSIST ? end : begin + 1); ++idx) {
+        // what the passes derive from the thread index belongs to one radix case each: it is computed there, per tile, and not
+        // hoisted out of the tile loop for all of them
+        int tid = tid_;
+        asm volatile("" : "+v"(tid));
+        const int slice = idx / ntiles, tile = idx - slice * ntiles, col0 = tile << tshift;
+        const bool skip = a.done && a.done[slice] != 0;
+        if constexpr (PERSIST) {
+            if (!skip) {
+#pragma unroll
+                for (int k = 0; k < FLEX_COL_PF; ++k) {
+                    const int e = tid + k * FLEX_COL_THREADS;
+                    if (e < nel) A[e] = pre[k];
+                }
+            }
+        } else {
+            if (skip) continue;
+            const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
+            for (int e = tid; e < nel; e += FLEX_COL_THREADS) {
+                const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
+                A[e] = col < a.n2 ? inb[goff(a.in_std, i, col)] : c32{0.f, 0.f};
+            }
+        }
+        __syncthreads();   // the tile (and, the first time, the twiddle table) is in LDS; nobody reads the previous tile any more
+        if constexpr (PERSIST) request(idx + 1);
+        if (skip) continue;
+        c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)n * a.n2 : wk_slice_stride(n, a.n2));
+
+        c32* X = A;
+        c32* Y = B;
+        if (mode != COL_INV) {
+            X = flex_transform<0, FWD, true>(A, B, tw, a.tw, pl, tshift, tid, FLEX_COL_THREADS);
+            Y = X == A ? B : A;
+        }
+        bool emptied = false;
+        if (iter || (mode == COL_FWD && a.tau != nullptr)) {
+            const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
+            const int op = mode == COL_ITER_SOFT ? 1 : (mode == COL_ITER_GARROTE ? 2 : a.op);   // callers pass COL_ITER + a.op
+            bool any = false;
+            const Shrink shr(tau, op);
+            for (int e = tid; e < nel; e += FLEX_COL_THREADS) {
+                const c32 v = shr(X[e]);
+                X[e] = v;
+                any = any || v.x != 0.0f || v.y != 0.0f;
+            }
+            const int kept = __syncthreads_or(any ? 1 : 0);
+            if (iter && a.nzflag != nullptr) {   // a tile the threshold emptied stays zeros: say so instead of transforming and storing it
+                if (tid == 0) a.nzflag[(size_t)slice * ntiles + tile] = kept ? 1 : 0;
+                if (!kept) {
+                    // the row pass skips whole 8-column blocks: an empty tile NARROWER than a block must still leave zeros behind for
+                    // the case that a sibling tile of its block kept something (see col_kernel)
+                    if (T < 8)
+                        for (int e = tid; e < nel; e += FLEX_COL_THREADS) {
+                            const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
+                            if (col < a.n2) outb[goff(a.out_std, i, col)] = c32{0.f, 0.f};
+                        }
+                    emptied = true;
+                }
+            }
+        }
+        if (emptied) continue;
+        if (mode == COL_STATS) {
+            // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
+            float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
+            for (int e = tid; e < nel; e += FLEX_COL_THREADS) {
+                if (col0 + (e & (T - 1)) >= a.n2) continue;
+                const c32 v = X[e];
+                const float p = v.x * v.x + v.y * v.y;
+                if (lex_greater(v.x, v.y, lr, li)) { lr = v.x; li = v.y; }
+                mx = fmaxf(mx, p);
+                mn = fminf(mn, p);
+                sq += p;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float orr = __shfl_down(lr, o, 64), oi = __shfl_down(li, o, 64);
+                const float omx = __shfl_down(mx, o, 64), omn = __shfl_down(mn, o, 64), osq = __shfl_down(sq, o, 64);
+                if (lex_greater(orr, oi, lr, li)) { lr = orr; li = oi; }
+                mx = fmaxf(mx, omx);
+                mn = fminf(mn, omn);
+                sq += osq;
+            }
+            if ((tid & 63) == 0) {
+                float* o = r + (tid >> 6) * 5;
+                o[0] = lr; o[1] = li; o[2] = mx; o[3] = mn; o[4] = sq;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int t = 1; t < FLEX_COL_THREADS / 64; ++t) {
+                    const float* o = r + t * 5;
+                    if (lex_greater(o[0], o[1], lr, li)) { lr = o[0]; li = o[1]; }
+                    mx = fmaxf(mx, o[2]);
+                    mn = fminf(mn, o[3]);
+                    sq += o[4];
+                }
+                float* p = a.partials + ((size_t)slice * ntiles + tile) * STATS_PARTIAL;
+                p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
+            }
+            continue;   // (the barrier at the top of the next tile separates this tile's use of r[] from the next one's)
+        }
+        if (iter || mode == COL_INV) X = flex_transform<0, INV, true>(X, Y, tw, a.tw, pl, tshift, tid, FLEX_COL_THREADS);
+        for (int e = tid; e < nel; e += FLEX_COL_THREADS) {
+            const int c = e & (T - 1), i = e >> tshift, col = col0 + c;
+            if (col < a.n2) outb[goff(a.out_std, i, col)] = X[e];
+        }
     }
 }
 
@@ -924,9 +973,24 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
     while ((1 << tshift) < T) ++tshift;
     const FlexFactors pl = flex_factors(n);
     const size_t lds = col_lds(n, T);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_col_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
+    if ((size_t)n * T > (size_t)FLEX_COL_PF * FLEX_COL_THREADS) return hipErrorNotSupported;   // (never: col_lds <= FLEX_LDS_MAX)
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    // Long columns (one workgroup per CU): contiguous runs of tiles, the next tile prefetched.  Short ones share a CU and cover
+    // each other's loads, and the chirp-z form reads its tables from global memory between the passes (a wait for those is a
+    // wait for the prefetch): one tile per workgroup there (measured: 300-point columns 0.23 vs 0.27 ms, 1001-point 2.7 vs 4.0).
+    const int ntiles = (a.n2 + T - 1) / T, total = ntiles * a.nslices;
+    static const bool no_persist = getenv("P3D_FLEX_COL_NO_PERSIST") != nullptr;
+    const bool persist = !no_persist && !pl.blue && lds + 512 > 80 * 1024;
+    const int grid = !persist ? total : (total < cus ? total : cus), per = (total + grid - 1) / grid;
+    const void* fn = persist ? reinterpret_cast<const void*>(flex_col_kernel<true>) : reinterpret_cast<const void*>(flex_col_kernel<false>);
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);
     if (e != hipSuccess) return e;
-    flex_col_kernel<<<dim3((a.n2 + T - 1) / T, a.nslices), FLEX_COL_THREADS, lds, st>>>(a, pl, mode, tshift);
+    if (persist) flex_col_kernel<true><<<(total + per - 1) / per, FLEX_COL_THREADS, lds, st>>>(a, pl, mode, tshift, ntiles, per);
+    else flex_col_kernel<false><<<total, FLEX_COL_THREADS, lds, st>>>(a, pl, mode, tshift, ntiles, 1);
     return hipGetLastError();
 }
 
