@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -117,7 +118,7 @@ size_t row_lds_inplace(int n, int LB) { const size_t L = flex_factors(n).m; retu
 // in-place passes (flex_pass_inplace): in-register radices only, at most one butterfly per thread in every pass
 bool flex_inplace_ok(const FlexFactors& pl, int tpr)
 {
-    if (pl.blue || pl.nf <= 0) return false;
+    if (pl.nf <= 0) return false;
     for (int p = 0; p < pl.nf; ++p) {
         const int R = pl.f[p];
         if (R > 16) return false;
@@ -389,8 +390,10 @@ __device__ __forceinline__ void flex_pass_inplace(c32* A, const c32* tw, PassArg
 // the in-register radices: R -> (R1, R2)
 #define P3D_FLEX_RADICES(X) X(2, 2, 1) X(3, 3, 1) X(4, 4, 1) X(5, 5, 1) X(6, 2, 3) X(7, 7, 1) X(8, 2, 4) X(9, 3, 3) X(10, 2, 5) X(12, 3, 4) X(14, 2, 7) X(15, 3, 5) X(16, 4, 4)
 
+// (force-inlined, like everything that is handed the FlexFactors: a call that survives until late makes the compiler copy the
+// kernel argument to scratch memory, and its per-pass entries are then read back with vector loads)
 template <int SYNC, int DIR>
-__device__ void flex_fft_inplace(c32* A, const c32* tw, const FlexFactors& pl, int first)
+__device__ __forceinline__ void flex_fft_inplace(c32* A, const c32* tw, const FlexFactors& pl, int first)
 {
     // the first pass has no twiddles (ns = 1)
     switch (pl.f[0]) {
@@ -413,6 +416,30 @@ __device__ void flex_fft_inplace(c32* A, const c32* tw, const FlexFactors& pl, i
         }
         flex_sync<SYNC>();
     }
+}
+
+// flex_transform (below) for one line with in-place passes: directly, or in the chirp-z form on the M = pl.m points of the
+// line's buffer (every element-wise step is done by the thread that owns the index, the passes synchronise among themselves)
+template <int SYNC, int DIR>
+__device__ __forceinline__ void flex_transform_inplace(c32* A, const c32* tw, const c32* gt, const FlexFactors& pl, int first, int step)
+{
+    if (!pl.blue) { flex_fft_inplace<SYNC, DIR>(A, tw, pl, first); return; }
+    const int n = pl.n, M = pl.m;
+    const c32* const chirp = gt + M;
+    const c32* const bhat = gt + M + n;
+    const float inv_m = 1.0f / (float)M;
+    for (int e = first; e < M; e += step) {
+        c32 v{0.f, 0.f};
+        if (e < n) v = conj_if<DIR>(A[e]) * chirp[e];
+        A[e] = v;
+    }
+    flex_sync<SYNC>();
+    flex_fft_inplace<SYNC, FWD>(A, tw, pl, first);
+    for (int e = first; e < M; e += step) A[e] = A[e] * bhat[e];
+    flex_sync<SYNC>();
+    flex_fft_inplace<SYNC, INV>(A, tw, pl, first);
+    for (int e = first; e < n; e += step) A[e] = conj_if<DIR>((A[e] * chirp[e]) * inv_m);
+    flex_sync<SYNC>();
 }
 
 // large prime factor R: direct O(R^2) butterflies, inputs re-read from LDS
@@ -523,8 +550,9 @@ constexpr int FLEX_COL_THREADS = 1024;   // 16 waves per CU although a tile of l
 constexpr int FLEX_COL_PF = 10;   // 2 T L <= FLEX_LDS_MAX / 8  =>  n T / 1024 <= 9.4
 
 template <bool PERSIST, bool BIGP>   // PERSIST false: one tile per workgroup (per = 1), loaded straight into LDS; BIGP: see flex_fft
-__global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArgs a, const FlexFactors pl, int mode, int tshift, int ntiles, int per)
+__global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArgs a, const FlexFactors* __restrict__ plp, int mode, int tshift, int ntiles, int per)
 {
+    const FlexFactors& pl = *plp;   // behind the line's twiddle table (flex_build_table): uniform address, scalar loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ float r[(FLEX_COL_THREADS / 64) * 5];
     const int n = pl.n, L = pl.m, T = 1 << tshift, tid_ = threadIdx.x;
@@ -686,8 +714,9 @@ __global__ __launch_bounds__(FLEX_COL_THREADS) void flex_col_kernel(const ColArg
 // rows per workgroup, half the LDS, twice the resident waves), LB rows per workgroup; modes ROW_FIRST / ROW_MID / ROW_LAST as in
 // row_kernel (p3d_kernels.hpp)
 template <int TPR, bool INPL>
-__global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
+__global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const FlexFactors* __restrict__ plp, int mode, int LB)
 {
+    const FlexFactors& pl = *plp;
     constexpr bool inpl = INPL;
     constexpr int SYNC = TPR == 64 ? 1 : 0;
     __shared__ double rsum[4];
@@ -754,7 +783,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
         flex_sync<SYNC>();
-        if constexpr (INPL) flex_fft_inplace<SYNC, INV>(A, tw, pl, lane);
+        if constexpr (INPL) flex_transform_inplace<SYNC, INV>(A, tw, a.tw, pl, lane, TPR);
         else X = flex_transform<SYNC, INV, false, true>(A, B, tw, a.tw, pl, 0, lane, TPR);
         for (int i = lane; i < n; i += TPR) {
             c32 xn = X[i] * a.scale;
@@ -792,15 +821,21 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
         for (int o = 32; o > 0; o >>= 1) ws += __shfl_down(ws, o, 64);
         if constexpr (TPR == 64) {
             if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = ws;
-        } else {   // two wavefronts per row
+        } else {   // two or four wavefronts per row
+            constexpr int W = TPR / 64;
             if ((tid & 63) == 0) rsum[tid >> 6] = ws;
             __syncthreads();
-            if (lane == 0 && valid) a.sums[(size_t)slice * a.n1 + row] = rsum[2 * line] + rsum[2 * line + 1];
+            if (lane == 0 && valid) {
+                double t = rsum[W * line];
+#pragma unroll
+                for (int w = 1; w < W; ++w) t += rsum[W * line + w];
+                a.sums[(size_t)slice * a.n1 + row] = t;
+            }
         }
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        if constexpr (INPL) flex_fft_inplace<SYNC, FWD>(A, tw, pl, lane);
+        if constexpr (INPL) flex_transform_inplace<SYNC, FWD>(A, tw, a.tw, pl, lane, TPR);
         else X = flex_transform<SYNC, FWD, false, true>(X, Y, tw, a.tw, pl, 0, lane, TPR);
         if (valid)
             for (int i = lane; i < n; i += TPR) wrow[(size_t)(i >> 3) * wblk + (i & 7)] = X[i];
@@ -811,8 +846,9 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
 // transform, z = r_a + i r_b, and the work buffer holds columns 0 ... n/2 of the row spectra.  The line lives in LDS here, so the
 // partner Z[n - k] of the split is simply another element of the same buffer.  Any real mask (float weights), no compaction.
 template <int TPR, bool INPL>
-__global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, const FlexFactors pl, int mode, int LB)
+__global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, const FlexFactors* __restrict__ plp, int mode, int LB)
 {
+    const FlexFactors& pl = *plp;
     constexpr int SYNC = TPR == 64 ? 1 : 0;
     __shared__ double rsum[8];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -875,7 +911,7 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
             A[i] = c32{r0.x - r1.y, r0.y + r1.x};
         }
         flex_sync<SYNC>();
-        if constexpr (INPL) flex_fft_inplace<SYNC, INV>(A, tw, pl, lane);
+        if constexpr (INPL) flex_transform_inplace<SYNC, INV>(A, tw, a.tw, pl, lane, TPR);
         else X = flex_transform<SYNC, INV, false, true>(A, B, tw, a.tw, pl, 0, lane, TPR);
         const bool handback = mode == ROW_LAST && a.only_done != 0;
         for (int i = lane; i < n; i += TPR) {
@@ -914,7 +950,7 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
     }
     if (mode != ROW_LAST) {
         c32* Y = X == A ? B : A;
-        if constexpr (INPL) flex_fft_inplace<SYNC, FWD>(A, tw, pl, lane);
+        if constexpr (INPL) flex_transform_inplace<SYNC, FWD>(A, tw, a.tw, pl, lane, TPR);
         else X = flex_transform<SYNC, FWD, false, true>(X, Y, tw, a.tw, pl, 0, lane, TPR);
         if (valid)
             for (int k = lane; k <= H; k += TPR) {
@@ -925,6 +961,11 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
             }
     }
 }
+
+// The pass list of a length sits behind its device table (flex_build_table).  It is read through a pointer: as a by-value kernel
+// argument with run-time indexed arrays it was copied to scratch memory by some instantiations (260 bytes, vector loads per pass).
+size_t flex_table_len(const FlexFactors& pl) { return pl.blue ? (size_t)2 * pl.m + pl.n : (size_t)pl.n; }
+const FlexFactors* device_factors(const c32* table, const FlexFactors& pl) { return reinterpret_cast<const FlexFactors*>(table + flex_table_len(pl)); }
 
 // row-pair passes for float32 cubes (mode = ROW_FIRST / ROW_MID / ROW_LAST)
 hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
@@ -958,7 +999,7 @@ hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_real_kernel<TPR, IP>),                       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);                     \
         if (e != hipSuccess) return e;                                                                                         \
-        flex_row_real_kernel<TPR, IP><<<grid, TPR * lb, lds, st>>>(a, pl, mode, lb);                                           \
+        flex_row_real_kernel<TPR, IP><<<grid, TPR * lb, lds, st>>>(a, device_factors(a.tw, pl), mode, lb);                                           \
     } while (0)
     if (two_) { if (inpl) P3D_FLEX_ROW(128, true); else P3D_FLEX_ROW(128, false); }
     else { if (inpl) P3D_FLEX_ROW(64, true); else P3D_FLEX_ROW(64, false); }
@@ -979,17 +1020,20 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;
     static const bool no_inplace = getenv("P3D_FLEX_NO_INPLACE") != nullptr;
-    bool two_ = two;
+    int tpr = two ? 128 : 64;
     int inpl = 0;
     if (!no_inplace) {
-        if (flex_inplace_ok(pl, two ? 128 : 64)) inpl = 1;
-        else if (!two && flex_inplace_ok(pl, 128)) { inpl = 1; two_ = true; }
+        // in-place passes want one butterfly per thread: more wavefronts per row where the passes are wide (four for the
+        // 2048-point transforms of the chirp-z form of ~1000-point rows: 20 resident waves per CU instead of 6)
+        for (int t = tpr; t <= 256 && !inpl; t *= 2)
+            if (flex_inplace_ok(pl, t)) { inpl = 1; tpr = t; }
     }
-    int lb = two_ ? LB / 2 : LB;
+    int lb = tpr == 128 && !inpl ? LB / 2 : LB;
     if (lb < 1) lb = 1;
     if (inpl) {   // 256 threads per workgroup; the single buffers let four of them share a CU
-        lb = two_ ? 2 : 4;
+        lb = 256 / tpr;
         while (lb > 1 && row_lds_inplace(n, lb) > FLEX_LDS_MAX) lb /= 2;
+        if (row_lds_inplace(n, lb) > FLEX_LDS_MAX) return hipErrorNotSupported;
     }
     const size_t lds = inpl ? row_lds_inplace(n, lb) : row_lds(n, lb);
     const dim3 grid((a.n1 + lb - 1) / lb, a.nslices);
@@ -998,9 +1042,10 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_row_kernel<TPR, IP>),                            \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);                     \
         if (e != hipSuccess) return e;                                                                                         \
-        flex_row_kernel<TPR, IP><<<grid, TPR * lb, lds, st>>>(a, pl, mode, lb);                                                \
+        flex_row_kernel<TPR, IP><<<grid, TPR * lb, lds, st>>>(a, device_factors(a.tw, pl), mode, lb);                                                \
     } while (0)
-    if (two_) { if (inpl) P3D_FLEX_ROW(128, true); else P3D_FLEX_ROW(128, false); }
+    if (tpr == 256) P3D_FLEX_ROW(256, true);
+    else if (tpr == 128) { if (inpl) P3D_FLEX_ROW(128, true); else P3D_FLEX_ROW(128, false); }
     else { if (inpl) P3D_FLEX_ROW(64, true); else P3D_FLEX_ROW(64, false); }
 #undef P3D_FLEX_ROW
     return hipGetLastError();
@@ -1040,7 +1085,7 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flex_col_kernel<PS, BP>),                         \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLEX_LDS_MAX);                 \
         if (e != hipSuccess) return e;                                                                                           \
-        flex_col_kernel<PS, BP><<<PS ? (total + per - 1) / per : total, FLEX_COL_THREADS, lds, st>>>(a, pl, mode, tshift, ntiles, PS ? per : 1); \
+        flex_col_kernel<PS, BP><<<PS ? (total + per - 1) / per : total, FLEX_COL_THREADS, lds, st>>>(a, device_factors(a.tw, pl), mode, tshift, ntiles, PS ? per : 1); \
     } while (0)
     if (persist) { if (bigp) P3D_FLEX_COL(true, true); else P3D_FLEX_COL(true, false); }
     else { if (bigp) P3D_FLEX_COL(false, true); else P3D_FLEX_COL(false, false); }
@@ -1057,9 +1102,15 @@ hipError_t flex_no_pipe(const RowArgs&, int, hipStream_t) { return hipErrorNotSu
 void flex_build_table(int n, std::vector<c32>& out)
 {
     const FlexFactors pl = flex_factors(n);
+    auto append_factors = [&] {   // read by the kernels through device_factors()
+        const size_t at = out.size();
+        out.resize(at + (sizeof(FlexFactors) + sizeof(c32) - 1) / sizeof(c32), c32{0.f, 0.f});
+        memcpy(out.data() + at, &pl, sizeof(FlexFactors));
+    };
     if (!pl.blue) {
         out.resize(n);
         gen_build_twiddles(n, out.data());
+        append_factors();
         return;
     }
     const int M = pl.m;
@@ -1105,6 +1156,7 @@ void flex_build_table(int n, std::vector<c32>& out)
         bi = ai;
     }
     for (int k = 0; k < M; ++k) out[(size_t)M + n + k] = c32{(float)br[k], (float)bi[k]};
+    append_factors();
 }
 
 bool flex_supported(int n) { return n >= 2 && n <= GEN_MAX_N && gen_make_plan(n).nf > 0 && flex_factors(n).nf > 0 && pick_col_tile(n) > 0 && pick_row_lines(n) > 0; }
