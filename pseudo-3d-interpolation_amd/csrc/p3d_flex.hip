@@ -1025,8 +1025,11 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     if (!no_inplace) {
         // in-place passes want one butterfly per thread: more wavefronts per row where the passes are wide (four for the
         // 2048-point transforms of the chirp-z form of ~1000-point rows: 20 resident waves per CU instead of 6)
+        // (four only where the passes keep 40 % of the 256 lanes busy: 600 = 15 x 10 x 4 would use a third of them and lost 9 %)
+        int butterflies = 0;
+        for (int p = 0; p < pl.nf; ++p) butterflies += pl.m / pl.f[p];
         for (int t = tpr; t <= 256 && !inpl; t *= 2)
-            if (flex_inplace_ok(pl, t)) { inpl = 1; tpr = t; }
+            if (flex_inplace_ok(pl, t) && (t < 256 || 5 * butterflies >= 2 * pl.nf * t)) { inpl = 1; tpr = t; }
     }
     int lb = tpr == 128 && !inpl ? LB / 2 : LB;
     if (lb < 1) lb = 1;
