@@ -214,13 +214,15 @@ __device__ __forceinline__ T smooth2_at(const T* a, size_t ld, int H, int W, int
 // analysis of one level: in (H x W) -> cA, cH, cV, cD (Ho x Wo each).  Workgroup (256 threads as TILE lanes x 256/TILE rows) =
 // TILE x TILE coefficients of every subband.  LDS traffic is what bounds these kernels, so axis 1 reads sample pairs (8 B per
 // lane, conflict-free) and axis 0 slides a window down a column, every loaded sample feeding all outputs it belongs to.
-template <typename T, int TILE>
+// LT: the filter length at compile time (0: read from `f`).  With it the tile geometry is constant, the tap loops unroll and
+// their coefficients stay in registers -- these kernels are bound by instruction issue, not by memory.
+template <typename T, int TILE, int LT>
 __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_slice, int H, int W, T* cA, size_t cA_slice, T* det, size_t det_slice, int Ho, int Wo,
                                                         Filters f, int tiles_x, int ntiles, int ns, Thresh th)
 {
     extern __shared__ __align__(16) unsigned char w_smem[];
     constexpr int LX = TILE, LY = 256 / TILE, R = TILE / LY > 0 ? TILE / LY : 1;
-    const int L = f.len, IH = 2 * TILE + L - 2, IW = IH;  // L is even: IW is even, rows of s_in start 8-byte aligned for float
+    const int L = LT ? LT : f.len, IH = 2 * TILE + L - 2, IW = IH;  // L is even: IW is even, rows of s_in start 8-byte aligned for float
     T* s_in = reinterpret_cast<T*>(w_smem);
     T* s_lo = s_in + (size_t)IH * IW;
     T* s_hi = s_lo + (size_t)IH * TILE;
@@ -401,14 +403,14 @@ __device__ __forceinline__ void store_out(void* out, int, size_t g, float v) { r
 
 // synthesis of one level: (a, cH, cV, cD) (Ho x Wo valid samples each; a may sit in a larger array) -> rec (RH x RW).
 // Workgroup = 2 TILE x 2 TILE output samples; same thread layout and LDS economy as the analysis kernel.
-template <typename T, int TILE>
+template <typename T, int TILE, int LT>
 __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det, size_t det_slice, int Ho, int Wo, T* rec,
                                                          size_t rec_slice, int RH, int RW, Filters f, int tiles_x, int ntiles, int ns, Update u)
 {
     extern __shared__ __align__(16) unsigned char w_smem[];
-    __shared__ double red[256];
+    __shared__ double red[4];
     constexpr int LX = TILE, LY = 256 / TILE, OH = 2 * TILE, OW = 2 * TILE, R = OH / LY;   // R output rows per thread along axis 0
-    const int L = f.len, HL = L / 2, KH = TILE + HL - 1, KW = KH;
+    const int L = LT ? LT : f.len, HL = L / 2, KH = TILE + HL - 1, KW = KH;
     T* s_a = reinterpret_cast<T*>(w_smem);
     T* s_h = s_a + (size_t)KH * KW;
     T* s_v = s_h + (size_t)KH * KW;
@@ -561,14 +563,12 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
             }
         }
     }
-    if (u.enabled) {
-        red[threadIdx.x] = acc;
+    if (u.enabled) {   // tile sum: shuffle tree per wavefront, then the four wavefronts through LDS
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
-        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0 && dn == 0) atomicAdd(u.sums + s, red[0]);
+        if (threadIdx.x == 0 && dn == 0) atomicAdd(u.sums + s, (red[0] + red[1]) + (red[2] + red[3]));
     }
 }
 
@@ -804,9 +804,11 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
     p->fused = !(env && env[0] == '1') && p->tile_c > 0 && p->tile_r > 0;
     if (p->fused) {
         const int big = 150 * 1024;
-        const void* kernels[] = {(const void*)dwt2_tile_kernel<c32, 32>,  (const void*)dwt2_tile_kernel<c32, 16>,  (const void*)dwt2_tile_kernel<float, 32>,
-                                 (const void*)dwt2_tile_kernel<float, 16>, (const void*)idwt2_tile_kernel<c32, 32>, (const void*)idwt2_tile_kernel<c32, 16>,
-                                 (const void*)idwt2_tile_kernel<float, 32>, (const void*)idwt2_tile_kernel<float, 16>};
+#define P3D_W_KERNELS(LT) (const void*)dwt2_tile_kernel<c32, 32, LT>, (const void*)dwt2_tile_kernel<c32, 16, LT>, (const void*)dwt2_tile_kernel<float, 32, LT>, \
+                         (const void*)dwt2_tile_kernel<float, 16, LT>, (const void*)idwt2_tile_kernel<c32, 32, LT>, (const void*)idwt2_tile_kernel<c32, 16, LT>, \
+                         (const void*)idwt2_tile_kernel<float, 32, LT>, (const void*)idwt2_tile_kernel<float, 16, LT>
+        const void* kernels[] = {P3D_W_KERNELS(0), P3D_W_KERNELS(4), P3D_W_KERNELS(8)};
+#undef P3D_W_KERNELS
         for (const void* k : kernels)
             if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, big)) != hipSuccess) return bail("hipFuncSetAttribute", e);
     }
@@ -849,10 +851,11 @@ static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th)
         Thresh t{nullptr, 0, 0, 0, 0, 0, -1, -1};
         if (th) { t = *th; t.lvl = p->nlev - l; }
         const int tx = (Wo + tile - 1) / tile, ty = (Ho + tile - 1) / tile;
-        if (tile == 32)
-            dwt2_tile_kernel<T, 32><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, coef + p->doff[l], p->ncoef, Ho, Wo, p->f, tx, tx * ty, ns, t);
-        else
-            dwt2_tile_kernel<T, 16><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, coef + p->doff[l], p->ncoef, Ho, Wo, p->f, tx, tx * ty, ns, t);
+#define P3D_W_DWT(TL, LT) dwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, coef + p->doff[l], p->ncoef, Ho, Wo, p->f, tx, tx * ty, ns, t)
+        const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;   // db4 / sym4 and db2 have kernels of their own
+        if (tile == 32) { if (lt == 8) P3D_W_DWT(32, 8); else if (lt == 4) P3D_W_DWT(32, 4); else P3D_W_DWT(32, 0); }
+        else { if (lt == 8) P3D_W_DWT(16, 8); else if (lt == 4) P3D_W_DWT(16, 4); else P3D_W_DWT(16, 0); }
+#undef P3D_W_DWT
     }
     W_TRY(hipGetLastError());
     return P3D_OK;
@@ -875,12 +878,12 @@ static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u)
         // with the re-insertion fused only the nil x nxl crop of the level-0 reconstruction is needed
         const int OHt = up.enabled ? up.n1 : RH, OWt = up.enabled ? up.n2 : RW;
         const int tx = (OWt + 2 * tile - 1) / (2 * tile), ty = (OHt + 2 * tile - 1) / (2 * tile);
-        if (tile == 32)
-            idwt2_tile_kernel<T, 32><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, coef + p->doff[l], p->ncoef, Ho, Wo, as<T>(p->rec[l - 1]),
-                                                                            (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up);
-        else
-            idwt2_tile_kernel<T, 16><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, coef + p->doff[l], p->ncoef, Ho, Wo, as<T>(p->rec[l - 1]),
-                                                                            (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up);
+#define P3D_W_IDWT(TL, LT) idwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, coef + p->doff[l], p->ncoef, Ho, Wo, as<T>(p->rec[l - 1]), \
+                                                                                     (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up)
+        const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
+        if (tile == 32) { if (lt == 8) P3D_W_IDWT(32, 8); else if (lt == 4) P3D_W_IDWT(32, 4); else P3D_W_IDWT(32, 0); }
+        else { if (lt == 8) P3D_W_IDWT(16, 8); else if (lt == 4) P3D_W_IDWT(16, 4); else P3D_W_IDWT(16, 0); }
+#undef P3D_W_IDWT
     }
     W_TRY(hipGetLastError());
     return P3D_OK;
