@@ -125,6 +125,18 @@ int p3d_pocs_stats_dev(p3d_plan* plan, const void* x_dev, int dtype, int nslices
 int p3d_pocs_prime_dev(p3d_plan* plan, const void* x_dev, int dtype, const float* mask_dev, int nslices, double* stats_host);
 int p3d_pocs_stats(p3d_plan* plan, const void* x_host, int dtype, int nslices, double* stats_host);
 
+/* thresh_model = 'data-driven' (get_threshold_decay, functions/POCS.py:356-362): the schedule is read off the sorted forward
+ * transform of the slice, complex numbers in NumPy's lexicographic order.  Two steps, so that the bounds are formed by the caller
+ * in the reference's own arithmetic (tau = p * x_fwd.max(), complex64):
+ *   p3d_pocs_sorted_spectrum   x (HOST or device, complex64 [nslices][nil][nxl]) -> fft2 -> sorted per slice, descending, kept
+ *                              in the plan's staging buffers; peaks_host [nslices][2] = x_fwd.max() (POCS.py:288)
+ *   p3d_pocs_data_driven_pick  bounds_host [nslices][4] = tau_min (re, im), tau_max (re, im) ->
+ *                              count_host [nslices] = Nv = #{tau_min < X < tau_max} (0: the reference raises IndexError),
+ *                              tau_host [nslices][niter][2] = v[0], v[ceil(i (Nv - 1) / (niter - 1))] (float32 pairs)
+ * The pick must follow the sort directly (any other call on the plan in between invalidates the sorted keys: P3D_ERR_INVALID). */
+int p3d_pocs_sorted_spectrum(p3d_plan* plan, const void* x, int nslices, float* peaks_host);
+int p3d_pocs_data_driven_pick(p3d_plan* plan, int nslices, int niter, const float* bounds_host, float* tau_host, int64_t* count_host);
+
 /* The POCS loop (POCS.py:549-632) for a batch of slices sharing one trace mask.
  *   x        [nslices][nil][nxl] observed data, zeros at missing traces, dtype as given
  *   mask     [nil][nxl] float32, 1 = observed trace, 0 = missing (cube_POCS_interpolation_3D.py:242-244)

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_pocs_prime_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "p3d_pocs_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_pocs_sorted_spectrum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "p3d_pocs_data_driven_pick": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "p3d_pocs_run_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(PocsParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_double)]),
@@ -262,6 +264,29 @@ class Plan:
         st = np.empty((xc.shape[0], STATS_PER_SLICE), np.float64)
         check(lib().p3d_pocs_stats(self.handle, _ptr(xc), dt, xc.shape[0], _ptr(st)))
         return st
+
+    def sorted_spectrum(self, x):
+        """fft2 of every slice, sorted on the device in NumPy's complex order (kept in the plan); returns x_fwd.max() per slice
+        (complex64) -- first half of the 'data-driven' schedule (POCS.py:356-362)."""
+        xc = np.ascontiguousarray(x, dtype=np.complex64)
+        if xc.ndim != 3 or xc.shape[1:] != (self.nil, self.nxl):
+            raise ValueError(f"cube shape {xc.shape} != (n, {self.nil}, {self.nxl})")
+        peaks = np.empty((xc.shape[0], 2), np.float32)
+        check(lib().p3d_pocs_sorted_spectrum(self.handle, _ptr(xc), xc.shape[0], _ptr(peaks)))
+        return peaks.view(np.complex64)[:, 0]
+
+    def data_driven_pick(self, tau_min, tau_max, niter):
+        """Second half: per slice the number of coefficients strictly between the bounds (complex64, NumPy's order) and the
+        niter thresholds picked from them (POCS.py:359-362); must follow sorted_spectrum directly."""
+        lo = np.ascontiguousarray(tau_min, dtype=np.complex64)
+        hi = np.ascontiguousarray(tau_max, dtype=np.complex64)
+        n = lo.shape[0]
+        bounds = np.empty((n, 4), np.float32)
+        bounds[:, 0], bounds[:, 1], bounds[:, 2], bounds[:, 3] = lo.real, lo.imag, hi.real, hi.imag
+        tau = np.empty((n, int(niter), 2), np.float32)
+        count = np.empty((n,), np.int64)
+        check(lib().p3d_pocs_data_driven_pick(self.handle, n, int(niter), _ptr(bounds), _ptr(tau), _ptr(count)))
+        return tau.view(np.complex64)[..., 0], count
 
     def stats_dev(self, x_ptr, dtype, nslices):
         st = np.empty((nslices, STATS_PER_SLICE), np.float64)

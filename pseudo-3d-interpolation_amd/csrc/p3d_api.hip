@@ -18,6 +18,7 @@
 #include "p3d_internal.hpp"
 #include "p3d_flex.hpp"
 #include "p3d_resident.hpp"
+#include "p3d_select.hpp"
 #include "p3d_kernels.hpp"
 
 namespace p3d {
@@ -325,6 +326,7 @@ struct p3d_plan {
     // p3d_pocs_prime_dev: the first pass of a job run ahead of it (statistics + work buffer + compact samples of exactly this cube)
     struct Primed { bool valid = false; const void* x = nullptr; const float* mask = nullptr; int dtype = 0, nslices = 0, nonbinary = 0, violation = 0; unsigned nobs = 0; } primed;
     double* sum0 = nullptr;     // [max_slices] sum |x_obs| of the primed cube
+    int sorted_slices = 0;      // p3d_pocs_sorted_spectrum: st_x holds the sorted order keys of that many slices (0: none)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof_events;
     double prof_col_ms = 0, prof_row_ms = 0;
@@ -570,6 +572,7 @@ static int check_batch(p3d_plan* p, int nslices)
 {
     if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
     p->primed.valid = false;   // whoever comes through here is about to use the work buffer (p3d_pocs_run_dev reads the state first)
+    p->sorted_slices = 0;      // ... and possibly the staging buffers (p3d_pocs_data_driven_pick reads the state first)
     if (nslices < 1 || nslices > p->max_slices)
         return fail(P3D_ERR_INVALID, "nslices = %d outside 1..max_slices (%d)", nslices, p->max_slices);
     return P3D_OK;
@@ -754,6 +757,55 @@ int p3d_fft2_c64(p3d_plan* p, const void* in, void* out, int nslices, int invers
     HIP_TRY(hipMemcpy(p->st_x, in, bytes, hipMemcpyHostToDevice));
     if ((rc = p3d_fft2_c64_dev(p, p->st_x, p->st_out, nslices, inverse))) return rc;
     HIP_TRY(hipMemcpy(out, p->st_out, bytes, hipMemcpyDeviceToHost));
+    return P3D_OK;
+}
+
+// 'data-driven' schedule (POCS.py:356-362) without downloading the spectrum: see include/p3d.h and p3d_select.hip
+int p3d_pocs_sorted_spectrum(p3d_plan* p, const void* x, int nslices, float* peaks)
+{
+    int rc = check_batch(p, nslices);
+    if (rc) return rc;
+    if (!x || !peaks) return fail(P3D_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t per = p->slice_elems(), bytes = sizeof(c32) * per * nslices;
+    if (per * (size_t)nslices > 0xffffffffull) return fail(P3D_ERR_UNSUPPORTED, "%zu samples per batch: the segmented sort indexes with 32 bits", per * (size_t)nslices);
+    if ((rc = ensure_staging(p, sizeof(c32) * per * p->max_slices))) return rc;
+    HIP_TRY(hipMemcpy(p->st_x, x, bytes, hipMemcpyDefault));
+    if ((rc = fft2_enqueue(p, p->st_x, p->st_out, nslices, 0))) return rc;
+    float* dpeaks = nullptr;
+    HIP_TRY(hipMalloc((void**)&dpeaks, sizeof(float) * 2 * nslices));
+    const hipError_t e = lex_sort_desc((c32*)p->st_out, p->st_x, per, nslices, dpeaks, p->stream);   // keys in st_out, sorted in st_x
+    hipError_t e2 = hipSuccess;
+    if (e == hipSuccess) e2 = hipMemcpy(peaks, dpeaks, sizeof(float) * 2 * nslices, hipMemcpyDeviceToHost);
+    hipFree(dpeaks);
+    HIP_TRY(e);
+    HIP_TRY(e2);
+    p->sorted_slices = nslices;
+    return P3D_OK;
+}
+
+int p3d_pocs_data_driven_pick(p3d_plan* p, int nslices, int niter, const float* bounds, float* tau, int64_t* count)
+{
+    if (!p) return fail(P3D_ERR_INVALID, "NULL plan");
+    if (!bounds || !tau || !count || niter < 1) return fail(P3D_ERR_INVALID, "NULL buffer or niter < 1");
+    if (p->sorted_slices != nslices || nslices < 1)
+        return fail(P3D_ERR_INVALID, "p3d_pocs_sorted_spectrum has not just run on %d slices of this plan", nslices);
+    HIP_TRY(hipSetDevice(p->device));
+    float *dbounds = nullptr, *dtau = nullptr;
+    long long* dcount = nullptr;
+    hipError_t e = hipMalloc((void**)&dbounds, sizeof(float) * 4 * nslices);
+    if (e == hipSuccess) e = hipMalloc((void**)&dtau, sizeof(float) * 2 * (size_t)niter * nslices);
+    if (e == hipSuccess) e = hipMalloc((void**)&dcount, sizeof(long long) * nslices);
+    if (e == hipSuccess) e = hipMemsetAsync(dtau, 0, sizeof(float) * 2 * (size_t)niter * nslices, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dbounds, bounds, sizeof(float) * 4 * nslices, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = data_driven_pick(p->st_x, p->slice_elems(), nslices, niter, dbounds, dtau, dcount, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tau, dtau, sizeof(float) * 2 * (size_t)niter * nslices, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(count, dcount, sizeof(long long) * nslices, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (dbounds) hipFree(dbounds);
+    if (dtau) hipFree(dtau);
+    if (dcount) hipFree(dcount);
+    HIP_TRY(e);
     return P3D_OK;
 }
 

@@ -112,6 +112,31 @@ def _data_driven(x_fwd, niter, p_max, p_min):
     return tau
 
 
+def _data_driven_batch(plan, chunk, active, niter, p_max, p_min):
+    """'data-driven' schedules of a batch of slices (POCS.py:356-362).  The spectrum stays on the device: sorted there in NumPy's
+    complex order, the bounds formed here exactly as the reference forms them (p * x_fwd.max(): a Python float times a complex64
+    scalar), the picks read back.  p_min='adaptive' takes its bound from np.linalg.norm of the spectrum: that one is computed on
+    the downloaded spectrum as before."""
+    n = chunk.shape[0]
+    tau = np.zeros((n, niter), np.complex128)
+    live = np.flatnonzero(active)
+    if live.size == 0:
+        return tau
+    if isinstance(p_min, str):
+        X0 = plan.fft2(chunk.astype(np.complex64))
+        for s in live:
+            tau[s] = _data_driven(X0[s], niter, p_max, p_min)
+        return tau
+    peaks = plan.sorted_spectrum(chunk)                      # x_fwd.max() per slice, complex64
+    lo = np.asarray([p_min * pk for pk in peaks])            # weak Python scalar times complex64 scalar -> complex64 (POCS.py:293-294)
+    hi = np.asarray([p_max * pk for pk in peaks])
+    picks, count = plan.data_driven_pick(lo, hi, niter)
+    if np.any(count[live] == 0):
+        raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # v[0] of an empty selection (POCS.py:360)
+    tau[live] = picks[live]
+    return tau
+
+
 def get_threshold_decay(
     thresh_model,
     niter: int,
@@ -533,10 +558,7 @@ def pocs_cube(
             stats[~active, ..., 1] = 0.0
             tau = _shearlet_schedule_from_stats(stats, (nil, nxl), thresh_model, niter, p_max, p_min, decay_kind)
         elif thresh_model == 'data-driven':
-            X0 = plan.fft2(chunk.astype(np.complex64))
-            tau = np.zeros((n, niter), np.complex128)
-            for s in np.flatnonzero(active):
-                tau[s] = _data_driven(X0[s], niter, p_max, p_min)
+            tau = _data_driven_batch(plan, chunk, active, niter, p_max, p_min)
         else:
             stats = plan.stats(chunk)
             stats[~active] = 1.0  # keep NaNs of empty slices out of the (unused) schedule rows

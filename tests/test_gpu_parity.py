@@ -544,6 +544,35 @@ def test_generic_path_early_exit_and_zero_slice(P, orc):
             assert rel_l2(got[s], want[s]) < TOL
 
 
+@pytest.mark.parametrize("shape,niter", [((64, 64), 10), ((100, 48), 7), ((1024, 1024), 50), ((32, 32), 1)])
+def test_data_driven_schedule_is_picked_on_the_device(P, ffi, orc, shape, niter):
+    """thresh_model='data-driven' (POCS.py:356-362): sort + bounds + picks on the device are, value for value, NumPy's complex
+    sort of the downloaded spectrum; an all-zero slice keeps a zero schedule; an empty selection raises like v[0] does."""
+    nil, nxl = shape
+    mask = orc.synthetic_mask(nil, nxl, 0.6)
+    cube = np.stack([orc.synthetic_slice(nil, nxl, s) * mask for s in range(3)]).astype(np.complex64)
+    cube[1] = 0
+    active = cube.reshape(3, -1).any(axis=1)
+    with ffi.Plan(nil, nxl, 3) as plan:
+        got = P._data_driven_batch(plan, cube, active, niter, 0.99, 1e-3)
+        X0 = plan.fft2(cube)
+        for s in (0, 2):
+            want = P._data_driven(X0[s], niter, 0.99, 1e-3)
+            assert want.dtype == np.complex64
+            np.testing.assert_array_equal(got[s].astype(np.complex64), want)
+        assert not got[1].any()
+        # the whole job: same result through the public entry point as with the host-side schedule
+        if niter > 1 and nil <= 128:
+            res = P.pocs_cube(cube, mask, niter=niter, thresh_op="hard", thresh_model="data-driven", eps=0.0, p_max=0.99, p_min=1e-3)
+            tau = np.zeros((3, niter), np.complex128)
+            for s in (0, 2):
+                tau[s] = P._data_driven(X0[s], niter, 0.99, 1e-3)
+            ref, _, _, _ = plan.run(cube, mask.astype(np.float32), tau, niter, thresh_op="hard", active=active)
+            np.testing.assert_array_equal(res, ref)
+        with pytest.raises(IndexError):
+            P._data_driven_batch(plan, cube, active, niter, 1e-30, 1e-3)   # tau_max below tau_min: nothing in between
+
+
 @pytest.mark.parametrize("op,shape", [("hard-percentile", (64, 64)), ("soft-percentile", (48, 40)), ("garrote-percentile", (128, 32))])
 def test_percentile_operators_vs_oracle(P, orc, op, shape):
     _, mask, obs = orc.synthetic_cube(shape[0], shape[1], 3, 0.5)
