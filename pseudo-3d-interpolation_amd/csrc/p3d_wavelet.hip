@@ -434,41 +434,65 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
     // valid outputs of this tile (the last tile of an axis is mostly empty) and the coefficients they need
     const int nvh = min(OH, (u.enabled ? u.n1 : RH) - m0), nvw = min(OW, (u.enabled ? u.n2 : RW) - n0);
     const int KHv = (nvh + 1) / 2 + HL - 1, KWv = (nvw + 1) / 2 + HL - 1;
-    constexpr int KR = TILE == 32 ? 5 : 3, MC = (TILE + MAXL / 2 - 1 + LX - 1) / LX;
-    for (int rb = ty; rb < KHv; rb += KR * LY) {
-        T va[KR][MC], vh[KR][MC], vv[KR][MC], vd[KR][MC];
+    if constexpr (LT != 0) {
+        // the KH x KW coefficients of the tile as ONE index range over the 256 threads (5 loads per array and thread for db4
+        // instead of 5 x 2, half of them for the three columns beyond the lanes' own); LDS index = that index (pitch KW)
+        constexpr int KHc = TILE + LT / 2 - 1, KWc = KHc, NE = (KHc * KWc + 255) / 256;
+        T va[NE], vh[NE], vv[NE], vd[NE];
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            const int kr = rb + k * LY, gr = kr0 + kr;
-#pragma unroll
-            for (int m = 0; m < MC; ++m) {
-                const int kc = tx + m * LX, gc = kc0 + kc;
-                va[k][m] = vh[k][m] = vv[k][m] = vd[k][m] = zero_of<T>();
-                if (kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
-                    const size_t o = (size_t)gr * Wo + gc;
-                    va[k][m] = pa[(size_t)gr * a_ld + gc];
-                    vh[k][m] = pd[o];
-                    vv[k][m] = pd[cnt + o];
-                    vd[k][m] = pd[2 * cnt + o];
-                }
+        for (int k = 0; k < NE; ++k) {
+            const int e = (int)threadIdx.x + k * 256, kr = e / KWc, kc = e - kr * KWc, gr = kr0 + kr, gc = kc0 + kc;
+            va[k] = vh[k] = vv[k] = vd[k] = zero_of<T>();
+            if (kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
+                const size_t o = (size_t)gr * Wo + gc;
+                va[k] = pa[(size_t)gr * a_ld + gc];
+                vh[k] = pd[o];
+                vv[k] = pd[cnt + o];
+                vd[k] = pd[2 * cnt + o];
             }
         }
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            const int kr = rb + k * LY;
-#pragma unroll
-            for (int m = 0; m < MC; ++m) {
-                const int kc = tx + m * LX, i = kr * KW + kc;
-                if (kr < KHv && kc < KWv) { s_a[i] = va[k][m]; s_h[i] = vh[k][m]; s_v[i] = vv[k][m]; s_d[i] = vd[k][m]; }
+        for (int k = 0; k < NE; ++k) {
+            const int e = (int)threadIdx.x + k * 256, kr = e / KWc, kc = e - kr * KWc;
+            if (kr < KHv && kc < KWv) { s_a[e] = va[k]; s_h[e] = vh[k]; s_v[e] = vv[k]; s_d[e] = vd[k]; }
+        }
+    } else {
+        constexpr int KR = TILE == 32 ? 5 : 3, MC = (TILE + MAXL / 2 - 1 + LX - 1) / LX;
+        for (int rb = ty; rb < KHv; rb += KR * LY) {
+            T va[KR][MC], vh[KR][MC], vv[KR][MC], vd[KR][MC];
+    #pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int kr = rb + k * LY, gr = kr0 + kr;
+    #pragma unroll
+                for (int m = 0; m < MC; ++m) {
+                    const int kc = tx + m * LX, gc = kc0 + kc;
+                    va[k][m] = vh[k][m] = vv[k][m] = vd[k][m] = zero_of<T>();
+                    if (kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
+                        const size_t o = (size_t)gr * Wo + gc;
+                        va[k][m] = pa[(size_t)gr * a_ld + gc];
+                        vh[k][m] = pd[o];
+                        vv[k][m] = pd[cnt + o];
+                        vd[k][m] = pd[2 * cnt + o];
+                    }
+                }
+            }
+    #pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int kr = rb + k * LY;
+    #pragma unroll
+                for (int m = 0; m < MC; ++m) {
+                    const int kc = tx + m * LX, i = kr * KW + kc;
+                    if (kr < KHv && kc < KWv) { s_a[i] = va[k][m]; s_h[i] = vh[k][m]; s_v[i] = vv[k][m]; s_d[i] = vd[k][m]; }
+                }
             }
         }
     }
     __syncthreads();
     // undo axis 0: out[m] = sum_t a[m/2 + t] rec_lo[(m&1) + L-2 - 2t] + d[...] rec_hi[...], t < L/2.  Column kc, output rows
     // ml = ty*R + q; rows 2i and 2i+1 read the same coefficients.  Taps from LDS, as in the analysis kernel.
-    for (int kc = tx; kc < KWv && ty * R < nvh; kc += LX) {
+    auto undo_axis0 = [&](const int kc, const int tyg) {
         Acc<T> lo[R / 2], hi[R / 2];   // (even row, odd row) pairs
-        const int i0 = (ty * R / 2) * KW + kc;
+        const int i0 = (tyg * R / 2) * KW + kc;
         for (int t = 0; t < HL; ++t) {
             const float4 g = s_tap[t];        // rec_lo[L-2-2t], rec_hi[L-2-2t] (even rows), rec_lo[L-1-2t], rec_hi[L-1-2t] (odd rows)
 #pragma unroll
@@ -482,10 +506,20 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
         }
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
-            s_lo[(ty * R + 2 * q) * KW + kc] = lo[q].first();
-            s_lo[(ty * R + 2 * q + 1) * KW + kc] = lo[q].second();
-            s_hi[(ty * R + 2 * q) * KW + kc] = hi[q].first();
-            s_hi[(ty * R + 2 * q + 1) * KW + kc] = hi[q].second();
+            s_lo[(tyg * R + 2 * q) * KW + kc] = lo[q].first();
+            s_lo[(tyg * R + 2 * q + 1) * KW + kc] = lo[q].second();
+            s_hi[(tyg * R + 2 * q) * KW + kc] = hi[q].first();
+            s_hi[(tyg * R + 2 * q + 1) * KW + kc] = hi[q].second();
+        }
+    };
+    if (tx < KWv && ty * R < nvh) undo_axis0(tx, ty);
+    // the L/2 - 1 columns beyond the lanes' own (3 for db4): as (column, row group) items on the first lanes of the workgroup --
+    // a second sweep `kc += LX` cost every wavefront a full pass for three active lanes
+    {
+        const int extra = KWv - LX;
+        for (int it = threadIdx.x; it < extra * LY; it += 256) {
+            const int tyg = it / extra, kc = LX + (it - tyg * extra);
+            if (tyg * R < nvh) undo_axis0(kc, tyg);
         }
     }
     __syncthreads();
