@@ -552,10 +552,11 @@ int p3d_memcpy_d2h(p3d_plan* p, void* dst, const void* src, size_t bytes)
 // ---- internal helpers ---------------------------------------------------------------------------
 // Diagnostic switches of one job: every one selects a slower, equivalent path.  Read once per call of
 // p3d_pocs_run_dev, on the calling thread, and handed down as plain values -- the launch paths never consult the environment.
-struct RunSwitches { bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore, force_colpipe, no_colpipe; };
+struct RunSwitches { bool no_pct_fused; bool no_mask_bits, no_compact, no_real, no_sparse, real_2048, no_resident, no_tstore, force_colpipe, no_colpipe; };
 static RunSwitches read_switches()
 {
     RunSwitches s;
+    s.no_pct_fused = getenv("P3D_NO_PCT_FUSED") != nullptr;
     s.no_mask_bits = getenv("P3D_NO_MASK_BITS") != nullptr;
     s.no_compact = getenv("P3D_NO_COMPACT") != nullptr;
     s.no_real = getenv("P3D_NO_REAL") != nullptr;
@@ -1064,7 +1065,11 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
 
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
 
-    if (percentile && !p->generic) {
+    // The -percentile operators rank the moduli of the whole spectrum (np.percentile, POCS.py:43-57).  The fused passes can do it
+    // where the column-blocked work buffer holds exactly the slice (no padding columns): the column pass is split into forward
+    // transform | rank + threshold | inverse transform.  Otherwise:
+    const bool pct_fused = percentile && !p->generic && !sw.no_pct_fused && wk_slice_stride(p->nil, p->nxl) == p->slice_elems();
+    if (percentile && !p->generic && !pct_fused) {
         // the tuned kernels never materialise the spectrum; ranking it needs the unfused pipeline -> a second, generic plan
         if (!p->pct_plan) {
             p3d_plan* q = nullptr;
@@ -1151,7 +1156,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // Small slices (32 ... 128 points per axis, at most 8192 per slice): the whole job in ONE kernel, a workgroup per slice, the
     // slice in registers and LDS for all iterations (p3d_resident.hip).  Bit-identical to the passes below, which stay for the
     // options it does not cover (APOCS, non-binary masks) and behind P3D_NO_RESIDENT=1.
-    if (!nonbinary && !adaptive && !sw.no_resident && !flex_rows && !is_flex(p->ops_col) && resident_supported(p->nil, p->nxl) &&
+    if (!nonbinary && !adaptive && !percentile && !sw.no_resident && !flex_rows && !is_flex(p->ops_col) && resident_supported(p->nil, p->nxl) &&
         (size_t)p->nil * p->nxl <= RESIDENT_MAX_POINTS) {
         ResidentArgs ra{};
         ra.x = x; ra.out = out; ra.bits = p->bits; ra.tau = p->tau; ra.done = p->done; ra.sums = p->sums;
@@ -1215,7 +1220,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // Real cubes with the hard operator: the spectrum stays Hermitian, so row pairs share one complex transform and the work
     // buffer holds half the columns (row_real_kernel).  Needs the compact observed samples and the lane-mask tables.
     // (The flexible-length row pass keeps the pair in LDS and takes any real mask: no compact samples, no tables needed there.)
-    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && p->ops_row->row_real != nullptr && !sw.no_real &&
+    bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && !percentile && p->ops_row->row_real != nullptr && !sw.no_real &&
                      (flex_rows ? p->nil % 2 == 0 : (compact && r.bits64 && r.cbase && p->pipe_wgs > 0));
     if (real_path) {
         const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
@@ -1253,7 +1258,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     c.niter = niter;
     c.op = base_op;
     // tiles of the spectrum that the threshold empties are neither transformed back, stored nor read again
-    const bool sparse = p->sparse_ok && !sw.no_sparse;
+    const bool sparse = p->sparse_ok && !sw.no_sparse && !percentile;   // (a percentile keeps a fixed share of the coefficients)
     const int nblocks = (p->nxl + 7) / 8, groups = flex_rows ? 1 : p->ops_row->tpl / 8;
     const int col_t = is_flex(p->ops_col) ? flex_col_tile(p->nil) : p->ops_col->col_tile;
     if (sparse) {
@@ -1275,10 +1280,56 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     const int tiles_work = (n2_work + col_t - 1) / col_t;
     c.n2 = n2_work;
 
+    // -percentile operators: ranks and interpolation weights of np.percentile for every iteration (tau holds the percentages)
+    std::vector<unsigned> pct_sel_h;
+    std::vector<float> pct_frac_h;
+    if (percentile) {
+        const size_t per_slice = p->slice_elems();
+        if (!p->pct_sel) {
+            HIP_TRY(hipMalloc((void**)&p->pct_sel, sizeof(unsigned) * 16 * (size_t)p->max_slices));
+            HIP_TRY(hipMalloc((void**)&p->pct_hist, sizeof(unsigned) * 2048 * (size_t)p->max_slices));
+            HIP_TRY(hipMalloc((void**)&p->pct_frac, sizeof(float) * (size_t)p->max_slices));
+        }
+        pct_sel_h.assign((size_t)niter * nslices * 16, 0u);
+        pct_frac_h.assign((size_t)niter * nslices, 0.f);
+        for (int k = 0; k < niter; ++k)
+            for (int s = 0; s < nslices; ++s) {
+                const double perc = tau[2 * ((size_t)s * niter + k)];
+                double pos = perc / 100.0 * (double)(per_slice - 1);
+                if (!(pos >= 0.0)) pos = 0.0;
+                if (pos > (double)(per_slice - 1)) pos = (double)(per_slice - 1);
+                const double fl = std::floor(pos);
+                unsigned* sel = &pct_sel_h[(size_t)k * nslices * 16];
+                sel[(size_t)s * 8] = (unsigned)fl;
+                sel[((size_t)nslices + s) * 8] = (unsigned)std::min(fl + 1.0, (double)(per_slice - 1));
+                pct_frac_h[(size_t)k * nslices + s] = (float)(pos - fl);
+            }
+        HIP_TRY(hipMemsetAsync(p->pct_hist, 0, sizeof(unsigned) * 2048 * (size_t)nslices, p->stream));
+    }
+
     HIP_TRY(stamp());
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
-        {
+        if (percentile) {
+            // forward column transform | rank |X|, tau_k = the interpolated order statistic, threshold | inverse column transform
+            const size_t per_slice = p->slice_elems();
+            ColArgs cf = c;
+            cf.tau = nullptr;
+            cf.nzflag = nullptr;
+            HIP_TRY(p->ops_col->col(COL_FWD, cf, p->stream));
+            HIP_TRY(hipMemcpyAsync(p->pct_sel, &pct_sel_h[(size_t)k * nslices * 16], sizeof(unsigned) * 16 * (size_t)nslices, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(p->pct_frac, &pct_frac_h[(size_t)k * nslices], sizeof(float) * nslices, hipMemcpyHostToDevice, p->stream));
+            for (int which = 0; which < 2; ++which) {
+                unsigned* sel = p->pct_sel + (size_t)which * nslices * 8;
+                for (int level = 0; level < 3; ++level) {
+                    HIP_TRY(gen_launch_pct_hist(p->work, per_slice, sel, p->pct_hist, level, nslices, p->stream));
+                    HIP_TRY(gen_launch_pct_scan(sel, p->pct_hist, level, nslices, p->stream));
+                }
+            }
+            HIP_TRY(gen_launch_pct_tau(p->pct_sel, p->pct_sel + (size_t)nslices * 8, p->pct_frac, p->tau, niter, k, nslices, p->stream));
+            HIP_TRY(gen_launch_shrink(p->work, p->tau, niter, k, base_op, nslices, per_slice, c.done, p->stream));
+            HIP_TRY(p->ops_col->col(COL_INV, cf, p->stream));
+        } else {
             hipError_t ce = hipErrorNotSupported;
             if (colpipe) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
             if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_ITER, c, p->stream);

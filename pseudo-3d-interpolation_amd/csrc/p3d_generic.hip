@@ -207,34 +207,62 @@ __global__ void gen_stats_kernel(const c32* w, float* partial, size_t per_slice)
 // sel[s*8 + ..]: [0] rank still to find inside the current prefix, [1] prefix bits found so far, [2] result bits
 __global__ void pct_hist_kernel(const c32* w, size_t per_slice, const unsigned* sel, unsigned* hist, int level)
 {
+    // (a workgroup counts into LDS first: the top bits of |X| fall into a handful of bins, and every thread of the slice used to
+    // queue up on those few words of global memory)
+    __shared__ unsigned h[2048];
     const int s = blockIdx.y;
     const unsigned prefix = sel[s * 8 + 1];
     const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
     const int bits = level == 2 ? 10 : 11;
     const unsigned pmask = level == 0 ? 0u : (level == 1 ? 0xFFE00000u : 0xFFFFFC00u);
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_slice; i += (size_t)gridDim.x * blockDim.x) {
         const c32 v = w[(size_t)s * per_slice + i];
         const unsigned key = __float_as_uint(sqrtf(v.x * v.x + v.y * v.y));
-        if ((key & pmask) == prefix) atomicAdd(&hist[(size_t)s * 2048 + ((key >> shift) & ((1u << bits) - 1u))], 1u);
+        if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & ((1u << bits) - 1u)], 1u);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+        if (h[i] != 0u) atomicAdd(&hist[(size_t)s * 2048 + i], h[i]);
 }
 __global__ void pct_scan_kernel(unsigned* sel, unsigned* hist, int level, int nslices)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nslices) return;
+    // one wavefront per slice: lane l sums bins [32 l, 32 l + 32), a shuffle scan finds the lane whose range holds the rank
+    const int s = blockIdx.x, lane = threadIdx.x;
     const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
-    const int nb = level == 2 ? 1024 : 2048;
-    unsigned rank = sel[s * 8 + 0], run = 0;
-    int b = 0;
-    for (; b < nb; ++b) {
-        const unsigned c = hist[(size_t)s * 2048 + b];
-        if (rank < run + c) break;
-        run += c;
+    const int nb = level == 2 ? 1024 : 2048, per = nb / 64;
+    unsigned* h = hist + (size_t)s * 2048;
+    const unsigned rank = sel[s * 8 + 0];
+    unsigned mine = 0;
+    for (int i = 0; i < per; ++i) mine += h[lane * per + i];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
     }
-    if (b == nb) b = nb - 1;
-    sel[s * 8 + 0] = rank - run;
-    sel[s * 8 + 1] |= (unsigned)b << shift;
-    for (int i = 0; i < 2048; ++i) hist[(size_t)s * 2048 + i] = 0;
+    const unsigned before = incl - mine;
+    const bool holds = rank >= before && rank < incl;
+    const unsigned long long vote = __ballot(holds);
+    // (rank beyond the total -- cannot happen for ranks < per_slice -- falls into the last bin, as the serial scan did)
+    const int owner = vote ? __ffsll((long long)vote) - 1 : 63;
+    if (lane == owner) {
+        unsigned run = before;
+        int b = lane * per;
+        const int end = b + per;
+        for (; b < end; ++b) {
+            const unsigned c = h[b];
+            if (rank < run + c) break;
+            run += c;
+        }
+        if (b >= nb) b = nb - 1;
+        if (b == end) { b = end - 1; run -= h[b]; }
+        sel[s * 8 + 0] = rank - run;
+        sel[s * 8 + 1] |= (unsigned)b << shift;
+    }
+    __syncthreads();
+    for (int i = lane; i < 2048; i += 64) h[i] = 0;
 }
 // tau[s] = lo + (hi - lo) * frac   (np.percentile, linear interpolation between the two neighbouring order statistics)
 __global__ void pct_tau_kernel(const unsigned* sel_lo, const unsigned* sel_hi, const float* frac, c32* tau, int niter, int iter, int nslices)
@@ -247,13 +275,14 @@ __global__ void pct_tau_kernel(const unsigned* sel_lo, const unsigned* sel_hi, c
 
 hipError_t gen_launch_pct_hist(const c32* w, size_t per_slice, const unsigned* sel, unsigned* hist, int level, int nslices, hipStream_t st)
 {
-    const unsigned bx = (unsigned)((per_slice + 255) / 256 < 512 ? (per_slice + 255) / 256 : 512);
+    const size_t want = (per_slice + 4095) / 4096;   // ~16 samples per thread
+    const unsigned bx = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
     pct_hist_kernel<<<dim3(bx, nslices), 256, 0, st>>>(w, per_slice, sel, hist, level);
     return hipGetLastError();
 }
 hipError_t gen_launch_pct_scan(unsigned* sel, unsigned* hist, int level, int nslices, hipStream_t st)
 {
-    pct_scan_kernel<<<(nslices + 63) / 64, 64, 0, st>>>(sel, hist, level, nslices);
+    pct_scan_kernel<<<nslices, 64, 0, st>>>(sel, hist, level, nslices);
     return hipGetLastError();
 }
 hipError_t gen_launch_pct_tau(const unsigned* sel_lo, const unsigned* sel_hi, const float* frac, c32* tau, int niter, int iter, int nslices,

@@ -573,8 +573,12 @@ def test_data_driven_schedule_is_picked_on_the_device(P, ffi, orc, shape, niter)
             P._data_driven_batch(plan, cube, active, niter, 1e-30, 1e-3)   # tau_max below tau_min: nothing in between
 
 
-@pytest.mark.parametrize("op,shape", [("hard-percentile", (64, 64)), ("soft-percentile", (48, 40)), ("garrote-percentile", (128, 32))])
-def test_percentile_operators_vs_oracle(P, orc, op, shape):
+@pytest.mark.parametrize("op,shape", [("hard-percentile", (64, 64)), ("soft-percentile", (48, 40)), ("garrote-percentile", (128, 32)),
+                                      ("hard-percentile", (256, 512)), ("soft-percentile", (100, 36))])
+def test_percentile_operators_vs_oracle(P, orc, op, shape, monkeypatch):
+    """np.percentile of the spectrum moduli per iteration (POCS.py:43-57).  Ranked inside the fused passes (column pass split
+    into forward | rank + threshold | inverse) where the work buffer holds exactly the slice (every shape here but 100 x 36),
+    on the unfused pipeline otherwise; both against the oracle, and against each other."""
     _, mask, obs = orc.synthetic_cube(shape[0], shape[1], 3, 0.5)
     # percentages well inside the bulk of the distribution: neighbouring order statistics are then far apart compared to
     # float32 rounding and the kept / zeroed sets are unambiguous
@@ -583,6 +587,10 @@ def test_percentile_operators_vs_oracle(P, orc, op, shape):
     want = orc.pocs_cube(obs.astype(np.complex128), mask, **params)
     for s in range(3):
         assert rel_l2(got[s], want[s]) < (TOL if op != "garrote-percentile" else 2e-4), (s, rel_l2(got[s], want[s]))
+    monkeypatch.setenv("P3D_NO_PCT_FUSED", "1")
+    unfused = P.pocs_cube(obs, mask, **params)
+    for s in range(3):
+        assert rel_l2(got[s], unfused[s]) < (TOL if op != "garrote-percentile" else 2e-4), (s, rel_l2(got[s], unfused[s]))
 
 
 def test_batching_is_transparent(P, orc):
