@@ -539,7 +539,9 @@ def main():
                         "iterations_per_s_best": K / float(np.min(times)) * scale,
                         "note": "`value` = steps / median job time; a job = statistics + schedule + the K iterations + final store"},
             "steady_state_iterations_per_s": None if steady is None else steady * scale,
-            "fixed_ms_per_job": None if steady is None else seconds * 1e3 - K * 1e3 / steady,
+            # (the steady rate comes from the per-launch HIP events of a profiled repeat; on cubes whose iteration takes a fraction
+            # of a millisecond the event records themselves lengthen it, and the difference below would come out negative: null)
+            "fixed_ms_per_job": None if steady is None or seconds * 1e3 < K * 1e3 / steady else seconds * 1e3 - K * 1e3 / steady,
             "slice_iterations_per_s": K / seconds * nslices,
             "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / (seconds / scale),
             "device_ms_rank0": float(np.median(dev_times)),
