@@ -1,9 +1,10 @@
 #!/bin/bash
 # Run on the GPU box:  bash tools/pmc_kernels.sh <outdir-name> "<counters>" <script.py>   -> per-kernel counter means (torch-free scripts only)
+# ONE TCC counter (FETCH_SIZE, WRITE_SIZE ...) per call: two of them in one pass hung the run on this pool
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$1; PMC="$2"; shift 2
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT -- python3 $R/$1 > $OUT.log 2>&1 || { tail -5 $OUT.log; exit 1; }
+timeout -k 10 150 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT -- python3 $R/$1 > $OUT.log 2>&1 || { tail -5 $OUT.log; exit 1; }
 cd $R
 f=$(find $OUT -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<PY
