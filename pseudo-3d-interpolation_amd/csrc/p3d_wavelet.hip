@@ -245,7 +245,24 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     // 32-bit element offsets from the slice base (a level of one slice has < 2^31 samples) keep the address arithmetic short --
     // it, not the filtering, is most of the VALU work of this kernel.
     constexpr int KR = TILE == 32 ? 9 : 6, MC = (2 * TILE + MAXL - 2 + LX - 1) / LX;   // db4 .. coif2 at TILE 32: one batch
-    if (inside) {
+    if (LT != 0 && inside && vh == TILE && vw == TILE) {
+        // a whole interior tile with the filter length known: its IH x IW samples as ONE index range over the 256 threads
+        // (20 loads per thread for db4 where the row / column-step batches below issue 27), LDS index = that index
+        constexpr int IHc = 2 * TILE + LT - 2, IWc = IHc, NE = (IHc * IWc + 255) / 256;
+        const T* g = src + (size_t)r0 * W + c0;
+        T v[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = (int)threadIdx.x + k * 256, r = e / IWc, c = e - r * IWc;
+            v[k] = zero_of<T>();
+            if (e < IHc * IWc) v[k] = g[(unsigned)r * (unsigned)W + (unsigned)c];
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = (int)threadIdx.x + k * 256;
+            if (e < IHc * IWc) s_in[e] = v[k];
+        }
+    } else if (inside) {
         const T* g = src + (size_t)r0 * W + c0;
         for (int rb = ty; rb < IHv; rb += KR * LY) {
             T v[KR][MC];
