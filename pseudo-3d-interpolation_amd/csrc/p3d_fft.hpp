@@ -237,15 +237,20 @@ struct Plan {
 //     them, at compile-time offsets from one per-thread base (no address arithmetic, no extra registers).
 //     Forward table first, inverse table at offset N.  Twice the LDS: used by the row pass, which is
 //     limited by registers, not by LDS.
+// P3D_EXP_HALFWG (experiment builds only, WRONG results): the inverse table aliases the forward one -- what a shared table would
+// cost in LDS -- to time two 8-row workgroups per CU in row_pipe64_kernel (profiles/r02_rowpass_two_workgroups.txt)
+#ifndef P3D_EXP_HALFWG
+#define P3D_EXP_HALFWG 0
+#endif
 template <int N>
 struct PassTables {
     static constexpr int off(int dir, int p)
     {
-        int o = dir == FWD ? 0 : N;
+        int o = dir == FWD ? 0 : (P3D_EXP_HALFWG ? 0 : N);
         for (int q = 1; q < p; ++q) o += (Plan<N>::radix(dir, q) - 1) * Plan<N>::ns(dir, q);
         return o;
     }
-    static constexpr int slots() { return 2 * N; }
+    static constexpr int slots() { return P3D_EXP_HALFWG ? N : 2 * N; }
     static void build(c32* out)
     {
         using PL = Plan<N>;

@@ -748,7 +748,7 @@ constexpr int pipe64_rows()
     constexpr int TPL = Plan<N>::TPL;
     // rows of several wavefronts synchronise the whole workgroup at every exchange of a transform: two rows per workgroup (the
     // pair that shares 128-byte lines), several workgroups per CU (2048 samples: 2.19 ms against 2.83 with 7 rows, 5.87 before)
-    int rows = TPL > 64 ? P3D_PIPE64_MAXROWS : 1024 / TPL;
+    int rows = TPL > 64 ? P3D_PIPE64_MAXROWS : ((P3D_EXP_HALFWG && TPL == 64) ? 8 : 1024 / TPL);
     while (rows > 1 && sizeof(c32) * (PassTables<N>::slots() + (size_t)rows * (LdsRow::stride(N) + (TPL == 64 ? 4 : 0))) + 16 * sizeof(double) > 160 * 1024) --rows;
     return rows;
 }
@@ -856,7 +856,7 @@ enum PipeMode { PIPE_MID = 0, PIPE_FIRST = 1, PIPE_LAST = 2 };
 // LDS before they are stored, so that ONE dwordx4 instruction writes the 1-KiB run [16 rows][8 columns] of a column block -- whole
 // 128-byte lines, half the line accesses of sixteen rows' 64-byte pieces and half the store instructions (8 instead of 16).
 template <int N, int DT, bool SPARSE, int PM, bool TS = false>
-__global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
+__global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;
