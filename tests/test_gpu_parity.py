@@ -44,7 +44,10 @@ def _rand_c(shape, seed):
                                    (4096, 4), (4, 4096), (1024, 1024),
                                    # any-length fallback (mixed radix 2/3/4/5/7 + direct butterflies for larger primes)
                                    (90, 50), (31, 17), (48, 20), (3, 5), (1, 7), (100, 128), (128, 100), (1000, 6),
-                                   (11, 13), (121, 49), (4501, 4), (6, 2500)])
+                                   (11, 13), (121, 49), (4501, 4), (6, 2500),
+                                   # in-register 11- / 13-point butterflies, rows in place on four wavefronts (1500 direct, 999 chirp-z),
+                                   # persistent column pass (1100, 1300, 2000: one workgroup per CU)
+                                   (1100, 16), (16, 1300), (8, 1500), (999, 16), (16, 999), (2000, 8), (1430, 24)])
 def test_fft2_matches_numpy(ffi, shape):
     n = 3 if shape[0] * shape[1] <= 1 << 18 else 2
     x = _rand_c((n,) + shape, 1)
@@ -734,7 +737,8 @@ def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeyp
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143)])   # last two: chirp-z lengths
+@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143), (48, 999), (330, 52)])
+# (74: chirp-z; 143 = 11 x 13, 330 = 30 x 11, 52 = 4 x 13: in-register prime butterflies; 999: chirp-z rows in place on four wavefronts)
 @pytest.mark.parametrize("kw", [
     dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2),
     dict(niter=8, thresh_op="soft", thresh_model="linear", eps=0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
