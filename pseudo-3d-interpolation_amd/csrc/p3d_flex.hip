@@ -219,8 +219,11 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R])
         const c32 a = x[0] + x[1], b = x[0] - x[1];
         x[0] = a; x[1] = b;
     } else if constexpr (R == 4) {
-        const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], d = mul_di<DIR>(x[1] - x[3]);
-        x[0] = a + s; x[1] = b + d; x[2] = a - s; x[3] = b - d;
+        // b +- DIR i (x1 - x3): one packed add each, the rotation carried by the operand selects (add_ib / sub_ib, p3d_fft.hpp)
+        const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], t = x[1] - x[3];
+        x[0] = a + s; x[2] = a - s;
+        x[1] = DIR > 0 ? add_ib(b, t) : sub_ib(b, t);
+        x[3] = DIR > 0 ? sub_ib(b, t) : add_ib(b, t);
     } else {
         // odd prime: pair x[q] with x[R-q].  W^(qk) = cos + i (DIR sin) gives  X[k], X[R-k] = A_k +- i B_k  with
         // A_k = x0 + sum_q cos(2 pi q k / R) (x[q] + x[R-q]),  B_k = sum_q (DIR sin(2 pi q k / R)) (x[q] - x[R-q]):
@@ -245,8 +248,8 @@ __device__ __forceinline__ void dft_small(c32 (&x)[R])
                 A = A + sp[q - 1] * wq.x;
                 B = B + dm[q - 1] * wq.y;
             }
-            x[k] = c32{A.x - B.y, A.y + B.x};
-            x[R - k] = c32{A.x + B.y, A.y - B.x};
+            x[k] = add_ib(A, B);        // A + i B
+            x[R - k] = sub_ib(A, B);    // A - i B
         }
     }
 }
@@ -333,7 +336,7 @@ __device__ __forceinline__ void flex_pass(const c32* A, c32* B, const c32* tw, P
         } else {
             const int twi = jm * pa.ts;
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = in[t * mstride] * conj_if<DIR>(tw[t * twi]);
+            for (int t = 1; t < R; ++t) v[t] = DIR > 0 ? mul_conj(in[t * mstride], tw[t * twi]) : in[t * mstride] * tw[t * twi];
         }
         radix_apply<R1, R2, DIR>(v);
 #pragma unroll
@@ -375,7 +378,7 @@ __device__ __forceinline__ void flex_pass_inplace(c32* A, const c32* tw, PassArg
         } else {
             const int twi = jm * pa.ts;
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = in[t * pa.nb] * conj_if<DIR>(tw[t * twi]);
+            for (int t = 1; t < R; ++t) v[t] = DIR > 0 ? mul_conj(in[t * pa.nb], tw[t * twi]) : in[t * pa.nb] * tw[t * twi];
         }
     }
     flex_sync<SYNC>();   // every input of the pass is in registers
