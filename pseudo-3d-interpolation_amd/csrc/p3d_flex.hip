@@ -785,19 +785,35 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
             if (nzf) kept = kept && nzf[i >> tsh] != 0;
             A[i] = kept ? wrow[(size_t)(i >> 3) * wblk + (i & 7)] : c32{0.f, 0.f};
         }
+        // The observed samples and weights of the row are requested HERE, in front of the inverse transform, and used after it
+        // (rows of up to PFN * TPR samples; longer rows load the rest where they use it): the pass is latency bound -- 70 % of its
+        // wave cycles were waits -- and these two loads sat, fully exposed, between the transforms.
+        // Only in the two-buffer kernel with one wavefront per row (four waves per SIMD whatever it does: 1024 x 600 69 -> 81 Gpt/s).
+        // The in-place kernels run six waves per SIMD on 77 registers and lose more to the 24 registers of the prefetch than the
+        // exposed loads cost them (1000 x 1000: 1.02 -> 1.14 ms; 960 x 768 on four wavefronts per row: 57.8 -> 50.5 Gpt/s).
+        constexpr int PFN = (!INPL && TPR == 64) ? 8 : 0;
+        c32 xo_pre[PFN ? PFN : 1];
+        float m_pre[PFN ? PFN : 1];
+        const bool need_obs = !a.plain && valid;
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int i = lane + q * TPR;
+            xo_pre[q] = c32{0.f, 0.f};
+            m_pre[q] = 0.f;
+            if (i < n && need_obs) xo_pre[q] = obs_at(i);
+            if (i < n && mrow && !a.plain) m_pre[q] = mrow[i];
+        }
         flex_sync<SYNC>();
         if constexpr (INPL) flex_transform_inplace<SYNC, INV>(A, tw, a.tw, pl, lane, TPR);
         else X = flex_transform<SYNC, INV, false, true>(A, B, tw, a.tw, pl, 0, lane, TPR);
-        for (int i = lane; i < n; i += TPR) {
+        auto update = [&](const int i, const c32 xo, const float mk) {
             c32 xn = X[i] * a.scale;
             float m = 0.f;
-            c32 xo{0.f, 0.f};
-            if (!a.plain && valid) xo = obs_at(i);
             if (mode == ROW_LAST && a.only_done) {
                 // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
-                if (a.alpha == 1.0f && mrow && mrow[i] == 1.0f) xn = xo;
+                if (a.alpha == 1.0f && mrow && mk == 1.0f) xn = xo;
             } else if (!a.plain) {
-                m = mrow ? mrow[i] : 0.f;
+                m = mk;
                 const float w = 1.0f - a.alpha * m;        // POCS.py:616
                 xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
             }
@@ -815,7 +831,12 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
                     X[i] = xn;
                 }
             }
-        }
+        };
+#pragma unroll
+        for (int q = 0; q < PFN; ++q)
+            if (lane + q * TPR < n) update(lane + q * TPR, xo_pre[q], m_pre[q]);
+        for (int i = lane + PFN * TPR; i < n; i += TPR)
+            update(i, need_obs ? obs_at(i) : c32{0.f, 0.f}, (mrow && !a.plain) ? mrow[i] : 0.f);
         flex_sync<SYNC>();
     }
     if (a.sums != nullptr) {
