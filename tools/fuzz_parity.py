@@ -11,7 +11,8 @@ from oracle import pocs_oracle as orc
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-LENS = [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 20, 48, 60, 75, 100, 120, 250, 300, 500, 1000]
+LENS = [16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 20, 48, 60, 75, 100, 120, 250, 300, 500, 1000,
+        110, 130, 143, 286, 770, 37, 74, 999, 1500, 1100]   # 11- / 13-point butterflies, chirp-z, four-wavefront rows
 bad = 0
 for case in range(ncases):
     while True:
