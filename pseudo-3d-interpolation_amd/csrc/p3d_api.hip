@@ -717,7 +717,13 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     c.in = p->work;
     c.out = p->work;
     c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only);
-    HIP_TRY(p->ops_col->col(COL_SHRINK, c, p->stream));
+    // columns of 2048 points and more: one 8-column tile per CU, so the persistent pass (next tile requested while this one is
+    // transformed) has something to give (see p3d_pocs_run_dev); P3D_NO_COLPIPE=1 switches it off
+    const bool no_colpipe = getenv("P3D_NO_COLPIPE") != nullptr;
+    hipError_t ce = hipErrorNotSupported;
+    if (!no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
+    if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_SHRINK, c, p->stream);
+    HIP_TRY(ce);
     return P3D_OK;
 }
 

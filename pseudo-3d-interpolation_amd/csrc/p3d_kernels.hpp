@@ -1727,7 +1727,9 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 #ifndef P3D_COLPIPE_WAVES_PER_EU
 #define P3D_COLPIPE_WAVES_PER_EU 4
 #endif
-template <int N, int T, int OP>
+// SHEAR: the column pass of a SHEARLET iteration instead (COL_SHRINK of col_kernel: inverse transform, 1/N, real part, threshold
+// with the shearlet's own tau, forward transform; every tile is stored) -- `slice` then counts (slice, shearlet) pairs.
+template <int N, int T, int OP, bool SHEAR = false>
 __global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col_pipe_kernel(const ColArgs a)
 {
     using PL = Plan<N>;
@@ -1756,7 +1758,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col
     typedef const int __attribute__((address_space(4))) * kint_t;
     const kint_t k_done = (kint_t)a.done;
     typedef const unsigned long long __attribute__((address_space(4))) * ktau_t;
-    const ktau_t k_tau = (ktau_t)a.tau;   // [nslices][niter] float2, constant during the launch
+    const ktau_t k_tau = (ktau_t)(SHEAR ? a.sh.tau : a.tau);   // [nslices][niter] (SHEAR: [slice][niter][nsh]) float2, constant during the launch
     struct Tile { unsigned slice, tile; bool on; };
     auto locate = [&](unsigned g) -> Tile {
         Tile t;
@@ -1805,13 +1807,31 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col
         asm volatile("" : "+v"(tl_r));   // (the transforms' LDS / twiddle addresses are recomputed per tile instead of living in registers across the loop)
         // (the threshold through the scalar path: a vector load here would sit BEHIND the sixteen loads of the next tile in the
         // in-order vmcnt queue, and waiting for it would wait for them)
-        const unsigned long long tau_bits = k_tau[(size_t)cur.slice * a.niter + a.iter];
-        line_fft<N, FWD, false>(v, lds, tw, tl_r);
-        const Shrink shr(c32{__uint_as_float((unsigned)tau_bits), __uint_as_float((unsigned)(tau_bits >> 32))}, OP);
+        unsigned long long tau_bits;
+        if constexpr (SHEAR) {
+            const unsigned b = cur.slice / (unsigned)a.sh.nsh, sh = cur.slice - b * (unsigned)a.sh.nsh;
+            tau_bits = k_tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + sh];
+        } else {
+            tau_bits = k_tau[(size_t)cur.slice * a.niter + a.iter];
+        }
+        if constexpr (SHEAR) {
+            line_fft<N, INV, false>(v, lds, tw, tl_r);
+            const Shrink shr(c32{__uint_as_float((unsigned)tau_bits), __uint_as_float((unsigned)(tau_bits >> 32))}, a.sh.op);
+            const float scale = 1.0f / ((float)N * (float)a.n2);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = shr(v[q]);
+            for (int q = 0; q < PPT; ++q) {
+                c32 c = v[q] * scale;
+                if (a.sh.real_only) c.y = 0.f;   // FFST returns the real part for real data
+                v[q] = shr(c);
+            }
+        } else {
+            line_fft<N, FWD, false>(v, lds, tw, tl_r);
+            const Shrink shr(c32{__uint_as_float((unsigned)tau_bits), __uint_as_float((unsigned)(tau_bits >> 32))}, OP);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) v[q] = shr(v[q]);
+        }
         bool kept = true;
-        if (a.nzflag != nullptr) {   // a tile the threshold emptied is zeros after the inverse transform too: say so instead (see col_kernel)
+        if (!SHEAR && a.nzflag != nullptr) {   // a tile the threshold emptied is zeros after the inverse transform too: say so instead (see col_kernel)
             unsigned bits = 0;
 #pragma unroll
             for (int q = 0; q < PPT; ++q) bits |= __float_as_uint(v[q].x) | __float_as_uint(v[q].y);
@@ -1822,7 +1842,8 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col
         // the sixteen stores of a kept tile the wait for the loads is vmcnt(16) -- they were issued first --, not the vmcnt(0) a join
         // of "stores or no stores" would force (dense spectra: 1.71 -> see profiles/r02_colpass_persistent.txt).
         if (kept) {   // workgroup-uniform
-            line_fft<N, INV, false>(v, lds, tw, tl_r);
+            if constexpr (SHEAR) line_fft<N, FWD, false>(v, lds, tw, tl_r);
+            else line_fft<N, INV, false>(v, lds, tw, tl_r);
             bool valid;
             const unsigned vo = lane_off(cur, valid);
             const __amdgpu_buffer_rsrc_t osrd = buf_srd(reinterpret_cast<char*>(a.out) + (size_t)cur.slice * slice_bytes, slice_bytes);
@@ -2087,7 +2108,10 @@ hipError_t launch_col_pipe(const ColArgs& a, int cus, hipStream_t st)
         if ((e = allow_lds(col_pipe_kernel<N, T, OP>, lds)) != hipSuccess) return e;          \
         col_pipe_kernel<N, T, OP><<<grid, T * Plan<N>::TPL, lds, st>>>(a);                    \
     } while (0)
-        if (a.op == 1) P3D_COLPIPE(1); else if (a.op == 2) P3D_COLPIPE(2); else P3D_COLPIPE(0);
+        if (a.sh.tau != nullptr) {   // the column pass of a SHEARLET iteration
+            if ((e = allow_lds(col_pipe_kernel<N, T, 0, true>, lds)) != hipSuccess) return e;
+            col_pipe_kernel<N, T, 0, true><<<grid, T * Plan<N>::TPL, lds, st>>>(a);
+        } else if (a.op == 1) P3D_COLPIPE(1); else if (a.op == 2) P3D_COLPIPE(2); else P3D_COLPIPE(0);
 #undef P3D_COLPIPE
         return hipGetLastError();
     } else {

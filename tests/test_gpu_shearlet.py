@@ -137,7 +137,7 @@ def test_shearlet_golden_runs(so):
         P.POCS_algorithm(xin, mask, transform=shearletTransformSpect, itransform=inverseShearletTransformSpect, transform_kind="SHEARLET")
 
 
-def test_shearlet_config4_slice_at_its_own_size(so):
+def test_shearlet_config4_slice_at_its_own_size(so, monkeypatch):
     """BASELINE configs[4]'s slice as stated: 2048 x 1024 (iline x xline), J = 5 scales = 125 shearlets, 80 % missing, hard threshold,
     exponential decay -- the first iterations of the schedule against the oracle (its multi-threaded real-transform form, which is
     held to the plain oracle loop on a small slice first), plus the size-independent properties on the device: observed traces
@@ -170,6 +170,10 @@ def test_shearlet_config4_slice_at_its_own_size(so):
         assert np.array_equal(got[s][keep], cube[s][keep])                       # observed traces are handed back exactly
     alone = P.pocs_cube(cube[1:2], mask, transform_kind="SHEARLET", auxiliary_data=psi, eps=0.0, **kw)
     assert np.array_equal(alone[0], got[1])                                      # batching is transparent
+    monkeypatch.setenv("P3D_NO_COLPIPE", "1")                                    # 2048-point columns take the persistent column pass:
+    plain = P.pocs_cube(cube[1:2], mask, transform_kind="SHEARLET", auxiliary_data=psi, eps=0.0, **kw)
+    monkeypatch.delenv("P3D_NO_COLPIPE")
+    assert np.array_equal(plain[0], got[1])                                      # ... the same bits as the one-launch pass
     info = {}
     want = so.pocs_slice_shearlet_real(cube[0].astype(np.float64), mask, psi, info=info, **kw)
     err = rel_l2(got[0], want)
