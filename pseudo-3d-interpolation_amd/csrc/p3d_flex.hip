@@ -7,14 +7,19 @@
 // RowArgs / ColArgs interface and on the same column-blocked work buffer, so that every caller in p3d_api.hip (POCS loop,
 // statistics, fft2 hooks, early exit, APOCS) runs unchanged and a slice may mix a tuned axis with a flexible one.
 //
-// Line FFT: mixed-radix Stockham autosort in LDS (ping-pong), factor list computed on the host (odd factors first: the
-// strided writes of a pass with small stride then have an odd stride in banks), radix 2 / 4 butterflies hard-wired, radix 3 / 5
-// / 7 as direct DFTs with constants from the twiddle table, larger primes as direct O(p^2) butterflies.  The twiddle table
-// exp(-2 pi i k / n) sits in LDS.
+// Line FFT: mixed-radix Stockham autosort in LDS.  The factor list AND everything a pass derives from it (strides, twiddle step,
+// the multiplier of its one division) are computed on the host and sit behind the line's twiddle table (FlexFactors); radices are
+// in-register butterflies: 2 ... 16 folded from two factors where possible, 11 and 13 on their own (odd radices first: the strided
+// writes of a pass with small stride then have an odd stride in banks); larger primes run in the chirp-z form on a padded length,
+// or as direct O(p^2) passes where that does not fit.  The direction of a transform is a template parameter, the first pass
+// multiplies by no twiddles.  The twiddle table exp(-2 pi i k / n) sits in LDS.
 //   column pass: a workgroup owns T columns (one 64-byte column block for T = 8); element i of column c lives at X[i*T + c],
-//                which is exactly the tile's layout in the work buffer: loads and stores are linear copies.
-//   row pass:    one wavefront per row (wave-level synchronisation only), LB rows per workgroup.
+//                which is exactly the tile's layout in the work buffer: loads and stores are linear copies.  Long columns (one
+//                workgroup per CU) run persistent workgroups that request the next tile into registers ahead of the transforms.
+//   row pass:    one, two or four wavefronts per row, LB rows per workgroup; in place (one LDS buffer per row, one butterfly per
+//                thread and pass) wherever every pass fits the row's threads, two buffers otherwise.
 // Arithmetic is float32 like the tuned path; results agree with it to rounding (different pass structure).
+// What the round-1 version of this file did wrong, and the measurements: profiles/r02_flex_shape_sweep.txt.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -136,7 +141,6 @@ int pick_row_lines(int n)   // rows per workgroup at one wavefront per row
 // the direction of a transform is a template parameter (DIR = FWD: exp(-...), INV: exp(+...)): as a run-time value it cost a
 // select per twiddle and per butterfly constant
 template <int DIR> __device__ __forceinline__ c32 conj_if(c32 w) { return DIR > 0 ? c32{w.x, -w.y} : w; }
-template <int DIR> __device__ __forceinline__ c32 mul_di(c32 a) { return DIR > 0 ? c32{-a.y, a.x} : c32{a.y, -a.x}; }   // a * (DIR * i)
 
 // exp(2 pi i q / R) for the in-register butterflies: compile-time constants (they used to be read from the twiddle table once per
 // pass: wave-uniform values that the compiler parked in scalar registers -- and spilled, one v_readlane per use)
