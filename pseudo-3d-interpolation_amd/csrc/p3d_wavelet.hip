@@ -11,8 +11,10 @@
 //   * multilevel 2-D: level count floor(log2(min(shape) / (L - 1))); when an approximation is one sample longer than the
 //     details of the next finer level its last sample is ignored;
 //   * complex input = real and imaginary parts transformed independently (the filters are real).
-// Kernels are deliberately simple (one thread per output sample, every pass through HBM): this path exists for coverage and
-// parity (BASELINE configs[3]); the FFT path is the tuned one.
+// The loop runs on the tile kernels (dwt2_tile_kernel / idwt2_tile_kernel: one launch per level and direction, a tile + halo in
+// LDS, both axes filtered there, thresholds and the re-insertion fused into the stores; filter length as a template parameter
+// for db4 / sym4 and db2); the one-thread-per-output-sample per-axis kernels below them are the reference form kept behind
+// P3D_WAVELET_UNFUSED=1 and used for filter banks whose tiles do not fit LDS.  Measurements: profiles/r02_wavelet_levels.txt.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
