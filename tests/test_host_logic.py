@@ -72,6 +72,51 @@ def test_batched_schedule_equals_scalar_schedule():
                     assert np.allclose(got[s], want, rtol=1e-13, atol=0), (model, kind, p_min)
 
 
+class _NumpyPlan:
+    """Stand-in for the device plan in the host-side tests of the 'data-driven' schedule: the three calls _data_driven_batch makes,
+    answered by NumPy exactly as include/p3d.h specifies them (complex64 spectrum, NumPy's lexicographic complex order)."""
+
+    def fft2(self, x):
+        return np.fft.fft2(np.asarray(x, np.complex64)).astype(np.complex64)
+
+    def sorted_spectrum(self, x):
+        X = self.fft2(x)
+        self._sorted = [np.sort(s.ravel())[::-1] for s in X]
+        return np.asarray([s[0] for s in self._sorted], np.complex64)
+
+    def data_driven_pick(self, lo, hi, niter):
+        tau = np.zeros((len(self._sorted), niter), np.complex64)
+        count = np.zeros(len(self._sorted), np.int64)
+        for s, v in enumerate(self._sorted):
+            sel = v[(v > np.complex64(lo[s])) & (v < np.complex64(hi[s]))]
+            count[s] = sel.size
+            if sel.size:
+                idx = [0] + [-(-(i * (sel.size - 1)) // (niter - 1)) for i in range(1, niter)]   # integer ceil
+                tau[s] = sel[idx]
+        return tau, count
+
+
+def test_data_driven_batch_is_the_reference_schedule_per_slice():
+    """_data_driven_batch (bounds on the host in the reference's arithmetic, sort + picks behind the plan) against _data_driven
+    (POCS.py:356-362 restated, pinned by the golden schedules above) -- including the integer form of the reference's float64 ceil,
+    an all-zero slice, the 'adaptive' lower bound (host path) and the IndexError of an empty selection."""
+    rng = np.random.default_rng(5)
+    cube = (rng.standard_normal((4, 24, 20)) + 1j * rng.standard_normal((4, 24, 20))).astype(np.complex64)
+    cube[2] = 0
+    active = cube.reshape(4, -1).any(axis=1)
+    plan = _NumpyPlan()
+    for niter in (1, 2, 7, 33):
+        got = P._data_driven_batch(plan, cube, active, niter, 0.99, 1e-3)
+        X0 = plan.fft2(cube)
+        for s in (0, 1, 3):
+            np.testing.assert_array_equal(got[s].astype(np.complex64), P._data_driven(X0[s], niter, 0.99, 1e-3))
+        assert not got[2].any()
+    adaptive = P._data_driven_batch(plan, cube, active, 5, 0.99, 'adaptive')
+    np.testing.assert_array_equal(adaptive[0].astype(np.complex64), P._data_driven(plan.fft2(cube)[0], 5, 0.99, 'adaptive'))
+    with pytest.raises(IndexError):
+        P._data_driven_batch(plan, cube, active, 5, 1e-30, 1e-3)
+
+
 def test_error_contract_matches_reference():
     tab = {str(r[0]): (str(r[1]), str(r[2])) for r in load_golden("errors.npz")["table"]}
     x = np.ones((8, 8), np.complex64)
