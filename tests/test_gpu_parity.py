@@ -574,6 +574,11 @@ def test_data_driven_schedule_is_picked_on_the_device(P, ffi, orc, shape, niter)
             np.testing.assert_array_equal(res, ref)
         with pytest.raises(IndexError):
             P._data_driven_batch(plan, cube, active, niter, 1e-30, 1e-3)   # tau_max below tau_min: nothing in between
+        # the sorted keys live in the plan's staging buffers: a pick that does not follow its sort directly is refused, not guessed
+        plan.sorted_spectrum(cube)
+        plan.fft2(cube[:1])
+        with pytest.raises(ffi.P3DError):
+            plan.data_driven_pick(np.zeros(3, np.complex64), np.ones(3, np.complex64), niter)
 
 
 @pytest.mark.parametrize("op,shape", [("hard-percentile", (64, 64)), ("soft-percentile", (48, 40)), ("garrote-percentile", (128, 32)),
