@@ -412,13 +412,22 @@ def main():
             it_ms = float(np.median(dev_times)) / K   # HIP events of the library around the K-iteration loop, on the plan's stream
             achieved = alg_bytes / (it_ms * 1e-3) / 1e9
             steady = 1e3 / it_ms
+            w_traffic, w_from = None, None
+            wfile = os.path.join(ROOT, "profiles", "r02_wavelet_traffic.json")
+            if kind == "WAVELET" and (nil, nxl, nslices) == (512, 512, 256) and world == 1 and os.path.exists(wfile):
+                try:   # counters of the same loop, collected by tools/pmc_kernels.sh (one TCC counter per pass)
+                    with open(wfile) as fh:
+                        w_traffic = json.load(fh).get("hbm_bytes_per_iteration")
+                    w_from = "profiles/r02_wavelet_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same loop (tools/wavelet_bench.py), round 2"
+                except (OSError, ValueError):
+                    w_traffic, w_from = None, None
             roof = {
                 "bound": "hbm",
                 "kernel": ("dwt2_tile_kernel / idwt2_tile_kernel chain (one launch per level and direction)" if kind == "WAVELET" else
                            "row_kernel<ROW_SPREAD_INV> + col_kernel<COL_SHRINK> + row_kernel<ROW_GATHER_FWD> + the two fft2 passes")
                           + f" = one POCS iteration of {n_local} slices",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "traffic_from": None,
+                "traffic": w_traffic, "traffic_from": w_from,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": it_ms,
             }
 
