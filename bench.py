@@ -421,6 +421,15 @@ def main():
                     w_from = "profiles/r02_wavelet_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same loop (tools/wavelet_bench.py), round 2"
                 except (OSError, ValueError):
                     w_traffic, w_from = None, None
+            sfile = os.path.join(ROOT, "profiles", "r02_shearlet_traffic.json")
+            if kind == "SHEARLET" and (nil, nxl) == (2048, 1024) and os.path.exists(sfile):
+                try:   # per slice-iteration, scaled to this rank's slices
+                    with open(sfile) as fh:
+                        w_traffic = json.load(fh).get("hbm_bytes_per_slice_iteration") * n_local
+                    w_from = ("profiles/r02_shearlet_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/shearlet_bench.py "
+                              "(4 slices of this shape), per slice-iteration x the slices of this rank, round 2")
+                except (OSError, ValueError, TypeError):
+                    w_traffic, w_from = None, None
             roof = {
                 "bound": "hbm",
                 "kernel": ("dwt2_tile_kernel / idwt2_tile_kernel chain (one launch per level and direction)" if kind == "WAVELET" else
