@@ -225,6 +225,9 @@ __device__ __forceinline__ double wave_sum(double v)
 // =================================================================================================
 // space (row) pass
 // =================================================================================================
+#ifndef P3D_SHEAR_XCD
+#define P3D_SHEAR_XCD 1
+#endif
 // BITS: the trace mask is binary and comes as one packed 16-bit word per thread and row.
 template <int N, int MODE, bool BITS>
 __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >= 512 ? 4 : 3)) void row_kernel(const RowArgs a)
@@ -243,8 +246,19 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
     const int tid = threadIdx.x;
     const int line = tid / TPL;
     const int tl = tid - line * TPL;
-    const int slice = blockIdx.y;
-    const int row = blockIdx.x * LB + line;
+    int slice = blockIdx.y, rgroup = blockIdx.x;
+    if constexpr (MODE == ROW_SPREAD_INV || MODE == ROW_GATHER_FWD) {
+        // The shearlet spectra Psi_s (4 B per point and shearlet, 1 GiB at 2048 x 1024 x 125) are the same for every slice of the
+        // batch: the workgroups that hold the SAME rows of different slices are made neighbours on one XCD (ids g, g + 8, ... of the
+        // linear grid), so that they walk through the shearlets together and all but one of them find Psi in that XCD's L2.
+        const unsigned gx = gridDim.x, nb = gridDim.y;
+        if (P3D_SHEAR_XCD && nb > 1 && gx % 8 == 0) {
+            const unsigned id = blockIdx.y * gx + blockIdx.x, xcd = id & 7u, j = id >> 3;
+            slice = (int)(j % nb);
+            rgroup = (int)((j / nb) * 8 + xcd);
+        }
+    }
+    const int row = rgroup * LB + line;
     const bool valid = row < a.n1;
 
     const int dn = a.done ? a.done[slice] : 0;
