@@ -329,7 +329,12 @@ class Plan:
 
     def prime_dev(self, x_ptr, dtype, mask_ptr, nslices):
         """`stats_dev` that doubles as the first pass of the job: follow it with ``run_dev(..., primed=True)`` on the same
-        pointers and batch (include/p3d.h, p3d_pocs_prime_dev)."""
+        pointers and batch (include/p3d.h, p3d_pocs_prime_dev).
+
+        ``primed=True`` is a promise about the CONTENTS of the two device buffers: the plan can only check that pointers, dtype and
+        batch are the ones it primed and that nothing else ran on it in between -- a caller that rewrites ``x`` or ``mask`` in
+        place between the two calls must not pass the flag (the run would use the work buffer, compact samples and ``sum |x_obs|``
+        of the old contents)."""
         st = np.empty((nslices, STATS_PER_SLICE), np.float64)
         check(lib().p3d_pocs_prime_dev(self.handle, x_ptr, dtype, mask_ptr, nslices, _ptr(st)))
         return st

@@ -194,6 +194,13 @@ static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row
     if (threadIdx.x == 0) sums_row[s] = sh[0];
 }
 
+// ---- sums[0] of slices that are switched off from the start (done < 0) reads as zero --------------------------
+static __global__ void zero_off_sums_kernel(double* sums0, const int* done, int nslices)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nslices && done[s] != 0) sums0[s] = 0.0;
+}
+
 // ---- convergence bookkeeping (POCS.py:622, 631) ------------------------------------------------
 static __global__ void conv_kernel(const double* sums, int* done, int nslices, int iter, double eps)
 {
@@ -318,6 +325,10 @@ struct p3d_plan {
     int tiles = 0;
     int cus = 0;          // compute units of the device
     int pipe_wgs = 0;     // compute units handed to the persistent row pass (0: not available for this shape)
+    // experiment switches read from the environment ONCE, when the plan is created (the launch paths never consult it):
+    int host_sw = 0;      // P3D_SW_* bits for the flexible-length launchers
+    int flex_over = 0;    // P3D_FLEX_COL_OVER (0: the launcher's default)
+    bool no_colpipe = false;   // P3D_NO_COLPIPE, for the SHEARLET column pass (FFT jobs read it per job: RunSwitches)
     // staging for host-pointer entry points
     void* st_x = nullptr;
     void* st_out = nullptr;
@@ -418,6 +429,9 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
     p->generic = generic;
     p->ops_col = generic ? nullptr : oc;
     p->ops_row = generic ? nullptr : orow;
+    p->host_sw = (getenv("P3D_FLEX_COL_NO_PERSIST") ? P3D_SW_FLEX_NO_PERSIST : 0) | (getenv("P3D_FLEX_NO_INPLACE") ? P3D_SW_FLEX_NO_INPLACE : 0);
+    p->flex_over = getenv("P3D_FLEX_COL_OVER") ? atoi(getenv("P3D_FLEX_COL_OVER")) : 0;
+    p->no_colpipe = getenv("P3D_NO_COLPIPE") != nullptr;
     if (generic) {
         p->gcol = gen_make_plan(nil);
         p->grow = gen_make_plan(nxl);
@@ -588,6 +602,7 @@ static RowArgs row_args(p3d_plan* p, int nslices)
     r.alpha = 1.0f;
     r.scale = (float)(1.0 / ((double)p->nil * (double)p->nxl));
     r.len = p->nxl;
+    r.host_sw = p->host_sw;
     return r;
 }
 
@@ -598,6 +613,9 @@ static ColArgs col_args(p3d_plan* p, int nslices)
     c.n2 = p->nxl;
     c.nslices = nslices;
     c.len = p->nil;
+    c.cus = p->cus;
+    c.host_sw = p->host_sw;
+    c.flex_over = p->flex_over;
     return c;
 }
 
@@ -718,10 +736,9 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     c.out = p->work;
     c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only);
     // columns of 2048 points and more: one 8-column tile per CU, so the persistent pass (next tile requested while this one is
-    // transformed) has something to give (see p3d_pocs_run_dev); P3D_NO_COLPIPE=1 switches it off
-    const bool no_colpipe = getenv("P3D_NO_COLPIPE") != nullptr;
+    // transformed) has something to give (see p3d_pocs_run_dev); P3D_NO_COLPIPE=1 (read when the plan is created) switches it off
     hipError_t ce = hipErrorNotSupported;
-    if (!no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
+    if (!p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
     if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_SHRINK, c, p->stream);
     HIP_TRY(ce);
     return P3D_OK;
@@ -1237,6 +1254,8 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     const bool primed = primed_in && !real_path && !adaptive;
     if (primed) {
         HIP_TRY(hipMemcpyAsync(p->sums, p->sum0, sizeof(double) * nslices, hipMemcpyDeviceToDevice, p->stream));
+        // the primed pass knew nothing of `active`: a slice the caller switched off reports sums[0] = 0, as on the unprimed path
+        if (any_off) zero_off_sums_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices);
         if (primed_state.violation) r.xc = nullptr;
     } else if (!real_path) {
         HIP_TRY(first_row_pass(p, r));
@@ -1506,9 +1525,9 @@ static int axis0_fft(int device, c32* work, int nfft, size_t ntr, int inverse)
     c.nslices = 1;
     c.len = nfft;
     c.in_std = c.out_std = 1;
+    HIP_TRY(hipDeviceGetAttribute(&c.cus, hipDeviceAttributeMultiprocessorCount, device));   // (no plan here: the device the caller named)
     HIP_TRY(ops->col(inverse ? COL_INV : COL_FWD, c, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    (void)device;
     return P3D_OK;
 }
 

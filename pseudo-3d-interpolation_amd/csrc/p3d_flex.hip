@@ -1006,7 +1006,7 @@ hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;
-    static const bool no_inplace = getenv("P3D_FLEX_NO_INPLACE") != nullptr;
+    const bool no_inplace = (a.host_sw & P3D_SW_FLEX_NO_INPLACE) != 0;
     bool two_ = two;
     int inpl = 0;
     if (!no_inplace) {
@@ -1047,7 +1047,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;
-    static const bool no_inplace = getenv("P3D_FLEX_NO_INPLACE") != nullptr;
+    const bool no_inplace = (a.host_sw & P3D_SW_FLEX_NO_INPLACE) != 0;
     int tpr = two ? 128 : 64;
     int inpl = 0;
     if (!no_inplace) {
@@ -1092,20 +1092,20 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
     const FlexFactors pl = flex_factors(n);
     const size_t lds = col_lds(n, T);
     if ((size_t)n * T > (size_t)FLEX_COL_PF * FLEX_COL_THREADS) return hipErrorNotSupported;   // (never: col_lds <= FLEX_LDS_MAX)
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
+    int cus = a.cus;   // the plan's device (a.cus = 0: a caller without a plan -- ask the current device)
+    if (cus <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
     // Long columns (one workgroup per CU): contiguous runs of tiles, the next tile prefetched.  Short ones share a CU and cover
     // each other's loads, and the chirp-z form reads its tables from global memory between the passes (a wait for those is a
     // wait for the prefetch): one tile per workgroup there (measured: 300-point columns 0.23 vs 0.27 ms, 1001-point 2.7 vs 4.0).
     const int ntiles = (a.n2 + T - 1) / T, total = ntiles * a.nslices;
-    static const bool no_persist = getenv("P3D_FLEX_COL_NO_PERSIST") != nullptr;
+    const bool no_persist = (a.host_sw & P3D_SW_FLEX_NO_PERSIST) != 0;
     const bool persist = !no_persist && !pl.blue && lds + 512 > 80 * 1024;
     // eight workgroups' worth of runs per CU: the hardware hands the next run to the CU that is free (kept tiles cost twice an
     // emptied one and cluster around the low wavenumbers: one run per CU left some CUs with 45 % more work -- 0.90 vs 0.65 ms)
-    static const int over = getenv("P3D_FLEX_COL_OVER") ? atoi(getenv("P3D_FLEX_COL_OVER")) : 8;
+    const int over = a.flex_over > 0 ? a.flex_over : 8;
     const int want = cus * (over > 0 ? over : 1);
     const int grid = !persist ? total : (total < want ? total : want), per = (total + grid - 1) / grid;
     bool bigp = false;

@@ -146,6 +146,9 @@ struct CompactIndex {
 // the row, register q)
 __host__ __device__ constexpr size_t pipe64_word(size_t row_or_slice, int wpl, int wsub, int q) { return (row_or_slice * wpl + wsub) * 16 + q; }
 
+// experiment switches a plan reads from the environment when it is created and hands to the launchers (RowArgs / ColArgs::host_sw)
+enum { P3D_SW_FLEX_NO_PERSIST = 1, P3D_SW_FLEX_NO_INPLACE = 2 };
+
 struct RowArgs {
     const void* x;         // observed cube (c64 or f32), [nslices][n1][N]
     const float* mask;     // [n1][N] float weights (generic path) or nullptr
@@ -186,6 +189,7 @@ struct RowArgs {
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
     int real_2048;         // host side only: the row-pair path for rows of 2048 samples is switched on (experiment switch P3D_REAL_2048)
     int tstore;            // host side only: rows of one wavefront hand their transforms round through LDS and store 1-KiB runs (P3D_NO_TSTORE unset)
+    int host_sw;           // host side only: P3D_SW_* experiment switches of the plan (read from the environment once per plan)
     ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD
 };
 
@@ -207,6 +211,9 @@ struct ColArgs {
     int len;            // N, the column length (see RowArgs::len)
     uint8_t* nzflag;    // COL_ITER*: [nslices][tiles] 1 = the tile kept at least one coefficient; tiles that kept none are
                         // neither transformed back nor stored (nullptr: always store)
+    int cus;            // host side only: compute units of the plan's device (0: ask the current device)
+    int host_sw;        // host side only: P3D_SW_* experiment switches of the plan
+    int flex_over;      // host side only: runs per CU of the persistent flexible-length column pass (P3D_FLEX_COL_OVER, default 8)
 };
 
 // |x| for the cost sums: the hardware square root (1 ulp) without the IEEE fix-up sequence the library call expands to (8 more

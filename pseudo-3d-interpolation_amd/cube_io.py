@@ -26,6 +26,9 @@ from .functions.backends import h5py_enabled, xarray_enabled
 # attributes that belong to the HDF5 / netCDF-4 machinery, not to the user
 _NC_INTERNAL = {'CLASS', 'NAME', 'DIMENSION_LIST', 'REFERENCE_LIST', '_Netcdf4Dimid', '_Netcdf4Coordinates', '_NCProperties',
                 '_nc3_strict', '_FillValue', 'missing_value', 'scale_factor', 'add_offset'}
+# NAME of a dimension scale that carries no coordinate values; netCDF-C (nc4hdf.c) and h5netcdf write this text FOLLOWED by the
+# dimension's length formatted '%10d'
+_NOT_A_VARIABLE = 'This is a netCDF dimension but not a netCDF variable.'
 
 
 class Cube:
@@ -149,7 +152,8 @@ def _save_nc_h5py(cube, path):
             else:   # a dimension without coordinate values: an empty scale of the right length, as netCDF-4 writes it
                 n = next(np.shape(cube.data_vars[k])[cube.dims[k].index(d)] for k in cube.dims if d in cube.dims[k])
                 ds = f.create_dataset(d, shape=(n,), dtype='f4')
-            ds.make_scale(d if d in cube.coords else 'This is a netCDF dimension but not a netCDF variable.')
+            # netCDF-C / h5netcdf append the length, formatted '%10d', to the NAME of a coordinate-less dimension
+            ds.make_scale(d if d in cube.coords else _NOT_A_VARIABLE + '%10d' % ds.shape[0])
             ds.attrs['_Netcdf4Dimid'] = np.int32(i)
             if ds.dtype.kind == 'f' and d in cube.coords:
                 ds.attrs['_FillValue'] = np.array([np.nan], ds.dtype)
@@ -197,7 +201,7 @@ def _open_nc_h5py(path):
 
         for _, name in order:
             ds = f[name]
-            is_var = _attr_in(ds.attrs.get('NAME', b'')) != 'This is a netCDF dimension but not a netCDF variable.'
+            is_var = not str(_attr_in(ds.attrs.get('NAME', b''))).startswith(_NOT_A_VARIABLE)
             if is_var:
                 coords[name] = decode(ds)
                 coord_attrs[name] = {k: _attr_in(v) for k, v in ds.attrs.items() if k not in _NC_INTERNAL}

@@ -61,7 +61,7 @@ with h5py.File(other, 'w') as f:
     tw = f.create_dataset('twt', data=np.linspace(0.0, 1.0, 4)); tw.make_scale('twt'); tw.attrs['_Netcdf4Dimid'] = np.int32(0)
     il = f.create_dataset('iline', data=np.arange(3, dtype=np.int32)); il.make_scale('iline'); il.attrs['_Netcdf4Dimid'] = np.int32(1)
     xl = f.create_dataset('xline', shape=(2,), dtype='f4')            # dimension without coordinate values
-    xl.make_scale('This is a netCDF dimension but not a netCDF variable.'); xl.attrs['_Netcdf4Dimid'] = np.int32(2)
+    xl.make_scale('This is a netCDF dimension but not a netCDF variable.%10d' % 2); xl.attrs['_Netcdf4Dimid'] = np.int32(2)   # as netCDF-C / h5netcdf write it
     raw = np.array([[[10, 20], [30, -999], [50, 60]]] * 4, dtype=np.int16)
     env = f.create_dataset('env', data=raw)
     for a, s in enumerate((tw, il, xl)):
@@ -77,4 +77,16 @@ want = raw * 0.5 + 1.0
 want[:, 1, 1] = np.nan
 assert np.array_equal(got.data_vars['env'], want, equal_nan=True)
 assert np.isnan(got.data_vars['amp'][0, 1]) and got.data_vars['amp'].dtype == np.float32 and got.data_vars['amp'][2, 1] == 5.0
+
+# ---- a cube with a coordinate-less dimension: written with the length suffix, read back as a dimension (not as fill values) ----
+nocoord = cube_io.Cube({'amp': np.arange(6, dtype=np.float32).reshape(2, 3)}, {'amp': ('iline', 'xline')}, {'iline': np.arange(2)}, {}, {}, {})
+p3 = os.path.join(tmp, 'nocoord.nc')
+cube_io.save_cube(nocoord, p3)
+with h5py.File(p3, 'r') as f:
+    assert f['xline'].attrs['NAME'] == b'This is a netCDF dimension but not a netCDF variable.         3'
+again = cube_io.open_cube(p3)
+assert set(again.coords) == {'iline'} and again.dims['amp'] == ('iline', 'xline') and np.array_equal(again.data_vars['amp'], nocoord.data_vars['amp'])
+with h5py.File(p3, 'r+') as f:     # the bare text (what round 2 wrote) is still recognised
+    f['xline'].attrs['NAME'] = np.bytes_('This is a netCDF dimension but not a netCDF variable.')
+assert set(cube_io.open_cube(p3).coords) == {'iline'}
 print('NC CHECKS OK')

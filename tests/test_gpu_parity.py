@@ -506,9 +506,11 @@ def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
     with ffi.Plan(nil, nxl, n) as plan:
         x, o, m = plan.alloc(obs.nbytes).upload(obs), plan.alloc(obs.nbytes), plan.alloc(maskf.nbytes).upload(maskf)
 
-        def run(primed, spoil=False):
+        def run(primed, spoil=False, switch_off=None):
             st = plan.prime_dev(x.ptr, dt, m.ptr, n) if primed else plan.stats_dev(x.ptr, dt, n)
             active = st[:, 2] > 0
+            if switch_off is not None:
+                active[switch_off] = False       # a NON-zero slice the caller does not want processed
             st[~active] = 1.0
             tau = orc_schedule(st)
             if spoil:
@@ -528,6 +530,12 @@ def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
         for other in (b, c):
             assert np.array_equal(a[0], other[0]) and np.array_equal(a[1], other[1]) and np.array_equal(a[2], other[2]) and np.array_equal(a[3], other[3])
         assert not a[1][2].any() and a[2][2] == 0
+        # the primed pass knows nothing of `active`: a non-zero slice switched off by the caller must still report sums[0] = 0 and
+        # zero iterations, exactly like the unprimed path
+        d, e = run(False, switch_off=1), run(True, switch_off=1)
+        assert np.array_equal(d[2], e[2]) and np.array_equal(d[3], e[3]) and d[2][1] == 0 and e[3][0, 1] == 0.0
+        keep = [0, 3]
+        assert np.array_equal(d[1][keep], e[1][keep]) and np.array_equal(d[1][keep], a[1][keep])
         for buf in (x, o, m):
             buf.free()
 
