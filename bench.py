@@ -2,32 +2,47 @@
 """
 bench.py -- POCS iterations/s (BASELINE.json metric) on N MI355X GPUs.
 
-    python bench.py [--gpus 1] [--steps K] [--warmup W] [--config {0,1,2,3,4}] [--repeats R] [--density M]
+    python bench.py [--gpus 1] [--steps K] [--warmup W] [--config {0,1,2,3,4}] [--repeats R] [--density M] [--only-main]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one POCS iteration of the whole cube: every (iline, xline) slice goes once through forward transform ->
 threshold -> inverse transform -> re-insertion of the observed traces -> cost sum.  The timed region is one complete job of K
 iterations on a cube already resident in HBM: statistics of transform(x_obs), threshold schedule (host, a few scalars per
-slice), the K iterations, final store of the result.  The job is repeated R (>= 5) times; `value` is K / the MEDIAN job time
+slice), the K iterations, final store of the result.  The job is repeated R (>= 3) times; `value` is K / the MEDIAN job time
 (max over ranks per repeat), min and max are printed beside it.  For N > 1 the slice axis is cut into N contiguous blocks,
-one rank per GPU; there is no collective inside the timed region -- the blocks are gathered with one RCCL all_gather
-afterwards (timed separately, "gather_ms").  Rank 0 prints ONE JSON line.
+one rank per GPU; there is no collective inside the timed region -- the blocks are gathered afterwards with one RCCL collective
+on device tensors (all_gather, and gather-to-root beside it; both timed, "gather_ms").  Rank 0 prints ONE JSON line.
 
---config selects the BASELINE.json configuration (default 2 = the metric's cube, 1024 x 1024 x 512 complex64):
+--config selects the BASELINE.json configuration of the line's `value` (default 2 = the metric's cube):
     0  64 x 64 x 128 complex64, 50 % missing, FFT, hard, 20 iterations
     1  512 x 512 x 256 complex64, 70 % missing, FFT, hard, exponential decay, 50 iterations
     2  1024 x 1024 x 512 complex64, 80 % missing, FFT, hard, exponential decay, 100 iterations
     3  512 x 512 x 256 float32, 70 % missing, WAVELET db4 ('smooth'), soft, 50 iterations
-    4  2048 x 1024 x 1024 float32, 80 % missing, SHEARLET (125 shearlets), hard, 100 iterations -- timed on a SAMPLE of the
-       cube's slices (--nslices, default 8) and of its iterations (default 5): one GPU holds 2 GiB of coefficients per slice
---steps overrides the iteration count (the driver runs --steps 20).
+    4  2048 x 1024 x 1024 float32, 80 % missing, SHEARLET (125 shearlets), hard, 100 iterations.  One GPU holds 2 GiB of
+       coefficients per slice, so the cube is worked through in batches of 8 slices; the line times a SAMPLE of the cube
+       (--nslices, default 8 slices PER RANK, each rank's sample taken from its own block of the 1024 slices) over the FULL
+       100-iteration schedule, and scales the rate by sample / cube.  `--nslices 1024` runs the whole cube.
+--steps overrides the iteration count of the line's configuration (the driver runs --steps 20).
+
+The default line (config 2) also carries `other_configs`: configs[1], [3] and [4] (N > 1: configs[4] only -- it is the other
+configuration BASELINE.json defines on 8 GPUs) run in the same process at their OWN iteration counts, each with value,
+steady-state rate and a `roofline` object whose launch_ms and algorithmic_bytes_per_launch let the fraction be recomputed; and
+`end_to_end`: the same job through the host-buffer entry point (NumPy cube in, NumPy cube out: PCIe both ways, chunk pipeline).
+--only-main leaves both out (profiling runs: tools/profile.sh).
+
+`roofline.traffic` is read from profiles/traffic_config<i>.json (PMC passes over this file, tools/profile.sh) and is reported
+only when that file was measured on the kernel sources of this tree (`kernel_source_hash`); otherwise it is null and the stale
+measurement is named under `traffic_last_measured`.
 
 Inputs are generated without any torch random-number kernel (NumPy noise pool + plane waves / index writes + the library's
-own inverse FFT), so that `rocprofv3 --pmc ... -- python3 bench.py` completes (round 1: counter collection aborted inside
-torch's normal_ kernel).
+own inverse FFT) and with ~1 500 torch dispatches per cube, so that `rocprofv3 --pmc ... -- python3 bench.py` completes: counter
+collection on this image does not survive some ten thousand dispatches of one process, whichever kernels they are
+(profiles/r02_pmc_on_bench.txt; the counter budget per pass is a separate matter, profiles/r03_pmc_counter_budget.txt).
 """
 import argparse
+import glob
+import hashlib
 import json
 import math
 import os
@@ -41,13 +56,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+SHEARLET_BATCH = 8        # slices per p3d_shearlet_run call (8 x 125 work slices of 16 MiB = 16 GiB)
 
 CONFIGS = {
     0: dict(kind="FFT", nil=64, nxl=64, nslices=128, missing=0.5, steps=20, op="hard", real=False),
     1: dict(kind="FFT", nil=512, nxl=512, nslices=256, missing=0.7, steps=50, op="hard", real=False),
     2: dict(kind="FFT", nil=1024, nxl=1024, nslices=512, missing=0.8, steps=100, op="hard", real=False),
     3: dict(kind="WAVELET", nil=512, nxl=512, nslices=256, missing=0.7, steps=50, op="soft", real=True, wavelet="db4"),
-    4: dict(kind="SHEARLET", nil=2048, nxl=1024, nslices=8, cube_slices=1024, missing=0.8, steps=5, cube_steps=100, op="hard", real=True),
+    4: dict(kind="SHEARLET", nil=2048, nxl=1024, nslices=None, sample_per_rank=SHEARLET_BATCH, cube_slices=1024, missing=0.8, steps=100,
+            op="hard", real=True),
 }
 # ALGORITHMIC bytes per point and iteration:
 #   FFT, complex64: iterate read 8 + written 8 + observed data 8 + float32 weight 4                                        = 28
@@ -62,10 +79,10 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[i] (default: the metric's cube)")
     ap.add_argument("--steps", type=int, default=None, help="POCS iterations in the timed job (default: the configuration's)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the job (0: as many as fill ~1.5 s, between 5 and 15)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the job (0: as many as fill ~1.5 s, between 3 and 15)")
     ap.add_argument("--nil", type=int, default=None)
     ap.add_argument("--nxl", type=int, default=None)
-    ap.add_argument("--nslices", type=int, default=None, help="slices of the whole cube (sharded over the GPUs)")
+    ap.add_argument("--nslices", type=int, default=None, help="slices worked on by all GPUs together (config 4: the sample of the cube)")
     ap.add_argument("--missing", type=float, default=None)
     ap.add_argument("--thresh-op", default=None)
     ap.add_argument("--alpha", type=float, default=1.0, help="re-insertion weight (the metric's setting: 1)")
@@ -78,7 +95,43 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the side runs (sparse shortcut off, real cube, density curve)")
+    ap.add_argument("--only-main", action="store_true", help="no other_configs, no end_to_end (profiling runs)")
+    ap.add_argument("--no-end-to-end", action="store_true")
     return ap.parse_args()
+
+
+def kernel_source_hash():
+    """sha256[:16] over the kernel sources of this tree (csrc/*.hip, *.hpp, Makefile): stamps PMC traffic measurements."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pseudo-3d-interpolation_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + [os.path.join(csrc, "Makefile")]):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(config, workload_key, scale=1.0):
+    """(traffic, traffic_from, last_measured) from profiles/traffic_config<i>.json.  A measurement counts only for the kernel sources it
+    was taken on; a stale one is named, not reported."""
+    path = os.path.join(ROOT, "profiles", f"traffic_config{config}.json")
+    if not os.path.isfile(path):
+        return None, None, None
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        per = rec["hbm_bytes_per_iteration"]
+    except (OSError, ValueError, KeyError):
+        return None, None, None
+    info = {"file": f"profiles/traffic_config{config}.json", "hbm_bytes_per_iteration": per, "workload": rec.get("workload"),
+            "round": rec.get("round"), "kernel_source_hash": rec.get("kernel_source_hash"), "iterations": rec.get("iterations")}
+    if rec.get("workload_key") != workload_key:
+        return None, None, dict(info, why="measured on another workload")
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, None, dict(info, why="kernel sources changed since the measurement")
+    return per * scale, (f"profiles/traffic_config{config}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --config {config} "
+                         f"--only-main, round {rec.get('round')}, K = {rec.get('iterations')}; (FETCH_SIZE x 2 [gfx950] + WRITE_SIZE) x 1024 B per "
+                         f"iteration of the steady-state kernels"), None
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -217,48 +270,83 @@ def cpu_baseline_shearlet(x, mask, psi, op, nslices_cube):
     }
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+class Ctx:
+    """What every leg shares: torch, the process group, this rank's device."""
 
-    cfg = dict(CONFIGS[args.config])
-    for key, val in (("nil", args.nil), ("nxl", args.nxl), ("nslices", args.nslices), ("missing", args.missing), ("op", args.thresh_op)):
-        if val is not None:
-            cfg[key] = val
-    kind, nil, nxl, nslices, missing, op = cfg["kind"], cfg["nil"], cfg["nxl"], cfg["nslices"], cfg["missing"], cfg["op"]
-    K = args.steps if args.steps is not None else cfg["steps"]
-    W = args.warmup
-    cube_slices = cfg.get("cube_slices", nslices) if args.nslices is None else nslices   # config 4: a sample stands for the cube
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+            raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {args.gpus}")
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        # P3D_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the multi-rank code path where no second GPU exists
+        # (the numbers mean nothing then).  The real thing: one rank per GPU over RCCL.
+        self.rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
+        self.dev_index = local_rank % max(torch.cuda.device_count(), 1) if self.rehearsal else local_rank
+        torch.cuda.set_device(self.dev_index)
+        self.device = torch.device("cuda", self.dev_index)
+        if self.world > 1:
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.device)
 
-    import torch
-    import torch.distributed as dist
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
 
+    def max_over_ranks(self, sec):
+        if self.world > 1:
+            t = self.torch.tensor([sec], dtype=self.torch.float64, device="cpu" if self.rehearsal else self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            sec = float(t.item())
+        return sec
+
+
+def run_leg(ctx, config, K_override, main):
+    """One BASELINE configuration: generate its cube in HBM (this rank's block), time R jobs of K iterations, profile, side runs.
+    Returns the record of the leg (rank 0: complete; other ranks: the fields they computed)."""
+    args, torch, dist, rank, world = ctx.args, ctx.torch, ctx.dist, ctx.rank, ctx.world
     from pseudo_3d_interpolation_amd import _ffi
     from pseudo_3d_interpolation_amd.functions import POCS as P
     from pseudo_3d_interpolation_amd.sharding import slice_block
 
-    # P3D_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the multi-rank code path where no second GPU exists
-    # (the numbers mean nothing then).  The real thing: one rank per GPU over RCCL.
-    rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
-
-    lo, hi = slice_block(nslices, world, rank)
-    n_local = hi - lo
-    pts_local = n_local * nil * nxl
+    cfg = dict(CONFIGS[config])
+    if main:
+        for key, val in (("nil", args.nil), ("nxl", args.nxl), ("nslices", args.nslices), ("missing", args.missing), ("op", args.thresh_op)):
+            if val is not None:
+                cfg[key] = val
+    kind, nil, nxl, missing, op = cfg["kind"], cfg["nil"], cfg["nxl"], cfg["missing"], cfg["op"]
+    K = K_override if K_override is not None else cfg["steps"]
+    W = args.warmup
+    device, dev_index = ctx.device, ctx.dev_index
     p_min = args.p_min if args.p_min == "adaptive" else float(args.p_min)
+    density = args.density if (main and kind == "FFT") else 0
+
+    # ---- which slices this rank works on ---------------------------------------------------------
+    if kind == "SHEARLET" and cfg.get("cube_slices"):
+        # config 4: the cube's slice axis is cut into `world` blocks; all ranks together time a sample of `nslices` slices, every
+        # rank its share of the sample taken from the head of ITS block of the cube (--nslices 1024: the whole cube)
+        cube_slices = cfg["cube_slices"]
+        nslices = min(cube_slices, cfg["nslices"] if cfg["nslices"] is not None else cfg["sample_per_rank"] * world)
+        s_lo, s_hi = slice_block(nslices, world, rank)
+        n_local = s_hi - s_lo
+        lo = slice_block(cube_slices, world, rank)[0]
+    else:
+        nslices = cube_slices = cfg["nslices"]
+        lo, hi = slice_block(nslices, world, rank)
+        n_local = hi - lo
+    if n_local < 1:
+        raise SystemExit(f"rank {rank} of {world} has no slice to work on ({nslices} slices)")
+    pts_local = n_local * nil * nxl
 
     # ---- inputs, resident in HBM before the clock starts -----------------------------------------
     mask = (np.random.default_rng(42).random((nil, nxl)) >= missing).astype(np.uint8)   # SURVEY section 8d: shared trace mask
@@ -267,17 +355,17 @@ def main():
     fft_plan = _ffi.Plan(nil, nxl, n_local, device=dev_index) if kind == "FFT" else None
     xc = torch.empty((n_local, nil, nxl), dtype=torch.complex64, device=device)
 
-    def generate(density):
-        if density > 0:
-            fill_random_spectrum(torch, xc, nil, nxl, lo, pool, density, fft_plan)
+    def generate(dens):
+        if dens > 0:
+            fill_random_spectrum(torch, xc, nil, nxl, lo, pool, dens, fft_plan)
         else:
             fill_plane_waves(torch, xc, nil, nxl, lo, pool)
         xc.mul_(mask_t)
 
-    generate(args.density if kind == "FFT" else 0)
-    n_cpu = 0
+    generate(density)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and density == 0 and (main or kind != "SHEARLET")
     cpu_slices = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.density == 0:   # the CPU baseline is a single-GPU-run extra (rank 0, N = 1)
+    if want_cpu:   # the CPU baseline is a single-GPU-run extra (rank 0, N = 1)
         from oracle import pocs_oracle as orc  # the cpu_baseline leg (and the slices it is fed) -- nothing else touches the oracle
         n_cpu = max(1, min(os.cpu_count() or 1, 16, n_local)) if kind != "SHEARLET" else 1
         cpu_slices = np.stack([orc.synthetic_slice(nil, nxl, lo + s, real=cfg["real"]) for s in range(n_cpu)]) * mask
@@ -290,6 +378,7 @@ def main():
     out = torch.empty_like(x_obs)
     torch.cuda.synchronize()
     DT = _ffi.P3D_F32 if cfg["real"] else _ffi.P3D_C64
+    esz = 4 if cfg["real"] else 8
 
     # ---- the job of each transform kind ------------------------------------------------------------
     nsh = 0
@@ -317,38 +406,39 @@ def main():
         from pseudo_3d_interpolation_amd.functions import shearlets
         psi = shearlets.scalesShearsAndSpectra((nil, nxl), dtype=np.float32)
         nsh = psi.shape[-1]
-        plan = _ffi.ShearletPlan(psi, max_slices=n_local, device=dev_index)
+        batch = min(n_local, SHEARLET_BATCH)
+        plan = _ffi.ShearletPlan(psi, max_slices=batch, device=dev_index)
+        per = nil * nxl * esz
 
         def job(niter, profile=False):
-            stats = plan.stats_dev(x_obs.data_ptr(), DT, n_local)
-            tau = P._shearlet_schedule_from_stats(stats, (nil, nxl), "exponential", niter, 0.99, p_min, "values")
-            return plan.run_dev(x_obs.data_ptr(), DT, mask_t.data_ptr(), tau, niter, out.data_ptr(), n_local, thresh_op=op, eps=args.eps,
-                                alpha=args.alpha)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            # the rank's slices in batches of <= 8: statistics, schedule and the niter iterations of one batch, then the next
+            done_all, ms_all = [], 0.0
+            for b0 in range(0, n_local, batch):
+                nb = min(batch, n_local - b0)
+                xp, op_ = x_obs.data_ptr() + b0 * per, out.data_ptr() + b0 * per
+                stats = plan.stats_dev(xp, DT, nb)
+                tau = P._shearlet_schedule_from_stats(stats, (nil, nxl), "exponential", niter, 0.99, p_min, "values")
+                done, _, ms = plan.run_dev(xp, DT, mask_t.data_ptr(), tau, niter, op_, nb, thresh_op=op, eps=args.eps, alpha=args.alpha)
+                done_all.append(done)
+                ms_all += ms
+            return np.concatenate(done_all), None, ms_all
 
     def timed(niter):
         """One job of `niter` iterations between two fences; seconds = max over ranks."""
-        fence()
+        ctx.fence()
         t0 = time.perf_counter()
         res = job(niter)
-        fence()
-        sec = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([sec], dtype=torch.float64, device="cpu" if rehearsal else device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sec = float(t.item())
-        return sec, res
+        ctx.fence()
+        return ctx.max_over_ranks(time.perf_counter() - t0), res
 
     if W > 0:
-        job(W)
+        job(min(W, K))
     first_s, (done, _, dev_ms) = timed(K)
     assert args.eps > 0 or (int(done.min()) == K and int(done.max()) == K)
-    R = args.repeats if args.repeats > 0 else int(max(5, min(15, math.ceil(1.5 / max(first_s, 1e-4)))))
+    floor = 5 if main else 3
+    R = args.repeats if (args.repeats > 0 and main) else int(max(floor, min(15, math.ceil(1.5 / max(first_s, 1e-4)))))
+    if kind == "SHEARLET" and not (args.repeats > 0 and main):
+        R = 3 if first_s < 4.0 else 2
     times, dev_times = [first_s], [dev_ms]
     for _ in range(R - 1):
         sec, (_, _, dms) = timed(K)
@@ -370,6 +460,7 @@ def main():
     roof = None
     steady = None
     if rank == 0 and not args.no_profile:
+        default_shape = (nil, nxl) == (CONFIGS[config]["nil"], CONFIGS[config]["nxl"]) and density == 0 and op == CONFIGS[config]["op"]
         if kind == "FFT":
             prof, kept = profile_fft()
             it_ms = prof["colpass_ms"] + prof["rowpass_ms"]
@@ -377,18 +468,7 @@ def main():
             if resident:
                 it_ms = float(np.median(dev_times)) / K   # HIP events of the library around the kernel, on the plan's stream
             achieved = alg_bytes / (it_ms * 1e-3) / 1e9 if it_ms > 0 else 0.0
-            traffic, traffic_from = None, None
-            tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.isfile(tfile):
-                try:
-                    rec = json.load(open(tfile))
-                    if rec.get("workload") == f"{nil}x{nxl}x{n_local}" and args.density == 0:
-                        traffic = rec.get("hbm_bytes_per_iteration")
-                        traffic_from = (f"profiles/pmc_traffic.json: rocprofv3 --pmc passes, round {rec.get('round')}, of a K = "
-                                        f"{rec.get('iterations', 100)} job (this line: K = {K}; the kept-block fraction, hence the traffic, "
-                                        f"depends on K: {rec.get('nonzero_block_fraction', 'n/a')} there, {kept:.4f} here)")
-                except Exception:  # noqa
-                    traffic = None
+            traffic, traffic_from, last = measured_traffic(config, f"{nil}x{nxl}x{n_local}") if default_shape else (None, None, None)
             steady = 1e3 / it_ms if it_ms > 0 else None
             roof = {
                 "bound": "hbm",
@@ -398,7 +478,7 @@ def main():
                            f"col_kernel<{nil},COL_ITER> + the persistent row pass (row_pipe64_kernel<{nxl}> for rows of whole "
                            f"wavefronts, row_pipe_kernel otherwise) = one POCS iteration of {n_local} slices"),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_from": traffic_from,
+                "traffic": traffic, "traffic_from": traffic_from, "traffic_last_measured": last,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "launch_ms": it_ms,
                 "colpass_ms": prof["colpass_ms"], "rowpass_ms": prof["rowpass_ms"],
@@ -409,40 +489,29 @@ def main():
                 if prof["rowpass_ms"] else 0.0,
             }
         else:
-            it_ms = float(np.median(dev_times)) / K   # HIP events of the library around the K-iteration loop, on the plan's stream
+            it_ms = float(np.median(dev_times)) / K   # HIP events of the library around the K-iteration loop(s), on the plan's stream
             achieved = alg_bytes / (it_ms * 1e-3) / 1e9
             steady = 1e3 / it_ms
-            w_traffic, w_from = None, None
-            wfile = os.path.join(ROOT, "profiles", "r02_wavelet_traffic.json")
-            if kind == "WAVELET" and (nil, nxl, nslices) == (512, 512, 256) and world == 1 and os.path.exists(wfile):
-                try:   # counters of the same loop, collected by tools/pmc_kernels.sh (one TCC counter per pass)
-                    with open(wfile) as fh:
-                        w_traffic = json.load(fh).get("hbm_bytes_per_iteration")
-                    w_from = "profiles/r02_wavelet_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same loop (tools/wavelet_bench.py), round 2"
-                except (OSError, ValueError):
-                    w_traffic, w_from = None, None
-            sfile = os.path.join(ROOT, "profiles", "r02_shearlet_traffic.json")
-            if kind == "SHEARLET" and (nil, nxl) == (2048, 1024) and os.path.exists(sfile):
-                try:   # per slice-iteration, scaled to this rank's slices
-                    with open(sfile) as fh:
-                        w_traffic = json.load(fh).get("hbm_bytes_per_slice_iteration") * n_local
-                    w_from = ("profiles/r02_shearlet_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/shearlet_bench.py "
-                              "(4 slices of this shape), per slice-iteration x the slices of this rank, round 2")
-                except (OSError, ValueError, TypeError):
-                    w_traffic, w_from = None, None
+            # config 4: the traffic file holds bytes per slice-iteration; scale to this rank's slices
+            key = f"{nil}x{nxl}" + (f"x{n_local}" if kind == "WAVELET" else f"x{nsh}sh")
+            traffic, traffic_from, last = measured_traffic(config, key, scale=(n_local if kind == "SHEARLET" else 1.0)) if default_shape else (None, None, None)
             roof = {
                 "bound": "hbm",
-                "kernel": ("dwt2_tile_kernel / idwt2_tile_kernel chain (one launch per level and direction)" if kind == "WAVELET" else
-                           "row_kernel<ROW_SPREAD_INV> + col_kernel<COL_SHRINK> + row_kernel<ROW_GATHER_FWD> + the two fft2 passes")
+                "kernel": ("dwt2_tile_kernel / idwt2_tile_kernel chain (level 1 and 2 one launch per level and direction, the coarser levels "
+                           "in one slice-resident kernel)" if kind == "WAVELET" else
+                           "row_kernel<ROW_SPREAD_INV> + col_pipe_kernel<COL_SHRINK> + row_kernel<ROW_GATHER_FWD> + the two fft2 passes")
                           + f" = one POCS iteration of {n_local} slices",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": w_traffic, "traffic_from": w_from,
+                "traffic": traffic, "traffic_from": traffic_from, "traffic_last_measured": last,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": it_ms,
             }
+        if roof["traffic"]:
+            roof["moved_GBps"] = roof["traffic"] / (roof["launch_ms"] * 1e-3) / 1e9
+            roof["moved_frac"] = roof["moved_GBps"] / HBM_PEAK_GBPS
 
     # ---- the same job with the sparse-spectrum shortcut switched off (reported beside `value`, rank 0 only) ----
     dense_its = None
-    side = rank == 0 and not args.no_dense and kind == "FFT"
+    side = rank == 0 and not args.no_dense and kind == "FFT" and main
     if side and nz_fraction >= 0:
         os.environ["P3D_NO_SPARSE"] = "1"
         job(min(W, 3) or 1)
@@ -455,7 +524,7 @@ def main():
 
     # ---- the real-valued (float32, time-domain) cube of the same shape, reported beside `value` (rank 0, N = 1 only) ----
     real_its = None
-    if side and world == 1 and op == "hard" and args.config == 2:
+    if side and world == 1 and op == "hard" and config == 2:
         xr = x_obs.real.contiguous()
         outr = torch.empty_like(xr)
         torch.cuda.synchronize()
@@ -478,13 +547,36 @@ def main():
         real_its = K / float(np.median(rt))
         del xr, outr
 
+    # ---- end to end: host NumPy cube in -> host NumPy cube out through the host-buffer entry point (every rank its block) ----
+    e2e = None
+    if not args.only_main and not args.no_end_to_end and kind != "SHEARLET" and density == 0:
+        host = x_obs.cpu().numpy()
+        kw = dict(transform_kind=kind, thresh_op=op, thresh_model="exponential", eps=args.eps, alpha=args.alpha, p_max=0.99, p_min=p_min,
+                  device=dev_index, wavelet=cfg.get("wavelet"))
+        P.pocs_cube(host[:min(n_local, 64)], mask, niter=2, **kw)     # plans, device buffers, page-locked staging of the chunk pipeline
+        ctx.fence()
+        t0 = time.perf_counter()
+        res_host = P.pocs_cube(host, mask, niter=K, **kw)
+        ctx.fence()
+        e_s = ctx.max_over_ranks(time.perf_counter() - t0)
+        same = bool(np.array_equal(res_host, out.cpu().numpy())) if args.eps == 0 else None
+        e2e = {"iterations_per_s": K / e_s, "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / e_s, "seconds": e_s,
+               "host_bytes_in_plus_out": 2 * host.nbytes * world if world == 1 else 2 * host.nbytes,
+               "equals_resident_result": same,
+               "what": f"functions.POCS.pocs_cube(host cube, mask, niter={K}) per rank on its block: pageable NumPy array in, NumPy array "
+                       f"out, statistics + schedule + iterations + PCIe both ways (FFT: chunks of ~128 MiB, four in flight); max over ranks"}
+        del host, res_host
+        P.release_plans()
+
     # ---- how the rate depends on the data: the same job on denser spectra (rank 0, N = 1) ----
     by_density = None
-    if side and world == 1 and roof is not None and args.density == 0:
+    if side and world == 1 and roof is not None and density == 0:
         by_density = [{"coefficients_per_slice": "survey recipe (6 plane waves)", "nonzero_block_fraction": nz_fraction,
                        "iterations_per_s": K / seconds, "steady_state_iterations_per_s": steady, "roofline_frac": roof["frac"]}]
         for m in (96, 1024):
-            generate(m)
+            xc_ = x_obs
+            fill_random_spectrum(torch, xc_, nil, nxl, lo, pool, m, fft_plan)
+            xc_.mul_(mask_t)
             job(min(W, 3) or 1)
             torch.cuda.synchronize()
             d0 = time.perf_counter()
@@ -496,96 +588,157 @@ def main():
             by_density.append({"coefficients_per_slice": m, "nonzero_block_fraction": kept, "iterations_per_s": K / d_s,
                                "steady_state_iterations_per_s": 1e3 / it_ms, "roofline_frac": alg_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS})
 
-    # ---- the trivial gather of the blocks (outside the timed steps) -------------------------------
-    gather_ms = 0.0
-    if world > 1:
-        src = out.cpu() if rehearsal else out
-        blocks = [torch.empty_like(src) for _ in range(world)] if n_local * world == nslices else None
-        if blocks is not None:
-            fence()
+    # ---- the trivial gather of the blocks (outside the timed steps): device tensors, one collective ----
+    gather = None
+    if world > 1 and main:
+        from pseudo_3d_interpolation_amd.sharding import gather_blocks, gather_blocks_to_root
+        src = out.cpu() if ctx.rehearsal else out
+        gather = {}
+        for name, fn in (("all_gather", gather_blocks), ("gather_to_root", gather_blocks_to_root)):
+            ctx.fence()
             g0 = time.perf_counter()
-            dist.all_gather(blocks, src)
-            fence()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            del blocks
+            full = fn(src, nslices)
+            ctx.fence()
+            gather[name + "_ms"] = ctx.max_over_ranks(time.perf_counter() - g0) * 1e3
+            if rank == 0:
+                assert full.shape[0] == nslices
+            del full
+        gather["bytes_per_rank"] = int(src.numel() * src.element_size())
+        gather["note"] = ("all_gather lands the whole cube on every rank; gather_to_root (dist.gather of equal blocks, padded when uneven) only on "
+                          "rank 0 -- the 'trivial gather' of north_star; device tensors over RCCL/xGMI, no host round trip")
 
     cpu = None
     if rank == 0 and cpu_slices is not None:
         plan.close()
         del x_obs, out
         torch.cuda.empty_cache()
+        budget = args.cpu_seconds if main else min(args.cpu_seconds, 5.0)
         if kind == "SHEARLET":
             cpu = cpu_baseline_shearlet(cpu_slices[0], mask, psi, op, cube_slices)
         else:
             cs = cpu_slices if not cfg["real"] else cpu_slices.real.astype(np.float64)
-            cpu = cpu_baseline(kind, list(cs), mask, op, args.cpu_seconds, cube_slices, extra=cfg.get("wavelet"))
+            cpu = cpu_baseline(kind, list(cs), mask, op, budget, cube_slices, extra=cfg.get("wavelet"))
+    else:
+        plan.close()
+        del x_obs, out
+    del pool, mask_t
+    torch.cuda.empty_cache()
 
-    if rank == 0:
-        scale = nslices / cube_slices   # config 4: the sample's rate, expressed per whole cube
-        its = K / seconds * scale
-        dtype_s = "float32" if cfg["real"] else "complex64"
-        tag = f" (BASELINE configs[{args.config}])" if all(v is None for v in (args.nil, args.nxl, args.missing, args.thresh_op)) and \
-            (args.nslices is None or kind == "SHEARLET") else ""
-        what = {"FFT": "FFT transform", "WAVELET": f"wavelet transform ({cfg.get('wavelet')}, mode 'smooth')", "SHEARLET": f"shearlet transform ({nsh} shearlets)"}[kind]
-        workload = (f"{nil}x{nxl}x{cube_slices} {dtype_s} cube, {int(missing * 100)}% missing traces, {what}, {op} threshold, exponential decay, "
-                    f"{K} iterations" + tag)
-        if cube_slices != nslices:
-            workload += f"; timed on a sample of {nslices} of its {cube_slices} slices, rate scaled by {nslices}/{cube_slices}"
-        if kind == "SHEARLET" and K != cfg.get("cube_steps", K):
-            workload += f" ({K} of the configuration's {cfg['cube_steps']} iterations: the schedule of a {K}-iteration job)"
-        line = {
-            "metric": f"POCS iterations/s on the {nil}x{nxl}x{cube_slices} cube",
-            "value": its,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": seconds * 1e3 / K / scale,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": f"{dtype_s} (f32 arithmetic)",
-            "data": ("synthetic: 6 plane waves + 1% Gaussian noise per slice (seeded; NumPy noise pool, no torch RNG), random trace mask"
-                     if args.density == 0 or kind != "FFT" else
-                     f"synthetic: {args.density} random spectral coefficients + 1% Gaussian noise per slice (seeded), random trace mask"),
-            "config": {
-                "workload": workload,
-                "slices_per_gpu": n_local,
-                "parallelism": f"slice axis in {world} contiguous block(s), one rank per GPU, no collective in the loop",
-            },
-            "repeats": {"n": R, "job_s_median": seconds, "job_s_min": float(np.min(times)), "job_s_max": float(np.max(times)),
-                        "iterations_per_s_best": K / float(np.min(times)) * scale,
-                        "note": "`value` = steps / median job time; a job = statistics + schedule + the K iterations + final store"},
-            "steady_state_iterations_per_s": None if steady is None else steady * scale,
-            # (the steady rate comes from the per-launch HIP events of a profiled repeat; on cubes whose iteration takes a fraction
-            # of a millisecond the event records themselves lengthen it, and the difference below would come out negative: null)
-            "fixed_ms_per_job": None if steady is None or seconds * 1e3 < K * 1e3 / steady else seconds * 1e3 - K * 1e3 / steady,
-            "slice_iterations_per_s": K / seconds * nslices,
-            "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / (seconds / scale),
-            "device_ms_rank0": float(np.median(dev_times)),
-            "gather_ms": gather_ms,
-            "sparse_spectrum": None if kind != "FFT" else {
-                "nonzero_block_fraction": nz_fraction,
-                "note": "8-column blocks of the thresholded spectrum that kept a coefficient (rank 0, mean over slices and "
-                        "iterations); emptied blocks are not transformed back, stored or re-read -- exact. Data dependent: "
-                        "dense_path_iterations_per_s is the rate with the shortcut off (P3D_NO_SPARSE=1), from rank 0's block; "
-                        "by_density repeats the job on denser synthetic spectra",
-                "dense_path_iterations_per_s": dense_its,
-                "by_density": by_density,
-            },
-            "real_cube": None if real_its is None else {
-                "iterations_per_s": real_its,
-                "note": "the same job on the real part of the cube as float32 (a time-domain cube): rows share one complex transform "
-                        "in pairs and the work buffer holds half the spectrum; not the metric's configuration (complex64 slices)",
-            },
-            "roofline": roof,
-            "cpu_baseline": cpu,
-        }
+    if rank != 0:
+        return None
+    scale = nslices / cube_slices   # config 4: the sample's rate, expressed per whole cube
+    its = K / seconds * scale
+    dtype_s = "float32" if cfg["real"] else "complex64"
+    tag = f" (BASELINE configs[{config}])" if (nil, nxl, missing, op) == tuple(CONFIGS[config][k] for k in ("nil", "nxl", "missing", "op")) and \
+        (not main or args.nslices is None or kind == "SHEARLET") else ""
+    what = {"FFT": "FFT transform", "WAVELET": f"wavelet transform ({cfg.get('wavelet')}, mode 'smooth')", "SHEARLET": f"shearlet transform ({nsh} shearlets)"}[kind]
+    workload = (f"{nil}x{nxl}x{cube_slices} {dtype_s} cube, {int(missing * 100)}% missing traces, {what}, {op} threshold, exponential decay, "
+                f"{K} iterations" + tag)
+    if cube_slices != nslices:
+        workload += (f"; timed on a sample of {nslices} of its {cube_slices} slices ({n_local} per GPU, each GPU's sample taken from its own block of "
+                     f"the cube, batches of {min(n_local, SHEARLET_BATCH)}), all {K} iterations of the schedule, rate scaled by {nslices}/{cube_slices}")
+    return {
+        "metric": f"POCS iterations/s on the {nil}x{nxl}x{cube_slices} cube",
+        "value": its,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": seconds * 1e3 / K / scale,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": f"{dtype_s} (f32 arithmetic)",
+        "data": ("synthetic: 6 plane waves + 1% Gaussian noise per slice (seeded; NumPy noise pool, no torch RNG), random trace mask"
+                 if density == 0 else
+                 f"synthetic: {density} random spectral coefficients + 1% Gaussian noise per slice (seeded), random trace mask"),
+        "config": {
+            "workload": workload,
+            "slices_per_gpu": n_local,
+            "parallelism": f"slice axis in {world} contiguous block(s), one rank per GPU, no collective in the loop",
+        },
+        "repeats": {"n": R, "job_s_median": seconds, "job_s_min": float(np.min(times)), "job_s_max": float(np.max(times)),
+                    "iterations_per_s_best": K / float(np.min(times)) * scale,
+                    "note": "`value` = steps / median job time; a job = statistics + schedule + the K iterations + final store"},
+        # rank 0's loop time for its n_local slices; a sample leg's ranks run their shares side by side, so the cube rate is x sample/cube
+        "steady_state_iterations_per_s": None if steady is None else steady * scale,
+        # (the steady rate comes from the per-launch HIP events of a profiled repeat; on cubes whose iteration takes a fraction
+        # of a millisecond the event records themselves lengthen it, and the difference below would come out negative: null)
+        "fixed_ms_per_job": None if steady is None or seconds * 1e3 < K * 1e3 / steady else seconds * 1e3 - K * 1e3 / steady,
+        "slice_iterations_per_s": K / seconds * nslices,
+        "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / (seconds / scale),
+        "device_ms_rank0": float(np.median(dev_times)),
+        "gather_ms": None if gather is None else gather["all_gather_ms"],
+        "gather": gather,
+        "sparse_spectrum": None if kind != "FFT" else {
+            "nonzero_block_fraction": nz_fraction,
+            "note": "8-column blocks of the thresholded spectrum that kept a coefficient (rank 0, mean over slices and "
+                    "iterations); emptied blocks are not transformed back, stored or re-read -- exact. Data dependent: "
+                    "dense_path_iterations_per_s is the rate with the shortcut off (P3D_NO_SPARSE=1), from rank 0's block; "
+                    "by_density repeats the job on denser synthetic spectra",
+            "dense_path_iterations_per_s": dense_its,
+            "by_density": by_density,
+        },
+        "real_cube": None if real_its is None else {
+            "iterations_per_s": real_its,
+            "note": "the same job on the real part of the cube as float32 (a time-domain cube): rows share one complex transform "
+                    "in pairs and the work buffer holds half the spectrum; not the metric's configuration (complex64 slices)",
+        },
+        "end_to_end": e2e,
+        "roofline": roof,
+        "cpu_baseline": cpu,
+    }
+
+
+def compact(rec):
+    """What an `other_configs` entry keeps of a leg's record: enough to recompute its rate and roofline fraction."""
+    keep = ("value", "unit", "steps", "ms_per_step", "dtype", "steady_state_iterations_per_s", "fixed_ms_per_job", "slice_iterations_per_s",
+            "interpolated_traces_per_s", "end_to_end", "roofline", "cpu_baseline")
+    out = {"workload": rec["config"]["workload"], "slices_per_gpu": rec["config"]["slices_per_gpu"]}
+    out.update({k: rec[k] for k in keep})
+    out["repeats"] = {k: rec["repeats"][k] for k in ("n", "job_s_median", "job_s_min", "job_s_max")}
+    if rec.get("sparse_spectrum"):
+        out["nonzero_block_fraction"] = rec["sparse_spectrum"]["nonzero_block_fraction"]
+    return out
+
+
+def release(ctx):
+    """Between legs: the tensors of the finished leg died with its frame -- hand their memory back to the device."""
+    import gc
+    gc.collect()
+    ctx.torch.cuda.synchronize()
+    ctx.torch.cuda.empty_cache()
+
+
+def main():
+    args = parse_args()
+    ctx = Ctx(args)
+    t_all = time.perf_counter()
+    line = run_leg(ctx, args.config, args.steps, main=True)
+    release(ctx)
+    plain = all(v is None for v in (args.nil, args.nxl, args.nslices, args.missing, args.thresh_op)) and args.density == 0
+    if args.config == 2 and plain and not args.only_main:
+        others = {}
+        for c in ((1, 3, 4) if ctx.world == 1 else (4,)):
+            t0 = time.perf_counter()
+            try:
+                rec = run_leg(ctx, c, None, main=False)
+                release(ctx)
+                if ctx.rank == 0:
+                    others[str(c)] = compact(rec)
+                    others[str(c)]["leg_wall_s"] = time.perf_counter() - t0
+            except Exception as exc:  # noqa: BLE001 -- a failing side leg must not take the metric's line with it
+                if ctx.rank == 0:
+                    others[str(c)] = {"error": f"{type(exc).__name__}: {exc}"}
+        if ctx.rank == 0:
+            line["other_configs"] = others
+    if ctx.rank == 0:
+        line["kernel_source_hash"] = kernel_source_hash()
+        line["bench_wall_s"] = time.perf_counter() - t_all
         print(json.dumps(line), flush=True)
-
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@ this generator and the GPU transform are self-consistent and are tested as such;
 Only the one-off set-up lives here (NumPy, separable evaluation); the transform and the POCS loop run on the GPU
 (``_ffi.ShearletPlan``).
 """
+import os
+
 import numpy as np
 
 
@@ -69,34 +71,54 @@ def scalesShearsAndSpectra(shape, numOfScales=None, realCoefficients=True, fftsh
     wx = np.linspace(-X, X, nxl + (nxl % 2 == 0))[:nxl][None, :]
     cone_x = np.abs(wx) >= np.abs(wy)
     counts = [2 ** (j + 2) for j in range(J)]
-    psi = np.empty((nil, nxl, 1 + sum(counts)), dtype=dtype)
-    psi[..., 0] = np.where(cone_x, _scaling(wx), _scaling(wy))
+    nsh = 1 + sum(counts)
+    # built plane by plane in the layout the GPU plan uploads, (nsh, nil, nxl) -- a plane is one contiguous write -- and handed out
+    # as the (nil, nxl, nsh) VIEW of it that FFST's layout asks for (same values; `_ffi.ShearletPlan` moves the axis back without
+    # a copy).  Planes are independent: a few threads share them (NumPy's loops release the GIL).
+    stack = np.empty((nsh, nil, nxl), dtype=dtype)
+    stack[0] = np.where(cone_x, _scaling(wx), _scaling(wy))
     with np.errstate(divide='ignore', invalid='ignore'):
         slope_x = np.where(wx != 0, wy / np.where(wx != 0, wx, 1.0), wy * 4.0 ** J)   # wy / wx; the bump vanishes where wx = 0
         slope_y = np.where(wy != 0, wx / np.where(wy != 0, wy, 1.0), wx * 4.0 ** J)
+    jobs = []
     n = 1
     for j in range(J):
         a = 4.0 ** (-j)
-        radial_x, radial_y = _wavelet(a * wx), _wavelet(a * wy)
+        radial = (_wavelet(a * wx), _wavelet(a * wy))
         for k in range(-2 ** j, 2 ** j + 1):
-            along_x = radial_x * _bump(2.0 ** j * slope_x + k)
-            along_y = radial_y * _bump(2.0 ** j * slope_y + k)
-            if abs(k) == 2 ** j:
-                psi[..., n] = np.where(cone_x, along_x, along_y)
-                n += 1
-            else:
-                psi[..., n] = along_x
-                psi[..., n + 1] = along_y
-                n += 2
+            jobs.append((j, k, n, radial))
+            n += 1 if abs(k) == 2 ** j else 2
+
+    def plane(job):
+        j, k, n, (radial_x, radial_y) = job
+        along_x = radial_x * _bump(2.0 ** j * slope_x + k)
+        along_y = radial_y * _bump(2.0 ** j * slope_y + k)
+        if abs(k) == 2 ** j:
+            stack[n] = np.where(cone_x, along_x, along_y)
+        else:
+            stack[n] = along_x
+            stack[n + 1] = along_y
+
+    workers = max(1, min(8, (os.cpu_count() or 1), len(jobs))) if nil * nxl >= (1 << 16) else 1
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(plane, jobs))
+    else:
+        for job in jobs:
+            plane(job)
     # an even extent keeps the Nyquist line (index 0 of the centred grid) without its mirror image: give it the root mean square
     # of both so that the spectra stay symmetric (real shearlets) and their squares still sum to one
     fine = slice(1 + sum(counts[:-1]), None)
     if nil % 2 == 0:
         c0 = 1 - nxl % 2
-        line = psi[0, c0:, fine].copy()
-        psi[0, c0:, fine] = np.sqrt(0.5 * (line ** 2 + line[::-1] ** 2))
+        line = stack[fine, 0, c0:].copy()
+        stack[fine, 0, c0:] = np.sqrt(0.5 * (line ** 2 + line[:, ::-1] ** 2))
     if nxl % 2 == 0:
         r0 = 1 - nil % 2
-        line = psi[r0:, 0, fine].copy()
-        psi[r0:, 0, fine] = np.sqrt(0.5 * (line ** 2 + line[::-1] ** 2))
-    return np.fft.ifftshift(psi, axes=(0, 1)) if fftshift_spectra else psi
+        line = stack[fine, r0:, 0].copy()
+        stack[fine, r0:, 0] = np.sqrt(0.5 * (line ** 2 + line[:, ::-1] ** 2))
+    if fftshift_spectra:
+        for i in range(nsh):   # plane by plane: np.fft.ifftshift of the whole stack would hold a second copy of it
+            stack[i] = np.fft.ifftshift(stack[i])
+    return np.moveaxis(stack, 0, -1)

@@ -3,9 +3,14 @@ farm, cube_POCS_interpolation_3D.py:291-340).
 
 Slices are independent (one ``POCS_algorithm`` call each in the reference), so the slice axis is cut
 into ``world`` contiguous blocks, every rank runs its block on its own GPU, and the blocks are put
-together again with ONE collective at the end (``all_gather`` over RCCL/xGMI when the tensors live on
-GPUs; the same code runs over gloo on CPU tensors, which is how the tests exercise it).
+together again with ONE collective at the end: ``gather`` to rank 0 (the "trivial gather" -- only the
+rank that writes the result cube needs all of it) or ``all_gather`` (every rank ends up with the cube).
+On GPUs the collective moves DEVICE tensors over RCCL/xGMI -- the block never visits the host between
+the last kernel and the collective; the same code runs over gloo on CPU tensors, which is how the
+tests exercise it.
 """
+import os
+
 import numpy as np
 
 
@@ -23,9 +28,8 @@ def block_sizes(nslices, world):
     return [slice_block(nslices, world, r)[1] - slice_block(nslices, world, r)[0] for r in range(world)]
 
 
-def gather_blocks(local, nslices, group=None):
-    """All-gather per-rank blocks (torch tensors, leading axis = slices of this rank) into the full
-    cube on every rank.  Uneven blocks are padded to the largest one for the collective."""
+def _padded(local, nslices, group):
+    """(block padded to the largest block of the sharding, sizes of all blocks)."""
     import torch
     import torch.distributed as dist
 
@@ -37,31 +41,117 @@ def gather_blocks(local, nslices, group=None):
     if local.shape[0] < biggest:
         pad = torch.zeros((biggest - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
-    parts = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(parts, local.contiguous(), group=group)
-    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+    return local.contiguous(), sizes
 
 
-def pocs_cube_sharded(cube, mask, group=None, compute=None, **params):
-    """Run :func:`functions.POCS.pocs_cube` on this rank's block of ``cube`` (NumPy, the whole cube is
-    visible to every rank, e.g. memory-mapped) and return the gathered result as a NumPy array.
-
-    ``compute(block, mask, **params)`` defaults to the HIP ``pocs_cube`` on device ``LOCAL_RANK``.
-    """
-    import os
-
+def gather_blocks(local, nslices, group=None):
+    """All-gather per-rank blocks (torch tensors, leading axis = slices of this rank) into the full
+    cube on every rank.  Uneven blocks are padded to the largest one for the collective."""
     import torch
     import torch.distributed as dist
 
+    local, sizes = _padded(local, nslices, group)
+    parts = [torch.empty_like(local) for _ in sizes]
+    dist.all_gather(parts, local, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+def gather_blocks_to_root(local, nslices, group=None, root=0):
+    """Gather the per-rank blocks on rank ``root`` only (``dist.gather``: one receive per peer on the root, one send on everybody
+    else -- 1/world of all_gather's traffic and no second copy of the cube on the other ranks).  Returns the full cube on the
+    root and an empty tensor (0 slices) elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    local, sizes = _padded(local, nslices, group)
+    me = dist.get_rank(group)
+    dst = dist.get_global_rank(group, root) if group is not None else root
+    parts = [torch.empty_like(local) for _ in sizes] if me == root else None
+    dist.gather(local, parts, dst=dst, group=group)
+    if me != root:
+        return local[:0]
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+def pocs_block_on_device(block, mask, device=0, **params):
+    """``functions.POCS.pocs_cube`` for one rank's block with the RESULT LEFT ON THE GPU: the block is uploaded once into a torch
+    tensor, statistics / schedule / iterations run on raw device pointers (``Plan.prime_dev`` + ``run_dev``) and the result comes
+    back as a device tensor (complex64 or float32) -- what the gather collective wants.  FFT transform with a statistics-driven
+    schedule; everything else is computed by ``pocs_cube`` (host arrays) and uploaded."""
+    import torch
+
+    from . import _ffi
+    from .functions import POCS as P
+
+    block = np.asarray(block)
+    dev = torch.device("cuda", int(device))
+    kind = str(params.get("transform_kind", "FFT")).upper()
+    model = params.get("thresh_model", "exponential")
+    fast = (kind == "FFT" and model != "data-driven" and block.ndim == 3 and block.shape[0] > 0 and
+            block.dtype in (np.complex64, np.float32) and params.get("thresh_op", "hard") in _ffi.P3D_OP)
+    if not fast:
+        res = np.ascontiguousarray(P.pocs_cube(block, mask, device=int(device), **params))
+        return torch.from_numpy(res).to(dev)
+    P._check_common(np.asarray(mask), kind, params.get("thresh_op", "hard"))
+    n, nil, nxl = block.shape
+    niter = int(params.get("niter", 50))
+    p_min = params.get("p_min", 1e-5)
+    if isinstance(p_min, str) and p_min != "adaptive":
+        p_min = float(p_min)
+    x = torch.from_numpy(np.ascontiguousarray(block)).to(dev)
+    out = torch.empty_like(x)
+    m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32)).to(dev)
+    dt = _ffi.P3D_C64 if np.iscomplexobj(block) else _ffi.P3D_F32
+    torch.cuda.synchronize(dev)      # the plan works on its own stream
+    plan = P._get_plan(nil, nxl, n, int(device), slot=14)
+    stats = plan.prime_dev(x.data_ptr(), dt, m.data_ptr(), n)
+    active = ~(stats[:, 2] == 0)
+    stats[~active] = 1.0
+    tau = P._schedule_from_stats(stats, nil * nxl, model, niter, float(params.get("p_max", 0.99)), p_min, params.get("decay_kind", "values"))
+    if params.get("sqrt_decay", False):
+        tau = np.sqrt(tau)
+    plan.run_dev(x.data_ptr(), dt, m.data_ptr(), tau, niter, out.data_ptr(), n, thresh_op=params.get("thresh_op", "hard"),
+                 version=params.get("version", "regular"), eps=float(params.get("eps", 1e-9)), alpha=float(params.get("alpha", 1.0)),
+                 active=active, primed=True, want_sums=False)
+    return out
+
+
+def pocs_cube_sharded(cube, mask, group=None, compute=None, gather="root", **params):
+    """Run the POCS interpolation of ``cube`` (NumPy, the whole cube is visible to every rank, e.g. memory-mapped) sharded over the
+    ranks of ``group`` and return the gathered result as a NumPy array: on every rank with ``gather='all'``, on rank 0 only (``None``
+    elsewhere) with ``gather='root'``.
+
+    ``compute(block, mask, **params)`` defaults to the HIP path on device ``LOCAL_RANK`` with the result kept on the device
+    (:func:`pocs_block_on_device`), so that over RCCL the collective moves device tensors and only the gathered cube is downloaded;
+    a ``compute`` that returns NumPy (the gloo tests inject one) is gathered on CPU tensors.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if gather not in ("root", "all"):
+        raise ValueError("gather must be 'root' or 'all'")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = slice_block(cube.shape[0], world, rank)
-    if compute is None:
-        from .functions.POCS import pocs_cube as compute  # noqa: N813
-        params.setdefault("device", int(os.environ.get("LOCAL_RANK", rank)))
-    block = np.ascontiguousarray(compute(np.asarray(cube[lo:hi]), mask, **params))
     on_gpu = dist.get_backend(group) == "nccl"
-    t = torch.from_numpy(block.view(np.float32) if np.iscomplexobj(block) else block)
-    if on_gpu:
-        t = t.to(torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank))))
-    full = gather_blocks(t, cube.shape[0], group).cpu().numpy()
-    return full.view(block.dtype) if np.iscomplexobj(block) else full
+    local_dev = int(os.environ.get("LOCAL_RANK", rank))
+    if compute is None:
+        block = pocs_block_on_device(np.asarray(cube[lo:hi]), mask, device=local_dev, **params)
+        if not on_gpu:
+            block = block.cpu()
+    else:
+        block = compute(np.asarray(cube[lo:hi]), mask, **params)
+    complex_np = None
+    if not torch.is_tensor(block):
+        block = np.ascontiguousarray(block)
+        complex_np = block.dtype if np.iscomplexobj(block) else None
+        block = torch.from_numpy(block.view(np.float32 if block.dtype == np.complex64 else np.float64) if complex_np is not None else block)
+        if on_gpu:
+            block = block.to(torch.device("cuda", local_dev))
+    elif block.is_complex():
+        complex_np = np.complex64 if block.dtype == torch.complex64 else np.complex128
+        block = torch.view_as_real(block).flatten(-2)      # (n, nil, 2 nxl) reals: every backend moves those
+    full = gather_blocks(block, cube.shape[0], group) if gather == "all" else gather_blocks_to_root(block, cube.shape[0], group)
+    if gather == "root" and rank != 0:
+        return None
+    full = full.cpu().numpy()
+    return full.view(complex_np) if complex_np is not None else full

@@ -44,12 +44,25 @@ def fake_pocs(block, m, **kw):          # stands in for the GPU call: the test i
     assert block.shape[0] == hi - lo and kw["niter"] == 3
     seen.append((lo, hi))
     return block * (1 - m) * 2 + block * m
-full = pocs_cube_sharded(cube, mask, compute=fake_pocs, niter=3)
 want = cube * (1 - mask) * 2 + cube * mask
+full = pocs_cube_sharded(cube, mask, compute=fake_pocs, gather="all", niter=3)          # the cube on every rank
 assert full.dtype == cube.dtype and full.shape == cube.shape
 assert np.array_equal(full, want), rank
-real = pocs_cube_sharded(cube.real.copy(), mask, compute=lambda b, m, **kw: b + 1, niter=3)
+root = pocs_cube_sharded(cube, mask, compute=fake_pocs, niter=3)                        # default: the trivial gather to rank 0
+assert (root is None) == (rank != 0)
+if rank == 0:
+    assert root.dtype == cube.dtype and np.array_equal(root, want)
+real = pocs_cube_sharded(cube.real.copy(), mask, compute=lambda b, m, **kw: b + 1, gather="all", niter=3)
 assert np.array_equal(real, cube.real + 1)
+import torch
+from pseudo_3d_interpolation_amd.sharding import gather_blocks, gather_blocks_to_root
+lo, hi = slice_block(n, world, rank)
+mine = torch.from_numpy(cube.real[lo:hi].copy())
+assert torch.equal(gather_blocks(mine, n), torch.from_numpy(cube.real.copy()))
+got = gather_blocks_to_root(mine, n)
+assert got.shape[0] == (n if rank == 0 else 0) and (rank != 0 or torch.equal(got, torch.from_numpy(cube.real.copy())))
+as_tensor = pocs_cube_sharded(cube, mask, compute=lambda b, m, **kw: torch.from_numpy(np.ascontiguousarray(b * 3)), gather="all", niter=3)
+assert as_tensor.dtype == cube.dtype and np.array_equal(as_tensor, cube * 3)            # a compute that hands back a (complex) tensor
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", seen)
