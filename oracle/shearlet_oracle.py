@@ -75,8 +75,16 @@ def number_of_scales(shape):
     return max(int(np.floor(0.5 * np.log2(np.max(shape)))), 1)
 
 
-def scales_shears_and_spectra(shape, num_scales=None):
-    """Psi (nil, nxl, nsh), real, FFT order; nsh = 1 + sum_j 2^(j+2)."""
+def scales_shears_and_spectra(shape, num_scales=None, contiguous=True):
+    """Psi (nil, nxl, nsh), real, FFT order; nsh = 1 + sum_j 2^(j+2).  `contiguous=False` hands out the (nil, nxl, nsh) VIEW of the
+    (nsh, nil, nxl) stack the planes are built in (same values, no 2-GiB transposing copy for configs[4]'s frame; reductions over
+    such a view add up in another order, so the pinned bit-for-bit schedules use the default).
+
+    Evaluated plane by plane into an (nsh, nil, nxl) stack (one contiguous write per shearlet, a few threads share the planes) and
+    returned as the (nil, nxl, nsh) view of it: the arithmetic per sample is the one written out in `_shearlet_spect`; only the
+    order of evaluation was arranged so that configs[4]'s 2048 x 1024 x 125 frame takes seconds instead of minutes."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
     nil, nxl = int(shape[0]), int(shape[1])
     J = number_of_scales(shape) if num_scales is None else int(num_scales)
     odd = (nil + (nil % 2 == 0), nxl + (nxl % 2 == 0))
@@ -87,24 +95,39 @@ def scales_shears_and_spectra(shape, num_scales=None):
     hor = np.abs(xi_x) >= np.abs(xi_y)
     ver = ~hor
     per_scale = [2 ** (j + 2) for j in range(J)]
-    psi = np.zeros(odd + (1 + sum(per_scale),))
-    psi[..., 0] = meyer_scaling(xi_x) * hor + meyer_scaling(xi_y) * ver
-    pos = 1
+    nsh = 1 + sum(per_scale)
+    psi = np.zeros((nsh, nil, nxl))
+
+    def put(pos, plane):            # crop the odd grid to the slice shape
+        psi[pos] = plane[:nil, :nxl]
+
+    put(0, meyer_scaling(xi_x) * hor + meyer_scaling(xi_y) * ver)
+    jobs, pos = [], 1
     for j in range(J):
-        a = 2.0 ** (-2 * j)
         for k in range(-2 ** j, 2 ** j + 1):
-            s = k * 2.0 ** (-j)
-            p_hor = _shearlet_spect(xi_x, xi_y, a, s)
-            p_ver = _shearlet_spect(xi_y, xi_x, a, s)
-            if abs(k) == 2 ** j:            # seam: one element glued from both cones
-                psi[..., pos] = p_hor * hor + p_ver * ver
-                pos += 1
-            else:
-                psi[..., pos] = p_hor
-                psi[..., pos + 1] = p_ver
-                pos += 2
-    assert pos == psi.shape[-1]
-    psi = psi[:nil, :nxl]
+            jobs.append((j, k, pos))
+            pos += 1 if abs(k) == 2 ** j else 2
+    assert pos == nsh
+
+    def one(job):
+        j, k, pos = job
+        a = 2.0 ** (-2 * j)
+        s = k * 2.0 ** (-j)
+        p_hor = _shearlet_spect(xi_x, xi_y, a, s)
+        p_ver = _shearlet_spect(xi_y, xi_x, a, s)
+        if abs(k) == 2 ** j:            # seam: one element glued from both cones
+            put(pos, p_hor * hor + p_ver * ver)
+        else:
+            put(pos, p_hor)
+            put(pos + 1, p_ver)
+
+    workers = max(1, min(8, os.cpu_count() or 1)) if nil * nxl >= (1 << 16) else 1
+    if workers > 1:
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(one, jobs))
+    else:
+        for job in jobs:
+            one(job)
     # even extent: row / column 0 of the centred grid is the Nyquist line, which has no mirror partner on the grid; pair it with
     # itself (finest scale only -- coarser shearlets vanish there) so that Psi(-xi) = Psi(xi) and the frame identity survives
     first = 1 + sum(per_scale[:-1])
@@ -112,13 +135,16 @@ def scales_shears_and_spectra(shape, num_scales=None):
     # non-zero, and leaves the symmetric k = 0 element alone)
     if nil % 2 == 0:
         c0 = 1 - nxl % 2                     # the mirror of column c is nxl - c (even extent) or nxl - 1 - c (odd extent)
-        row = psi[0, c0:, first:].copy()
-        psi[0, c0:, first:] = np.sqrt(0.5 * (row ** 2 + row[::-1] ** 2))
+        row = psi[first:, 0, c0:].copy()
+        psi[first:, 0, c0:] = np.sqrt(0.5 * (row ** 2 + row[:, ::-1] ** 2))
     if nxl % 2 == 0:
         r0 = 1 - nil % 2
-        col = psi[r0:, 0, first:].copy()
-        psi[r0:, 0, first:] = np.sqrt(0.5 * (col ** 2 + col[::-1] ** 2))
-    return np.fft.ifftshift(psi, axes=(0, 1))
+        col = psi[first:, r0:, 0].copy()
+        psi[first:, r0:, 0] = np.sqrt(0.5 * (col ** 2 + col[:, ::-1] ** 2))
+    for i in range(nsh):
+        psi[i] = np.fft.ifftshift(psi[i])
+    view = np.moveaxis(psi, 0, -1)
+    return np.ascontiguousarray(view) if contiguous else view
 
 
 # ---- the transform pair handed to POCS_algorithm ------------------------------------------------------------------------
@@ -217,19 +243,13 @@ def pocs_cube_shearlet(cube, mask, Psi, infos=None, **params):
 
 
 # ---- the same loop for large REAL slices, evaluated with multi-threaded real transforms ------------------------------------------
-def pocs_slice_shearlet_real(x, mask, Psi, niter=50, thresh_op="hard", thresh_model="exponential", alpha=1.0, p_max=0.99,
-                             p_min=1e-5, workers=-1, info=None):
-    """`pocs_slice_shearlet(..., version='regular', eps=0)` for a REAL slice and real spectra with Psi_s(-k) = Psi_s(k) (what
-    `scales_shears_and_spectra` builds): ST_s = ifft2(Psi_s fft2(x)) is then real and equals irfft2 of the half spectrum, so the
-    loop runs on `scipy.fft.rfft2 / irfft2` with `workers` threads -- half the arithmetic of the complex transforms and all cores,
-    which is what makes BASELINE configs[4]'s slice (2048 x 1024, 125 shearlets: 250 two-million-point transforms per iteration)
-    checkable in a test.  Same arithmetic otherwise (float64, POCS.py:589-619); tests/test_gpu_shearlet.py holds it to
-    `pocs_slice_shearlet` on a small slice before using it."""
+def real_transform_pair(Psi, shape, workers=-1):
+    """(fwd, inv) of the frame for REAL slices of `shape` and real spectra with Psi_s(-k) = Psi_s(k): coefficients [s][i][j] through
+    `scipy.fft.rfft2 / irfft2` on the half spectrum (see pocs_slice_shearlet_real)."""
     import scipy.fft as sf
-    x = np.asarray(x, dtype=np.float64)
-    if np.iscomplexobj(Psi) or x.ndim != 2:
+    if np.iscomplexobj(Psi) or len(shape) != 2:
         raise ValueError("real 2-D slice and real spectra expected")
-    n1, n2 = x.shape
+    n1, n2 = shape
     half = np.ascontiguousarray(np.moveaxis(np.asarray(Psi)[:, : n2 // 2 + 1, :], -1, 0), dtype=np.float64)   # [s][k1][k2 <= n2/2]
 
     def fwd(v):
@@ -238,6 +258,30 @@ def pocs_slice_shearlet_real(x, mask, Psi, niter=50, thresh_op="hard", thresh_mo
     def inv(st):
         return sf.irfft2((sf.rfft2(st, axes=(1, 2), workers=workers) * half).sum(axis=0), s=(n1, n2))
 
+    return fwd, inv
+
+
+def shearlet_step_real(prev, x, mask, Psi, tau_k, thresh_op="hard", alpha=1.0, workers=-1, pair=None):
+    """ONE iteration (POCS.py:589-619, version 'regular') from the real iterate `prev`: returns the new iterate, the coefficients
+    [s][i][j] before the threshold and after it.  tau_k: one threshold per shearlet."""
+    prev = np.asarray(prev, dtype=np.float64)
+    fwd, inv = pair if pair is not None else real_transform_pair(Psi, prev.shape, workers)
+    st = fwd(prev)
+    shr = base.apply_threshold(st, np.asarray(tau_k)[:, None, None], kind=thresh_op)
+    nxt = inv(shr) * (1.0 - alpha * np.asarray(mask, dtype=np.float64)) + np.asarray(x, dtype=np.float64) * alpha
+    return nxt, st, shr
+
+
+def pocs_slice_shearlet_real(x, mask, Psi, niter=50, thresh_op="hard", thresh_model="exponential", alpha=1.0, p_max=0.99,
+                             p_min=1e-5, workers=-1, info=None):
+    """`pocs_slice_shearlet(..., version='regular', eps=0)` for a REAL slice and real spectra with Psi_s(-k) = Psi_s(k) (what
+    `scales_shears_and_spectra` builds): ST_s = ifft2(Psi_s fft2(x)) is then real and equals irfft2 of the half spectrum, so the
+    loop runs on `scipy.fft.rfft2 / irfft2` with `workers` threads -- half the arithmetic of the complex transforms and all cores,
+    which is what makes BASELINE configs[4]'s slice (2048 x 1024, 125 shearlets: 250 two-million-point transforms per iteration)
+    checkable in a test.  Same arithmetic otherwise (float64, POCS.py:589-619); tests/test_gpu_shearlet.py holds it to
+    `pocs_slice_shearlet` on a small slice before using it."""
+    x = np.asarray(x, dtype=np.float64)
+    fwd, inv = real_transform_pair(Psi, x.shape, workers)
     st0 = fwd(x)
     tau = shearlet_schedule(thresh_model, int(niter), float(p_max), p_min, np.moveaxis(st0, 0, -1), "values")  # (niter, nsh)
     w = 1.0 - alpha * np.asarray(mask, dtype=np.float64)

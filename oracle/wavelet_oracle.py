@@ -202,6 +202,23 @@ def pocs_slice_wavelet(x, mask, wavelet="coif5", niter=50, thresh_op="hard", thr
     return cur if complex_in else np.real(cur)
 
 
+def wavelet_step(prev, x, mask, wavelet, tau_k, thresh_op="hard", alpha=1.0, keep=None):
+    """ONE iteration of the loop above from the iterate `prev` (POCS.py:585-619, version 'regular'): returns the new iterate, the
+    detail arrays before the threshold and after it.  `keep` (same nesting as the details, boolean) replays given keep/zero
+    decisions of the hard operator instead of taking its own."""
+    bank = filter_bank(wavelet)
+    coeffs = wavedec2(prev, bank)
+    lowpass, details = coeffs[0], coeffs[1:]
+    tau_k = np.broadcast_to(tau_k, (len(details), 3))
+    if keep is None:
+        shr = [tuple(base.apply_threshold(details[l][d], tau_k[l][d], kind=thresh_op) for d in range(3)) for l in range(len(details))]
+    else:
+        shr = [tuple(np.where(keep[l][d], details[l][d], 0) for d in range(3)) for l in range(len(details))]
+    crop = tuple(slice(n) for n in np.shape(prev))
+    cur = waverec2([lowpass] + shr, bank)[crop] * (1 - alpha * mask) + x * alpha
+    return cur, details, shr
+
+
 def pocs_cube_wavelet(cube, mask, infos=None, **params):
     cube = np.asarray(cube)
     out = np.empty_like(cube)

@@ -850,7 +850,7 @@ int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, 
         p->tau_cap = nslices;
     }
     std::vector<c32> tau_f(nslices);
-    for (int s = 0; s < nslices; ++s) tau_f[s] = c32{(float)tau[2 * s], (float)tau[2 * s + 1]};
+    for (int s = 0; s < nslices; ++s) tau_f[s] = tau_for_device(tau[2 * s], tau[2 * s + 1], op == P3D_OP_HARD);
     HIP_TRY(hipMemcpy(p->tau, tau_f.data(), sizeof(c32) * nslices, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->st_x, in, bytes, hipMemcpyHostToDevice));
     if (p->generic) {
@@ -1064,7 +1064,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         p->sums_cap = nsum;
     }
     std::vector<c32> tau_f(ntau);
-    for (size_t i = 0; i < ntau; ++i) tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+    for (size_t i = 0; i < ntau; ++i) tau_f[i] = tau_for_device(tau[2 * i], tau[2 * i + 1], prm->thresh_op == P3D_OP_HARD);
     std::vector<int> done_h(nslices, 0);
     if (active)
         for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;

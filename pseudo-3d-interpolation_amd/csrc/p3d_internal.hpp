@@ -7,6 +7,22 @@
 
 namespace p3d {
 
+// A threshold of the host's float64 schedule as the float32 kernels get it.  The reference compares FLOAT32 moduli with a FLOAT64
+// (complex128) threshold in double precision -- np.less(np.absolute(X), tau) with tau a NumPy float64 / complex128 scalar
+// (threshold_operator.py:110-112; NEP 50 promotes the comparison, complex operands compare lexicographically).  For a float v and a
+// double t:  v < t  <=>  v < the smallest float >= t, and the lexicographic tie "v == Re tau and 0 < Im tau" needs Re tau to BE a
+// float.  So the hard operator gets Re tau rounded UP and the sign of Im tau only where the tie can happen; rounding to nearest would
+// keep, half of the time, a coefficient whose modulus is the float just below tau.  (Soft / garrote are continuous in tau and the
+// percentile operators carry percentages: nearest.)
+inline c32 tau_for_device(double re, double im, bool hard)
+{
+    if (!hard) return c32{(float)re, (float)im};
+    float t = (float)re;
+    if ((double)t < re) t = __builtin_nextafterf(t, __builtin_inff());
+    const bool tie = im > 0.0 && (double)t == re;
+    return c32{t, tie ? 1.0f : 0.0f};
+}
+
 // thread-local message returned by p3d_last_error() (p3d_api.hip)
 void set_last_error(const char* msg);
 

@@ -372,7 +372,7 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
     }
     std::vector<c32> tau_f(ntau);
     for (size_t i = 0; i < ntau; ++i) {
-        tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+        tau_f[i] = p3d::tau_for_device(tau[2 * i], tau[2 * i + 1], prm->thresh_op == P3D_OP_HARD);
         if (real_only && tau[2 * i + 1] != 0.0) return sfail(P3D_ERR_INVALID, "complex thresholds need a complex64 cube");
     }
     std::vector<int> done_h(nslices, 0);

@@ -1143,7 +1143,7 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     std::vector<c32> tau_f(ntau);
     bool real_tau = true;
     for (size_t i = 0; i < ntau; ++i) {
-        tau_f[i] = c32{(float)tau[2 * i], (float)tau[2 * i + 1]};
+        tau_f[i] = p3d::tau_for_device(tau[2 * i], tau[2 * i + 1], prm->thresh_op == P3D_OP_HARD);
         real_tau = real_tau && tau[2 * i + 1] == 0.0;
     }
     // float32 cubes with real thresholds stay real through the whole loop (what PyWavelets does for real input)

@@ -50,6 +50,8 @@ def gather_blocks(local, nslices, group=None):
     import torch
     import torch.distributed as dist
 
+    if local.is_complex():   # not every backend moves complex elements (gloo's gather refuses them): as (re, im) pairs
+        return torch.view_as_complex(gather_blocks(torch.view_as_real(local), nslices, group))
     local, sizes = _padded(local, nslices, group)
     parts = [torch.empty_like(local) for _ in sizes]
     dist.all_gather(parts, local, group=group)
@@ -63,6 +65,8 @@ def gather_blocks_to_root(local, nslices, group=None, root=0):
     import torch
     import torch.distributed as dist
 
+    if local.is_complex():
+        return torch.view_as_complex(gather_blocks_to_root(torch.view_as_real(local), nslices, group, root))
     local, sizes = _padded(local, nslices, group)
     me = dist.get_rank(group)
     dst = dist.get_global_rank(group, root) if group is not None else root
@@ -149,7 +153,7 @@ def pocs_cube_sharded(cube, mask, group=None, compute=None, gather="root", **par
             block = block.to(torch.device("cuda", local_dev))
     elif block.is_complex():
         complex_np = np.complex64 if block.dtype == torch.complex64 else np.complex128
-        block = torch.view_as_real(block).flatten(-2)      # (n, nil, 2 nxl) reals: every backend moves those
+        block = torch.view_as_real(block).flatten(-2)      # (n, nil, 2 nxl) reals
     full = gather_blocks(block, cube.shape[0], group) if gather == "all" else gather_blocks_to_root(block, cube.shape[0], group)
     if gather == "root" and rank != 0:
         return None

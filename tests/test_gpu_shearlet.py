@@ -159,6 +159,9 @@ def test_shearlet_config4_slice_at_its_own_size(so, monkeypatch):
     shape = (2048, 1024)
     psi = shearlets.scalesShearsAndSpectra(shape)
     assert psi.shape == shape + (125,)
+    # the oracle runs on ITS OWN spectra (written independently of the product's generator); the two frames agree to rounding
+    psi_orc = so.scales_shears_and_spectra(shape, contiguous=False)
+    assert psi_orc.shape == psi.shape and max(float(np.abs(psi[..., i] - psi_orc[..., i]).max()) for i in range(125)) < 1e-13
     mask = po.synthetic_mask(*shape, 0.8)
     cube = np.stack([po.synthetic_slice(*shape, 40 + i, real=True) for i in range(2)]) * mask
     cube = cube.astype(np.float32)
@@ -175,7 +178,7 @@ def test_shearlet_config4_slice_at_its_own_size(so, monkeypatch):
     monkeypatch.delenv("P3D_NO_COLPIPE")
     assert np.array_equal(plain[0], got[1])                                      # ... the same bits as the one-launch pass
     info = {}
-    want = so.pocs_slice_shearlet_real(cube[0].astype(np.float64), mask, psi, info=info, **kw)
+    want = so.pocs_slice_shearlet_real(cube[0].astype(np.float64), mask, psi_orc, info=info, **kw)
     err = rel_l2(got[0], want)
     truth = po.synthetic_slice(*shape, 40, real=True)
     print(f"configs[4] slice 2048x1024x125 shearlets, 4 iterations (hard): device-vs-oracle rel-L2 {err:.3e}; "
@@ -183,3 +186,45 @@ def test_shearlet_config4_slice_at_its_own_size(so, monkeypatch):
     assert err <= 2e-4, err                                                      # hard threshold: float32 decision flips (layer B)
     np.testing.assert_allclose(res[0]["costs"], info["costs"], rtol=2e-2, atol=1e-12)
     P.release_plans()
+
+
+def test_shearlet_floor_step_at_config4_size(ffi, so):
+    """Layer B (decision level) for BASELINE configs[4] in the regime its 100-iteration schedule ends in: 2048 x 1024, 125 shearlets,
+    80 % missing, hard threshold, tau_s = p_min * peak_s = 1e-3 of every shearlet's peak coefficient -- the incoherent floor, where
+    tens of thousands of coefficients crowd around the threshold.  The iterate is DEVICE-produced (60 iterations of the
+    100-iteration schedule); from it the device takes one step with the final thresholds and the oracle (float64, on its own spectra)
+    takes the same step.  The two may differ only by keep/zero decisions inside the float32 tie band around tau
+    (||c| - tau_s| <= 2e-6 max|c_s|): the synthesis of a Parseval frame does not amplify, so
+        || device - oracle ||_2  <=  || coefficients in the band ||_2  +  rounding (3e-6 || oracle ||_2)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    shape, K, late = (2048, 1024), 100, 60
+    psi = shearlets.scalesShearsAndSpectra(shape, dtype=np.float32)
+    psi_orc = so.scales_shears_and_spectra(shape, contiguous=False)
+    mask = po.synthetic_mask(*shape, 0.8)
+    maskf = mask.astype(np.float32)
+    x = (po.synthetic_slice(*shape, 41, real=True) * mask).astype(np.float32)[None]
+    with ffi.ShearletPlan(psi, max_slices=1) as plan:
+        stats = plan.stats(x)
+        tau = P._shearlet_schedule_from_stats(stats, shape, "exponential", K, 0.99, 1e-3, "values")      # (1, K, nsh)
+        assert tau.shape == (1, K, 125) and np.allclose(tau[0, -1], 1e-3 * stats[0, :, 0], rtol=1e-12)
+        it_late = plan.run(x, maskf, tau[:, :late], late, thresh_op="hard")[0]                              # device iterate after 60 iterations
+        assert np.isfinite(it_late).all()
+        t_floor = tau[:, -1:]                                                                             # (1, 1, nsh): the schedule's last entry
+        dev = plan.run(it_late, maskf, t_floor, 1, thresh_op="hard")[0][0]                                # one step with x_obs := the iterate
+    prev = it_late[0].astype(np.float64)
+    want, st, shr = so.shearlet_step_real(prev, prev, mask, psi_orc, t_floor[0, 0].real, "hard")
+    peak = np.abs(st).max(axis=(1, 2))
+    band = np.abs(np.abs(st) - t_floor[0, 0].real[:, None, None]) <= 2e-6 * peak[:, None, None]
+    band_norm = float(np.sqrt(np.sum(st[band] ** 2)))
+    kept = float(np.count_nonzero(shr)) / st.size
+    diff = float(np.linalg.norm(dev - want))
+    print(f"configs[4] floor step 2048x1024x125: {int(band.sum())} of {st.size} coefficients in the tie band ({band.mean():.2e}), kept "
+          f"{kept:.3f}; ||device - oracle|| = {diff:.3e} (rel {diff / np.linalg.norm(want):.2e}), band energy {band_norm:.3e}, "
+          f"rounding allowance {3e-6 * np.linalg.norm(want):.3e}")
+    assert band.mean() < 0.01, "the tie band should be a sliver of the coefficients"
+    assert 0.001 < kept < 0.9                                                                            # a threshold inside the floor, not above / below everything
+    assert diff <= band_norm + 3e-6 * np.linalg.norm(want), (diff, band_norm)
+    keep = mask.astype(bool)
+    assert np.array_equal(dev[keep], it_late[0][keep])                                                   # observed positions handed back exactly

@@ -262,3 +262,45 @@ def test_wavelet_config3_at_its_own_size(wo):
         assert got.dtype == np.float32 and np.isfinite(got).all()
         assert err64 <= 10 * spread, (err64, spread)
         assert err32 <= 3 * spread, (err32, spread)
+
+
+@pytest.mark.parametrize("op", ["soft", "hard"])
+def test_wavelet_floor_step_at_config3_size(ffi, wo, op):
+    """Layer B for BASELINE configs[3] in the regime its schedule ends in: 512 x 512 float32, db4 / 'smooth', 70 % missing, thresholds
+    tau[level, detail] = p_min * peak = 1e-3 of every detail array's peak (the last entry of the 50-iteration schedule).  The iterate
+    is DEVICE-produced (30 iterations of that schedule -- by then it has grown by orders of magnitude); from it
+    the device and the float64 oracle take ONE step each.  soft (the configuration's operator) is continuous: the step must agree to
+    float32 rounding.  hard: the two may differ only through keep/zero decisions inside the tie band ||d| - tau| <= 2e-6 max|d| of
+    each detail array; a db4 synthesis step amplifies by < 2 per level and axis pair, so the difference is bounded by a small multiple
+    of the band's energy."""
+    from oracle import pocs_oracle as po
+    n, K, late = 512, 50, 30
+    mask = po.synthetic_mask(n, n, 0.7)
+    maskf = mask.astype(np.float32)
+    x = (po.synthetic_slice(n, n, 0, real=True) * mask).astype(np.float32)
+    bank = wo.filter_bank("db4")
+    tau = wo.wavelet_schedule("exponential", K, 0.99, 1e-3, wo.wavedec2(x.astype(np.float64), bank)[1:])      # (K, nlev, 3)
+    with ffi.WaveletPlan(n, n, 1, wavelet="db4") as plan:
+        it_late = plan.run(x[None], maskf, tau[None, :late], late, thresh_op=op)[0][0]
+        assert np.isfinite(it_late).all()
+        dev = plan.run(it_late[None], maskf, tau[None, -1:], 1, thresh_op=op)[0][0]
+    prev = it_late.astype(np.float64)
+    want, details, shr = wo.wavelet_step(prev, prev, mask, "db4", tau[-1], op)
+    diff, ref = float(np.linalg.norm(dev - want)), float(np.linalg.norm(want))
+    band_sq, nband, ncoef = 0.0, 0, 0
+    for lvl in range(len(details)):
+        for d in range(3):
+            a = details[lvl][d]
+            b = np.abs(np.abs(a) - tau[-1, lvl, d]) <= 2e-6 * np.abs(a).max()
+            band_sq += float(np.sum(a[b] ** 2))
+            nband += int(b.sum())
+            ncoef += a.size
+    print(f"configs[3] floor step ({op}): iterate max|x| {np.abs(prev).max():.3e}; ||device - oracle|| / ||oracle|| = {diff / ref:.3e}; "
+          f"{nband} of {ncoef} detail coefficients in the tie band, band energy {band_sq ** 0.5:.3e}")
+    if op == "soft":
+        assert diff <= 3e-6 * ref, diff / ref
+    else:
+        assert nband < 0.01 * ncoef
+        assert diff <= 4.0 * band_sq ** 0.5 + 3e-6 * ref, (diff, band_sq ** 0.5)
+    keep = mask.astype(bool)
+    assert np.array_equal(dev[keep], it_late[keep])

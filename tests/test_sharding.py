@@ -61,6 +61,10 @@ mine = torch.from_numpy(cube.real[lo:hi].copy())
 assert torch.equal(gather_blocks(mine, n), torch.from_numpy(cube.real.copy()))
 got = gather_blocks_to_root(mine, n)
 assert got.shape[0] == (n if rank == 0 else 0) and (rank != 0 or torch.equal(got, torch.from_numpy(cube.real.copy())))
+cplx = torch.from_numpy(cube[lo:hi].copy())                                             # complex blocks go as (re, im) pairs
+assert torch.equal(gather_blocks(cplx, n), torch.from_numpy(cube))
+got = gather_blocks_to_root(cplx, n)
+assert got.dtype == torch.complex64 and (rank != 0 or torch.equal(got, torch.from_numpy(cube)))
 as_tensor = pocs_cube_sharded(cube, mask, compute=lambda b, m, **kw: torch.from_numpy(np.ascontiguousarray(b * 3)), gather="all", niter=3)
 assert as_tensor.dtype == cube.dtype and np.array_equal(as_tensor, cube * 3)            # a compute that hands back a (complex) tensor
 dist.barrier()
