@@ -126,8 +126,9 @@ def test_hard_threshold_compares_like_the_reference_in_double(ffi, shape):
             assert want == survives                   # (the table above IS NumPy's answer)
             kept = bool(plan.fft2_shrink(x, tau, "hard")[0, 0, 0] != 0)
             assert kept == survives, (tau, kept)
-            out = plan.run(x, np.zeros(shape, np.float32), np.array([[tau]]), 1, thresh_op="hard")[0]   # the loop's column pass: all traces missing
-            assert bool(np.abs(out).max() > 0) == survives, (tau, "loop")
+            # the loop's column pass, all traces "missing": out = ifft2(T(fft2(x))) * (1 - mask) + x  (POCS.py:616-619) = 2 x or x
+            out = plan.run(x, np.zeros(shape, np.float32), np.array([[tau]]), 1, thresh_op="hard")[0]
+            assert np.allclose(np.abs(out), 1.0 if survives else 0.5, rtol=1e-6), (tau, "loop", float(np.abs(out).max()))
 
 
 # ------------------------------------------------------------------------------------------------
