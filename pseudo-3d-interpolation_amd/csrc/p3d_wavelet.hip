@@ -393,6 +393,163 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     }
 }
 
+// ---- the coarse levels of a slice in ONE workgroup -------------------------------------------------------------------------------
+// From the first level LC whose input approximation fits LDS (512 x 512, db4, float32: level 3, a 133 x 133 approximation) the levels
+// are a few ten thousand samples per slice: as tile kernels they were eight launches of latency (profiles/r02_wavelet_levels.txt:
+// 108 of 660 us per iteration).  Here one workgroup carries a slice through analysis LC .. nlev (details thresholded and stored to
+// the coefficient vector as the tile kernels store them) and straight back through synthesis nlev .. LC; approximations never leave
+// LDS, and rec[LC - 1] comes out as the input of the level-(LC-1) tile synthesis.  The arithmetic of every output sample is the
+// tile kernels' (same taps in the same order, the 'smooth' extension evaluated by the same formula), so the two paths agree bit
+// for bit (tests/test_gpu_wavelet.py); P3D_WAVELET_NO_COARSE=1 keeps the tile kernels for all levels.
+// LDS: X = the level's input (h[LC-1] x w[LC-1] samples, later the approximations / reconstructions, all smaller), Y = the
+// row-filtered rows of the analysis incl. their extension rows (2 x (2 h[LC] + L - 2) x w[LC]; the synthesis needs less).
+constexpr int MAXLEV = 16;
+constexpr int COARSE_THREADS = 1024;
+struct CoarseArgs {
+    const void* in;        // approx[LC-1] (T) [slice][h[LC-1] * w[LC-1]]                        (do_fwd)
+    size_t in_slice;
+    void* coef;            // coefficient vectors (T) [slice][ncoef]
+    size_t coef_slice;
+    void* rec;             // rec[LC-1] (T) [slice][rh * rw]                                       (do_inv)
+    size_t rec_slice;
+    size_t doff[MAXLEV + 1];
+    int h[MAXLEV + 1], w[MAXLEV + 1];
+    int nlev, LC, do_fwd, do_inv, x_elems, ns;
+};
+
+template <typename T, int LT>
+__global__ __launch_bounds__(COARSE_THREADS) void wcoarse_kernel(CoarseArgs a, Filters f, Thresh th)
+{
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    __shared__ float4 s_dec[MAXL / 2], s_rec[MAXL / 2];
+    const int L = LT ? LT : f.len, HL = L / 2;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= a.ns) return;
+    T* X = reinterpret_cast<T*>(w_smem);
+    T* Y = X + a.x_elems;
+    if (tid < HL) {
+        const int j = 2 * tid, k = L - 2 - 2 * tid;
+        s_dec[tid] = float4{f.dec_lo[j], f.dec_hi[j], f.dec_lo[j + 1], f.dec_hi[j + 1]};
+        s_rec[tid] = float4{f.rec_lo[k], f.rec_hi[k], f.rec_lo[k + 1], f.rec_hi[k + 1]};
+    }
+    T* coef = reinterpret_cast<T*>(a.coef) + (size_t)s * a.coef_slice;
+    if (a.do_fwd) {
+        const T* src = reinterpret_cast<const T*>(a.in) + (size_t)s * a.in_slice;
+        const int n = a.h[a.LC - 1] * a.w[a.LC - 1];
+        for (int i = tid; i < n; i += COARSE_THREADS) X[i] = src[i];
+    }
+    __syncthreads();
+    if (a.do_fwd) {
+        for (int l = a.LC; l <= a.nlev; ++l) {
+            const int H = a.h[l - 1], W = a.w[l - 1], Ho = a.h[l], Wo = a.w[l], rows = 2 * Ho + L - 2;
+            T* ylo = Y;
+            T* yhi = Y + rows * Wo;
+            // axis 1 of the 'smooth'-extended input (smooth2_at: extension along axis 0, then along axis 1), rows -(L-2) .. 2 Ho - 1
+            for (int i = tid; i < rows * Wo; i += COARSE_THREADS) {
+                const int e = i / Wo, o = i - e * Wo, r = e - (L - 2), top = 2 * o + 1;
+                Acc<T> ad;
+                if (r >= 0 && r < H && top - (L - 1) >= 0 && top < W) {
+                    const T* q = X + r * W + top;
+                    for (int jj = 0; jj < HL; ++jj) {
+                        const float4 g = s_dec[jj];
+                        ad.tap(g.x, g.y, q[-2 * jj]);
+                        ad.tap(g.z, g.w, q[-2 * jj - 1]);
+                    }
+                } else {
+                    for (int jj = 0; jj < HL; ++jj) {
+                        const float4 g = s_dec[jj];
+                        ad.tap(g.x, g.y, smooth2_at(X, (size_t)W, H, W, r, top - 2 * jj));
+                        ad.tap(g.z, g.w, smooth2_at(X, (size_t)W, H, W, r, top - 2 * jj - 1));
+                    }
+                }
+                ylo[i] = ad.first();
+                yhi[i] = ad.second();
+            }
+            __syncthreads();
+            // axis 0: cA stays in LDS (X, pitch Wo) for the next level, the details are thresholded and stored
+            c32 t0{0.f, 0.f}, t1{0.f, 0.f}, t2{0.f, 0.f};
+            if (th.tau) {
+                const c32* t = th.tau + (((size_t)s * th.niter + th.iter) * th.nlev + (a.nlev - l)) * 3;
+                t0 = t[0]; t1 = t[1]; t2 = t[2];
+            }
+            const ShrinkTile<T> sh0(t0, th.op), sh1(t1, th.op), sh2(t2, th.op);
+            const size_t cnt = (size_t)Ho * Wo;
+            T* det = coef + a.doff[l];
+            for (int i = tid; i < Ho * Wo; i += COARSE_THREADS) {
+                const int p = i / Wo, o = i - p * Wo;
+                const T* cl = ylo + (2 * p + L - 1) * Wo + o;
+                const T* ch = yhi + (2 * p + L - 1) * Wo + o;
+                Acc<T> fl, fh;
+                for (int jj = 0; jj < HL; ++jj) {
+                    const float4 g = s_dec[jj];
+                    fl.tap(g.x, g.y, cl[-2 * jj * Wo]);
+                    fh.tap(g.x, g.y, ch[-2 * jj * Wo]);
+                    fl.tap(g.z, g.w, cl[-(2 * jj + 1) * Wo]);
+                    fh.tap(g.z, g.w, ch[-(2 * jj + 1) * Wo]);
+                }
+                T da = fl.second(), ad = fh.first(), dd = fh.second();
+                if (th.tau) { da = sh0(da); ad = sh1(ad); dd = sh2(dd); }
+                X[i] = fl.first();
+                if (l == a.nlev) coef[i] = fl.first();
+                det[i] = da;
+                det[cnt + i] = ad;
+                det[2 * cnt + i] = dd;
+            }
+            __syncthreads();   // (also: the details just stored are read back by the synthesis below)
+        }
+    } else if (a.do_inv) {
+        const int n = a.h[a.nlev] * a.w[a.nlev];
+        for (int i = tid; i < n; i += COARSE_THREADS) X[i] = coef[i];
+        __syncthreads();
+    }
+    if (!a.do_inv) return;
+    for (int l = a.nlev; l >= a.LC; --l) {
+        const int Ho = a.h[l], Wo = a.w[l], RH = 2 * Ho - L + 2, RW = 2 * Wo - L + 2;
+        // the approximation: cA (pitch Wo) at the coarsest level, else the reconstruction of level l (pitch 2 w[l+1] - L + 2,
+        // possibly one row / column larger than Ho x Wo: the extra samples are ignored, as in pywt.waverec2)
+        const int a_ld = l == a.nlev ? Wo : 2 * a.w[l + 1] - L + 2;
+        const size_t cnt = (size_t)Ho * Wo;
+        const T* det = coef + a.doff[l];
+        T* ylo = Y;
+        T* yhi = Y + RH * Wo;
+        // undo axis 0: rows 2i and 2i + 1 share the coefficients k = i .. i + L/2 - 1
+        for (int i = tid; i < (RH / 2) * Wo; i += COARSE_THREADS) {
+            const int ip = i / Wo, kc = i - ip * Wo;
+            Acc<T> lo, hi;
+            for (int t = 0; t < HL; ++t) {
+                const float4 g = s_rec[t];
+                const int k = ip + t;
+                const size_t o = (size_t)k * Wo + kc;
+                lo.tap(g.x, g.z, X[k * a_ld + kc]);
+                lo.tap(g.y, g.w, det[o]);
+                hi.tap(g.x, g.z, det[cnt + o]);
+                hi.tap(g.y, g.w, det[2 * cnt + o]);
+            }
+            ylo[(2 * ip) * Wo + kc] = lo.first();
+            ylo[(2 * ip + 1) * Wo + kc] = lo.second();
+            yhi[(2 * ip) * Wo + kc] = hi.first();
+            yhi[(2 * ip + 1) * Wo + kc] = hi.second();
+        }
+        __syncthreads();
+        // undo axis 1: outputs 2i and 2i + 1 of row m share the coefficients i .. i + L/2 - 1
+        T* out = l > a.LC ? X : reinterpret_cast<T*>(a.rec) + (size_t)s * a.rec_slice;
+        for (int i = tid; i < RH * (RW / 2); i += COARSE_THREADS) {
+            const int m = i / (RW / 2), ii = i - m * (RW / 2);
+            const T* ql = ylo + m * Wo + ii;
+            const T* qh = yhi + m * Wo + ii;
+            Acc<T> eo;
+            for (int t = 0; t < HL; ++t) {
+                const float4 g = s_rec[t];
+                eo.tap(g.x, g.z, ql[t]);
+                eo.tap(g.y, g.w, qh[t]);
+            }
+            out[m * RW + 2 * ii] = eo.first();
+            out[m * RW + 2 * ii + 1] = eo.second();
+        }
+        __syncthreads();
+    }
+}
+
 // what the last synthesis step (level 1) does with its output instead of storing it: crop + re-insertion (POCS.py:609, 616-619)
 struct Update {
     int enabled;
@@ -755,6 +912,10 @@ struct p3d_wplan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool fused = true;              // tile kernels (one launch per level and direction); P3D_WAVELET_UNFUSED=1 selects the per-axis kernels
     int tile_c = 0, tile_r = 0;     // coefficients per tile edge for complex64 / float32 work buffers
+    // first level carried by the one-workgroup-per-slice kernel (wcoarse_kernel) for complex64 / float32 work buffers; 0: none
+    int lc_c = 0, lc_r = 0;
+    int cx_c = 0, cx_r = 0;         // ... elements of its LDS region X
+    size_t clds_c = 0, clds_r = 0;  // ... its dynamic LDS bytes
     size_t per() const { return (size_t)nil * nxl; }
 };
 
@@ -771,6 +932,24 @@ static int pick_tile(int L, size_t esz)
     if (L % 2) return 0;                                   // the pair loads of the tile kernels need an even tap count
     if (tile_lds(32, L, esz) <= 80 * 1024) return 32;      // two or more workgroups per CU
     return tile_lds(16, L, esz) <= 150 * 1024 ? 16 : 0;
+}
+
+// First level LC >= 2 from which the rest of a slice's pyramid fits one workgroup's LDS (see wcoarse_kernel); 0 if none does.
+static int coarse_fit(const p3d_wplan* p, size_t esz, int* x_elems, size_t* lds)
+{
+    const int L = p->f.len;
+    if (L % 2 || p->nlev > MAXLEV) return 0;
+    const size_t budget = 160 * 1024 - 2 * sizeof(float4) * (MAXL / 2) - 256;
+    for (int lc = 2; lc <= p->nlev; ++lc) {
+        size_t x = (size_t)p->h[lc - 1] * p->w[lc - 1], y = 0;
+        for (int l = lc; l <= p->nlev; ++l) {
+            const size_t rh = 2 * (size_t)p->h[l] - L + 2, rw = 2 * (size_t)p->w[l] - L + 2;
+            x = std::max(x, std::max((size_t)p->h[l] * p->w[l], rh * rw));
+            y = std::max(y, 2 * std::max((2 * (size_t)p->h[l] + L - 2), rh) * (size_t)p->w[l]);
+        }
+        if ((x + y) * esz <= budget) { *x_elems = (int)x; *lds = (x + y) * esz; return lc; }
+    }
+    return 0;
 }
 
 extern "C" int p3d_wavelet_plan_destroy(p3d_wplan* p)
@@ -855,6 +1034,15 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
     p->tile_r = pick_tile(flen, sizeof(float));
     const char* env = getenv("P3D_WAVELET_UNFUSED");
     p->fused = !(env && env[0] == '1') && p->tile_c > 0 && p->tile_r > 0;
+    if (p->fused && !getenv("P3D_WAVELET_NO_COARSE")) {
+        p->lc_c = coarse_fit(p, sizeof(c32), &p->cx_c, &p->clds_c);
+        p->lc_r = coarse_fit(p, sizeof(float), &p->cx_r, &p->clds_r);
+        const void* ck[] = {(const void*)wcoarse_kernel<c32, 0>, (const void*)wcoarse_kernel<c32, 4>, (const void*)wcoarse_kernel<c32, 8>,
+                            (const void*)wcoarse_kernel<float, 0>, (const void*)wcoarse_kernel<float, 4>, (const void*)wcoarse_kernel<float, 8>};
+        for (const void* k : ck)
+            if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2 * (int)sizeof(float4) * (MAXL / 2) - 256)) != hipSuccess)
+                return bail("hipFuncSetAttribute", e);
+    }
     if (p->fused) {
         const int big = 150 * 1024;
 #define P3D_W_KERNELS(LT) (const void*)dwt2_tile_kernel<c32, 32, LT>, (const void*)dwt2_tile_kernel<c32, 16, LT>, (const void*)dwt2_tile_kernel<float, 32, LT>, \
@@ -890,13 +1078,41 @@ template <typename T> static T* as(c32* p) { return reinterpret_cast<T*>(p); }
 // thresholded as they are produced (threshold_wavelet, POCS.py:105-166) -- the approximation is never touched (POCS.py:586-587).
 template <typename T> static int tile_of(const p3d_wplan* p) { return sizeof(T) == sizeof(float) ? p->tile_r : p->tile_c; }
 
+template <typename T> static int coarse_level(const p3d_wplan* p) { return sizeof(T) == sizeof(float) ? p->lc_r : p->lc_c; }
+
+// levels LC .. nlev of every slice in one workgroup each: analysis (approx[LC-1] -> thresholded details, cA) and / or synthesis
+// (-> rec[LC-1])
 template <typename T>
-static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th)
+static int w_coarse(p3d_wplan* p, int ns, const Thresh* th, bool fwd, bool inv)
+{
+    const int lc = coarse_level<T>(p);
+    CoarseArgs a{};
+    a.in = p->approx[lc - 1]; a.in_slice = (size_t)p->h[lc - 1] * p->w[lc - 1];
+    a.coef = p->coef; a.coef_slice = p->ncoef;
+    a.rec = p->rec[lc - 1]; a.rec_slice = (size_t)p->rh[lc - 1] * p->rw[lc - 1];
+    for (int l = 0; l <= p->nlev; ++l) { a.h[l] = p->h[l]; a.w[l] = p->w[l]; a.doff[l] = p->doff[l]; }
+    a.nlev = p->nlev; a.LC = lc; a.do_fwd = fwd ? 1 : 0; a.do_inv = inv ? 1 : 0; a.ns = ns;
+    a.x_elems = sizeof(T) == sizeof(float) ? p->cx_r : p->cx_c;
+    const size_t lds = sizeof(T) == sizeof(float) ? p->clds_r : p->clds_c;
+    Thresh t{nullptr, 0, 0, 0, 0, 0, -1, -1};
+    if (th) t = *th;
+    const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
+    if (lt == 8) wcoarse_kernel<T, 8><<<ns, COARSE_THREADS, lds, p->stream>>>(a, p->f, t);
+    else if (lt == 4) wcoarse_kernel<T, 4><<<ns, COARSE_THREADS, lds, p->stream>>>(a, p->f, t);
+    else wcoarse_kernel<T, 0><<<ns, COARSE_THREADS, lds, p->stream>>>(a, p->f, t);
+    W_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+// fuse_inverse: the coarse kernel also runs its synthesis (the loop; w_inverse_fused is then told so)
+template <typename T>
+static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th, bool fuse_inverse = false)
 {
     const int tile = tile_of<T>(p), ns8 = (ns + 7) / 8 * 8;
     const size_t lds = tile_lds(tile, p->f.len, sizeof(T));
     T* coef = as<T>(p->coef);
-    for (int l = 1; l <= p->nlev; ++l) {
+    const int lc = coarse_level<T>(p), last_tile_level = lc ? lc - 1 : p->nlev;
+    for (int l = 1; l <= last_tile_level; ++l) {
         const T* src = l == 1 ? as<T>(p->feed) : as<T>(p->approx[l - 1]);
         const int H = p->h[l - 1], W = p->w[l - 1], Ho = p->h[l], Wo = p->w[l];
         T* cA = l == p->nlev ? coef : as<T>(p->approx[l]);
@@ -911,17 +1127,23 @@ static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th)
 #undef P3D_W_DWT
     }
     W_TRY(hipGetLastError());
+    if (lc) return w_coarse<T>(p, ns, th, true, fuse_inverse);
     return P3D_OK;
 }
 
 // `u`: what to do with the level-0 reconstruction (nullptr: store it in rec[0])
 template <typename T>
-static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u)
+static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u, bool coarse_done = false)
 {
     const int tile = tile_of<T>(p), ns8 = (ns + 7) / 8 * 8;
     const size_t lds = tile_lds(tile, p->f.len, sizeof(T));
     T* coef = as<T>(p->coef);
-    for (int l = p->nlev; l >= 1; --l) {
+    const int lc = coarse_level<T>(p);
+    if (lc && !coarse_done) {
+        const int rc = w_coarse<T>(p, ns, nullptr, false, true);
+        if (rc) return rc;
+    }
+    for (int l = lc ? lc - 1 : p->nlev; l >= 1; --l) {
         const int Ho = p->h[l], Wo = p->w[l], RH = p->rh[l - 1], RW = p->rw[l - 1];
         const T* a = l == p->nlev ? coef : as<T>(p->rec[l]);
         const size_t a_ld = l == p->nlev ? (size_t)Wo : (size_t)p->rw[l];
@@ -1039,7 +1261,7 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
     for (int k = 0; k < niter; ++k) {
         const bool last = k + 1 == niter;
         const Thresh th{p->tau, niter, k, p->nlev, 0, prm->thresh_op, -1, -1};
-        int rc = w_forward<T>(p, nslices, &th);
+        int rc = p->fused ? w_forward_fused<T>(p, nslices, &th, true) : w_forward<T>(p, nslices, &th);
         if (rc) return rc;
         if (p->fused) {
             Update u{};
@@ -1047,7 +1269,7 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
             u.sums = p->sums + (size_t)(k + 1) * nslices;
             u.adaptive = (adaptive && !last) ? 1 : 0; u.write_out = (early || last) ? 1 : 0; u.zero_fill = last ? 1 : 0;
             u.alpha = (float)prm->alpha; u.n1 = p->nil; u.n2 = p->nxl; u.done = p->done;
-            if ((rc = w_inverse_fused<T>(p, nslices, &u))) return rc;
+            if ((rc = w_inverse_fused<T>(p, nslices, &u, true))) return rc;
         } else {
             if ((rc = w_inverse<T>(p, nslices))) return rc;
             wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->st_x, dtype, p->mask,

@@ -304,3 +304,43 @@ def test_wavelet_floor_step_at_config3_size(ffi, wo, op):
         assert diff <= 4.0 * band_sq ** 0.5 + 3e-6 * ref, (diff, band_sq ** 0.5)
     keep = mask.astype(bool)
     assert np.array_equal(dev[keep], it_late[keep])
+
+
+@pytest.mark.parametrize("shape,wavelet,real,op", [((512, 512), "db4", True, "soft"), ((512, 512), "db4", False, "hard"), ((200, 333), "coif5", True, "garrote"),
+                                                    ((96, 80), "sym5", False, "soft"), ((64, 64), "db2", True, "hard"), ((256, 128), "haar", True, "soft"),
+                                                    ((300, 300), "bior2.2", True, "hard")])
+def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypatch, shape, wavelet, real, op):
+    """wcoarse_kernel (levels LC .. nlev of a slice in one workgroup, analysis and synthesis back to back) against the tile kernels
+    launched level by level (P3D_WAVELET_NO_COARSE=1): the same taps in the same order -- decompositions, reconstructions, the loop's
+    results, cost sums and iteration counts are the same BITS."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    nil, nxl = shape
+    mask = po.synthetic_mask(nil, nxl, 0.6)
+    cube = np.stack([po.synthetic_slice(nil, nxl, 10 + s, real=real) for s in range(3)]) * mask
+    cube = cube.astype(np.float32 if real else np.complex64)
+    cube[1] = 0
+    kw = dict(transform_kind="WAVELET", wavelet=wavelet, niter=6, thresh_op=op, thresh_model="exponential", p_max=0.99, p_min=1e-2, eps=1e-12)
+
+    def run():
+        P.release_plans()
+        res = []
+        out = P.pocs_cube(cube, mask, results=res, **kw)
+        with ffi.WaveletPlan(nil, nxl, 2, wavelet=wavelet) as plan:
+            coef = plan.wavedec2(cube[[0, 2]].astype(np.complex64))
+            back = plan.waverec2(coef)
+            st = plan.stats(cube[[0, 2]])
+        return out, [(r["niterations"], r["costs"]) for r in res], coef, back, st
+
+    a = run()
+    monkeypatch.setenv("P3D_WAVELET_NO_COARSE", "1")
+    b = run()
+    monkeypatch.delenv("P3D_WAVELET_NO_COARSE")
+    P.release_plans()
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    with ffi.WaveletPlan(nil, nxl, 2, wavelet=wavelet) as plan:   # and the decomposition is PyWavelets' (the oracle's)
+        ref = wo.wavedec2(cube[0].astype(np.complex128), wo.filter_bank(wavelet))
+        got = plan.unpack(a[2][0])
+        scale = np.abs(ref[0]).max()
+        assert np.abs(got[0] - ref[0]).max() <= 5e-6 * scale
