@@ -119,7 +119,7 @@ def test_hard_threshold_compares_like_the_reference_in_double(ffi, shape):
     M = 0.5 * n                                       # |X[0, 0]|, exactly representable
     with ffi.Plan(*shape, 1) as plan:
         X = plan.fft2(x)
-        assert abs(X[0, 0, 0]) == M and np.count_nonzero(X) == 1
+        assert abs(X[0, 0, 0]) == M and np.sort(np.abs(X).ravel())[-2] < 1e-5 * M      # (lengths that are no powers of two leave rounding dust elsewhere)
         for tau, survives in ((M, True), (M * (1 + 1e-9), False), (M * (1 - 1e-9), True), (np.nextafter(np.float32(M), np.float32(np.inf)).item(), False),
                               (complex(M, 1.0), False), (complex(M * (1 - 1e-9), 1.0), True), (complex(M * (1 + 1e-9), -1.0), False)):
             want = not (np.less(np.abs(X[0, 0, 0]), np.complex128(tau)) if isinstance(tau, complex) else np.less(np.abs(X[0, 0, 0]), np.float64(tau)))
