@@ -338,7 +338,9 @@ def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypa
     b = run()
     monkeypatch.delenv("P3D_WAVELET_NO_COARSE")
     P.release_plans()
-    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[0], b[0]) and [n for n, _ in a[1]] == [n for n, _ in b[1]]
+    for (_, ca), (_, cb) in zip(a[1], b[1]):      # (the cost sums add their per-tile partial sums atomically: last bits vary run to run)
+        np.testing.assert_allclose(ca, cb, rtol=1e-9)
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     with ffi.WaveletPlan(nil, nxl, 2, wavelet=wavelet) as plan:   # and the decomposition is PyWavelets' (the oracle's)
         ref = wo.wavedec2(cube[0].astype(np.complex128), wo.filter_bank(wavelet))
