@@ -247,6 +247,11 @@ int p3d_wavelet_run(p3d_wplan* plan, const void* x, int dtype, const float* mask
 typedef struct p3d_splan p3d_splan;
 int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, int nxl, int nsh, const float* psi, int max_slices);
 int p3d_shearlet_plan_destroy(p3d_splan* plan);
+/* How much of the frame the loop has to touch: a shearlet's spectrum vanishes on most rows of the frequency plane (a Parseval frame
+ * covers every frequency about twice), and the fused passes skip the 8-row groups on which it does -- exact, those rows carry only
+ * zeros through the iteration.  row_group_fraction: share of the (shearlet, 8-row group) pairs that are NOT skipped (1.0: dense
+ * path, e.g. P3D_SHEARLET_NO_SUPPORT=1 or the unfused passes). */
+int p3d_shearlet_info(p3d_splan* plan, double* row_group_fraction);
 /* test hooks: x HOST complex64 [nslices][nil][nxl] <-> st HOST complex64 [nslices][nsh][nil][nxl] */
 int p3d_shearlet_transform_c64(p3d_splan* plan, const void* x, void* st, int nslices);
 int p3d_shearlet_inverse_c64(p3d_splan* plan, const void* st, void* x, int nslices);

@@ -708,33 +708,34 @@ namespace p3d {
 // ---- the three fused passes of one SHEARLET iteration (p3d_shearlet.hip); power-of-two plans only ----------------------------
 bool shearlet_fused_supported(p3d_plan* plan) { return plan && !plan->generic && plan->ops_row->tpl > 0 && plan->ops_col->tpl > 0; }
 
-static ShearArgs shear_args(const float* psi, const c32* tau, int nsh, int niter, int iter, int op, int real_only)
+static ShearArgs shear_args(const float* psi, const c32* tau, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup, int sup_words)
 {
     ShearArgs a{};
     a.psi = psi; a.tau = tau; a.nsh = nsh; a.niter = niter; a.iter = iter; a.op = op; a.real_only = real_only;
+    a.sup = sup; a.sup_words = sup_words;
     return a;
 }
 
-int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int nsh)
+int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int nsh, const unsigned* sup, int sup_words)
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
     RowArgs r = row_args(p, nb);   // one workgroup row-group per slice; the shearlets are looped over inside
     r.x = F;
     r.work = p->work;
-    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0);
+    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0, sup, sup_words);
     HIP_TRY(p->ops_row->row(ROW_SPREAD_INV, r, p->stream));
     return P3D_OK;
 }
 
-int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only)
+int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup, int sup_words)
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
     ColArgs c = col_args(p, nb * nsh);
     c.in = p->work;
     c.out = p->work;
-    c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only);
+    c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only, sup, sup_words);
     // columns of 2048 points and more: one 8-column tile per CU, so the persistent pass (next tile requested while this one is
     // transformed) has something to give (see p3d_pocs_run_dev); P3D_NO_COLPIPE=1 (read when the plan is created) switches it off
     hipError_t ce = hipErrorNotSupported;
@@ -744,14 +745,14 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     return P3D_OK;
 }
 
-int shearlet_gather_fwd(p3d_plan* p, const float* psi, c32* out, int nb, int nsh)
+int shearlet_gather_fwd(p3d_plan* p, const float* psi, c32* out, int nb, int nsh, const unsigned* sup, int sup_words)
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
     RowArgs r = row_args(p, nb);
     r.work = p->work;
     r.out = out;
-    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0);
+    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0, sup, sup_words);
     HIP_TRY(p->ops_row->row(ROW_GATHER_FWD, r, p->stream));
     return P3D_OK;
 }

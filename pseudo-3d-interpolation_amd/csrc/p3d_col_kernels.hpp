@@ -76,8 +76,12 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
         const c32 tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
         const float scale = 1.0f / ((float)N * (float)a.n2);
+        // rows on which Psi_s vanishes were not stored by the spread pass and are not read by the gather pass (ShearArgs::sup)
+        unsigned rows_on = 0;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) v[q] = inb[eoff(0, tl + TPL * q)];
+        for (int q = 0; q < PPT; ++q) rows_on |= (shear_group_on(a.sh, s, (tl + TPL * q) >> 3) ? 1u : 0u) << q;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = ((rows_on >> q) & 1u) ? inb[eoff(0, tl + TPL * q)] : c32{0.f, 0.f};
         line_fft<N, INV, false>(v, lds, tw, tl);
         const Shrink shr(tau, a.sh.op);
 #pragma unroll
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         line_fft<N, FWD, false>(v, lds, tw, tl);
         if (valid) {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) outb[eoff(0, tl + TPL * q)] = v[q];
+            for (int q = 0; q < PPT; ++q)
+                if ((rows_on >> q) & 1u) outb[eoff(0, tl + TPL * q)] = v[q];
         }
         return;
     }
@@ -253,12 +258,31 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col
         const int vcol = valid ? col : 0;
         return (((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7) + (unsigned)tl * 8) * 8u;
     };
+    // SHEAR: bit q of the result = rows tl + TPL q of shearlet `slice % nsh` belong to a row group on which its spectrum does not vanish
+    // (ShearArgs::sup; the 8 rows of a wavefront's register q are one group, so the words come through the scalar path -- a vector
+    // load would sit behind the prefetched tile in the in-order vmcnt queue, like the threshold below).  Others: all rows.
+    typedef const unsigned __attribute__((address_space(4))) * ksup_t;
+    const ksup_t k_sup = (ksup_t)a.sh.sup;
+    auto rows_of = [&](const Tile& t) -> unsigned {
+        if constexpr (!SHEAR) return 0xffffu;
+        if (k_sup == nullptr) return 0xffffu;
+        const unsigned sh = t.slice % (unsigned)a.sh.nsh;
+        const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane(tl >> 3);
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const unsigned g = g0 + (unsigned)(TPL / 8) * q;
+            m |= ((k_sup[(size_t)sh * a.sh.sup_words + (g >> 5)] >> (g & 31u)) & 1u) << q;
+        }
+        return m;
+    };
     auto issue = [&](raw64 (&dst)[PPT], const Tile& t) {
         bool valid;
         const unsigned vo = lane_off(t, valid);
         const __amdgpu_buffer_rsrc_t srd = buf_srd(reinterpret_cast<const char*>(a.in) + (size_t)t.slice * slice_bytes, slice_bytes);
+        const unsigned on = rows_of(t);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) dst[q] = buf_load_raw64(srd, vo, (unsigned)(TPL * q) * 64u);
+        for (int q = 0; q < PPT; ++q) dst[q] = buf_load_raw64(srd, (!SHEAR || ((on >> q) & 1u)) ? vo : BUF_OOB, (unsigned)(TPL * q) * 64u);   // out of range: zero, no access
     };
 
     // Each workgroup takes a CONTIGUOUS run of tiles (on the headline cube: one whole slice, 8 MiB of consecutive addresses).  Handing
@@ -325,8 +349,9 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, P3D_COLPIPE_WAVES_PER_EU) void col
             const unsigned vo = lane_off(cur, valid);
             const __amdgpu_buffer_rsrc_t osrd = buf_srd(reinterpret_cast<char*>(a.out) + (size_t)cur.slice * slice_bytes, slice_bytes);
             const unsigned so_v = (valid && cur.on) ? vo : BUF_OOB;
+            const unsigned on = rows_of(cur);
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) buf_store_c32(osrd, so_v, (unsigned)(TPL * q) * 64u, v[q]);
+            for (int q = 0; q < PPT; ++q) buf_store_c32(osrd, (!SHEAR || ((on >> q) & 1u)) ? so_v : BUF_OOB, (unsigned)(TPL * q) * 64u, v[q]);
             // (the empty asm statements "use" the values HERE: without them the copies are renamed away and the wait moves to the
             // first butterfly of the next trip -- behind the next issue of loads, where it covers the stores again)
 #pragma unroll

@@ -58,7 +58,19 @@ struct ShearArgs {
     const float* psi;
     const c32* tau;
     int nsh, niter, iter, op, real_only;
+    // Rows on which a shearlet's spectrum vanishes altogether carry nothing through the whole iteration (Psi_s * F is zero there, and
+    // what the column pass would produce there is multiplied by Psi_s = 0 again): bit g of sup[s * sup_words + g / 32 ...] says that
+    // rows 8 g ... 8 g + 7 of Psi_s hold a non-zero sample.  The three passes skip the other row groups -- neither computed,
+    // stored nor read; a Parseval frame covers every frequency about twice, so well over half of the (shearlet, row) pairs go
+    // (configs[4]: 57 % of the groups).  nullptr: dense.
+    const unsigned* sup;
+    int sup_words;
 };
+// row group of 8 rows `g` of shearlet `s` holds a non-zero spectrum sample (dense when there is no table)
+__device__ __forceinline__ bool shear_group_on(const ShearArgs& sh, int s, int g)
+{
+    return sh.sup == nullptr || ((sh.sup[(size_t)s * sh.sup_words + (g >> 5)] >> (g & 31)) & 1u) != 0u;
+}
 
 #ifndef P3D_ROW1024_MAXMODE
 #define P3D_ROW1024_MAXMODE 2
@@ -205,5 +217,47 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// ---- buffer addressing (wave-uniform descriptor + per-lane 32-bit byte offset) --------------------------------------------------
+// A predicated access is written as an UNCONDITIONAL buffer instruction whose switched-off lanes carry an offset beyond the
+// descriptor's range: the hardware range check returns zero for such a load lane / drops such a store lane without touching
+// memory.  That matters beyond the saved branch: `s_waitcnt vmcnt` counts in issue order, and hipcc can only count exactly through
+// straight-line code -- with one `s_cbranch_execz` per predicated global_load (what `if (lane_pred) x = *p;` compiles to) every
+// wait of the loop became vmcnt(0), i.e. each row waited for the write acknowledgements of the row before it
+// (profiles/r02_rowpass_*.txt).
+typedef unsigned p3d_u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned BUF_OOB = 0x80000000u;   // every descriptor below spans less than 2 GiB
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_srd(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// (loads whose results are carried around a loop travel as raw 64-bit integers: a loop-carried pair of floats invites the
+// vectoriser to keep it shuffled, and the copies that undo the shuffle sit -- with their wait -- in front of the back edge)
+typedef unsigned long long raw64;
+__device__ __forceinline__ raw64 buf_load_raw64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const p3d_u2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return (raw64)t.x | ((raw64)t.y << 32);
+}
+__device__ __forceinline__ c32 raw_c32(raw64 u) { return c32{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))}; }
+__device__ __forceinline__ c32 buf_load_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return raw_c32(buf_load_raw64(r, voff, soff)); }
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, (int)voff, (int)soff, 0);
+}
+typedef unsigned p3d_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store_2c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 a, c32 b)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(p3d_u4{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y)}, r,
+                                           (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{(unsigned)u, (unsigned)(u >> 32)}, r, (int)voff, (int)soff, 0);
+}
 
 }  // namespace p3d

@@ -157,14 +157,20 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
         c32 fr[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) fr[q] = valid ? f[off + TPL * q] : c32{0.f, 0.f};
+        // (row groups of 8 on which Psi_s vanishes are skipped, see ShearArgs::sup: a workgroup's rows span the groups g0 ... g1)
+        const int g0 = (rgroup * LB) >> 3, g1 = min(rgroup * LB + LB - 1, a.n1 - 1) >> 3;
         for (int s = 0; s < a.sh.nsh; ++s) {
+            bool any = false;
+            for (int g = g0; g <= g1; ++g) any = any || shear_group_on(a.sh, s, g);
+            if (!any) continue;   // workgroup-uniform
+            const bool mine = valid && shear_group_on(a.sh, s, vrow >> 3);
             const float* const w = a.sh.psi + (size_t)s * a.n1 * N;
             c32* const ws = a.work + ((size_t)slice * a.sh.nsh + s) * wk_slice_stride(a.n1, N);
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) v[q] = fr[q] * (valid ? w[off + TPL * q] : 0.f);
+            for (int q = 0; q < PPT; ++q) v[q] = fr[q] * (mine ? w[off + TPL * q] : 0.f);
             line_fft<N, INV, WAVE>(v, lds, tw, tl);
             __syncthreads();   // adjacent rows share 128-byte lines of the work buffer: store them together
-            if (valid) {
+            if (mine) {
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) wk_q_ptr<TPL>(ws, q, tl, wblk)[wlane] = v[q];
             }
@@ -175,18 +181,23 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
         c32 acc[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) acc[q] = c32{0.f, 0.f};
+        const int g0 = (rgroup * LB) >> 3, g1 = min(rgroup * LB + LB - 1, a.n1 - 1) >> 3;
         for (int s = 0; s < a.sh.nsh; ++s) {
+            bool any = false;
+            for (int g = g0; g <= g1; ++g) any = any || shear_group_on(a.sh, s, g);
+            if (!any) continue;   // Psi_s = 0 on all rows of this workgroup: they add nothing (and the column pass did not store them)
+            const bool mine = valid && shear_group_on(a.sh, s, vrow >> 3);
             const c32* const ws = a.work + ((size_t)slice * a.sh.nsh + s) * wk_slice_stride(a.n1, N);
             const float* const w = a.sh.psi + (size_t)s * a.n1 * N;
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) v[q] = valid ? wk_q_ptr<TPL>(ws, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+            for (int q = 0; q < PPT; ++q) v[q] = mine ? wk_q_ptr<TPL>(ws, q, tl, wblk)[wlane] : c32{0.f, 0.f};
             line_fft<N, FWD, WAVE>(v, lds, tw, tl);
             // the weights are fetched after the transform, four at a time, to keep the register count of the transform
 #pragma unroll
             for (int g = 0; g < PPT; g += 4) {
                 float wq[4];
 #pragma unroll
-                for (int i = 0; i < 4 && g + i < PPT; ++i) wq[i] = valid ? w[off + TPL * (g + i)] : 0.f;
+                for (int i = 0; i < 4 && g + i < PPT; ++i) wq[i] = mine ? w[off + TPL * (g + i)] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4 && g + i < PPT; ++i) acc[g + i] = acc[g + i] + v[g + i] * wq[i];
             }

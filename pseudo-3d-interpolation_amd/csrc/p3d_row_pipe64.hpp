@@ -69,49 +69,6 @@ constexpr size_t pipe64_lds_bytes() { return sizeof(c32) * (PassTables<N>::slots
 template <int N>
 constexpr int pipe64_threads() { return pipe64_rows<N>() * Plan<N>::TPL; }
 
-// ---- buffer addressing (wave-uniform descriptor + per-lane 32-bit byte offset) --------------------------------------------------
-// A predicated access is written as an UNCONDITIONAL buffer instruction whose switched-off lanes carry an offset beyond the
-// descriptor's range: the hardware range check returns zero for such a load lane / drops such a store lane without touching
-// memory.  That matters beyond the saved branch: `s_waitcnt vmcnt` counts in issue order, and hipcc can only count exactly through
-// straight-line code -- with one `s_cbranch_execz` per predicated global_load (what `if (lane_pred) x = *p;` compiles to) every
-// wait of the loop became vmcnt(0), i.e. each row waited for the write acknowledgements of the row before it
-// (profiles/r02_rowpass_*.txt).
-typedef unsigned p3d_u2 __attribute__((ext_vector_type(2)));
-constexpr unsigned BUF_OOB = 0x80000000u;   // every descriptor below spans less than 2 GiB
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_srd(const void* base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-// (loads whose results are carried around a loop travel as raw 64-bit integers: a loop-carried pair of floats invites the
-// vectoriser to keep it shuffled, and the copies that undo the shuffle sit -- with their wait -- in front of the back edge)
-typedef unsigned long long raw64;
-__device__ __forceinline__ raw64 buf_load_raw64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    const p3d_u2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
-    return (raw64)t.x | ((raw64)t.y << 32);
-}
-__device__ __forceinline__ c32 raw_c32(raw64 u) { return c32{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))}; }
-__device__ __forceinline__ c32 buf_load_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return raw_c32(buf_load_raw64(r, voff, soff)); }
-__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ void buf_store_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 v)
-{
-    __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, (int)voff, (int)soff, 0);
-}
-typedef unsigned p3d_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void buf_store_2c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, c32 a, c32 b)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(p3d_u4{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y)}, r,
-                                           (int)voff, (int)soff, 0);
-}
-__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{(unsigned)u, (unsigned)(u >> 32)}, r, (int)voff, (int)soff, 0);
-}
-
 // In-kernel stamps (diagnostic build -DP3D_STAMPS=1 only, tools/rowpass_stamps.sh): cycles each wave of row_pipe64_kernel spends
 // between fixed points of a row, summed over its rows, in a buffer of their own that nothing else reads.
 #ifndef P3D_STAMPS

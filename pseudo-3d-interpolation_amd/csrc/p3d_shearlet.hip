@@ -98,6 +98,18 @@ __global__ void sthreshold_kernel(c32* U, size_t per, int nsh, const c32* tau, i
     }
 }
 
+// bit g of sup[s * words + g / 32] = rows 8 g ... 8 g + 7 of Psi_s hold a non-zero sample (one wavefront per (s, g); sup zeroed before)
+__global__ void rowsup_kernel(const float* psi, unsigned* sup, int nil, int nxl, int words)
+{
+    const int s = blockIdx.y, g = blockIdx.x;
+    const int r0 = 8 * g, r1 = min(r0 + 8, nil);
+    const float* p = psi + ((size_t)s * nil + r0) * nxl;
+    const size_t n = (size_t)(r1 - r0) * nxl;
+    bool any = false;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) any = any || (p[i] != 0.0f);
+    if (__ballot(any) != 0ull && threadIdx.x == 0) atomicOr(sup + (size_t)s * words + (g >> 5), 1u << (g & 31));
+}
+
 // per (slice, shearlet): lexicographic (real data: signed) maximum, max |c|, min |c|, sum |c|^2 -> stats[(b*nsh + s)*5 ..]
 __global__ void sstats_kernel(const c32* U, size_t per, int real_only, float* stats)
 {
@@ -198,6 +210,9 @@ struct p3d_splan {
     p3d_plan* fft = nullptr;  // batched 2-D FFT of up to max_slices * nsh slices
     hipStream_t stream = nullptr;
     float* psi = nullptr;      // [nsh][nil][nxl]
+    unsigned* sup = nullptr;   // [nsh][sup_words] bitmap of the 8-row groups on which Psi_s does not vanish (fused passes; nullptr: dense)
+    int sup_words = 0;
+    double sup_fraction = 1.0; // share of the (shearlet, row group) pairs that are on
     bool fused = false;        // three fused passes per iteration (power-of-two extents); P3D_SHEARLET_UNFUSED=1 disables
     c32 *U = nullptr, *F = nullptr, *feed = nullptr, *tau = nullptr;
     size_t tau_cap = 0, sums_cap = 0;
@@ -214,7 +229,7 @@ extern "C" int p3d_shearlet_plan_destroy(p3d_splan* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->psi, p->U, p->F, p->feed, p->tau, p->sums, p->done, p->stats, p->mask, p->st_x, p->st_out};
+    void* bufs[] = {p->psi, p->sup, p->U, p->F, p->feed, p->tau, p->sums, p->done, p->stats, p->mask, p->st_x, p->st_out};
     for (void* b : bufs) if (b) hipFree(b);
     if (p->ev0) hipEventDestroy(p->ev0);
     if (p->ev1) hipEventDestroy(p->ev1);
@@ -257,6 +272,20 @@ extern "C" int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, in
     if ((e = hipMemcpy(p->psi, psi, sizeof(float) * per * nsh, hipMemcpyHostToDevice)) != hipSuccess) return bail("upload of Psi", e);
     const char* env = getenv("P3D_SHEARLET_UNFUSED");
     p->fused = p3d::shearlet_fused_supported(p->fft) && !(env && env[0] == '1');
+    if (p->fused && !getenv("P3D_SHEARLET_NO_SUPPORT")) {
+        // which 8-row groups of every spectrum hold anything at all: the fused passes skip the others (ShearArgs::sup)
+        const int groups = (nil + 7) / 8, words = (groups + 31) / 32;
+        if ((e = hipMalloc((void**)&p->sup, sizeof(unsigned) * (size_t)nsh * words)) != hipSuccess) return bail("sup", e);
+        if ((e = hipMemsetAsync(p->sup, 0, sizeof(unsigned) * (size_t)nsh * words, p->stream)) != hipSuccess) return bail("sup", e);
+        rowsup_kernel<<<dim3(groups, nsh), 64, 0, p->stream>>>(p->psi, p->sup, nil, nxl, words);
+        std::vector<unsigned> host((size_t)nsh * words);
+        if ((e = hipMemcpyAsync(host.data(), p->sup, sizeof(unsigned) * host.size(), hipMemcpyDeviceToHost, p->stream)) != hipSuccess) return bail("sup", e);
+        if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) return bail("sup", e);
+        size_t on = 0;
+        for (unsigned w : host) on += (size_t)__builtin_popcount(w);
+        p->sup_words = words;
+        p->sup_fraction = (double)on / ((double)groups * nsh);
+    }
     *out = p;
     return P3D_OK;
 }
@@ -294,6 +323,13 @@ static int s_inverse(p3d_splan* p, int ns, const int* done)
 }
 
 extern "C" {
+
+int p3d_shearlet_info(p3d_splan* p, double* row_group_fraction)
+{
+    if (!p || !row_group_fraction) return sfail(P3D_ERR_INVALID, "NULL argument");
+    *row_group_fraction = p->sup ? p->sup_fraction : 1.0;
+    return P3D_OK;
+}
 
 // test hooks: x HOST complex64 [nslices][nil][nxl] <-> st HOST complex64 [nslices][nsh][nil][nxl]
 int p3d_shearlet_transform_c64(p3d_splan* p, const void* x, void* st, int nslices)
@@ -392,9 +428,9 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
             // three passes over the coefficients instead of twelve: spectra x Psi_s folded into the inverse row pass, the
             // threshold into the column pass between its two transforms, x Psi_s and the sum over s into the forward row pass
             S_RC(p3d::fft2_async(p->fft, p->feed, p->F, nslices, 0));
-            S_RC(p3d::shearlet_spread_inv(p->fft, p->F, p->psi, nslices, nsh));
-            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0));
-            S_RC(p3d::shearlet_gather_fwd(p->fft, p->psi, p->F, nslices, nsh));
+            S_RC(p3d::shearlet_spread_inv(p->fft, p->F, p->psi, nslices, nsh, p->sup, p->sup_words));
+            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, p->sup, p->sup_words));
+            S_RC(p3d::shearlet_gather_fwd(p->fft, p->psi, p->F, nslices, nsh, p->sup, p->sup_words));
             S_RC(p3d::fft2_async(p->fft, p->F, p->F, nslices, 1));
         } else {
             S_RC(s_forward(p, nslices, real_only, p->done));
