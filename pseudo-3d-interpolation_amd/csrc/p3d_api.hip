@@ -728,7 +728,7 @@ int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int
     return P3D_OK;
 }
 
-int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup, int sup_words)
+int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup, int sup_words, bool pair)
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
@@ -739,7 +739,8 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     // columns of 2048 points and more: one 8-column tile per CU, so the persistent pass (next tile requested while this one is
     // transformed) has something to give (see p3d_pocs_run_dev); P3D_NO_COLPIPE=1 (read when the plan is created) switches it off
     hipError_t ce = hipErrorNotSupported;
-    if (!p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
+    if (pair && real_only && p->ops_col->col_shear_pair != nullptr) ce = p->ops_col->col_shear_pair(c, p->stream);   // two columns per transform
+    if (ce == hipErrorNotSupported && !p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
     if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_SHRINK, c, p->stream);
     HIP_TRY(ce);
     return P3D_OK;

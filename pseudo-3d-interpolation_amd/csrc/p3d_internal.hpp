@@ -41,8 +41,9 @@ bool shearlet_fused_supported(p3d_plan* plan);
 // work[b*nsh + s] = inverse row FFT of psi_s * F[b]
 int shearlet_spread_inv(p3d_plan* plan, const c32* F, const float* psi, int nb, int nsh, const unsigned* sup = nullptr, int sup_words = 0);
 // per work slice: inverse column FFT, 1/(nil*nxl), real part if real_only, threshold with tau[b][iter][s], forward column FFT
+// pair: float32 cubes with symmetric spectra may send two columns through one transform (p3d_col_shear.hpp)
 int shearlet_col_shrink(p3d_plan* plan, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup = nullptr,
-                        int sup_words = 0);
+                        int sup_words = 0, bool pair = false);
 // out[b] = sum_s psi_s * forward row FFT of work[b*nsh + s]
 int shearlet_gather_fwd(p3d_plan* plan, const float* psi, c32* out, int nb, int nsh, const unsigned* sup = nullptr, int sup_words = 0);
 // sup: device bitmap [nsh][sup_words] of the 8-row groups on which a shearlet's spectrum does not vanish (ShearArgs::sup); the three

@@ -30,6 +30,7 @@
 #include "p3d_row_pipe64.hpp"
 #include "p3d_row_real.hpp"
 #include "p3d_col_kernels.hpp"
+#include "p3d_col_shear.hpp"
 
 // The kernels live in one header per pass (p3d_row_kernels.hpp: one-launch and per-lane persistent row pass; p3d_row_pipe64.hpp: the
 // wave-uniform persistent row pass; p3d_row_real.hpp: float32 cubes; p3d_col_kernels.hpp: the column pass); this file keeps the launch
@@ -325,6 +326,7 @@ struct LineOps {
     hipError_t (*row_real)(int mode, const RowArgs&, int cus, hipStream_t);   // REAL_* passes (hipErrorNotSupported where absent)
     hipError_t (*row_pipe64)(int pm, const RowArgs&, int cus, hipStream_t);   // PIPE_FIRST / PIPE_MID / PIPE_LAST (hipErrorNotSupported where absent)
     hipError_t (*col_pipe)(const ColArgs&, int cus, hipStream_t);             // persistent COL_ITER (hipErrorNotSupported where absent)
+    hipError_t (*col_shear_pair)(const ColArgs&, hipStream_t);                // SHEARLET column pass of float32 cubes, two columns per transform
 };
 
 }  // namespace p3d

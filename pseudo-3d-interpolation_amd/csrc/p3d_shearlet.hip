@@ -110,6 +110,21 @@ __global__ void rowsup_kernel(const float* psi, unsigned* sup, int nil, int nxl,
     if (__ballot(any) != 0ull && threadIdx.x == 0) atomicOr(sup + (size_t)s * words + (g >> 5), 1u << (g & 31));
 }
 
+// *asym is raised when some Psi_s(-k) != Psi_s(k) (exact comparison): real slices then have complex coefficients, and the
+// two-columns-per-transform column pass (p3d_col_shear.hpp), which relies on real ones, stays off
+__global__ void psisym_kernel(const float* psi, int* asym, int nil, int nxl, int nsh)
+{
+    const size_t per = (size_t)nil * nxl, total = per * nsh;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = i / per, r = i - s * per;
+        const int k1 = (int)(r / nxl), k2 = (int)(r - (size_t)k1 * nxl);
+        const int m1 = k1 ? nil - k1 : 0, m2 = k2 ? nxl - k2 : 0;
+        bad = bad || (psi[i] != psi[s * per + (size_t)m1 * nxl + m2]);
+    }
+    if (bad) atomicOr(asym, 1);
+}
+
 // per (slice, shearlet): lexicographic (real data: signed) maximum, max |c|, min |c|, sum |c|^2 -> stats[(b*nsh + s)*5 ..]
 __global__ void sstats_kernel(const c32* U, size_t per, int real_only, float* stats)
 {
@@ -213,6 +228,7 @@ struct p3d_splan {
     unsigned* sup = nullptr;   // [nsh][sup_words] bitmap of the 8-row groups on which Psi_s does not vanish (fused passes; nullptr: dense)
     int sup_words = 0;
     double sup_fraction = 1.0; // share of the (shearlet, row group) pairs that are on
+    bool pair = false;         // float32 cubes: two columns per transform in the column pass (spectra symmetric; P3D_SHEARLET_NO_PAIR unset)
     bool fused = false;        // three fused passes per iteration (power-of-two extents); P3D_SHEARLET_UNFUSED=1 disables
     c32 *U = nullptr, *F = nullptr, *feed = nullptr, *tau = nullptr;
     size_t tau_cap = 0, sums_cap = 0;
@@ -285,6 +301,20 @@ extern "C" int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, in
         for (unsigned w : host) on += (size_t)__builtin_popcount(w);
         p->sup_words = words;
         p->sup_fraction = (double)on / ((double)groups * nsh);
+    }
+    if (p->fused && !getenv("P3D_SHEARLET_NO_PAIR")) {
+        int* flag = nullptr;
+        int asym = 1;
+        if ((e = hipMalloc((void**)&flag, sizeof(int))) != hipSuccess) return bail("flag", e);
+        e = hipMemsetAsync(flag, 0, sizeof(int), p->stream);
+        if (e == hipSuccess) {
+            psisym_kernel<<<1024, 256, 0, p->stream>>>(p->psi, flag, nil, nxl, nsh);
+            e = hipMemcpyAsync(&asym, flag, sizeof(int), hipMemcpyDeviceToHost, p->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        hipFree(flag);
+        if (e != hipSuccess) return bail("symmetry check of Psi", e);
+        p->pair = asym == 0;
     }
     *out = p;
     return P3D_OK;
@@ -429,7 +459,7 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
             // threshold into the column pass between its two transforms, x Psi_s and the sum over s into the forward row pass
             S_RC(p3d::fft2_async(p->fft, p->feed, p->F, nslices, 0));
             S_RC(p3d::shearlet_spread_inv(p->fft, p->F, p->psi, nslices, nsh, p->sup, p->sup_words));
-            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, p->sup, p->sup_words));
+            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, p->sup, p->sup_words, p->pair));
             S_RC(p3d::shearlet_gather_fwd(p->fft, p->psi, p->F, nslices, nsh, p->sup, p->sup_words));
             S_RC(p3d::fft2_async(p->fft, p->F, p->F, nslices, 1));
         } else {
