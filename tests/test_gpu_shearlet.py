@@ -281,7 +281,7 @@ def test_skipping_rows_off_a_shearlets_support_changes_nothing(ffi, shape, real,
         np.testing.assert_allclose(ra["costs"], rb["costs"], rtol=1e-9)
 
 
-@pytest.mark.parametrize("shape", [(512, 64), (1024, 128), (2048, 64), (4096, 32), (256, 256)])
+@pytest.mark.parametrize("shape", [(512, 256), (1024, 512), (2048, 128), (4096, 64), (256, 256)])
 @pytest.mark.parametrize("op", ["soft", "hard"])
 def test_two_columns_per_transform_against_the_general_column_pass(so, shape, op, monkeypatch):
     """float32 cubes, symmetric spectra: the column pass packs two columns into one complex transform (real coefficients: Z = W_A +
@@ -305,12 +305,15 @@ def test_two_columns_per_transform_against_the_general_column_pass(so, shape, op
     monkeypatch.setenv("P3D_SHEARLET_NO_PAIR", "1")
     general = run(psi)
     monkeypatch.delenv("P3D_SHEARLET_NO_PAIR")
-    want = so.pocs_cube_shearlet(cube.astype(np.float64), mask, so.scales_shears_and_spectra(shape), thresh_op=op, thresh_model="exponential",
-                                 niter=4, p_max=0.99, p_min=1e-2, eps=0.0)
+    psi_o = so.scales_shears_and_spectra(shape, contiguous=False)
+    want = np.stack([so.pocs_slice_shearlet_real(c.astype(np.float64), mask, psi_o, thresh_op=op, thresh_model="exponential", niter=4, p_max=0.99, p_min=1e-2)
+                     for c in cube])
     d = rel_l2(paired, general)
+    assert np.isfinite(paired).all() and np.isfinite(general).all()
     print(f"{nil}x{nxl} {op}: paired-vs-general {d:.2e}; vs oracle: paired {rel_l2(paired, want):.2e}, general {rel_l2(general, want):.2e}")
     assert d <= (2e-6 if op == "soft" else 2e-4)
-    assert rel_l2(paired, want) <= max(3 * rel_l2(general, want), 1e-5 if op == "soft" else 2e-4)
+    if np.isfinite(want).all():   # (a very oblong grid leaves some fine-scale shearlets without a single sample: the reference's schedule is NaN there)
+        assert rel_l2(paired, want) <= max(3 * rel_l2(general, want), 1e-5 if op == "soft" else 2e-4)
     # a frame that is NOT symmetric (real slices then have complex coefficients, of which the reference keeps the real part): the plan
     # notices and keeps the general pass -- with or without the switch the same bits
     lop = np.array(psi, copy=True)
