@@ -708,22 +708,27 @@ namespace p3d {
 // ---- the three fused passes of one SHEARLET iteration (p3d_shearlet.hip); power-of-two plans only ----------------------------
 bool shearlet_fused_supported(p3d_plan* plan) { return plan && !plan->generic && plan->ops_row->tpl > 0 && plan->ops_col->tpl > 0; }
 
-static ShearArgs shear_args(const float* psi, const c32* tau, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup, int sup_words)
+static ShearArgs shear_args(const float* psi, const c32* tau, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup, int sup_words, bool half)
 {
     ShearArgs a{};
     a.psi = psi; a.tau = tau; a.nsh = nsh; a.niter = niter; a.iter = iter; a.op = op; a.real_only = real_only;
-    a.sup = sup; a.sup_words = sup_words;
+    a.sup = sup; a.sup_words = sup_words; a.half = half ? 1 : 0;
     return a;
 }
+bool shearlet_pair_supported(p3d_plan* p)
+{
+    return shearlet_fused_supported(p) && p->ops_col->col_shear_pair != nullptr && p->ops_col->tpl >= 32 && p->ops_col->tpl <= 256 && p->nxl % 8 == 0 &&
+           (double)wk_slice_stride(p->nil, p->nxl) < 4294967296.0 / 8.0;
+}
 
-int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int nsh, const unsigned* sup, int sup_words)
+int shearlet_spread_inv(p3d_plan* p, const c32* F, const float* psi, int nb, int nsh, const unsigned* sup, int sup_words, bool pair)
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
     RowArgs r = row_args(p, nb);   // one workgroup row-group per slice; the shearlets are looped over inside
     r.x = F;
     r.work = p->work;
-    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0, sup, sup_words);
+    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0, sup, sup_words, pair);
     HIP_TRY(p->ops_row->row(ROW_SPREAD_INV, r, p->stream));
     return P3D_OK;
 }
@@ -735,25 +740,29 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     ColArgs c = col_args(p, nb * nsh);
     c.in = p->work;
     c.out = p->work;
-    c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only, sup, sup_words);
+    c.sh = shear_args(nullptr, tau, nsh, niter, iter, op, real_only, sup, sup_words, pair);
     // columns of 2048 points and more: one 8-column tile per CU, so the persistent pass (next tile requested while this one is
     // transformed) has something to give (see p3d_pocs_run_dev); P3D_NO_COLPIPE=1 (read when the plan is created) switches it off
     hipError_t ce = hipErrorNotSupported;
-    if (pair && real_only && p->ops_col->col_shear_pair != nullptr) ce = p->ops_col->col_shear_pair(c, p->stream);   // two columns per transform
-    if (ce == hipErrorNotSupported && !p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
+    if (pair) {   // two columns per transform on Hermitian work slices: the other two passes ran / will run on half the rows, no way back
+        if (!real_only || !shearlet_pair_supported(p)) return fail(P3D_ERR_INVALID, "the paired column pass does not apply to this plan");
+        HIP_TRY(p->ops_col->col_shear_pair(c, p->stream));
+        return P3D_OK;
+    }
+    if (!p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
     if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_SHRINK, c, p->stream);
     HIP_TRY(ce);
     return P3D_OK;
 }
 
-int shearlet_gather_fwd(p3d_plan* p, const float* psi, c32* out, int nb, int nsh, const unsigned* sup, int sup_words)
+int shearlet_gather_fwd(p3d_plan* p, const float* psi, c32* out, int nb, int nsh, const unsigned* sup, int sup_words, bool pair)
 {
     int rc = check_batch(p, nb * nsh);
     if (rc) return rc;
     RowArgs r = row_args(p, nb);
     r.work = p->work;
     r.out = out;
-    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0, sup, sup_words);
+    r.sh = shear_args(psi, nullptr, nsh, 0, 0, 0, 0, sup, sup_words, pair);
     HIP_TRY(p->ops_row->row(ROW_GATHER_FWD, r, p->stream));
     return P3D_OK;
 }

@@ -78,17 +78,21 @@ void col_shear_pair_kernel(const ColArgs a)
     const int slice = blockIdx.y, tile = blockIdx.x;
     const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
     ColTablesHalf<N>::template load<THREADS>(twl, a.tw, tid);
-    // rows on which Psi_s vanishes were not stored by the spread pass and are not read by the gather pass (ShearArgs::sup): the
-    // words of this shearlet's bitmap are wave-uniform, bit (tl >> 3) + (TPL / 8) q
-    constexpr int GQ = TPL / 8, WORDS = (N / 8 + 31) / 32;
-    unsigned supw[WORDS];
-#pragma unroll
-    for (int w = 0; w < WORDS; ++w) supw[w] = a.sh.sup ? a.sh.sup[(size_t)s * a.sh.sup_words + w] : 0xffffffffu;
-    unsigned rows_on = 0;
-#pragma unroll
-    for (int q = 0; q < PPT; ++q) rows_on |= ((supw[(GQ * q) >> 5] >> (((GQ * q) & 31) + (tl >> 3))) & 1u) << q;
+    // rows on which Psi_s vanishes were not stored by the spread pass and are not read by the gather pass (ShearArgs::sup).  With
+    // Hermitian work slices (ShearArgs::half) row k > N/2 is the conjugate of row N - k: a thread loads THAT row (bit of its group).
+    constexpr int WORDS = (N / 8 + 31) / 32;
+    __shared__ unsigned s_sup[WORDS];
+    if (tid < WORDS) s_sup[tid] = a.sh.sup ? a.sh.sup[(size_t)s * a.sh.sup_words + tid] : 0xffffffffu;
     const c32 tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
     __syncthreads();
+    const bool half = a.sh.half != 0;
+    unsigned rows_on = 0, mirrored = 0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int k = tl + TPL * q, kk = (half && k > N / 2) ? N - k : k, g = kk >> 3;
+        rows_on |= ((s_sup[g >> 5] >> (g & 31)) & 1u) << q;
+        mirrored |= (kk != k ? 1u : 0u) << q;
+    }
 
     const LDS lds{data + j};
     c32* const base = a.out + (size_t)slice * wk_slice_stride(N, a.n2);   // in place (a.in == a.out)
@@ -99,7 +103,11 @@ void col_shear_pair_kernel(const ColArgs a)
     for (int q = 0; q < PPT; ++q) {
         v[q] = c32{0.f, 0.f};
         if ((rows_on >> q) & 1u) {
-            const f4 ab = *reinterpret_cast<const f4*>(base + org + (unsigned)(TPL * q) * 8u);
+            const int k = tl + TPL * q;
+            const bool mir = (mirrored >> q) & 1u;
+            const unsigned off = mir ? ((unsigned)tile * N + (unsigned)(N - k)) * 8u + 2u * (unsigned)j : org + (unsigned)(TPL * q) * 8u;
+            f4 ab = *reinterpret_cast<const f4*>(base + off);
+            if (mir) { ab.y = -ab.y; ab.w = -ab.w; }          // row N - k holds the conjugates
             v[q] = add_ib(c32{ab.x, ab.y}, c32{ab.z, ab.w});   // Z = W_A + i W_B
         }
     }
@@ -121,7 +129,7 @@ void col_shear_pair_kernel(const ColArgs a)
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        if ((rows_on >> q) & 1u) {
+        if (((rows_on & ~mirrored) >> q) & 1u) {    // (Hermitian work slices: rows 0 ... N/2 only)
             const int k = tl + TPL * q;
             const c32 p = lds.at((N - k) & (N - 1));
             const c32 z = v[q];

@@ -39,13 +39,17 @@ int fft2_async(p3d_plan* plan, const c32* in, c32* out, int nslices, int inverse
 // final inverse transform, i.e. out = sum_s Psi_s * fft2(T_s(ifft2(Psi_s * F))).
 bool shearlet_fused_supported(p3d_plan* plan);
 // work[b*nsh + s] = inverse row FFT of psi_s * F[b]
-int shearlet_spread_inv(p3d_plan* plan, const c32* F, const float* psi, int nb, int nsh, const unsigned* sup = nullptr, int sup_words = 0);
+int shearlet_spread_inv(p3d_plan* plan, const c32* F, const float* psi, int nb, int nsh, const unsigned* sup = nullptr, int sup_words = 0, bool pair = false);
 // per work slice: inverse column FFT, 1/(nil*nxl), real part if real_only, threshold with tau[b][iter][s], forward column FFT
 // pair: float32 cubes with symmetric spectra may send two columns through one transform (p3d_col_shear.hpp)
 int shearlet_col_shrink(p3d_plan* plan, const c32* tau, int nb, int nsh, int niter, int iter, int op, int real_only, const unsigned* sup = nullptr,
                         int sup_words = 0, bool pair = false);
 // out[b] = sum_s psi_s * forward row FFT of work[b*nsh + s]
-int shearlet_gather_fwd(p3d_plan* plan, const float* psi, c32* out, int nb, int nsh, const unsigned* sup = nullptr, int sup_words = 0);
+int shearlet_gather_fwd(p3d_plan* plan, const float* psi, c32* out, int nb, int nsh, const unsigned* sup = nullptr, int sup_words = 0, bool pair = false);
+// pair (all three passes alike, float32 cubes with symmetric spectra where shearlet_pair_supported): the work slices are Hermitian
+// along the rows -- only rows 0 ... nil/2 are computed, stored and read, the column pass sends two columns through one transform;
+// the rows nil/2 + 1 ... of the gather pass's output are then NOT written (the caller mirrors them)
+bool shearlet_pair_supported(p3d_plan* plan);
 // sup: device bitmap [nsh][sup_words] of the 8-row groups on which a shearlet's spectrum does not vanish (ShearArgs::sup); the three
 // passes of one iteration must be given the SAME table (a group one pass skips is never stored for the next to read)
 

@@ -75,7 +75,12 @@ template <int N, int MODE, bool BITS>
 hipError_t launch_row_one(const RowArgs& a, hipStream_t st)
 {
     constexpr int LB = row_threads<N, MODE>() / Plan<N>::TPL;
-    const dim3 grid((a.n1 + LB - 1) / LB, a.nslices);
+    unsigned gx = (unsigned)((a.n1 + LB - 1) / LB);
+    if constexpr (MODE == ROW_SPREAD_INV || MODE == ROW_GATHER_FWD) {   // rows 0 ... n1/2 only for Hermitian work slices; whole groups of 8 workgroups (XCD placement)
+        gx = (unsigned)((shear_rows(a.sh, a.n1) + LB - 1) / LB);
+        if (a.sh.half) gx = (gx + 7u) & ~7u;
+    }
+    const dim3 grid(gx, a.nslices);
     constexpr size_t lds = row_lds_bytes_mode<N, MODE>();
     hipError_t e = allow_lds(row_kernel<N, MODE, BITS>, lds);
     if (e != hipSuccess) return e;

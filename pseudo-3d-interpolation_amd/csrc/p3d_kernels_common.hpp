@@ -65,7 +65,12 @@ struct ShearArgs {
     // (configs[4]: 57 % of the groups).  nullptr: dense.
     const unsigned* sup;
     int sup_words;
+    // float32 cubes, symmetric spectra: the coefficients are real, so the work slices are Hermitian along the rows (row N - k = the
+    // conjugate of row k) and only rows 0 ... n1/2 are computed, stored and read; the column pass (p3d_col_shear.hpp) rebuilds the
+    // other half while it loads, the gather pass's output is completed by mirroring.  0: all rows.
+    int half;
 };
+__host__ __device__ inline int shear_rows(const ShearArgs& sh, int n1) { return sh.half ? n1 / 2 + 1 : n1; }
 // row group of 8 rows `g` of shearlet `s` holds a non-zero spectrum sample (dense when there is no table)
 __device__ __forceinline__ bool shear_group_on(const ShearArgs& sh, int s, int g)
 {

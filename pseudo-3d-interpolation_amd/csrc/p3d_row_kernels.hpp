@@ -43,7 +43,12 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
         }
     }
     const int row = rgroup * LB + line;
-    const bool valid = row < a.n1;
+    int nrows = a.n1;
+    if constexpr (MODE == ROW_SPREAD_INV || MODE == ROW_GATHER_FWD) {
+        nrows = shear_rows(a.sh, a.n1);
+        if (rgroup * LB >= nrows) return;   // (the grid is rounded up to whole groups of eight workgroups for the XCD placement)
+    }
+    const bool valid = row < nrows;
 
     const int dn = a.done ? a.done[slice] : 0;
     if (MODE == ROW_LAST && a.only_done) {
@@ -158,7 +163,7 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
 #pragma unroll
         for (int q = 0; q < PPT; ++q) fr[q] = valid ? f[off + TPL * q] : c32{0.f, 0.f};
         // (row groups of 8 on which Psi_s vanishes are skipped, see ShearArgs::sup: a workgroup's rows span the groups g0 ... g1)
-        const int g0 = (rgroup * LB) >> 3, g1 = min(rgroup * LB + LB - 1, a.n1 - 1) >> 3;
+        const int g0 = (rgroup * LB) >> 3, g1 = min(rgroup * LB + LB - 1, nrows - 1) >> 3;
         for (int s = 0; s < a.sh.nsh; ++s) {
             bool any = false;
             for (int g = g0; g <= g1; ++g) any = any || shear_group_on(a.sh, s, g);
@@ -181,7 +186,7 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
         c32 acc[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) acc[q] = c32{0.f, 0.f};
-        const int g0 = (rgroup * LB) >> 3, g1 = min(rgroup * LB + LB - 1, a.n1 - 1) >> 3;
+        const int g0 = (rgroup * LB) >> 3, g1 = min(rgroup * LB + LB - 1, nrows - 1) >> 3;
         for (int s = 0; s < a.sh.nsh; ++s) {
             bool any = false;
             for (int g = g0; g <= g1; ++g) any = any || shear_group_on(a.sh, s, g);

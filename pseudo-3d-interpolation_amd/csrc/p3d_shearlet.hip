@@ -125,6 +125,19 @@ __global__ void psisym_kernel(const float* psi, int* asym, int nil, int nxl, int
     if (bad) atomicOr(asym, 1);
 }
 
+// F[b][k1][k2] = conj F[b][n1 - k1][(n2 - k2) mod n2] for k1 = n1/2 + 1 ... n1 - 1: the spectrum of a real slice, completed from the
+// rows the gather pass computed (Hermitian work slices, ShearArgs::half)
+__global__ void mirror_rows_kernel(c32* F, int n1, int n2)
+{
+    c32* f = F + (size_t)blockIdx.y * n1 * n2;
+    const size_t total = (size_t)(n1 - n1 / 2 - 1) * n2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k1 = n1 / 2 + 1 + (int)(i / n2), k2 = (int)(i % n2);
+        const c32 m = f[(size_t)(n1 - k1) * n2 + (k2 ? n2 - k2 : 0)];
+        f[(size_t)k1 * n2 + k2] = c32{m.x, -m.y};
+    }
+}
+
 // per (slice, shearlet): lexicographic (real data: signed) maximum, max |c|, min |c|, sum |c|^2 -> stats[(b*nsh + s)*5 ..]
 __global__ void sstats_kernel(const c32* U, size_t per, int real_only, float* stats)
 {
@@ -314,7 +327,7 @@ extern "C" int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, in
         if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
         hipFree(flag);
         if (e != hipSuccess) return bail("symmetry check of Psi", e);
-        p->pair = asym == 0;
+        p->pair = asym == 0 && p3d::shearlet_pair_supported(p->fft);
     }
     *out = p;
     return P3D_OK;
@@ -458,9 +471,11 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
             // three passes over the coefficients instead of twelve: spectra x Psi_s folded into the inverse row pass, the
             // threshold into the column pass between its two transforms, x Psi_s and the sum over s into the forward row pass
             S_RC(p3d::fft2_async(p->fft, p->feed, p->F, nslices, 0));
-            S_RC(p3d::shearlet_spread_inv(p->fft, p->F, p->psi, nslices, nsh, p->sup, p->sup_words));
-            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, p->sup, p->sup_words, p->pair));
-            S_RC(p3d::shearlet_gather_fwd(p->fft, p->psi, p->F, nslices, nsh, p->sup, p->sup_words));
+            const bool pair = p->pair && real_only;
+            S_RC(p3d::shearlet_spread_inv(p->fft, p->F, p->psi, nslices, nsh, p->sup, p->sup_words, pair));
+            S_RC(p3d::shearlet_col_shrink(p->fft, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, p->sup, p->sup_words, pair));
+            S_RC(p3d::shearlet_gather_fwd(p->fft, p->psi, p->F, nslices, nsh, p->sup, p->sup_words, pair));
+            if (pair) mirror_rows_kernel<<<dim3(blocks_for((size_t)(p->nil / 2) * p->nxl, 512), nslices), 256, 0, p->stream>>>(p->F, p->nil, p->nxl);
             S_RC(p3d::fft2_async(p->fft, p->F, p->F, nslices, 1));
         } else {
             S_RC(s_forward(p, nslices, real_only, p->done));
