@@ -250,8 +250,11 @@ int p3d_shearlet_plan_destroy(p3d_splan* plan);
 /* How much of the frame the loop has to touch: a shearlet's spectrum vanishes on most rows of the frequency plane (a Parseval frame
  * covers every frequency about twice), and the fused passes skip the 8-row groups on which it does -- exact, those rows carry only
  * zeros through the iteration.  row_group_fraction: share of the (shearlet, 8-row group) pairs that are NOT skipped (1.0: dense
- * path, e.g. P3D_SHEARLET_NO_SUPPORT=1 or the unfused passes). */
-int p3d_shearlet_info(p3d_splan* plan, double* row_group_fraction);
+ * path, e.g. P3D_SHEARLET_NO_SUPPORT=1 or the unfused passes).  paired (may be NULL): 1 when float32 cubes take the Hermitian form of
+ * the loop -- symmetric spectra (Psi_s(-k) = Psi_s(k), FFST's realCoefficients=True) give real coefficients, the work slices are
+ * Hermitian along the rows, so only rows 0 ... nil/2 are computed / stored / read and the column pass sends two columns through
+ * one complex transform (results agree with the general form to float32 rounding; P3D_SHEARLET_NO_PAIR=1 switches it off). */
+int p3d_shearlet_info(p3d_splan* plan, double* row_group_fraction, int* paired);
 /* test hooks: x HOST complex64 [nslices][nil][nxl] <-> st HOST complex64 [nslices][nsh][nil][nxl] */
 int p3d_shearlet_transform_c64(p3d_splan* plan, const void* x, void* st, int nslices);
 int p3d_shearlet_inverse_c64(p3d_splan* plan, const void* st, void* x, int nslices);

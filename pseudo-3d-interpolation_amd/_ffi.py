@@ -92,7 +92,7 @@ PROTOTYPES = {
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_shearlet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "p3d_shearlet_plan_destroy": (C.c_int, [C.c_void_p]),
-    "p3d_shearlet_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "p3d_shearlet_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "p3d_shearlet_transform_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "p3d_shearlet_inverse_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "p3d_shearlet_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -525,10 +525,11 @@ class ShearletPlan:
         h = C.c_void_p()
         check(lib().p3d_shearlet_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.nsh, _ptr(dev_psi), self.max_slices))
         self.handle = h
-        frac = C.c_double(1.0)
-        check(lib().p3d_shearlet_info(self.handle, C.byref(frac)))
-        # share of the (shearlet, 8-row group) pairs on which the spectrum does not vanish: what the fused passes actually touch
-        self.row_group_fraction = frac.value
+        frac, paired = C.c_double(1.0), C.c_int(0)
+        check(lib().p3d_shearlet_info(self.handle, C.byref(frac), C.byref(paired)))
+        # share of the (shearlet, 8-row group) pairs on which the spectrum does not vanish: what the fused passes actually touch;
+        # float32 cubes on symmetric spectra additionally work on Hermitian half slices, two columns per transform
+        self.row_group_fraction, self.paired = frac.value, bool(paired.value)
 
     def close(self):
         if getattr(self, "handle", None):

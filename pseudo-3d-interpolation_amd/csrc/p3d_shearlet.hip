@@ -367,10 +367,11 @@ static int s_inverse(p3d_splan* p, int ns, const int* done)
 
 extern "C" {
 
-int p3d_shearlet_info(p3d_splan* p, double* row_group_fraction)
+int p3d_shearlet_info(p3d_splan* p, double* row_group_fraction, int* paired)
 {
     if (!p || !row_group_fraction) return sfail(P3D_ERR_INVALID, "NULL argument");
     *row_group_fraction = p->sup ? p->sup_fraction : 1.0;
+    if (paired) *paired = p->pair ? 1 : 0;
     return P3D_OK;
 }
 
