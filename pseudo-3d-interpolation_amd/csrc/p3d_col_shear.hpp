@@ -77,39 +77,57 @@ void col_shear_pair_kernel(const ColArgs a)
     const int tid = threadIdx.x, j = tid & 3, tl = tid >> 2;
     const int slice = blockIdx.y, tile = blockIdx.x;
     const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
-    ColTablesHalf<N>::template load<THREADS>(twl, a.tw, tid);
-    // rows on which Psi_s vanishes were not stored by the spread pass and are not read by the gather pass (ShearArgs::sup).  With
+    // Rows on which Psi_s vanishes were not stored by the spread pass and are not read by the gather pass (ShearArgs::sup).  With
     // Hermitian work slices (ShearArgs::half) row k > N/2 is the conjugate of row N - k: a thread loads THAT row (bit of its group).
-    constexpr int WORDS = (N / 8 + 31) / 32;
-    __shared__ unsigned s_sup[WORDS];
-    if (tid < WORDS) s_sup[tid] = a.sh.sup ? a.sh.sup[(size_t)s * a.sh.sup_words + tid] : 0xffffffffu;
-    const c32 tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
-    __syncthreads();
+    // The bitmap words of the shearlet are wave-uniform and come through the scalar path with compile-time word indices, so that the
+    // tile's loads can be issued right away -- the copy of the tables into LDS then runs under their latency.
+    //   row k = tl + TPL q, group (tl >> 3) + G q, G = TPL / 8 (a divisor or a multiple of 32: the word depends on q alone);
+    //   mirrored row N - k, group N/8 - G q - c with c = (tl + 7) >> 3: word of N/8 - G (q + 1) for c >= 1, of N/8 - G q for tl = 0.
+    constexpr int G = TPL / 8, NG = N / 8, WORDS = (NG + 31) / 32;
+    unsigned supw[WORDS];
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) supw[w] = a.sh.sup ? a.sh.sup[(size_t)s * a.sh.sup_words + w] : 0xffffffffu;
     const bool half = a.sh.half != 0;
+    const int c8 = (tl + 7) >> 3;
     unsigned rows_on = 0, mirrored = 0;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        const int k = tl + TPL * q, kk = (half && k > N / 2) ? N - k : k, g = kk >> 3;
-        rows_on |= ((s_sup[g >> 5] >> (g & 31)) & 1u) << q;
-        mirrored |= (kk != k ? 1u : 0u) << q;
+        const unsigned direct = (supw[(G * q) >> 5] >> (((G * q) & 31) + (tl >> 3))) & 1u;
+        unsigned bit = direct;
+        if (q >= PPT / 2) {
+            const bool mir = half && !(q == PPT / 2 && tl == 0);
+            const int gz = NG - G * q > 0 ? NG - G * q : 0, gl = NG - G * (q + 1) > 0 ? NG - G * (q + 1) : 0;   // (tl = 0 / tl > 0; constants once the loop is unrolled)
+            const unsigned m0 = (supw[(gz >> 5) < WORDS ? (gz >> 5) : 0] >> (gz & 31)) & 1u;
+            const unsigned m1 = (supw[gl >> 5] >> ((NG - G * q - c8) & 31)) & 1u;
+            if (mir) bit = tl == 0 ? m0 : m1;
+            mirrored |= (mir ? 1u : 0u) << q;
+        }
+        rows_on |= bit << q;
     }
+    const c32 tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
 
     const LDS lds{data + j};
     c32* const base = a.out + (size_t)slice * wk_slice_stride(N, a.n2);   // in place (a.in == a.out)
     const unsigned org = ((unsigned)tile * N + (unsigned)tl) * 8u + 2u * (unsigned)j;   // element (row tl, column pair j) of the tile's block; + TPL q rows
     typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 raw[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        raw[q] = f4{0.f, 0.f, 0.f, 0.f};
+        if ((rows_on >> q) & 1u) {
+            const int k = tl + TPL * q;
+            const unsigned off = ((mirrored >> q) & 1u) ? ((unsigned)tile * N + (unsigned)(N - k)) * 8u + 2u * (unsigned)j : org + (unsigned)(TPL * q) * 8u;
+            raw[q] = *reinterpret_cast<const f4*>(base + off);
+        }
+    }
+    ColTablesHalf<N>::template load<THREADS>(twl, a.tw, tid);
+    __syncthreads();
     c32 v[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        v[q] = c32{0.f, 0.f};
-        if ((rows_on >> q) & 1u) {
-            const int k = tl + TPL * q;
-            const bool mir = (mirrored >> q) & 1u;
-            const unsigned off = mir ? ((unsigned)tile * N + (unsigned)(N - k)) * 8u + 2u * (unsigned)j : org + (unsigned)(TPL * q) * 8u;
-            f4 ab = *reinterpret_cast<const f4*>(base + off);
-            if (mir) { ab.y = -ab.y; ab.w = -ab.w; }          // row N - k holds the conjugates
-            v[q] = add_ib(c32{ab.x, ab.y}, c32{ab.z, ab.w});   // Z = W_A + i W_B
-        }
+        f4 ab = raw[q];
+        if ((mirrored >> q) & 1u) { ab.y = -ab.y; ab.w = -ab.w; }   // row N - k holds the conjugates
+        v[q] = add_ib(c32{ab.x, ab.y}, c32{ab.z, ab.w});             // Z = W_A + i W_B
     }
     line_fft<N, INV, false>(v, lds, tw, tl);
     {
