@@ -782,6 +782,210 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
     }
 }
 
+// ---- level 1, steady state: synthesis of iteration k + re-insertion + analysis of iteration k + 1 in ONE kernel --------------------
+// Between two iterations the level-1 synthesis writes the new iterate (crop + re-insertion fused, idwt2_tile_kernel) and the level-1
+// analysis reads it straight back (dwt2_tile_kernel): 4 B/point written and 4.8 B/point read (halo) that exist only to cross a
+// kernel boundary -- a third of the loop's traffic.  Here a workgroup owns a TILE x TILE tile of the NEXT decomposition: it
+// reconstructs the (2 TILE + L - 2)^2 samples of the iterate that tile needs (its own 2 TILE x 2 TILE core plus the analysis halo,
+// recomputed rather than exchanged: x 1.2 synthesis work), applies crop + re-insertion (POCS.py:609, 616-619), extends by the
+// 'smooth' rule where the region leaves the slice, and filters both axes again; the iterate itself is never stored (`out` only when
+// asked: last iteration / early exit).  Cost sums and `out` cover the core, every sample exactly once.  The arithmetic of every
+// sample is that of the two kernels it replaces (same taps in the same order, same re-insertion expression): bit-identical results
+// (tests/test_gpu_wavelet.py), P3D_WAVELET_NO_L1FUSE=1 keeps the two launches.
+// The level-1 details are read (iteration k, with halo) and written (iteration k + 1) by different workgroups at the same time:
+// they alternate between two buffers.
+template <int TILE>
+__host__ __device__ constexpr size_t wfuse1_lds_elems(int L) { return (size_t)4 * (TILE + L - 2) * (TILE + L - 2) + (size_t)2 * (2 * TILE + L - 2) * (TILE + L - 2); }
+
+template <typename T, int TILE, int LT>
+__global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det_in, size_t det_in_slice, T* det_out, size_t det_out_slice,
+                                                     int Ho, int Wo, T* cA, size_t cA_slice, Filters f, int tiles_x, int ntiles, int ns, Update u, Thresh th)
+{
+    extern __shared__ __align__(16) unsigned char w_smem[];
+    __shared__ double red[4];
+    __shared__ float4 s_dec[MAXL / 2], s_rec[MAXL / 2];
+    constexpr int LX = TILE, LY = 256 / TILE, R = TILE / LY;
+    const int L = LT ? LT : f.len, HL = L / 2, IH = 2 * TILE + L - 2, IW = IH, KH = TILE + L - 2, KW = KH;
+    T* s_a = reinterpret_cast<T*>(w_smem);           // synthesis: four coefficient arrays [KH][KW] ...
+    T* s_h = s_a + (size_t)KH * KW;
+    T* s_v = s_h + (size_t)KH * KW;
+    T* s_d = s_v + (size_t)KH * KW;
+    T* s_lo = s_d + (size_t)KH * KW;                 // ... and the column-reconstructed halves [IH][KW]; analysis: row-filtered [IH][TILE] x 2
+    T* s_hi = s_lo + (size_t)IH * KW;
+    T* s_in = s_a;                                   // the iterate of the tile [IH][IW] takes the place of the coefficients (IH * IW <= 4 KH KW)
+    const int tid = threadIdx.x, tx = tid % LX, ty = tid / LX;
+    int s, tile;
+    if (!xcd_decode(ntiles, ns, s, tile)) return;
+    const int dn = u.done ? u.done[s] : 0;
+    if (dn != 0) return;                             // finished / empty slice: nothing feeds on it any more (uniform over the workgroup)
+    const int by = tile / tiles_x, bx = tile - by * tiles_x;
+    const int or0 = by * TILE, oc0 = bx * TILE, r0 = 2 * or0 - L + 2, c0 = 2 * oc0 - L + 2;
+    const int vh = min(TILE, Ho - or0), vw = min(TILE, Wo - oc0), IHv = 2 * vh + L - 2, IWv = 2 * vw + L - 2;
+    // the part of the region that lies inside the slice: rows m_lo ... m_hi (m_lo even: 0 or r0), columns n_lo ... n_hi
+    const int m_lo = max(r0, 0), m_hi = min(r0 + IHv, u.n1) - 1, n_lo = max(c0, 0), n_hi = min(c0 + IWv, u.n2) - 1;
+    const int nm = m_hi - m_lo + 1, nn = n_hi - n_lo + 1;            // (>= 2: a tile reaches at least L - 2 >= 2 samples into the slice)
+    const int kr0 = m_lo / 2, kc0 = n_lo / 2, KHv = m_hi / 2 + HL - kr0, KWv = n_hi / 2 + HL - kc0;
+    if (tid < HL) {
+        const int j = 2 * tid, k = L - 2 - 2 * tid;
+        s_dec[tid] = float4{f.dec_lo[j], f.dec_hi[j], f.dec_lo[j + 1], f.dec_hi[j + 1]};
+        s_rec[tid] = float4{f.rec_lo[k], f.rec_hi[k], f.rec_lo[k + 1], f.rec_hi[k + 1]};
+    }
+    const size_t cnt = (size_t)Ho * Wo;
+    const T* pa = a + (size_t)s * a_slice;
+    const T* pd = det_in + (size_t)s * det_in_slice;
+    // ---- coefficients of the region (zero beyond the arrays, as in idwt2_tile_kernel) ----
+    for (int e = tid; e < KH * KW; e += 256) {
+        const int kr = e / KW, kc = e - kr * KW, gr = kr0 + kr, gc = kc0 + kc;
+        if (kr < KHv && kc < KWv) {
+            T va = zero_of<T>(), vh_ = zero_of<T>(), vv = zero_of<T>(), vd = zero_of<T>();
+            if (gr < Ho && gc < Wo) {
+                const size_t o = (size_t)gr * Wo + gc;
+                va = pa[(size_t)gr * a_ld + gc];
+                vh_ = pd[o];
+                vv = pd[cnt + o];
+                vd = pd[2 * cnt + o];
+            }
+            s_a[e] = va; s_h[e] = vh_; s_v[e] = vv; s_d[e] = vd;
+        }
+    }
+    __syncthreads();
+    // ---- undo axis 0: rows m_lo + 2 ip, + 1 from coefficient rows ip ... ip + L/2 - 1 (local) ----
+    for (int e = tid; e < (IH / 2) * KW; e += 256) {
+        const int ip = e / KW, kc = e - ip * KW;
+        if (2 * ip < nm && kc < KWv) {
+            Acc<T> lo, hi;
+            for (int t = 0; t < HL; ++t) {
+                const float4 g = s_rec[t];
+                const int i = (ip + t) * KW + kc;
+                lo.tap(g.x, g.z, s_a[i]);
+                lo.tap(g.y, g.w, s_h[i]);
+                hi.tap(g.x, g.z, s_v[i]);
+                hi.tap(g.y, g.w, s_d[i]);
+            }
+            s_lo[(2 * ip) * KW + kc] = lo.first();
+            s_lo[(2 * ip + 1) * KW + kc] = lo.second();
+            s_hi[(2 * ip) * KW + kc] = hi.first();
+            s_hi[(2 * ip + 1) * KW + kc] = hi.second();
+        }
+    }
+    __syncthreads();
+    // ---- undo axis 1 + crop + re-insertion: samples (m_lo + m, n_lo + 2 ii), + 1 -> the tile's image of the iterate ----
+    double acc = 0.0;
+    {
+        const size_t per = (size_t)u.n1 * u.n2;
+        T* feed_img = s_in + (m_lo - r0) * IW + (n_lo - c0);
+        const int core_m0 = 2 * or0, core_n0 = 2 * oc0;   // the tile OWNS rows core_m0 ... + 2 TILE - 1 (cost sum, `out`)
+        for (int e = tid; e < IH * (IW / 2); e += 256) {
+            const int m = e / (IW / 2), ii = e - m * (IW / 2);
+            if (m >= nm || 2 * ii >= nn) continue;
+            const T* ql = s_lo + m * KW + ii;
+            const T* qh = s_hi + m * KW + ii;
+            Acc<T> eo;
+            for (int t = 0; t < HL; ++t) {
+                const float4 g = s_rec[t];
+                eo.tap(g.x, g.z, ql[t]);
+                eo.tap(g.y, g.w, qh[t]);
+            }
+            const int gm = m_lo + m;
+#pragma unroll
+            for (int ee = 0; ee < 2; ++ee) {
+                const int gn = n_lo + 2 * ii + ee;
+                if (gn > n_hi) continue;
+                const size_t li = (size_t)gm * u.n2 + gn, g = (size_t)s * per + li;
+                const T xo = load_x(u.x, u.dtype, g, (T*)nullptr);
+                const float mk = u.mask[li];
+                const float wgt = 1.0f - u.alpha * mk;
+                const T xn = cmulf(ee ? eo.second() : eo.first(), wgt) + cmulf(xo, u.alpha);
+                const bool mine = gm >= core_m0 && gm < core_m0 + 2 * TILE && gn >= core_n0 && gn < core_n0 + 2 * TILE;
+                if (mine) {
+                    if (u.write_out) store_out(u.out, u.dtype, g, xn);
+                    acc += (double)mag(xn);
+                }
+                T fd = xn;
+                if (u.adaptive) fd = (cmulf(xo, u.alpha) + cmulf(xn, wgt)) + cmulf(xo - cmulf(xn, mk), 1.0f - u.alpha);
+                feed_img[m * IW + 2 * ii + ee] = fd;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 'smooth' extension where the region leaves the slice (smooth2_at on the image: along axis 0, then along axis 1) ----
+    if (r0 < 0 || c0 < 0 || r0 + IHv > u.n1 || c0 + IWv > u.n2) {
+        for (int e = tid; e < IH * IW; e += 256) {
+            const int lr = e / IW, lc = e - lr * IW;
+            if (lr >= IHv || lc >= IWv) continue;
+            const int r = r0 + lr, c = c0 + lc;
+            if (r >= 0 && r < u.n1 && c >= 0 && c < u.n2) continue;
+            const int H = u.n1, W = u.n2;
+            const int rc = min(max(r, 0), H - 1), cc = min(max(c, 0), W - 1);
+            const int rn = r < 0 ? min(1, H - 1) : max(H - 2, 0), cn = c < 0 ? min(1, W - 1) : max(W - 2, 0);
+            const float tr = r < 0 ? (float)(-r) : (r >= H ? (float)(r - H + 1) : 0.f);
+            const float tc = c < 0 ? (float)(-c) : (c >= W ? (float)(c - W + 1) : 0.f);
+            const T x00 = s_in[(rc - r0) * IW + (cc - c0)], x10 = s_in[(rn - r0) * IW + (cc - c0)];
+            const T x01 = s_in[(rc - r0) * IW + (cn - c0)], x11 = s_in[(rn - r0) * IW + (cn - c0)];
+            s_in[e] = extrapolate(extrapolate(x00, x10, tr), extrapolate(x01, x11, tr), tc);
+        }
+        __syncthreads();
+    }
+    // ---- analysis of the next iteration: dwt2_tile_kernel from here on (s_lo / s_hi re-used with pitch TILE) ----
+    struct alignas(2 * sizeof(T)) Pair { T lo, hi; };
+    for (int r = ty; r < IHv; r += LY) {
+        if (tx >= vw) continue;
+        const Pair* q = reinterpret_cast<const Pair*>(s_in + r * IW + 2 * tx + L - 2);
+        Acc<T> ad;
+        for (int jj = 0; jj < HL; ++jj) {
+            const float4 g = s_dec[jj];
+            const Pair v = q[-jj];
+            ad.tap(g.x, g.y, v.hi);
+            ad.tap(g.z, g.w, v.lo);
+        }
+        s_lo[r * TILE + tx] = ad.first();
+        s_hi[r * TILE + tx] = ad.second();
+    }
+    __syncthreads();
+    if (tx < vw && ty * R < vh) {
+        Acc<T> fl[R], fh[R];
+        const T* cl = s_lo + (2 * ty * R + L - 1) * TILE + tx;
+        const T* ch = s_hi + (2 * ty * R + L - 1) * TILE + tx;
+        for (int jj = 0; jj < HL; ++jj) {
+            const float4 g = s_dec[jj];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int o = (2 * q - 2 * jj) * TILE;
+                fl[q].tap(g.x, g.y, cl[o]);
+                fh[q].tap(g.x, g.y, ch[o]);
+                fl[q].tap(g.z, g.w, cl[o - TILE]);
+                fh[q].tap(g.z, g.w, ch[o - TILE]);
+            }
+        }
+        c32 t0{0.f, 0.f}, t1{0.f, 0.f}, t2{0.f, 0.f};
+        if (th.tau) {
+            const c32* t = th.tau + (((size_t)s * th.niter + th.iter) * th.nlev + th.lvl) * 3;
+            t0 = t[0]; t1 = t[1]; t2 = t[2];
+        }
+        const ShrinkTile<T> sh0(t0, th.op), sh1(t1, th.op), sh2(t2, th.op);
+        const int gc = oc0 + tx;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int go = or0 + ty * R + q;
+            if (go >= Ho || gc >= Wo) continue;
+            T da = fl[q].second(), ad = fh[q].first(), dd = fh[q].second();
+            if (th.tau) { da = sh0(da); ad = sh1(ad); dd = sh2(dd); }
+            const size_t o = (size_t)go * Wo + gc;
+            cA[(size_t)s * cA_slice + o] = fl[q].first();
+            T* dp = det_out + (size_t)s * det_out_slice + o;
+            dp[0] = da;
+            dp[cnt] = ad;
+            dp[2 * cnt] = dd;
+        }
+    }
+    // ---- cost sum of the core ----
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) atomicAdd(u.sums + s, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
 // per (slice, level, detail): lexicographic max, max |d|, min |d| -> stats[((s*nlev + lvl)*3 + z)*4 ..]; one block each
 __device__ __forceinline__ float re_of(c32 v) { return v.x; }
 __device__ __forceinline__ float im_of(c32 v) { return v.y; }
@@ -912,6 +1116,9 @@ struct p3d_wplan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool fused = true;              // tile kernels (one launch per level and direction); P3D_WAVELET_UNFUSED=1 selects the per-axis kernels
     int tile_c = 0, tile_r = 0;     // coefficients per tile edge for complex64 / float32 work buffers
+    // level 1 of the steady state in one kernel (wfuse1_kernel): synthesis of iteration k + re-insertion + analysis of iteration k + 1
+    bool l1fuse_c = false, l1fuse_r = false;   // ... for complex64 / float32 work buffers
+    c32* det1_alt = nullptr;        // second buffer of the level-1 details [max_slices][3 h[1] w[1]] (they alternate)
     // first level carried by the one-workgroup-per-slice kernel (wcoarse_kernel) for complex64 / float32 work buffers; 0: none
     int lc_c = 0, lc_r = 0;
     int cx_c = 0, cx_r = 0;         // ... elements of its LDS region X
@@ -957,7 +1164,7 @@ extern "C" int p3d_wavelet_plan_destroy(p3d_wplan* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->coef, p->feed, p->lo, p->hi, p->tau, p->sums, p->done, p->stats, p->mask, p->st_x, p->st_out};
+    void* bufs[] = {p->det1_alt, p->coef, p->feed, p->lo, p->hi, p->tau, p->sums, p->done, p->stats, p->mask, p->st_x, p->st_out};
     for (void* b : bufs) if (b) hipFree(b);
     for (c32* b : p->approx) if (b) hipFree(b);
     for (c32* b : p->rec) if (b) hipFree(b);
@@ -1029,7 +1236,7 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
     ALLOC(p->mask, sizeof(float) * p->per());
     ALLOC(p->st_x, sizeof(c32) * p->per() * S);
     ALLOC(p->st_out, sizeof(c32) * p->per() * S);
-#undef ALLOC
+#define ALLOC2(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(#ptr, e)
     p->tile_c = pick_tile(flen, sizeof(c32));
     p->tile_r = pick_tile(flen, sizeof(float));
     const char* env = getenv("P3D_WAVELET_UNFUSED");
@@ -1042,6 +1249,21 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
         for (const void* k : ck)
             if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2 * (int)sizeof(float4) * (MAXL / 2) - 256)) != hipSuccess)
                 return bail("hipFuncSetAttribute", e);
+    }
+    if (p->fused && p->nlev >= 2 && !getenv("P3D_WAVELET_NO_L1FUSE")) {
+        // every tile of the level-1 decomposition must reach at least two samples into the slice along both axes (the 'smooth'
+        // extension is evaluated on the tile's own image of the iterate)
+        auto reaches = [&](int n, int no) { const int last = ((no - 1) / 32) * 32; return n >= 2 && 2 * last - flen + 2 <= n - 2; };
+        const bool geom = reaches(nil, p->h[1]) && reaches(nxl, p->w[1]);
+        p->l1fuse_c = geom && p->tile_c == 32 && wfuse1_lds_elems<32>(flen) * sizeof(c32) <= 150 * 1024;
+        p->l1fuse_r = geom && p->tile_r == 32 && wfuse1_lds_elems<32>(flen) * sizeof(float) <= 150 * 1024;
+        if (p->l1fuse_c || p->l1fuse_r) {
+            ALLOC2(p->det1_alt, sizeof(c32) * 3 * (size_t)p->h[1] * p->w[1] * S);
+            const void* fk[] = {(const void*)wfuse1_kernel<c32, 32, 0>, (const void*)wfuse1_kernel<c32, 32, 4>, (const void*)wfuse1_kernel<c32, 32, 8>,
+                                (const void*)wfuse1_kernel<float, 32, 0>, (const void*)wfuse1_kernel<float, 32, 4>, (const void*)wfuse1_kernel<float, 32, 8>};
+            for (const void* k : fk)
+                if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) return bail("hipFuncSetAttribute", e);
+        }
     }
     if (p->fused) {
         const int big = 150 * 1024;
@@ -1105,14 +1327,17 @@ static int w_coarse(p3d_wplan* p, int ns, const Thresh* th, bool fwd, bool inv)
 }
 
 // fuse_inverse: the coarse kernel also runs its synthesis (the loop; w_inverse_fused is then told so)
+// l_from / l_to: only the levels l_from ... min(l_to, nlev) (the loop with the level-1 kernel: level 1 and the rest apart);
+// det1 / det1_slice: where the level-1 details go (nullptr: into the coefficient vector)
 template <typename T>
-static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th, bool fuse_inverse = false)
+static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th, bool fuse_inverse = false, int l_from = 1, int l_to = 1 << 20, T* det1 = nullptr,
+                           size_t det1_slice = 0)
 {
     const int tile = tile_of<T>(p), ns8 = (ns + 7) / 8 * 8;
     const size_t lds = tile_lds(tile, p->f.len, sizeof(T));
     T* coef = as<T>(p->coef);
-    const int lc = coarse_level<T>(p), last_tile_level = lc ? lc - 1 : p->nlev;
-    for (int l = 1; l <= last_tile_level; ++l) {
+    const int lc = coarse_level<T>(p), last_tile_level = std::min(lc ? lc - 1 : p->nlev, l_to);
+    for (int l = l_from; l <= last_tile_level; ++l) {
         const T* src = l == 1 ? as<T>(p->feed) : as<T>(p->approx[l - 1]);
         const int H = p->h[l - 1], W = p->w[l - 1], Ho = p->h[l], Wo = p->w[l];
         T* cA = l == p->nlev ? coef : as<T>(p->approx[l]);
@@ -1120,30 +1345,34 @@ static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th, bool fuse_inv
         Thresh t{nullptr, 0, 0, 0, 0, 0, -1, -1};
         if (th) { t = *th; t.lvl = p->nlev - l; }
         const int tx = (Wo + tile - 1) / tile, ty = (Ho + tile - 1) / tile;
-#define P3D_W_DWT(TL, LT) dwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, coef + p->doff[l], p->ncoef, Ho, Wo, p->f, tx, tx * ty, ns, t)
+        T* const det = (l == 1 && det1) ? det1 : coef + p->doff[l];
+        const size_t det_slice = (l == 1 && det1) ? det1_slice : p->ncoef;
+#define P3D_W_DWT(TL, LT) dwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, det, det_slice, Ho, Wo, p->f, tx, tx * ty, ns, t)
         const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;   // db4 / sym4 and db2 have kernels of their own
         if (tile == 32) { if (lt == 8) P3D_W_DWT(32, 8); else if (lt == 4) P3D_W_DWT(32, 4); else P3D_W_DWT(32, 0); }
         else { if (lt == 8) P3D_W_DWT(16, 8); else if (lt == 4) P3D_W_DWT(16, 4); else P3D_W_DWT(16, 0); }
 #undef P3D_W_DWT
     }
     W_TRY(hipGetLastError());
-    if (lc) return w_coarse<T>(p, ns, th, true, fuse_inverse);
+    if (lc && lc <= l_to) return w_coarse<T>(p, ns, th, true, fuse_inverse);
     return P3D_OK;
 }
 
 // `u`: what to do with the level-0 reconstruction (nullptr: store it in rec[0])
+// l_from >= l >= l_to: only those levels (defaults: all of them); det1: where the level-1 details are (nullptr: the coefficient vector)
 template <typename T>
-static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u, bool coarse_done = false)
+static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u, bool coarse_done = false, int l_from = 1 << 20, int l_to = 1, const T* det1 = nullptr,
+                           size_t det1_slice = 0)
 {
     const int tile = tile_of<T>(p), ns8 = (ns + 7) / 8 * 8;
     const size_t lds = tile_lds(tile, p->f.len, sizeof(T));
     T* coef = as<T>(p->coef);
     const int lc = coarse_level<T>(p);
-    if (lc && !coarse_done) {
+    if (lc && !coarse_done && lc <= l_from) {
         const int rc = w_coarse<T>(p, ns, nullptr, false, true);
         if (rc) return rc;
     }
-    for (int l = lc ? lc - 1 : p->nlev; l >= 1; --l) {
+    for (int l = std::min(lc ? lc - 1 : p->nlev, l_from); l >= l_to; --l) {
         const int Ho = p->h[l], Wo = p->w[l], RH = p->rh[l - 1], RW = p->rw[l - 1];
         const T* a = l == p->nlev ? coef : as<T>(p->rec[l]);
         const size_t a_ld = l == p->nlev ? (size_t)Wo : (size_t)p->rw[l];
@@ -1153,7 +1382,9 @@ static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u, bool coarse_do
         // with the re-insertion fused only the nil x nxl crop of the level-0 reconstruction is needed
         const int OHt = up.enabled ? up.n1 : RH, OWt = up.enabled ? up.n2 : RW;
         const int tx = (OWt + 2 * tile - 1) / (2 * tile), ty = (OHt + 2 * tile - 1) / (2 * tile);
-#define P3D_W_IDWT(TL, LT) idwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, coef + p->doff[l], p->ncoef, Ho, Wo, as<T>(p->rec[l - 1]), \
+        const T* const det = (l == 1 && det1) ? det1 : coef + p->doff[l];
+        const size_t det_slice = (l == 1 && det1) ? det1_slice : p->ncoef;
+#define P3D_W_IDWT(TL, LT) idwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, det, det_slice, Ho, Wo, as<T>(p->rec[l - 1]), \
                                                                                      (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up)
         const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
         if (tile == 32) { if (lt == 8) P3D_W_IDWT(32, 8); else if (lt == 4) P3D_W_IDWT(32, 4); else P3D_W_IDWT(32, 0); }
@@ -1258,10 +1489,20 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
     const dim3 ugrid(blocks_for(p->per()) > 256 ? 256 : blocks_for(p->per()), nslices);
     wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->st_x, dtype, p->mask, p->st_out, p->sums, 0, adaptive ? 1 : 0, 0,
                                                    (float)prm->alpha, p->nil, p->nxl, p->done, 0);
+    const bool l1fuse = p->fused && (sizeof(T) == sizeof(float) ? p->l1fuse_r : p->l1fuse_c);
+    // level-1 details of iteration k live in buffer k % 2 (the level-1 kernel reads one while it writes the other)
+    const size_t cnt1 = (size_t)p->h[1] * p->w[1];
+    T* const det1[2] = {as<T>(p->coef) + p->doff[1], as<T>(p->det1_alt)};
+    const size_t det1_slice[2] = {p->ncoef, 3 * cnt1};
+    if (l1fuse) {
+        const Thresh th0{p->tau, niter, 0, p->nlev, 0, prm->thresh_op, -1, -1};
+        const int rc = w_forward_fused<T>(p, nslices, &th0, false, 1, 1, det1[0], det1_slice[0]);
+        if (rc) return rc;
+    }
     for (int k = 0; k < niter; ++k) {
         const bool last = k + 1 == niter;
         const Thresh th{p->tau, niter, k, p->nlev, 0, prm->thresh_op, -1, -1};
-        int rc = p->fused ? w_forward_fused<T>(p, nslices, &th, true) : w_forward<T>(p, nslices, &th);
+        int rc = l1fuse ? w_forward_fused<T>(p, nslices, &th, true, 2) : (p->fused ? w_forward_fused<T>(p, nslices, &th, true) : w_forward<T>(p, nslices, &th));
         if (rc) return rc;
         if (p->fused) {
             Update u{};
@@ -1269,7 +1510,27 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
             u.sums = p->sums + (size_t)(k + 1) * nslices;
             u.adaptive = (adaptive && !last) ? 1 : 0; u.write_out = (early || last) ? 1 : 0; u.zero_fill = last ? 1 : 0;
             u.alpha = (float)prm->alpha; u.n1 = p->nil; u.n2 = p->nxl; u.done = p->done;
-            if ((rc = w_inverse_fused<T>(p, nslices, &u, true))) return rc;
+            if (!l1fuse) {
+                if ((rc = w_inverse_fused<T>(p, nslices, &u, true))) return rc;
+            } else {
+                if ((rc = w_inverse_fused<T>(p, nslices, nullptr, true, 1 << 20, 2))) return rc;           // ... down to rec[1]
+                if (last) {
+                    if ((rc = w_inverse_fused<T>(p, nslices, &u, true, 1, 1, det1[k & 1], det1_slice[k & 1]))) return rc;
+                } else {   // level-1 synthesis of this iteration + re-insertion + level-1 analysis of the next one
+                    Thresh tn = th;
+                    tn.iter = k + 1; tn.lvl = p->nlev - 1;
+                    const int Ho = p->h[1], Wo = p->w[1], tx = (Wo + 31) / 32, ty = (Ho + 31) / 32, ns8 = (nslices + 7) / 8 * 8;
+                    const size_t lds = wfuse1_lds_elems<32>(p->f.len) * sizeof(T);
+                    // (both detail buffers are addressed with ONE slice stride inside the kernel: hand the larger-stride buffer its own launch form)
+                    const T* din = det1[k & 1];
+                    T* dout = det1[(k + 1) & 1];
+#define P3D_W_FUSE1(LT) wfuse1_kernel<T, 32, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(as<T>(p->rec[1]), (size_t)p->rw[1], (size_t)p->rh[1] * p->rw[1], din, det1_slice[k & 1], \
+                                                                                       dout, det1_slice[(k + 1) & 1], Ho, Wo, as<T>(p->approx[1]), cnt1, p->f, tx, tx * ty, nslices, u, tn)
+                    const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
+                    if (lt == 8) P3D_W_FUSE1(8); else if (lt == 4) P3D_W_FUSE1(4); else P3D_W_FUSE1(0);
+#undef P3D_W_FUSE1
+                }
+            }
         } else {
             if ((rc = w_inverse<T>(p, nslices))) return rc;
             wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->st_x, dtype, p->mask,

@@ -309,7 +309,8 @@ def test_wavelet_floor_step_at_config3_size(ffi, wo, op):
 
 @pytest.mark.parametrize("shape,wavelet,real,op", [((512, 512), "db4", True, "soft"), ((512, 512), "db4", False, "hard"), ((200, 333), "coif5", True, "garrote"),
                                                     ((96, 80), "sym5", False, "soft"), ((64, 64), "db2", True, "hard"), ((256, 128), "haar", True, "soft"),
-                                                    ((300, 300), "bior2.2", True, "hard")])
+                                                    ((300, 300), "bior2.2", True, "hard"), ((61, 59), "db4", True, "hard"), ((130, 70), "db2", False, "soft"),
+                                                    ((257, 255), "sym4", True, "soft")])
 def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypatch, shape, wavelet, real, op):
     """wcoarse_kernel (levels LC .. nlev of a slice in one workgroup, analysis and synthesis back to back) against the tile kernels
     launched level by level (P3D_WAVELET_NO_COARSE=1): the same taps in the same order -- decompositions, reconstructions, the loop's
@@ -321,7 +322,8 @@ def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypa
     cube = np.stack([po.synthetic_slice(nil, nxl, 10 + s, real=real) for s in range(3)]) * mask
     cube = cube.astype(np.float32 if real else np.complex64)
     cube[1] = 0
-    kw = dict(transform_kind="WAVELET", wavelet=wavelet, niter=6, thresh_op=op, thresh_model="exponential", p_max=0.99, p_min=1e-2, eps=1e-12)
+    kw = dict(transform_kind="WAVELET", wavelet=wavelet, niter=6, thresh_op=op, thresh_model="exponential", p_max=0.99, p_min=1e-2, eps=1e-12,
+              version="adaptive" if not real else "regular", alpha=0.9 if not real else 1.0)
 
     def run():
         P.release_plans()
@@ -334,14 +336,19 @@ def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypa
         return out, [(r["niterations"], r["costs"]) for r in res], coef, back, st
 
     a = run()
-    monkeypatch.setenv("P3D_WAVELET_NO_COARSE", "1")
-    b = run()
-    monkeypatch.delenv("P3D_WAVELET_NO_COARSE")
+    # ... and the level-1 kernel of the steady state (wfuse1_kernel: synthesis + re-insertion + next analysis in one launch) against
+    # the two launches it replaces (P3D_WAVELET_NO_L1FUSE=1), alone and together with the switch above
+    for switches in (("P3D_WAVELET_NO_L1FUSE",), ("P3D_WAVELET_NO_COARSE",), ("P3D_WAVELET_NO_L1FUSE", "P3D_WAVELET_NO_COARSE")):
+        for sw in switches:
+            monkeypatch.setenv(sw, "1")
+        b = run()
+        for sw in switches:
+            monkeypatch.delenv(sw)
+        assert np.array_equal(a[0], b[0]) and [n for n, _ in a[1]] == [n for n, _ in b[1]], switches
+        for (_, ca), (_, cb) in zip(a[1], b[1]):      # (the cost sums add their per-tile partial sums atomically: last bits vary run to run)
+            np.testing.assert_allclose(ca, cb, rtol=1e-9)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     P.release_plans()
-    assert np.array_equal(a[0], b[0]) and [n for n, _ in a[1]] == [n for n, _ in b[1]]
-    for (_, ca), (_, cb) in zip(a[1], b[1]):      # (the cost sums add their per-tile partial sums atomically: last bits vary run to run)
-        np.testing.assert_allclose(ca, cb, rtol=1e-9)
-    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     with ffi.WaveletPlan(nil, nxl, 2, wavelet=wavelet) as plan:   # and the decomposition is PyWavelets' (the oracle's)
         ref = wo.wavedec2(cube[0].astype(np.complex128), wo.filter_bank(wavelet))
         got = plan.unpack(a[2][0])
