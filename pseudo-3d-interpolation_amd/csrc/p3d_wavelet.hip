@@ -833,19 +833,62 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     const size_t cnt = (size_t)Ho * Wo;
     const T* pa = a + (size_t)s * a_slice;
     const T* pd = det_in + (size_t)s * det_in_slice;
-    // ---- coefficients of the region (zero beyond the arrays, as in idwt2_tile_kernel) ----
-    for (int e = tid; e < KH * KW; e += 256) {
-        const int kr = e / KW, kc = e - kr * KW, gr = kr0 + kr, gc = kc0 + kc;
-        if (kr < KHv && kc < KWv) {
-            T va = zero_of<T>(), vh_ = zero_of<T>(), vv = zero_of<T>(), vd = zero_of<T>();
-            if (gr < Ho && gc < Wo) {
+    // ---- coefficients of the region (zero beyond the arrays, as in idwt2_tile_kernel) and, right behind them, the observed samples
+    //      and mask weights of the region: all requests of a thread are in flight together (a load per loop trip would pay the
+    //      memory latency once per trip -- ten trips per tile) ----
+    constexpr int IHc = 2 * TILE + (LT ? LT : 2) - 2, KHc = TILE + (LT ? LT : 2) - 2;
+    constexpr int NE = LT ? (KHc * KHc + 255) / 256 : 1, NIT = LT ? (IHc * (IHc / 2) + 255) / 256 : 1;
+    const size_t per = (size_t)u.n1 * u.n2;
+    T xo[NIT][2];
+    float mk[NIT][2];
+    if constexpr (LT != 0) {
+        T va[NE], vh_[NE], vv[NE], vd[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i, kr = e / KHc, kc = e - kr * KHc, gr = kr0 + kr, gc = kc0 + kc;
+            va[i] = vh_[i] = vv[i] = vd[i] = zero_of<T>();
+            if (e < KHc * KHc && kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
                 const size_t o = (size_t)gr * Wo + gc;
-                va = pa[(size_t)gr * a_ld + gc];
-                vh_ = pd[o];
-                vv = pd[cnt + o];
-                vd = pd[2 * cnt + o];
+                va[i] = pa[(size_t)gr * a_ld + gc];
+                vh_[i] = pd[o];
+                vv[i] = pd[cnt + o];
+                vd[i] = pd[2 * cnt + o];
             }
-            s_a[e] = va; s_h[e] = vh_; s_v[e] = vv; s_d[e] = vd;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 256 * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+#pragma unroll
+            for (int ee = 0; ee < 2; ++ee) {
+                xo[it][ee] = zero_of<T>();
+                mk[it][ee] = 0.f;
+                const int gm = m_lo + m, gn = n_lo + 2 * ii + ee;
+                if (e < IHc * (IHc / 2) && m < nm && gn <= n_hi) {
+                    const size_t li = (size_t)gm * u.n2 + gn;
+                    xo[it][ee] = load_x(u.x, u.dtype, (size_t)s * per + li, (T*)nullptr);
+                    mk[it][ee] = u.mask[li];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i, kr = e / KHc, kc = e - kr * KHc;
+            if (e < KHc * KHc && kr < KHv && kc < KWv) { s_a[e] = va[i]; s_h[e] = vh_[i]; s_v[e] = vv[i]; s_d[e] = vd[i]; }
+        }
+    } else {
+        for (int e = tid; e < KH * KW; e += 256) {
+            const int kr = e / KW, kc = e - kr * KW, gr = kr0 + kr, gc = kc0 + kc;
+            if (kr < KHv && kc < KWv) {
+                T va = zero_of<T>(), vh_ = zero_of<T>(), vv = zero_of<T>(), vd = zero_of<T>();
+                if (gr < Ho && gc < Wo) {
+                    const size_t o = (size_t)gr * Wo + gc;
+                    va = pa[(size_t)gr * a_ld + gc];
+                    vh_ = pd[o];
+                    vv = pd[cnt + o];
+                    vd = pd[2 * cnt + o];
+                }
+                s_a[e] = va; s_h[e] = vh_; s_v[e] = vv; s_d[e] = vd;
+            }
         }
     }
     __syncthreads();
@@ -872,12 +915,9 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     // ---- undo axis 1 + crop + re-insertion: samples (m_lo + m, n_lo + 2 ii), + 1 -> the tile's image of the iterate ----
     double acc = 0.0;
     {
-        const size_t per = (size_t)u.n1 * u.n2;
         T* feed_img = s_in + (m_lo - r0) * IW + (n_lo - c0);
         const int core_m0 = 2 * or0, core_n0 = 2 * oc0;   // the tile OWNS rows core_m0 ... + 2 TILE - 1 (cost sum, `out`)
-        for (int e = tid; e < IH * (IW / 2); e += 256) {
-            const int m = e / (IW / 2), ii = e - m * (IW / 2);
-            if (m >= nm || 2 * ii >= nn) continue;
+        auto sample = [&](int m, int ii, const T (&xo2)[2], const float (&mk2)[2]) {
             const T* ql = s_lo + m * KW + ii;
             const T* qh = s_hi + m * KW + ii;
             Acc<T> eo;
@@ -891,19 +931,43 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
             for (int ee = 0; ee < 2; ++ee) {
                 const int gn = n_lo + 2 * ii + ee;
                 if (gn > n_hi) continue;
-                const size_t li = (size_t)gm * u.n2 + gn, g = (size_t)s * per + li;
-                const T xo = load_x(u.x, u.dtype, g, (T*)nullptr);
-                const float mk = u.mask[li];
-                const float wgt = 1.0f - u.alpha * mk;
-                const T xn = cmulf(ee ? eo.second() : eo.first(), wgt) + cmulf(xo, u.alpha);
+                const size_t g = (size_t)s * per + (size_t)gm * u.n2 + gn;
+                const float wgt = 1.0f - u.alpha * mk2[ee];
+                const T xn = cmulf(ee ? eo.second() : eo.first(), wgt) + cmulf(xo2[ee], u.alpha);
                 const bool mine = gm >= core_m0 && gm < core_m0 + 2 * TILE && gn >= core_n0 && gn < core_n0 + 2 * TILE;
                 if (mine) {
                     if (u.write_out) store_out(u.out, u.dtype, g, xn);
                     acc += (double)mag(xn);
                 }
                 T fd = xn;
-                if (u.adaptive) fd = (cmulf(xo, u.alpha) + cmulf(xn, wgt)) + cmulf(xo - cmulf(xn, mk), 1.0f - u.alpha);
+                if (u.adaptive) fd = (cmulf(xo2[ee], u.alpha) + cmulf(xn, wgt)) + cmulf(xo2[ee] - cmulf(xn, mk2[ee]), 1.0f - u.alpha);
                 feed_img[m * IW + 2 * ii + ee] = fd;
+            }
+        };
+        if constexpr (LT != 0) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + 256 * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+                if (e < IHc * (IHc / 2) && m < nm && 2 * ii < nn) sample(m, ii, xo[it], mk[it]);
+            }
+        } else {
+            for (int e = tid; e < IH * (IW / 2); e += 256) {
+                const int m = e / (IW / 2), ii = e - m * (IW / 2);
+                if (m >= nm || 2 * ii >= nn) continue;
+                T x2[2];
+                float m2[2];
+#pragma unroll
+                for (int ee = 0; ee < 2; ++ee) {
+                    x2[ee] = zero_of<T>();
+                    m2[ee] = 0.f;
+                    const int gn = n_lo + 2 * ii + ee;
+                    if (gn <= n_hi) {
+                        const size_t li = (size_t)(m_lo + m) * u.n2 + gn;
+                        x2[ee] = load_x(u.x, u.dtype, (size_t)s * per + li, (T*)nullptr);
+                        m2[ee] = u.mask[li];
+                    }
+                }
+                sample(m, ii, x2, m2);
             }
         }
     }

@@ -353,4 +353,4 @@ def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypa
         ref = wo.wavedec2(cube[0].astype(np.complex128), wo.filter_bank(wavelet))
         got = plan.unpack(a[2][0])
         scale = np.abs(ref[0]).max()
-        assert np.abs(got[0] - ref[0]).max() <= 5e-6 * scale
+        assert np.abs(got[0] - ref[0]).max() <= 2e-5 * scale     # (30-tap filters over four levels: ~1e-5 of the peak in float32)
