@@ -984,8 +984,10 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
             const int rn = r < 0 ? min(1, H - 1) : max(H - 2, 0), cn = c < 0 ? min(1, W - 1) : max(W - 2, 0);
             const float tr = r < 0 ? (float)(-r) : (r >= H ? (float)(r - H + 1) : 0.f);
             const float tc = c < 0 ? (float)(-c) : (c >= W ? (float)(c - W + 1) : 0.f);
-            const T x00 = s_in[(rc - r0) * IW + (cc - c0)], x10 = s_in[(rn - r0) * IW + (cc - c0)];
-            const T x01 = s_in[(rc - r0) * IW + (cn - c0)], x11 = s_in[(rn - r0) * IW + (cn - c0)];
+            // (a neighbour that carries weight 0 is not read: its place may lie outside the tile's image, and 0 x garbage is not 0)
+            const int lrc = rc - r0, lcc = cc - c0, lrn = tr != 0.f ? rn - r0 : lrc, lcn = tc != 0.f ? cn - c0 : lcc;
+            const T x00 = s_in[lrc * IW + lcc], x10 = s_in[lrn * IW + lcc];
+            const T x01 = s_in[lrc * IW + lcn], x11 = s_in[lrn * IW + lcn];
             s_in[e] = extrapolate(extrapolate(x00, x10, tr), extrapolate(x01, x11, tr), tc);
         }
         __syncthreads();
