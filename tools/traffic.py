@@ -53,7 +53,9 @@ for k in sorted(set(fetch) | set(write)):
         continue
     rb, wb = 2 * fetch[k][0] * 1024, write[k][0] * 1024
     n = max(fetch[k][1], write[k][1])
-    short = re.sub(r"\(.*$", "", k).replace("void ", "").replace("(anonymous namespace)::", "")[:90]
+    short = re.sub(r"\(.*$", "", k.replace("(anonymous namespace)::", "").replace("void ", ""))[:90]
+    if short in kernels:
+        short = short + f" #{len(kernels)}"
     kernels[short] = {"dispatches": n, "read_bytes_per_dispatch": rb / max(fetch[k][1], 1), "written_bytes_per_dispatch": wb / max(write[k][1], 1)}
     read_b += rb
     written_b += wb
