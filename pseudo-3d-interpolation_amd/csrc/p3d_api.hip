@@ -329,7 +329,6 @@ struct p3d_plan {
     int host_sw = 0;      // P3D_SW_* bits for the flexible-length launchers
     int flex_over = 0;    // P3D_FLEX_COL_OVER (0: the launcher's default)
     bool no_colpipe = false;   // P3D_NO_COLPIPE, for the SHEARLET column pass (FFT jobs read it per job: RunSwitches)
-    bool pair_one_launch = false;   // P3D_SHEARLET_PAIR_ONE_LAUNCH: the paired SHEARLET column pass one launch per tile instead of persistent
     // staging for host-pointer entry points
     void* st_x = nullptr;
     void* st_out = nullptr;
@@ -433,7 +432,6 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
     p->host_sw = (getenv("P3D_FLEX_COL_NO_PERSIST") ? P3D_SW_FLEX_NO_PERSIST : 0) | (getenv("P3D_FLEX_NO_INPLACE") ? P3D_SW_FLEX_NO_INPLACE : 0);
     p->flex_over = getenv("P3D_FLEX_COL_OVER") ? atoi(getenv("P3D_FLEX_COL_OVER")) : 0;
     p->no_colpipe = getenv("P3D_NO_COLPIPE") != nullptr;
-    p->pair_one_launch = getenv("P3D_SHEARLET_PAIR_ONE_LAUNCH") != nullptr;
     if (generic) {
         p->gcol = gen_make_plan(nil);
         p->grow = gen_make_plan(nxl);
@@ -748,10 +746,7 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     hipError_t ce = hipErrorNotSupported;
     if (pair) {   // two columns per transform on Hermitian work slices: the other two passes ran / will run on half the rows, no way back
         if (!real_only || !shearlet_pair_supported(p)) return fail(P3D_ERR_INVALID, "the paired column pass does not apply to this plan");
-        hipError_t pe = hipErrorNotSupported;
-        if (!p->pair_one_launch && p->ops_col->col_shear_pair_pipe != nullptr) pe = p->ops_col->col_shear_pair_pipe(c, p->cus, p->stream);
-        if (pe == hipErrorNotSupported) pe = p->ops_col->col_shear_pair(c, p->stream);
-        HIP_TRY(pe);
+        HIP_TRY(p->ops_col->col_shear_pair(c, p->stream));
         return P3D_OK;
     }
     if (!p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);

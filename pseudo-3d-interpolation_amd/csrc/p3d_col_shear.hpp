@@ -176,163 +176,4 @@ hipError_t launch_col_shear_pair(const ColArgs& a, hipStream_t st)
     }
 }
 
-// ---- the same pass as a persistent kernel ------------------------------------------------------------------------------------------
-// One launch per tile pays, per tile, a workgroup launch, the copy of the tables and a full memory latency before the first butterfly
-// (12 us per tile and workgroup measured, of which ~5 are transforms).  Here the workgroups stay (two per CU at N = 2048), copy the
-// tables once, walk through contiguous runs of tiles and request the NEXT tile's rows before they transform the current one.  To keep
-// that request small a thread loads only rows k <= N/2 of its line (9 accesses of 16 bytes instead of 16 -- the mirrored rows of the
-// one-launch kernel are second loads of rows another thread holds) and the tile's (N/2 + 1) x 64 bytes go through LDS once, where
-// every thread picks up the rows N - k it has to conjugate.  Every access is a buffer instruction whose switched-off lanes are out
-// of range (no branch: the compiler's vmcnt counting stays exact and the wait for the prefetch does not wait for the stores behind
-// it).  Same arithmetic as col_shear_pair_kernel: bit-identical results (P3D_SHEARLET_PAIR_ONE_LAUNCH=1 selects that one).
-template <int N>
-__global__ __launch_bounds__(4 * Plan<N>::TPL, (4 * Plan<N>::TPL / 64) * col_shear_pair_wgs_per_cu<N>() / 4 > 0 ? (4 * Plan<N>::TPL / 64) * col_shear_pair_wgs_per_cu<N>() / 4 : 1)
-void col_shear_pair_pipe_kernel(const ColArgs a)
-{
-    using PL = Plan<N>;
-    constexpr int TPL = PL::TPL, PPT = PL::PPT, THREADS = 4 * TPL, HQ = PPT / 2;
-    static_assert(PPT == 16 && TPL >= 32, "columns of 512 points and more");
-    using LDS = LdsColW<4>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    c32* twl = reinterpret_cast<c32*>(smem_raw);
-    c32* data = twl + ColTablesHalf<N>::slots();
-    const TwColHalf tw{twl};
-    const int tid = threadIdx.x, j = tid & 3, tl = tid >> 2;
-    ColTablesHalf<N>::template load<THREADS>(twl, a.tw, tid);
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4* const rawimg = reinterpret_cast<f4*>(data);      // [row k <= N/2][pair j]: the tile as loaded (before the transforms use the image)
-    static_assert((size_t)(N / 2 + 1) * 4 * sizeof(f4) <= sizeof(c32) * (size_t)LdsColW<4>::stride(N), "the raw tile fits the line image");
-
-    const unsigned tiles = (unsigned)a.n2 / 8u, total = (unsigned)a.nslices * tiles;
-    const unsigned per = (total + gridDim.x - 1) / gridDim.x;
-    const unsigned g_begin = blockIdx.x * per, g_end = g_begin + per < total ? g_begin + per : total;
-    const size_t sstride = wk_slice_stride(N, a.n2);
-    const unsigned slice_bytes = (unsigned)(sstride * 8);
-    typedef const unsigned __attribute__((address_space(4))) * ksup_t;
-    typedef const unsigned long long __attribute__((address_space(4))) * ktau_t;
-    const ksup_t k_sup = (ksup_t)a.sh.sup;
-    const ktau_t k_tau = (ktau_t)a.sh.tau;
-    constexpr int G = TPL / 8, NG = N / 8, WORDS = (NG + 31) / 32;
-    const int c8 = (tl + 7) >> 3;
-
-    // per tile: bit q of `direct` = row tl + TPL q (q <= 8) is on; bit q of `mirror` (q >= 8) = row N - (tl + TPL q) is on (see
-    // col_shear_pair_kernel for the word arithmetic)
-    struct Rows { unsigned direct, mirror; };
-    auto rows_of = [&](unsigned slice) -> Rows {
-        const unsigned sh = slice % (unsigned)a.sh.nsh;
-        unsigned supw[WORDS];
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) supw[w] = k_sup ? k_sup[(size_t)sh * a.sh.sup_words + w] : 0xffffffffu;
-        Rows r{0u, 0u};
-#pragma unroll
-        for (int q = 0; q <= HQ; ++q) {
-            const unsigned bit = (supw[(G * q) >> 5] >> (((G * q) & 31) + (tl >> 3))) & 1u;
-            if (q < HQ || tl == 0) r.direct |= bit << q;                     // (q = 8: row N/2, thread tl = 0 only)
-        }
-#pragma unroll
-        for (int q = HQ; q < PPT; ++q) {
-            if (q == HQ && tl == 0) continue;                               // row N/2 is its own mirror image: direct
-            const int gz = NG - G * q > 0 ? NG - G * q : 0, gl = NG - G * (q + 1) > 0 ? NG - G * (q + 1) : 0;
-            const unsigned m0 = (supw[(gz >> 5) < WORDS ? (gz >> 5) : 0] >> (gz & 31)) & 1u;
-            const unsigned m1 = (supw[gl >> 5] >> ((NG - G * q - c8) & 31)) & 1u;
-            r.mirror |= (tl == 0 ? m0 : m1) << q;
-        }
-        return r;
-    };
-    // the rows k <= N/2 of this thread: q = 0 ... 7, and q = 8 for tl = 0
-    auto issue = [&](p3d_u4v (&dst)[HQ + 1], unsigned g, bool on) {
-        const unsigned slice = on ? g / tiles : 0u, tile = on ? g - slice * tiles : 0u;
-        const Rows r = rows_of(slice);
-        const __amdgpu_buffer_rsrc_t srd = buf_srd(reinterpret_cast<const char*>(a.in) + (size_t)slice * slice_bytes, slice_bytes);
-        const unsigned vo = ((tile * N + (unsigned)tl) * 8u + 2u * (unsigned)j) * 8u;
-#pragma unroll
-        for (int q = 0; q <= HQ; ++q) dst[q] = buf_load_raw128(srd, (on && ((r.direct >> q) & 1u)) ? vo : BUF_OOB, (unsigned)(TPL * q) * 64u);   // out of range: zeros, no access
-    };
-
-    __syncthreads();   // tables in place
-    p3d_u4v nx[HQ + 1];
-    issue(nx, g_begin, g_begin < g_end);
-    for (unsigned i = 0; i < per; ++i) {   // (the same trip count for every workgroup: the loop holds workgroup barriers)
-        const unsigned g = g_begin + i;
-        const bool on = g < g_end;
-        const unsigned slice = on ? g / tiles : 0u, tile = on ? g - slice * tiles : 0u;
-        const Rows rows = rows_of(slice);
-        // the tile as loaded -> LDS, so that every thread can pick up the rows it has to conjugate
-#pragma unroll
-        for (int q = 0; q <= HQ; ++q) {
-            if (q < HQ || tl == 0) {
-                const int k = tl + TPL * q;
-                rawimg[k * 4 + j] = f4{__uint_as_float(nx[q].x), __uint_as_float(nx[q].y), __uint_as_float(nx[q].z), __uint_as_float(nx[q].w)};
-            }
-        }
-        c32 v[PPT];
-#pragma unroll
-        for (int q = 0; q < HQ; ++q)
-            v[q] = add_ib(c32{__uint_as_float(nx[q].x), __uint_as_float(nx[q].y)}, c32{__uint_as_float(nx[q].z), __uint_as_float(nx[q].w)});   // Z = W_A + i W_B
-        const c32 v_mid = add_ib(c32{__uint_as_float(nx[HQ].x), __uint_as_float(nx[HQ].y)}, c32{__uint_as_float(nx[HQ].z), __uint_as_float(nx[HQ].w)});
-        __syncthreads();
-#pragma unroll
-        for (int q = HQ; q < PPT; ++q) {
-            const int k = tl + TPL * q;
-            f4 ab = rawimg[((N - k) & (N - 1)) * 4 + j];
-            const bool mir = !(q == HQ && tl == 0);
-            if (!((rows.mirror >> q) & 1u) && mir) ab = f4{0.f, 0.f, 0.f, 0.f};    // (a row that is off was loaded as zeros by its owner as well; kept explicit)
-            if (mir) { ab.y = -ab.y; ab.w = -ab.w; }                                  // row N - k holds the conjugates
-            v[q] = add_ib(c32{ab.x, ab.y}, c32{ab.z, ab.w});
-        }
-        if (tl == 0) v[HQ] = v_mid;
-        __syncthreads();   // the raw image is read: the transforms may have the LDS
-        const unsigned long long tau_bits = k_tau[((size_t)(slice / (unsigned)a.sh.nsh) * a.sh.niter + a.sh.iter) * a.sh.nsh + slice % (unsigned)a.sh.nsh];
-        __builtin_amdgcn_sched_barrier(0);
-        issue(nx, g + 1, g + 1 < g_end);   // in flight during the transforms of this tile
-        __builtin_amdgcn_sched_barrier(0);
-        int tl_r = tl;
-        asm volatile("" : "+v"(tl_r));   // (the transforms' LDS / twiddle addresses are recomputed per tile instead of living in registers across the loop)
-        const LDS lds_r{data + j};
-        line_fft<N, INV, false>(v, lds_r, tw, tl_r);
-        {
-            const Shrink shr(c32{__uint_as_float((unsigned)tau_bits), __uint_as_float((unsigned)(tau_bits >> 32))}, a.sh.op);
-            const float scale = 1.0f / ((float)N * (float)a.n2);
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                const c32 ca = shr(c32{v[q].x * scale, 0.f}), cb = shr(c32{v[q].y * scale, 0.f});
-                v[q] = c32{ca.x, cb.x};
-            }
-        }
-        line_fft<N, FWD, false>(v, lds_r, tw, tl_r);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) lds_r.at(tl_r + TPL * q) = v[q];
-        __syncthreads();
-        const __amdgpu_buffer_rsrc_t osrd = buf_srd(reinterpret_cast<char*>(a.out) + (size_t)slice * slice_bytes, slice_bytes);
-        const unsigned vo = ((tile * N + (unsigned)tl) * 8u + 2u * (unsigned)j) * 8u;
-#pragma unroll
-        for (int q = 0; q <= HQ; ++q) {
-            const int k = tl_r + TPL * q;
-            const c32 p = lds_r.at((N - k) & (N - 1));
-            const c32 z = v[q];
-            buf_store_2c32(osrd, (on && ((rows.direct >> q) & 1u)) ? vo : BUF_OOB, (unsigned)(TPL * q) * 64u, c32{0.5f * (z.x + p.x), 0.5f * (z.y - p.y)},
-                           c32{0.5f * (z.y + p.y), 0.5f * (p.x - z.x)});
-        }
-        __syncthreads();   // the LDS image is free for the next tile
-    }
-}
-
-template <int N>
-hipError_t launch_col_shear_pair_pipe(const ColArgs& a, int cus, hipStream_t st)
-{
-    if constexpr (Plan<N>::PPT == 16 && Plan<N>::TPL >= 32 && 4 * Plan<N>::TPL <= 1024) {
-        if (a.sh.tau == nullptr || !a.sh.real_only || !a.sh.half || a.in != a.out || a.in_std || a.out_std || a.n2 % 8 != 0 || cus < 1) return hipErrorNotSupported;
-        if ((double)wk_slice_stride(N, a.n2) * 8.0 >= 2147483648.0) return hipErrorNotSupported;
-        constexpr size_t lds = col_shear_pair_lds<N>();
-        hipError_t e = hipSuccess;
-        if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_shear_pair_pipe_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        const long total = (long)a.nslices * (a.n2 / 8), wgs = (long)cus * col_shear_pair_wgs_per_cu<N>();
-        col_shear_pair_pipe_kernel<N><<<(unsigned)(total < wgs ? total : wgs), 4 * Plan<N>::TPL, lds, st>>>(a);
-        return hipGetLastError();
-    } else {
-        return hipErrorNotSupported;
-    }
-}
-
 }  // namespace p3d

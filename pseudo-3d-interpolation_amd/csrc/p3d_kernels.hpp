@@ -332,7 +332,6 @@ struct LineOps {
     hipError_t (*row_pipe64)(int pm, const RowArgs&, int cus, hipStream_t);   // PIPE_FIRST / PIPE_MID / PIPE_LAST (hipErrorNotSupported where absent)
     hipError_t (*col_pipe)(const ColArgs&, int cus, hipStream_t);             // persistent COL_ITER (hipErrorNotSupported where absent)
     hipError_t (*col_shear_pair)(const ColArgs&, hipStream_t);                // SHEARLET column pass of float32 cubes, two columns per transform
-    hipError_t (*col_shear_pair_pipe)(const ColArgs&, int cus, hipStream_t);  // ... as a persistent kernel with the next tile prefetched
 };
 
 }  // namespace p3d

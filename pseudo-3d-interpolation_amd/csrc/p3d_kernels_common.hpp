@@ -243,11 +243,6 @@ __device__ __forceinline__ raw64 buf_load_raw64(__amdgpu_buffer_rsrc_t r, unsign
     const p3d_u2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
     return (raw64)t.x | ((raw64)t.y << 32);
 }
-typedef unsigned p3d_u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ p3d_u4v buf_load_raw128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-}
 __device__ __forceinline__ c32 raw_c32(raw64 u) { return c32{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))}; }
 __device__ __forceinline__ c32 buf_load_c32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return raw_c32(buf_load_raw64(r, voff, soff)); }
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
