@@ -570,6 +570,12 @@ __device__ __forceinline__ c32 load_x(const void* x, int dtype, size_t g, c32*)
     return dtype == 0 ? reinterpret_cast<const c32*>(x)[g] : c32{reinterpret_cast<const float*>(x)[g], 0.f};
 }
 __device__ __forceinline__ float load_x(const void* x, int, size_t g, float*) { return reinterpret_cast<const float*>(x)[g]; }
+// the same from a slice base with a 32-bit element offset
+__device__ __forceinline__ c32 load_xs(const void* xs, int dtype, unsigned g, c32*)
+{
+    return dtype == 0 ? reinterpret_cast<const c32*>(xs)[g] : c32{reinterpret_cast<const float*>(xs)[g], 0.f};
+}
+__device__ __forceinline__ float load_xs(const void* xs, int, unsigned g, float*) { return reinterpret_cast<const float*>(xs)[g]; }
 __device__ __forceinline__ void store_out(void* out, int dtype, size_t g, c32 v)
 {
     if (dtype == 0) reinterpret_cast<c32*>(out)[g] = v;
@@ -839,6 +845,9 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     constexpr int IHc = 2 * TILE + (LT ? LT : 2) - 2, KHc = TILE + (LT ? LT : 2) - 2;
     constexpr int NE = LT ? (KHc * KHc + 255) / 256 : 1, NIT = LT ? (IHc * (IHc / 2) + 255) / 256 : 1;
     const size_t per = (size_t)u.n1 * u.n2;
+    const T* const pd1 = pd + cnt;
+    const T* const pd2 = pd + 2 * cnt;
+    const void* const xs = reinterpret_cast<const char*>(u.x) + (size_t)s * per * (u.dtype == 0 ? sizeof(c32) : sizeof(float));   // this slice's observed samples
     T xo[NIT][2];
     float mk[NIT][2];
     if constexpr (LT != 0) {
@@ -848,11 +857,12 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
             const int e = tid + 256 * i, kr = e / KHc, kc = e - kr * KHc, gr = kr0 + kr, gc = kc0 + kc;
             va[i] = vh_[i] = vv[i] = vd[i] = zero_of<T>();
             if (e < KHc * KHc && kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
-                const size_t o = (size_t)gr * Wo + gc;
-                va[i] = pa[(size_t)gr * a_ld + gc];
+                // (32-bit element offsets from wave-uniform bases: one level of one slice is far below 2^32 samples)
+                const unsigned o = (unsigned)gr * (unsigned)Wo + (unsigned)gc;
+                va[i] = pa[(unsigned)gr * (unsigned)a_ld + (unsigned)gc];
                 vh_[i] = pd[o];
-                vv[i] = pd[cnt + o];
-                vd[i] = pd[2 * cnt + o];
+                vv[i] = pd1[o];
+                vd[i] = pd2[o];
             }
         }
 #pragma unroll
@@ -864,8 +874,8 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
                 mk[it][ee] = 0.f;
                 const int gm = m_lo + m, gn = n_lo + 2 * ii + ee;
                 if (e < IHc * (IHc / 2) && m < nm && gn <= n_hi) {
-                    const size_t li = (size_t)gm * u.n2 + gn;
-                    xo[it][ee] = load_x(u.x, u.dtype, (size_t)s * per + li, (T*)nullptr);
+                    const unsigned li = (unsigned)gm * (unsigned)u.n2 + (unsigned)gn;
+                    xo[it][ee] = load_xs(xs, u.dtype, li, (T*)nullptr);
                     mk[it][ee] = u.mask[li];
                 }
             }
@@ -927,16 +937,15 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
                 eo.tap(g.y, g.w, qh[t]);
             }
             const int gm = m_lo + m;
+            const bool mine_m = (unsigned)(gm - core_m0) < (unsigned)(2 * TILE);
 #pragma unroll
             for (int ee = 0; ee < 2; ++ee) {
                 const int gn = n_lo + 2 * ii + ee;
                 if (gn > n_hi) continue;
-                const size_t g = (size_t)s * per + (size_t)gm * u.n2 + gn;
                 const float wgt = 1.0f - u.alpha * mk2[ee];
                 const T xn = cmulf(ee ? eo.second() : eo.first(), wgt) + cmulf(xo2[ee], u.alpha);
-                const bool mine = gm >= core_m0 && gm < core_m0 + 2 * TILE && gn >= core_n0 && gn < core_n0 + 2 * TILE;
-                if (mine) {
-                    if (u.write_out) store_out(u.out, u.dtype, g, xn);
+                if (mine_m && (unsigned)(gn - core_n0) < (unsigned)(2 * TILE)) {   // the tile's own core: cost sum, `out`
+                    if (u.write_out) store_out(u.out, u.dtype, (size_t)s * per + (size_t)gm * u.n2 + gn, xn);
                     acc += (double)mag(xn);
                 }
                 T fd = xn;
