@@ -25,8 +25,8 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     using LDS = LdsColW<CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
-    c32* data = twl + ColLds<N>::slots();
-    const typename ColTwSel<N>::type tw{twl};
+    c32* data = twl + ColTables<N>::slots();
+    const TwCol tw{twl};
 
     const int tid = threadIdx.x;
     const int c_lo = tid % CW;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 
     if (a.done && a.done[slice] != 0) return;
 
-    ColLds<N>::template load<THREADS>(twl, a.tw, tid);
+    for (int i = tid; i < ColTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
 
     const LDS lds{data + cbl * LDS::stride(N) + c_lo};

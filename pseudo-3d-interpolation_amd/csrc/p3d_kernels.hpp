@@ -43,7 +43,7 @@ namespace p3d {
 template <int N>
 constexpr int col_tile()
 {
-    return N >= 4096 ? 4 : (N >= 1024 ? 8 : (N == 512 ? 16 : (N == 256 ? 32 : 64)));  // N = 2048: 4-column tiles (2 WG/CU) measured slower (3.4 vs 2.6 ms); N = 4096: four columns with the half table (ColLds)
+    return N >= 4096 ? 2 : (N >= 1024 ? 8 : (N == 512 ? 16 : (N == 256 ? 32 : 64)));  // N = 2048: 4-column tiles (2 WG/CU) measured slower (3.4 vs 2.6 ms)
 }
 
 template <int N>
@@ -61,7 +61,7 @@ constexpr size_t col_lds_bytes()
 {
     constexpr int T = col_tile<N>();
     constexpr int CW = T < 8 ? T : 8;
-    return sizeof(c32) * (ColLds<N>::slots() + (size_t)(T / CW) * LdsColW<CW>::stride(N));
+    return sizeof(c32) * (ColTables<N>::slots() + (size_t)(T / CW) * LdsColW<CW>::stride(N));
 }
 
 template <class K>

@@ -265,56 +265,4 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{(unsigned)u, (unsigned)(u >> 32)}, r, (int)voff, (int)soff, 0);
 }
 
-// Column-pass tables with HALF the plain table: exp(-2 pi i k / N) for k < N/2 (the other half is its negative), then the ordered
-// rows of the middle pass as in ColTables.  7 KiB less at N = 2048 -- what lets two 4-line workgroups fit a CU's 160 KiB.
-template <int N>
-struct ColTablesHalf {
-    using PL = Plan<N>;
-    static constexpr int master() { return N / 2; }
-    static constexpr int mid_off(int dir) { return master() + (dir == FWD ? 0 : ColTables<N>::mid_len(FWD)); }
-    static constexpr int slots() { return master() + ColTables<N>::mid_len(FWD) + ColTables<N>::mid_len(INV); }
-    // copy from the plan's full ColTables image (device) into LDS
-    template <int THREADS>
-    static __device__ __forceinline__ void load(c32* lds, const c32* full, int tid)
-    {
-        for (int i = tid; i < master(); i += THREADS) lds[i] = full[i];
-        constexpr int NM = ColTables<N>::mid_len(FWD) + ColTables<N>::mid_len(INV);
-        for (int i = tid; i < NM; i += THREADS) lds[master() + i] = full[ColTables<N>::master() + i];
-    }
-};
-struct TwColHalf {
-    const c32* tw;
-    template <int N, int DIR, int P, int T>
-    __device__ __forceinline__ c32 mul(c32 a, int jm) const
-    {
-        using PL = Plan<N>;
-        if constexpr (P + 1 == PL::NPASS) {
-            const int k = T * jm;
-            c32 w = tw[k & (N / 2 - 1)];
-            if (k & (N / 2)) { w.x = -w.x; w.y = -w.y; }
-            return DIR > 0 ? mul_conj(a, w) : a * w;
-        } else {
-            return a * (tw + (ColTablesHalf<N>::mid_off(DIR) + (T - 1) * PL::ns(DIR, P)))[jm];
-        }
-    }
-};
-
-
-// Which image of the column tables a length's one-launch column pass keeps in LDS.  4096-point columns: the half table frees the
-// 14 KiB that let a FOUR-column tile (32-byte pieces per row, 1024 threads = 16 waves per CU) fit a CU's 160 KiB; with the full table
-// only two columns fit (16-byte pieces, 8 waves per CU: 2.2 ms per 2^29 points against 0.97 for 1024-point columns).
-template <int N>
-struct ColLds {
-    static constexpr bool HALF = N >= 4096;
-    static constexpr int slots() { return HALF ? ColTablesHalf<N>::slots() : ColTables<N>::slots(); }
-    template <int THREADS>
-    static __device__ __forceinline__ void load(c32* lds, const c32* full, int tid)
-    {
-        if constexpr (HALF) ColTablesHalf<N>::template load<THREADS>(lds, full, tid);
-        else for (int i = tid; i < ColTables<N>::slots(); i += THREADS) lds[i] = full[i];
-    }
-};
-template <int N> struct ColTwSel { using type = TwCol; };
-template <> struct ColTwSel<4096> { using type = TwColHalf; };
-
 }  // namespace p3d
