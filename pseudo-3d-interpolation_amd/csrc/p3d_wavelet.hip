@@ -843,11 +843,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     //      and mask weights of the region: all requests of a thread are in flight together (a load per loop trip would pay the
     //      memory latency once per trip -- ten trips per tile) ----
     constexpr int IHc = 2 * TILE + (LT ? LT : 2) - 2, KHc = TILE + (LT ? LT : 2) - 2;
-    // sliding windows of the two synthesis passes (compile-time filter length): a thread of the axis-0 pass owns RP row pairs of one
-    // column, a thread of the axis-1 pass CP column pairs of one row -- every coefficient is read from LDS once per thread instead of
-    // once per output, and the index arithmetic is paid per thread, not per output (it was two thirds of the vector instructions)
-    constexpr int RP = 6, NG0 = (IHc / 2 + RP - 1) / RP, CP = 5, NG1 = (IHc / 2 + CP - 1) / CP, NT1 = LT ? (IHc * NG1 + 255) / 256 : 1;
-    constexpr int NE = LT ? (KHc * KHc + 255) / 256 : 1, NIT = LT ? NT1 * CP : 1;
+    constexpr int NE = LT ? (KHc * KHc + 255) / 256 : 1, NIT = LT ? (IHc * (IHc / 2) + 255) / 256 : 1;
     const size_t per = (size_t)u.n1 * u.n2;
     const T* const pd1 = pd + cnt;
     const T* const pd2 = pd + 2 * cnt;
@@ -870,20 +866,17 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
             }
         }
 #pragma unroll
-        for (int tr = 0; tr < NT1; ++tr) {
-            const int item = tid + 256 * tr, m = item / NG1, cg = item - m * NG1;
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 256 * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
 #pragma unroll
-            for (int q = 0; q < CP; ++q) {
-#pragma unroll
-                for (int ee = 0; ee < 2; ++ee) {
-                    xo[tr * CP + q][ee] = zero_of<T>();
-                    mk[tr * CP + q][ee] = 0.f;
-                    const int gm = m_lo + m, gn = n_lo + 2 * (cg * CP + q) + ee;
-                    if (item < IHc * NG1 && m < nm && gn <= n_hi) {
-                        const unsigned li = (unsigned)gm * (unsigned)u.n2 + (unsigned)gn;
-                        xo[tr * CP + q][ee] = load_xs(xs, u.dtype, li, (T*)nullptr);
-                        mk[tr * CP + q][ee] = u.mask[li];
-                    }
+            for (int ee = 0; ee < 2; ++ee) {
+                xo[it][ee] = zero_of<T>();
+                mk[it][ee] = 0.f;
+                const int gm = m_lo + m, gn = n_lo + 2 * ii + ee;
+                if (e < IHc * (IHc / 2) && m < nm && gn <= n_hi) {
+                    const unsigned li = (unsigned)gm * (unsigned)u.n2 + (unsigned)gn;
+                    xo[it][ee] = load_xs(xs, u.dtype, li, (T*)nullptr);
+                    mk[it][ee] = u.mask[li];
                 }
             }
         }
@@ -910,61 +903,22 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     }
     __syncthreads();
     // ---- undo axis 0: rows m_lo + 2 ip, + 1 from coefficient rows ip ... ip + L/2 - 1 (local) ----
-    if constexpr (LT != 0) {
-        constexpr int HLc = LT / 2;
-        float4 g[HLc];
-#pragma unroll
-        for (int t = 0; t < HLc; ++t) g[t] = s_rec[t];
-        for (int item = tid; item < NG0 * KHc; item += 256) {
-            const int grp = item / KHc, kc = item - grp * KHc;
-            if (kc >= KWv || 2 * grp * RP >= nm) continue;
-            Acc<T> lo[RP], hi[RP];
-#pragma unroll
-            for (int r = 0; r < RP + HLc - 1; ++r) {
-                const int row = grp * RP + r;
-                if (row >= KHc) break;
-                const int i = row * KW + kc;
-                const T va = s_a[i], vh_ = s_h[i], vv = s_v[i], vd = s_d[i];
-#pragma unroll
-                for (int q = 0; q < RP; ++q) {      // pair q takes this row as its tap t = r - q (taps of a pair in rising t, a before h: as the tile kernel)
-                    const int t = r - q;
-                    if (t >= 0 && t < HLc) {
-                        lo[q].tap(g[t].x, g[t].z, va);
-                        lo[q].tap(g[t].y, g[t].w, vh_);
-                        hi[q].tap(g[t].x, g[t].z, vv);
-                        hi[q].tap(g[t].y, g[t].w, vd);
-                    }
-                }
+    for (int e = tid; e < (IH / 2) * KW; e += 256) {
+        const int ip = e / KW, kc = e - ip * KW;
+        if (2 * ip < nm && kc < KWv) {
+            Acc<T> lo, hi;
+            for (int t = 0; t < HL; ++t) {
+                const float4 g = s_rec[t];
+                const int i = (ip + t) * KW + kc;
+                lo.tap(g.x, g.z, s_a[i]);
+                lo.tap(g.y, g.w, s_h[i]);
+                hi.tap(g.x, g.z, s_v[i]);
+                hi.tap(g.y, g.w, s_d[i]);
             }
-#pragma unroll
-            for (int q = 0; q < RP; ++q) {
-                const int ip = grp * RP + q;
-                if (2 * ip < nm) {
-                    s_lo[(2 * ip) * KW + kc] = lo[q].first();
-                    s_lo[(2 * ip + 1) * KW + kc] = lo[q].second();
-                    s_hi[(2 * ip) * KW + kc] = hi[q].first();
-                    s_hi[(2 * ip + 1) * KW + kc] = hi[q].second();
-                }
-            }
-        }
-    } else {
-        for (int e = tid; e < (IH / 2) * KW; e += 256) {
-            const int ip = e / KW, kc = e - ip * KW;
-            if (2 * ip < nm && kc < KWv) {
-                Acc<T> lo, hi;
-                for (int t = 0; t < HL; ++t) {
-                    const float4 g = s_rec[t];
-                    const int i = (ip + t) * KW + kc;
-                    lo.tap(g.x, g.z, s_a[i]);
-                    lo.tap(g.y, g.w, s_h[i]);
-                    hi.tap(g.x, g.z, s_v[i]);
-                    hi.tap(g.y, g.w, s_d[i]);
-                }
-                s_lo[(2 * ip) * KW + kc] = lo.first();
-                s_lo[(2 * ip + 1) * KW + kc] = lo.second();
-                s_hi[(2 * ip) * KW + kc] = hi.first();
-                s_hi[(2 * ip + 1) * KW + kc] = hi.second();
-            }
+            s_lo[(2 * ip) * KW + kc] = lo.first();
+            s_lo[(2 * ip + 1) * KW + kc] = lo.second();
+            s_hi[(2 * ip) * KW + kc] = hi.first();
+            s_hi[(2 * ip + 1) * KW + kc] = hi.second();
         }
     }
     __syncthreads();
@@ -973,7 +927,15 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     {
         T* feed_img = s_in + (m_lo - r0) * IW + (n_lo - c0);
         const int core_m0 = 2 * or0, core_n0 = 2 * oc0;   // the tile OWNS rows core_m0 ... + 2 TILE - 1 (cost sum, `out`)
-        auto sample = [&](int m, int ii, const T (&xo2)[2], const float (&mk2)[2], const Acc<T>& eo) {
+        auto sample = [&](int m, int ii, const T (&xo2)[2], const float (&mk2)[2]) {
+            const T* ql = s_lo + m * KW + ii;
+            const T* qh = s_hi + m * KW + ii;
+            Acc<T> eo;
+            for (int t = 0; t < HL; ++t) {
+                const float4 g = s_rec[t];
+                eo.tap(g.x, g.z, ql[t]);
+                eo.tap(g.y, g.w, qh[t]);
+            }
             const int gm = m_lo + m;
             const bool mine_m = (unsigned)(gm - core_m0) < (unsigned)(2 * TILE);
 #pragma unroll
@@ -991,45 +953,11 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
                 feed_img[m * IW + 2 * ii + ee] = fd;
             }
         };
-        auto filter1 = [&](int m, int ii) -> Acc<T> {     // outputs 2 ii, 2 ii + 1 of row m from the coefficients ii ... ii + L/2 - 1
-            const T* ql = s_lo + m * KW + ii;
-            const T* qh = s_hi + m * KW + ii;
-            Acc<T> eo;
-            for (int t = 0; t < HL; ++t) {
-                const float4 g = s_rec[t];
-                eo.tap(g.x, g.z, ql[t]);
-                eo.tap(g.y, g.w, qh[t]);
-            }
-            return eo;
-        };
         if constexpr (LT != 0) {
-            constexpr int HLc = LT / 2;
-            float4 g[HLc];
 #pragma unroll
-            for (int t = 0; t < HLc; ++t) g[t] = s_rec[t];
-#pragma unroll
-            for (int tr = 0; tr < NT1; ++tr) {
-                const int item = tid + 256 * tr, m = item / NG1, cg = item - m * NG1;
-                if (item >= IHc * NG1 || m >= nm || 2 * cg * CP >= nn) continue;
-                Acc<T> eo[CP];
-                const T* ql = s_lo + m * KW + cg * CP;
-                const T* qh = s_hi + m * KW + cg * CP;
-#pragma unroll
-                for (int c = 0; c < CP + HLc - 1; ++c) {
-                    if (cg * CP + c >= KHc) break;
-                    const T vl = ql[c], vh_ = qh[c];
-#pragma unroll
-                    for (int q = 0; q < CP; ++q) {
-                        const int t = c - q;
-                        if (t >= 0 && t < HLc) {
-                            eo[q].tap(g[t].x, g[t].z, vl);
-                            eo[q].tap(g[t].y, g[t].w, vh_);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < CP; ++q)
-                    if (2 * (cg * CP + q) < nn) sample(m, cg * CP + q, xo[tr * CP + q], mk[tr * CP + q], eo[q]);
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + 256 * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+                if (e < IHc * (IHc / 2) && m < nm && 2 * ii < nn) sample(m, ii, xo[it], mk[it]);
             }
         } else {
             for (int e = tid; e < IH * (IW / 2); e += 256) {
@@ -1048,7 +976,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
                         m2[ee] = u.mask[li];
                     }
                 }
-                sample(m, ii, x2, m2, filter1(m, ii));
+                sample(m, ii, x2, m2);
             }
         }
     }
