@@ -1311,7 +1311,6 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
     ALLOC(p->mask, sizeof(float) * p->per());
     ALLOC(p->st_x, sizeof(c32) * p->per() * S);
     ALLOC(p->st_out, sizeof(c32) * p->per() * S);
-#define ALLOC2(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(#ptr, e)
     p->tile_c = pick_tile(flen, sizeof(c32));
     p->tile_r = pick_tile(flen, sizeof(float));
     const char* env = getenv("P3D_WAVELET_UNFUSED");
@@ -1333,13 +1332,14 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
         p->l1fuse_c = geom && p->tile_c == 32 && wfuse1_lds_elems<32>(flen) * sizeof(c32) <= 150 * 1024;
         p->l1fuse_r = geom && p->tile_r == 32 && wfuse1_lds_elems<32>(flen) * sizeof(float) <= 150 * 1024;
         if (p->l1fuse_c || p->l1fuse_r) {
-            ALLOC2(p->det1_alt, sizeof(c32) * 3 * (size_t)p->h[1] * p->w[1] * S);
+            ALLOC(p->det1_alt, sizeof(c32) * 3 * (size_t)p->h[1] * p->w[1] * S);
             const void* fk[] = {(const void*)wfuse1_kernel<c32, 32, 0>, (const void*)wfuse1_kernel<c32, 32, 4>, (const void*)wfuse1_kernel<c32, 32, 8>,
                                 (const void*)wfuse1_kernel<float, 32, 0>, (const void*)wfuse1_kernel<float, 32, 4>, (const void*)wfuse1_kernel<float, 32, 8>};
             for (const void* k : fk)
                 if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) return bail("hipFuncSetAttribute", e);
         }
     }
+#undef ALLOC
     if (p->fused) {
         const int big = 150 * 1024;
 #define P3D_W_KERNELS(LT) (const void*)dwt2_tile_kernel<c32, 32, LT>, (const void*)dwt2_tile_kernel<c32, 16, LT>, (const void*)dwt2_tile_kernel<float, 32, LT>, \
