@@ -504,7 +504,8 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
     TRY_OR_BAIL(hipMalloc((void**)&p->rowsum, sizeof(double) * (size_t)nil * max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->sum0, sizeof(double) * (size_t)max_slices));
     TRY_OR_BAIL(hipMalloc((void**)&p->done, sizeof(int) * max_slices));
-    TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)p->tiles * max_slices));
+    // (the paired shearlet statistics pass writes one record per 8 columns whatever the column tile of the length)
+    TRY_OR_BAIL(hipMalloc((void**)&p->partials, sizeof(float) * STATS_PARTIAL * (size_t)std::max(p->tiles, (nxl + 7) / 8) * max_slices));
 #undef TRY_OR_BAIL
     *out = p;
     return P3D_OK;
@@ -752,6 +753,34 @@ int shearlet_col_shrink(p3d_plan* p, const c32* tau, int nb, int nsh, int niter,
     if (!p->no_colpipe && p->cus > 0 && p->ops_col->col_pipe != nullptr && p->ops_col->n >= 2048) ce = p->ops_col->col_pipe(c, p->cus, p->stream);
     if (ce == hipErrorNotSupported) ce = p->ops_col->col(COL_SHRINK, c, p->stream);
     HIP_TRY(ce);
+    return P3D_OK;
+}
+
+int shearlet_col_stats_pair(p3d_plan* p, int nb, int nsh, const unsigned* sup, int sup_words, float* host_stats)
+{
+    int rc = check_batch(p, nb * nsh);
+    if (rc) return rc;
+    if (!shearlet_pair_supported(p) || !host_stats) return fail(P3D_ERR_INVALID, "the paired column pass does not apply to this plan");
+    ColArgs c = col_args(p, nb * nsh);
+    c.in = p->work;
+    c.out = p->work;
+    c.partials = p->partials;
+    c.sh = shear_args(nullptr, nullptr, nsh, 0, 0, 0, 1, sup, sup_words, true);
+    HIP_TRY(p->ops_col->col_shear_pair(c, p->stream));
+    const int tiles = p->nxl / 8;
+    std::vector<float> part((size_t)STATS_PARTIAL * tiles * nb * nsh);
+    HIP_TRY(hipMemcpyAsync(part.data(), p->partials, sizeof(float) * part.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int bs = 0; bs < nb * nsh; ++bs) {
+        float smax = -INFINITY, mx = 0.f, mn = INFINITY;
+        double sq = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            const float* q = &part[((size_t)bs * tiles + t) * STATS_PARTIAL];
+            smax = std::max(smax, q[0]); mx = std::max(mx, q[2]); mn = std::min(mn, q[3]); sq += q[4];
+        }
+        float* o = host_stats + (size_t)bs * 5;
+        o[0] = smax; o[1] = 0.f; o[2] = std::sqrt(mx); o[3] = std::sqrt(mn); o[4] = (float)sq;
+    }
     return P3D_OK;
 }
 

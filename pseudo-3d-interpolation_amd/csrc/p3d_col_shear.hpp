@@ -62,7 +62,9 @@ constexpr int col_shear_pair_wgs_per_cu()
 }
 
 // grid: (tiles of 8 columns, nb * nsh work slices); 4 * TPL threads
-template <int N>
+// STATS: the statistics pass of a job instead (p3d_shearlet_stats): inverse transform only, then signed maximum, max c^2, min c^2 and
+// sum c^2 of the tile's 8 x N real coefficients -> a.partials[(work slice, tile)][STATS_PARTIAL]
+template <int N, bool STATS = false>
 __global__ __launch_bounds__(4 * Plan<N>::TPL, (4 * Plan<N>::TPL / 64) * col_shear_pair_wgs_per_cu<N>() / 4 > 0 ? (4 * Plan<N>::TPL / 64) * col_shear_pair_wgs_per_cu<N>() / 4 : 1)
 void col_shear_pair_kernel(const ColArgs a)
 {
@@ -104,7 +106,8 @@ void col_shear_pair_kernel(const ColArgs a)
         }
         rows_on |= bit << q;
     }
-    const c32 tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
+    c32 tau{0.f, 0.f};
+    if constexpr (!STATS) tau = a.sh.tau[((size_t)b * a.sh.niter + a.sh.iter) * a.sh.nsh + s];
 
     const LDS lds{data + j};
     c32* const base = a.out + (size_t)slice * wk_slice_stride(N, a.n2);   // in place (a.in == a.out)
@@ -130,6 +133,43 @@ void col_shear_pair_kernel(const ColArgs a)
         v[q] = add_ib(c32{ab.x, ab.y}, c32{ab.z, ab.w});             // Z = W_A + i W_B
     }
     line_fft<N, INV, false>(v, lds, tw, tl);
+    if constexpr (STATS) {
+        const float scale = 1.0f / ((float)N * (float)a.n2);
+        float smax = -INFINITY, mx = 0.f, mn = INFINITY;
+        double sq = 0.0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const float ca = v[q].x * scale, cb = v[q].y * scale;     // the two columns' real coefficients
+            smax = fmaxf(smax, fmaxf(ca, cb));
+            const float pa = ca * ca, pb = cb * cb;
+            mx = fmaxf(mx, fmaxf(pa, pb));
+            mn = fminf(mn, fminf(pa, pb));
+            sq += (double)(pa + pb);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            smax = fmaxf(smax, __shfl_down(smax, o, 64));
+            mx = fmaxf(mx, __shfl_down(mx, o, 64));
+            mn = fminf(mn, __shfl_down(mn, o, 64));
+            sq += __shfl_down(sq, o, 64);
+        }
+        __syncthreads();   // the line image is free: partial results of the wavefronts go through it
+        double* red = reinterpret_cast<double*>(data);
+        constexpr int NW = THREADS / 64;
+        if ((tid & 63) == 0) { red[(tid >> 6) * 4 + 0] = smax; red[(tid >> 6) * 4 + 1] = mx; red[(tid >> 6) * 4 + 2] = mn; red[(tid >> 6) * 4 + 3] = sq; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) {
+                smax = fmaxf(smax, (float)red[w * 4]);
+                mx = fmaxf(mx, (float)red[w * 4 + 1]);
+                mn = fminf(mn, (float)red[w * 4 + 2]);
+                sq += red[w * 4 + 3];
+            }
+            float* p = a.partials + ((size_t)slice * gridDim.x + tile) * STATS_PARTIAL;
+            p[0] = smax; p[1] = 0.f; p[2] = mx; p[3] = mn; p[4] = (float)sq;
+        }
+        return;
+    }
     {
         const Shrink shr(tau, a.sh.op);
         const float scale = 1.0f / ((float)N * (float)a.n2);
@@ -163,13 +203,19 @@ template <int N>
 hipError_t launch_col_shear_pair(const ColArgs& a, hipStream_t st)
 {
     if constexpr (Plan<N>::PPT == 16 && Plan<N>::TPL >= 32 && 4 * Plan<N>::TPL <= 1024) {
-        if (a.sh.tau == nullptr || !a.sh.real_only || a.in != a.out || a.in_std || a.out_std || a.n2 % 8 != 0) return hipErrorNotSupported;
+        const bool stats = a.partials != nullptr;     // the statistics pass of a job (no thresholds yet)
+        if ((!stats && a.sh.tau == nullptr) || !a.sh.real_only || a.in != a.out || a.in_std || a.out_std || a.n2 % 8 != 0) return hipErrorNotSupported;
         if ((double)wk_slice_stride(N, a.n2) >= 4294967296.0 / 8.0) return hipErrorNotSupported;
         constexpr size_t lds = col_shear_pair_lds<N>();
         hipError_t e = hipSuccess;
-        if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_shear_pair_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         const dim3 grid(a.n2 / 8, a.nslices);
-        col_shear_pair_kernel<N><<<grid, 4 * Plan<N>::TPL, lds, st>>>(a);
+        if (stats) {
+            if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_shear_pair_kernel<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+            col_shear_pair_kernel<N, true><<<grid, 4 * Plan<N>::TPL, lds, st>>>(a);
+        } else {
+            if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_shear_pair_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+            col_shear_pair_kernel<N, false><<<grid, 4 * Plan<N>::TPL, lds, st>>>(a);
+        }
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

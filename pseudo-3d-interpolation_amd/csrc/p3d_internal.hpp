@@ -50,6 +50,9 @@ int shearlet_gather_fwd(p3d_plan* plan, const float* psi, c32* out, int nb, int 
 // along the rows -- only rows 0 ... nil/2 are computed, stored and read, the column pass sends two columns through one transform;
 // the rows nil/2 + 1 ... of the gather pass's output are then NOT written (the caller mirrors them)
 bool shearlet_pair_supported(p3d_plan* plan);
+// statistics of the coefficients for the schedule through the paired pass (float32 cubes, after shearlet_spread_inv(..., pair = true)):
+// host_stats [nb * nsh][5] = signed maximum, 0, max |c|, min |c|, sum c^2 per (slice, shearlet); synchronises the plan's stream
+int shearlet_col_stats_pair(p3d_plan* plan, int nb, int nsh, const unsigned* sup, int sup_words, float* host_stats);
 // sup: device bitmap [nsh][sup_words] of the 8-row groups on which a shearlet's spectrum does not vanish (ShearArgs::sup); the three
 // passes of one iteration must be given the SAME table (a group one pass skips is never stored for the next to read)
 

@@ -45,6 +45,36 @@ def test_transform_and_inverse(ffi, so, shape):
         assert np.allclose(stats[1, :, 4], (ref ** 2).sum(axis=(0, 1)), rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(512, 512), (1024, 512)])
+def test_statistics_of_a_float32_cube_through_the_paired_passes(ffi, so, shape, monkeypatch):
+    """float32 cubes on symmetric spectra take their coefficient statistics (the schedule's input) from the passes of the loop --
+    support rows, Hermitian half, two columns per transform -- instead of nsh dense transforms; both routes agree with each other and
+    with the float64 oracle to float32 rounding."""
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    from oracle import pocs_oracle as po
+    psi = shearlets.scalesShearsAndSpectra(shape, dtype=np.float32)
+    x = np.stack([po.synthetic_slice(*shape, 70 + s, real=True) for s in range(3)]).astype(np.float32)
+    with ffi.ShearletPlan(psi, max_slices=3) as plan:
+        assert plan.paired
+        fast = plan.stats(x)
+    monkeypatch.setenv("P3D_SHEARLET_NO_PAIR", "1")
+    with ffi.ShearletPlan(psi, max_slices=3) as plan:
+        assert not plan.paired
+        dense = plan.stats(x)
+    monkeypatch.delenv("P3D_SHEARLET_NO_PAIR")
+    ref = so.shearlet_transform(x[2].astype(np.float64), so.scales_shears_and_spectra(shape, contiguous=False))
+    top = np.abs(ref).max()
+    for st in (fast, dense):
+        assert np.allclose(st[2, :, 0], ref.max(axis=(0, 1)), rtol=2e-5, atol=1e-6 * top)
+        assert np.all(st[:, :, 1] == 0)
+        assert np.allclose(st[2, :, 2], np.abs(ref).max(axis=(0, 1)), rtol=2e-5, atol=1e-6 * top)
+        assert np.allclose(st[2, :, 4], (ref ** 2).sum(axis=(0, 1)), rtol=1e-4)
+    assert np.allclose(fast[..., 0], dense[..., 0], rtol=1e-5, atol=1e-6 * top)
+    assert np.allclose(fast[..., 2], dense[..., 2], rtol=1e-5, atol=1e-6 * top)
+    assert np.allclose(fast[..., 3], dense[..., 3], rtol=1e-2, atol=1e-6 * top)     # min |c|: a sample next to a zero crossing
+    assert np.allclose(fast[..., 4], dense[..., 4], rtol=1e-5, atol=1e-4 * dense[..., 4].max())     # (energies span 4 decades: float32 noise of the strong ones)
+
+
 def _case(so, shape, seed, complex_=False, missing=0.5, nslices=2, **kw):
     import pseudo_3d_interpolation_amd.functions.POCS as P
     from oracle import pocs_oracle as po
