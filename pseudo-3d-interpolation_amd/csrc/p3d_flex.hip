@@ -27,6 +27,7 @@
 #include <utility>
 #include <vector>
 
+#include "p3d_chirp.hpp"
 #include "p3d_flex.hpp"
 #include "p3d_kernels.hpp"
 
@@ -60,7 +61,6 @@ int largest_prime_factor(int n)
 
 constexpr int FLEX_REGISTER_PRIME_MAX = 13;   // prime factors up to here: in-register butterflies
 constexpr int FLEX_DIRECT_PRIME_MAX = 23;     // larger prime factors: chirp-z on a power of two instead of an O(p^2) pass
-constexpr int FLEX_BLUE_MAX_M = 4096;       // two LDS copies of a padded line: 2 * M * 8 B
 
 // Radices of the passes.  Every pass is one trip through LDS and one barrier, so two prime factors are folded into one
 // in-register butterfly wherever a supported product exists (16 = 4x4 ... 6 = 2x3); 11 and 13 are in-register butterflies of
@@ -75,14 +75,13 @@ FlexFactors flex_factors(int n)
     if (gen_make_plan(n).nf <= 0) { p.nf = -1; return p; }
     const int lp = largest_prime_factor(n);
     if (lp > FLEX_REGISTER_PRIME_MAX) {
-        int M = 2 * n - 1;   // the convolution length: the next 5-smooth number (radices 16 ... 2 cover it in three or four passes) ...
-        while (largest_prime_factor(M) > 5) ++M;
-        int P2 = 1;          // ... unless the next power of two is nearly as short: its radix-16 passes are the cheapest
-        while (P2 < 2 * n - 1) P2 *= 2;
-        if (4 * P2 <= 5 * M) M = P2;
-        // measured: up to M ~ 2048 (n <= 1024) the chirp-z form beats direct 17- ... 23-point passes; longer padded lines leave one
-        // or two columns per workgroup and only pay for primes that would otherwise cost an O(p^2) pass of real weight
-        if (M <= 2048 || (lp > FLEX_DIRECT_PRIME_MAX && M <= FLEX_BLUE_MAX_M)) { p.blue = 1; p.m = M; }
+        // the convolution length of the chirp-z form: the power of two >= 2n - 1, on which the register-resident engine runs
+        // (p3d_chirp.hip).  Columns beyond 1024 points leave two columns per workgroup there: primes 17 ... 23 stay direct O(p^2)
+        // passes for those.
+        int M = 1;
+        while (M < 2 * n - 1) M *= 2;
+        if (M < 64) M = 64;
+        if (chirp_supported(M) && (M <= 2048 || lp > FLEX_DIRECT_PRIME_MAX)) { p.blue = 1; p.m = M; }
     }
     int rem = p.m, k = 0;
     int radices[32];
@@ -114,6 +113,8 @@ size_t row_lds(int n, int LB) { const size_t L = flex_factors(n).m; return sizeo
 
 int pick_col_tile(int n)
 {
+    const FlexFactors pl = flex_factors(n);
+    if (pl.blue) return chirp_col_tile(pl.m);   // chirp-z lengths: the kernels of p3d_chirp.hip
     if (col_lds(n, 8) <= FLEX_LDS_MAX) return 8;   // a whole 64-byte column block, even at one workgroup per CU (4-column tiles
                                                    // with two workgroups per CU measured 10-18 % slower)
     for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
@@ -133,6 +134,7 @@ bool flex_inplace_ok(const FlexFactors& pl, int tpr)
 }
 int pick_row_lines(int n)   // rows per workgroup at one wavefront per row
 {
+    if (flex_factors(n).blue) return 1;   // (p3d_chirp.hip has its own launch shapes)
     for (int LB : {4, 2, 1}) if (row_lds(n, LB) <= FLEX_LDS_TWO) return LB;
     return row_lds(n, 1) <= FLEX_LDS_MAX ? 1 : 0;
 }
@@ -425,28 +427,11 @@ __device__ __forceinline__ void flex_fft_inplace(c32* A, const c32* tw, const Fl
     }
 }
 
-// flex_transform (below) for one line with in-place passes: directly, or in the chirp-z form on the M = pl.m points of the
-// line's buffer (every element-wise step is done by the thread that owns the index, the passes synchronise among themselves)
+// flex_transform (below) for one line with in-place passes
 template <int SYNC, int DIR>
-__device__ __forceinline__ void flex_transform_inplace(c32* A, const c32* tw, const c32* gt, const FlexFactors& pl, int first, int step)
+__device__ __forceinline__ void flex_transform_inplace(c32* A, const c32* tw, const c32*, const FlexFactors& pl, int first, int)
 {
-    if (!pl.blue) { flex_fft_inplace<SYNC, DIR>(A, tw, pl, first); return; }
-    const int n = pl.n, M = pl.m;
-    const c32* const chirp = gt + M;
-    const c32* const bhat = gt + M + n;
-    const float inv_m = 1.0f / (float)M;
-    for (int e = first; e < M; e += step) {
-        c32 v{0.f, 0.f};
-        if (e < n) v = conj_if<DIR>(A[e]) * chirp[e];
-        A[e] = v;
-    }
-    flex_sync<SYNC>();
-    flex_fft_inplace<SYNC, FWD>(A, tw, pl, first);
-    for (int e = first; e < M; e += step) A[e] = A[e] * bhat[e];
-    flex_sync<SYNC>();
-    flex_fft_inplace<SYNC, INV>(A, tw, pl, first);
-    for (int e = first; e < n; e += step) A[e] = conj_if<DIR>((A[e] * chirp[e]) * inv_m);
-    flex_sync<SYNC>();
+    flex_fft_inplace<SYNC, DIR>(A, tw, pl, first);
 }
 
 // large prime factor R: direct O(R^2) butterflies, inputs re-read from LDS
@@ -510,42 +495,12 @@ __device__ __forceinline__ c32* flex_fft(c32* A, c32* B, const c32* tw, const Fl
     return A;
 }
 
-// DFT of a line (or a tile of lines) of pl.n points (the first pl.n entries of buffers that hold pl.m).  Directly when the length
-// factors into small radices; otherwise in the chirp-z form on M = pl.m points:  X_k = c_k (a * conj c)_k with a_j = x_j c_j,
-// c_k = exp(-i pi k^2 / n), the convolution through two transforms of length M and the spectrum of conj c (gt: global table
-// [tw_M | c | FFT_M(conj c)]).  The inverse transform is conj(DFT(conj x)).  Unnormalised like flex_fft; the result is returned in
-// one of the two buffers.
+// DFT of a line (or a tile of lines) of pl.n points.  Unnormalised; the result is returned in one of the two buffers.  (Lengths with a
+// prime factor above 13 that run in the chirp-z form never come here: flex_row / flex_col hand them to p3d_chirp.hip.)
 template <int SYNC, int DIR, bool COLS, bool BIGP>
-__device__ __forceinline__ c32* flex_transform(c32* A, c32* B, const c32* tw, const c32* gt, const FlexFactors& pl, int tsh, int first, int step)
+__device__ __forceinline__ c32* flex_transform(c32* A, c32* B, const c32* tw, const c32*, const FlexFactors& pl, int tsh, int first, int step)
 {
-    if (!pl.blue) return flex_fft<SYNC, DIR, COLS, BIGP>(A, B, tw, pl, tsh, first, step);
-    const int n = pl.n, M = pl.m;
-    const c32* const chirp = gt + M;
-    const c32* const bhat = gt + M + n;
-    const float inv_m = 1.0f / (float)M;
-    const int total = COLS ? M << tsh : M;
-    for (int e = first; e < total; e += step) {   // element e = (i << tsh) + l sits at A[e] in both layouts
-        const int i = COLS ? e >> tsh : e;
-        c32 v{0.f, 0.f};
-        if (i < n) v = conj_if<DIR>(A[e]) * chirp[i];
-        A[e] = v;
-    }
-    flex_sync<SYNC>();
-    c32* X = flex_fft<SYNC, FWD, COLS, false>(A, B, tw, pl, tsh, first, step);   // (the padded length is 5-smooth)
-    c32* Y = X == A ? B : A;
-    for (int e = first; e < total; e += step) {
-        const int i = COLS ? e >> tsh : e;
-        X[e] = X[e] * bhat[i];
-    }
-    flex_sync<SYNC>();
-    X = flex_fft<SYNC, INV, COLS, false>(X, Y, tw, pl, tsh, first, step);
-    for (int e = first; e < total; e += step) {
-        const int i = COLS ? e >> tsh : e;
-        if (i >= n) continue;
-        X[e] = conj_if<DIR>((X[e] * chirp[i]) * inv_m);
-    }
-    flex_sync<SYNC>();
-    return X;
+    return flex_fft<SYNC, DIR, COLS, BIGP>(A, B, tw, pl, tsh, first, step);
 }
 
 // ---- column pass ------------------------------------------------------------------------------------------------------------------
@@ -995,6 +950,14 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
 size_t flex_table_len(const FlexFactors& pl) { return pl.blue ? (size_t)2 * pl.m + pl.n : (size_t)pl.n; }
 const FlexFactors* device_factors(const c32* table, const FlexFactors& pl) { return reinterpret_cast<const FlexFactors*>(table + flex_table_len(pl)); }
 
+// the tables of a chirp-z length inside its device table (flex_build_table): [exp(-2 pi i k / M) | chirp | spectrum of conj chirp |
+// FlexFactors | tables of the register-resident engine for M]
+ChirpTabs chirp_tabs(const c32* table, const FlexFactors& pl)
+{
+    const c32* const tuned = table + flex_table_len(pl) + (sizeof(FlexFactors) + sizeof(c32) - 1) / sizeof(c32);
+    return ChirpTabs{tuned, tuned + chirp_rowtab_slots(pl.m), table + pl.m, table + pl.m + pl.n, pl.n, pl.m};
+}
+
 // row-pair passes for float32 cubes (mode = ROW_FIRST / ROW_MID / ROW_LAST)
 hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
 {
@@ -1003,6 +966,7 @@ hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
     const int n = a.len, LB = pick_row_lines(n);
     if (LB == 0) return hipErrorNotSupported;
     const FlexFactors pl = flex_factors(n);
+    if (pl.blue) return chirp_row_real(mode, a, chirp_tabs(a.tw, pl), st);
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;
@@ -1042,6 +1006,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     const int n = a.len, LB = pick_row_lines(n);
     if (LB == 0) return hipErrorNotSupported;
     const FlexFactors pl = flex_factors(n);
+    if (pl.blue) return chirp_row(mode, a, chirp_tabs(a.tw, pl), st);
     // two wavefronts per row where the narrowest pass still has ~48 butterflies for them (measured: 500, 768, 1000 gain 20-25 %,
     // 600 = 15*10*4 loses 8 %) and rows can be paired
     int widest = 2;
@@ -1090,6 +1055,7 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
     int tshift = 0;
     while ((1 << tshift) < T) ++tshift;
     const FlexFactors pl = flex_factors(n);
+    if (pl.blue) return chirp_col(mode, a, chirp_tabs(a.tw, pl), st);
     const size_t lds = col_lds(n, T);
     if ((size_t)n * T > (size_t)FLEX_COL_PF * FLEX_COL_THREADS) return hipErrorNotSupported;   // (never: col_lds <= FLEX_LDS_MAX)
     int cus = a.cus;   // the plan's device (a.cus = 0: a caller without a plan -- ask the current device)
@@ -1188,6 +1154,9 @@ void flex_build_table(int n, std::vector<c32>& out)
     }
     for (int k = 0; k < M; ++k) out[(size_t)M + n + k] = c32{(float)br[k], (float)bi[k]};
     append_factors();
+    const size_t at = out.size();   // the twiddle tables of the register-resident engine for M points (p3d_chirp.hip)
+    out.resize(at + chirp_table_slots(M), c32{0.f, 0.f});
+    chirp_build_tables(M, out.data() + at);
 }
 
 bool flex_supported(int n) { return n >= 2 && n <= GEN_MAX_N && gen_make_plan(n).nf > 0 && flex_factors(n).nf > 0 && pick_col_tile(n) > 0 && pick_row_lines(n) > 0; }

@@ -785,8 +785,9 @@ def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeyp
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143), (48, 999), (330, 52)])
-# (74: chirp-z; 143 = 11 x 13, 330 = 30 x 11, 52 = 4 x 13: in-register prime butterflies; 999: chirp-z rows in place on four wavefronts)
+@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143), (48, 999), (330, 52), (1009, 34), (17, 1101)])
+# (74, 62, 999 = 27 x 37, 1009, 34, 17, 1101 = 3 x 367: chirp-z on 256 ... 4096 points, p3d_chirp.hip; 143 = 11 x 13, 330 = 30 x 11, 52 = 4 x 13: in-register
+# prime butterflies)
 @pytest.mark.parametrize("kw", [
     dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2),
     dict(niter=8, thresh_op="soft", thresh_model="linear", eps=0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
@@ -951,7 +952,10 @@ def test_one_process_several_devices_entry_point(ffi, orc):
     (60, 75, dict(niter=8, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),        # odd length: no Nyquist column
     (128, 1000, dict(niter=30, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),     # two wavefronts per pair, in-place passes
     (50, 600, dict(niter=6, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),
-    (62, 143, dict(niter=6, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),           # chirp-z rows (143 = 11 * 13)
+    (62, 143, dict(niter=6, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),           # 143 = 11 * 13: in-register prime butterflies
+    (62, 74, dict(niter=6, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2)),            # chirp-z on both axes (2 * 31, 2 * 37): p3d_chirp.hip
+    (46, 1009, dict(niter=30, thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2)),      # prime rows on 2048 points, two wavefronts per pair
+    (34, 1451, dict(niter=5, thresh_model="linear", eps=0, p_max=0.9, p_min=1e-2, alpha=0.8)),      # on 4096 points
 ])
 def test_real_cubes_share_one_transform_per_row_pair(nil, nxl, kw, monkeypatch):
     """float32 cubes with the hard operator: the spectrum is Hermitian, rows go through the row pass in pairs (one complex
