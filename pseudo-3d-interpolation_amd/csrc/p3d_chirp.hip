@@ -17,6 +17,8 @@
 // relative as the other paths (tests/test_gpu_parity.py: test_fft2_matches_numpy, test_flexible_lengths_against_the_oracle).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "p3d_chirp.hpp"
 #include "p3d_kernels.hpp"
 
@@ -83,23 +85,52 @@ __device__ __forceinline__ void chirp_dft(c32 (&v)[Plan<M>::PPT], LDS lds, TW tw
     }
 }
 
+// Launch shapes.  A workgroup holds the padded lines of its T columns / LB rows in LDS between the passes of a transform plus the
+// twiddle tables, and a CU should hold TWO workgroups (one covers the other's barriers and table loads; measured on 1009 x 1013:
+// row pass 2.39 -> ... ms): transforms of 2048 points run four lines per workgroup on the half table of p3d_col_shear.hpp (70 + 11 KiB).
+template <int M>
+struct ChirpCfg {
+    static constexpr bool HALF = M >= 2048;   // ColTablesHalf / TwColHalf in both passes
+    static constexpr int T = M == 2048 ? 4 : col_tile<M>();
+    static constexpr int LB = M >= 4096 ? 1 : (M == 2048 ? 4 : ROW_THREADS / Plan<M>::TPL);
+    static constexpr int ROW_WAVES = M >= 4096 ? 2 : (M == 1024 ? 3 : 4);   // waves per SIMD the LDS footprint allows anyway: the register budget follows it
+    using ColTab = std::conditional_t<HALF, ColTablesHalf<M>, ColTables<M>>;
+    using ColTw = std::conditional_t<HALF, TwColHalf, TwCol>;
+    static constexpr int row_slots() { return HALF ? ColTablesHalf<M>::slots() : PassTables<M>::slots(); }
+    using RowTw = std::conditional_t<HALF, TwColHalf, TwOrdered>;
+    static constexpr size_t col_lds() { return sizeof(c32) * (ColTab::slots() + (size_t)(T / (T < 8 ? T : 8)) * LdsColW<(T < 8 ? T : 8)>::stride(M)); }
+    static constexpr size_t row_lds() { return sizeof(c32) * (row_slots() + (size_t)LB * LdsRow::stride(M)) + 32 * sizeof(double); }
+};
+template <int M, int THREADS>
+__device__ __forceinline__ void chirp_load_col_tables(c32* twl, const c32* tab, int tid)
+{
+    if constexpr (ChirpCfg<M>::HALF) ColTablesHalf<M>::template load<THREADS>(twl, tab, tid);
+    else for (int i = tid; i < ColTables<M>::slots(); i += THREADS) twl[i] = tab[i];
+}
+template <int M, int THREADS>
+__device__ __forceinline__ void chirp_load_row_tables(c32* twl, const c32* tab, int tid)   // tab: ColTables image (HALF) or PassTables image
+{
+    if constexpr (ChirpCfg<M>::HALF) ColTablesHalf<M>::template load<THREADS>(twl, tab, tid);
+    else for (int i = tid; i < PassTables<M>::slots(); i += THREADS) twl[i] = tab[i];
+}
+
 // ---- column pass ------------------------------------------------------------------------------------------------------------------
 // col_kernel (p3d_col_kernels.hpp) on columns of n points: T columns per workgroup, CW = min(T, 8) of them from one 64-byte column
 // block.  MODE: COL_ITER (the operator comes in a.op), COL_STATS, COL_FWD (with the threshold when a.tau is given), COL_INV.
 template <int M, int MODE>
-__global__ __launch_bounds__(col_tile<M>() * Plan<M>::TPL, (col_tile<M>() * Plan<M>::TPL >= 1024 ? 4 : P3D_WAVES_PER_EU))
+__global__ __launch_bounds__(ChirpCfg<M>::T * Plan<M>::TPL, P3D_WAVES_PER_EU)
 void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpDev cz)
 {
     using PL = Plan<M>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT, H = PPT / 2;
-    constexpr int T = col_tile<M>();
+    constexpr int T = ChirpCfg<M>::T;
     constexpr int THREADS = T * TPL;
     constexpr int CW = T < 8 ? T : 8;
     using LDS = LdsColW<CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
-    c32* data = twl + ColTables<M>::slots();
-    const TwCol tw{twl};
+    c32* data = twl + ChirpCfg<M>::ColTab::slots();
+    const typename ChirpCfg<M>::ColTw tw{twl};
     const int n = cz.n;
 
     const int tid = threadIdx.x;
@@ -119,7 +150,7 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
     const bool valid = col < a.n2;
     if (a.done && a.done[slice] != 0) return;
 
-    for (int i = tid; i < ColTables<M>::slots(); i += THREADS) twl[i] = tab[i];
+    chirp_load_col_tables<M, THREADS>(twl, tab, tid);
     __syncthreads();
 
     const LDS lds{data + cbl * LDS::stride(M) + c_lo};
@@ -228,14 +259,13 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
 // row_kernel (p3d_row_kernels.hpp) on rows of n samples with the float weights of the trace mask (no packed words, no compact
 // samples: the contract of the flexible row pass).  LB = 256 / TPL rows per workgroup.
 template <int M>
-constexpr int chirp_row_lines() { return M >= 4096 ? 2 : ROW_THREADS / Plan<M>::TPL; }   // (4096: 64 KiB of tables per workgroup)
-// waves per SIMD the LDS footprint allows anyway (2048, 4096: one or two workgroups per CU): the register budget follows it
+constexpr int chirp_row_lines() { return ChirpCfg<M>::LB; }
 template <int M>
-constexpr int chirp_row_waves() { return M >= 2048 ? 2 : (M == 1024 ? 3 : 4); }
+constexpr int chirp_row_waves() { return ChirpCfg<M>::ROW_WAVES; }
 template <int M>
 constexpr int chirp_row_threads() { return chirp_row_lines<M>() * Plan<M>::TPL; }
 template <int M>
-constexpr size_t chirp_row_lds() { return sizeof(c32) * (PassTables<M>::slots() + chirp_row_lines<M>() * LdsRow::stride(M)) + 32 * sizeof(double); }
+constexpr size_t chirp_row_lds() { return ChirpCfg<M>::row_lds(); }
 
 template <int M, int MODE>
 __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void chirp_row_kernel(const RowArgs a, const c32* __restrict__ tab, const ChirpDev cz)
@@ -247,8 +277,8 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
     constexpr bool WAVE = TPL <= 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
-    c32* data = twl + PassTables<M>::slots();
-    const TwOrdered tw{twl};
+    c32* data = twl + ChirpCfg<M>::row_slots();
+    const typename ChirpCfg<M>::RowTw tw{twl};
     const int n = cz.n;
 
     const int tid = threadIdx.x;
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
         return;
     }
 
-    for (int i = tid; i < PassTables<M>::slots(); i += THREADS) twl[i] = tab[i];
+    chirp_load_row_tables<M, THREADS>(twl, tab, tid);
     __syncthreads();
 
     const LdsRow lds{data + line * LSTR};
@@ -321,17 +351,26 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
             if (nzf && kept) kept = nzf[i >> tsh] != 0;
             v[q] = kept ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
         }
-        // observed samples and weights: requested in front of the inverse transform, used after it
+        // observed samples and weights: requested in front of the inverse transform and used after it where the registers are there
+        // (transforms of 2048 points and more run at 128 registers per thread: they fetch them afterwards, the other workgroup covers)
+        constexpr bool EARLY = M < 2048;
         c32 xo[H];
         float mk[H];
         const bool need_obs = !a.plain && valid;
+        auto fetch = [&] {
 #pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int i = tl + TPL * q;
-            xo[q] = (need_obs && i < n) ? obs_at(i) : c32{0.f, 0.f};
-            mk[q] = (mrow && !a.plain && i < n) ? mrow[i] : 0.f;
-        }
+            for (int q = 0; q < H; ++q) {
+                const int i = tl + TPL * q;
+                xo[q] = (need_obs && i < n) ? obs_at(i) : c32{0.f, 0.f};
+                mk[q] = (mrow && !a.plain && i < n) ? mrow[i] : 0.f;
+            }
+        };
+        if constexpr (EARLY) fetch();
         chirp_dft<M, INV, WAVE>(v, lds, tw, tl, cz);
+        if constexpr (!EARLY) {
+            __builtin_amdgcn_sched_barrier(0);   // (not hoisted into the transform)
+            fetch();
+        }
 #pragma unroll
         for (int q = 0; q < H; ++q) {
             const int i = tl + TPL * q;
@@ -406,8 +445,8 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
     constexpr bool WAVE = TPL <= 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
-    c32* data = twl + PassTables<M>::slots();
-    const TwOrdered tw{twl};
+    c32* data = twl + ChirpCfg<M>::row_slots();
+    const typename ChirpCfg<M>::RowTw tw{twl};
     const int n = cz.n, Hn = n / 2;
 
     const int tid = threadIdx.x;
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
         return;
     }
 
-    for (int i = tid; i < PassTables<M>::slots(); i += THREADS) twl[i] = tab[i];
+    chirp_load_row_tables<M, THREADS>(twl, tab, tid);
     __syncthreads();
 
     const LdsRow lds{data + line * LSTR};
@@ -478,17 +517,25 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
             if (k == 0 || 2 * k == n) { r0.y = 0.f; r1.y = 0.f; }   // self-mirrored columns of a real row are real
             v[q] = c32{r0.x - r1.y, r0.y + r1.x};
         }
+        constexpr bool EARLY = M < 2048;   // (see chirp_row_kernel)
         float xoa[H], xob[H], mka[H], mkb[H];
+        auto fetch = [&] {
 #pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int i = tl + TPL * q;
-            const bool on = valid && i < n;
-            xoa[q] = on ? xa[i] : 0.f;
-            xob[q] = on ? xa[n + i] : 0.f;
-            mka[q] = (ma && i < n) ? ma[i] : 0.f;
-            mkb[q] = (ma && i < n) ? ma[n + i] : 0.f;
-        }
+            for (int q = 0; q < H; ++q) {
+                const int i = tl + TPL * q;
+                const bool on = valid && i < n;
+                xoa[q] = on ? xa[i] : 0.f;
+                xob[q] = on ? xa[n + i] : 0.f;
+                mka[q] = (ma && i < n) ? ma[i] : 0.f;
+                mkb[q] = (ma && i < n) ? ma[n + i] : 0.f;
+            }
+        };
+        if constexpr (EARLY) fetch();
         chirp_dft<M, INV, WAVE>(v, lds, tw, tl, cz);
+        if constexpr (!EARLY) {
+            __builtin_amdgcn_sched_barrier(0);   // (not hoisted into the transform)
+            fetch();
+        }
         const bool handback = MODE == ROW_LAST && a.only_done != 0;
 #pragma unroll
         for (int q = 0; q < H; ++q) {
@@ -557,10 +604,10 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
 template <int M>
 hipError_t launch_chirp_col(int mode, const ColArgs& a, const ChirpTabs& t, hipStream_t st)
 {
-    constexpr int T = col_tile<M>();
+    constexpr int T = ChirpCfg<M>::T;
     const ChirpDev cz{t.chirp, t.bhat, t.n, 1.0f / (float)M};
     const dim3 grid((a.n2 + T - 1) / T, a.nslices);
-    constexpr size_t lds = col_lds_bytes<M>();
+    constexpr size_t lds = ChirpCfg<M>::col_lds();
     static_assert(lds >= sizeof(float) * 5 * 16, "scratch of the statistics");
     hipError_t e = hipSuccess;
     ColArgs c = a;
@@ -590,15 +637,16 @@ hipError_t launch_chirp_row(int mode, const RowArgs& a, const ChirpTabs& t, hipS
     const int lines = REAL ? a.n1 / 2 : a.n1;
     const dim3 grid((lines + LB - 1) / LB, a.nslices);
     constexpr size_t lds = chirp_row_lds<M>();
+    const c32* const rtab = ChirpCfg<M>::HALF ? t.coltab : t.rowtab;   // (the half table is cut from the column pass's image)
     hipError_t e = hipSuccess;
 #define P3D_CHIRP_ROW(MODE)                                                                                     \
     do {                                                                                                        \
         if constexpr (REAL) {                                                                                   \
             if ((e = allow_lds(chirp_row_real_kernel<M, MODE>, lds)) != hipSuccess) return e;                   \
-            chirp_row_real_kernel<M, MODE><<<grid, chirp_row_threads<M>(), lds, st>>>(a, t.rowtab, cz);         \
+            chirp_row_real_kernel<M, MODE><<<grid, chirp_row_threads<M>(), lds, st>>>(a, rtab, cz);         \
         } else {                                                                                                \
             if ((e = allow_lds(chirp_row_kernel<M, MODE>, lds)) != hipSuccess) return e;                        \
-            chirp_row_kernel<M, MODE><<<grid, chirp_row_threads<M>(), lds, st>>>(a, t.rowtab, cz);              \
+            chirp_row_kernel<M, MODE><<<grid, chirp_row_threads<M>(), lds, st>>>(a, rtab, cz);              \
         }                                                                                                       \
     } while (0)
     switch (mode) {
@@ -628,7 +676,7 @@ bool chirp_supported(int m)
 int chirp_col_tile(int m)
 {
     switch (m) {
-#define P3D_CASE(MM) case MM: return col_tile<MM>();
+#define P3D_CASE(MM) case MM: return ChirpCfg<MM>::T;
         P3D_CHIRP_SIZES(P3D_CASE)
 #undef P3D_CASE
         default: return 0;
