@@ -92,8 +92,8 @@ template <int M>
 struct ChirpCfg {
     static constexpr bool HALF = M >= 2048;   // ColTablesHalf / TwColHalf in both passes
     static constexpr int T = M == 2048 ? 4 : col_tile<M>();
-    static constexpr int LB = M >= 4096 ? 1 : (M == 2048 ? 4 : ROW_THREADS / Plan<M>::TPL);
-    static constexpr int ROW_WAVES = M >= 4096 ? 2 : (M == 1024 ? 3 : 4);   // waves per SIMD the LDS footprint allows anyway: the register budget follows it
+    static constexpr int LB = M >= 4096 ? 1 : (M == 2048 ? 2 : ROW_THREADS / Plan<M>::TPL);
+    static constexpr int ROW_WAVES = M >= 4096 ? 2 : (M >= 1024 ? 3 : 4);   // waves per SIMD the LDS footprint allows anyway: the register budget follows it
     using ColTab = std::conditional_t<HALF, ColTablesHalf<M>, ColTables<M>>;
     using ColTw = std::conditional_t<HALF, TwColHalf, TwCol>;
     static constexpr int row_slots() { return HALF ? ColTablesHalf<M>::slots() : PassTables<M>::slots(); }
@@ -139,19 +139,20 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
     const int cbl = tid / (CW * TPL);
     const int slice = blockIdx.y;
     int tile = blockIdx.x;
-    if constexpr (T < 8) {   // the tiles of one 64-byte block on one XCD, back to back (see col_kernel)
+    const int ntiles = (a.n2 + T - 1) / T;
+    if constexpr (T < 8) {
+        // the tiles of one 64-byte block on one XCD, back to back (see col_kernel); the launcher rounds the grid up to whole groups of
+        // 8 x 8/T tiles so that this always applies -- a block fetched by 8/T workgroups on different XCDs comes from HBM 8/T times
         constexpr int G = 8 / T;
         if (P3D_XCD_PAIR && (gridDim.x % (8 * G)) == 0) {
             const int xcd = tile & 7, j = tile >> 3;
             tile = ((j / G) * 8 + xcd) * G + (j % G);
         }
     }
+    if (tile >= ntiles) return;
     const int col = tile * T + cbl * CW + c_lo;
     const bool valid = col < a.n2;
     if (a.done && a.done[slice] != 0) return;
-
-    chirp_load_col_tables<M, THREADS>(twl, tab, tid);
-    __syncthreads();
 
     const LDS lds{data + cbl * LDS::stride(M) + c_lo};
     constexpr bool ITER = MODE == COL_ITER;
@@ -169,6 +170,8 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
         const int r = tl + TPL * q;
         v[q] = r < n ? inb[in_org + (unsigned)r * in_pitch] : c32{0.f, 0.f};   // (columns past the edge re-read column 0)
     }
+    chirp_load_col_tables<M, THREADS>(twl, tab, tid);   // (under the latency of the tile's loads)
+    __syncthreads();
     if (MODE != COL_INV) chirp_dft<M, FWD, false>(v, lds, tw, tl, cz);
 
     if (ITER || (MODE == COL_FWD && a.tau != nullptr)) {
@@ -182,7 +185,7 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
 #pragma unroll
             for (int q = 0; q < H; ++q) bits |= __float_as_uint(v[q].x) | __float_as_uint(v[q].y);
             const int kept = __syncthreads_or(bits != 0u ? 1 : 0);
-            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
+            if (tid == 0) a.nzflag[(size_t)slice * ntiles + tile] = kept ? 1 : 0;
             if (!kept) {
                 // the row pass skips whole 8-column blocks: an empty tile narrower than a block leaves zeros behind for the case that a
                 // sibling tile of its block kept something
@@ -238,7 +241,7 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
                 mn = fminf(mn, red[w * 5 + 3]);
                 sq += red[w * 5 + 4];
             }
-            float* p = a.partials + ((size_t)slice * gridDim.x + blockIdx.x) * STATS_PARTIAL;
+            float* p = a.partials + ((size_t)slice * ntiles + tile) * STATS_PARTIAL;
             p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
         }
         return;
@@ -310,9 +313,6 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
         return;
     }
 
-    chirp_load_row_tables<M, THREADS>(twl, tab, tid);
-    __syncthreads();
-
     const LdsRow lds{data + line * LSTR};
     c32* const wslice = a.work + (size_t)slice * wk_slice_stride(a.n1, n);
     const unsigned wblk = (unsigned)a.n1 * 8;
@@ -340,17 +340,25 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
                 v[q] = x;
             }
         }
+        chirp_load_row_tables<M, THREADS>(twl, tab, tid);   // (under the latency of the row's loads)
+        __syncthreads();
     } else {
-        // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros
+        // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros.  The flags first, all of
+        // them, then the loads they allow, then the copy of the tables: three latencies one after the other otherwise
         const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
         const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);
+        unsigned keep = 0;
 #pragma unroll
         for (int q = 0; q < H; ++q) {
             const int i = tl + TPL * q;
             bool kept = valid && i < n;
             if (nzf && kept) kept = nzf[i >> tsh] != 0;
-            v[q] = kept ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+            keep |= (kept ? 1u : 0u) << q;
         }
+#pragma unroll
+        for (int q = 0; q < H; ++q) v[q] = ((keep >> q) & 1u) ? wk_q_ptr<TPL>(wslice, q, tl, wblk)[wlane] : c32{0.f, 0.f};
+        chirp_load_row_tables<M, THREADS>(twl, tab, tid);
+        __syncthreads();
         // observed samples and weights: requested in front of the inverse transform and used after it where the registers are there
         // (transforms of 2048 points and more run at 128 registers per thread: they fetch them afterwards, the other workgroup covers)
         constexpr bool EARLY = M < 2048;
@@ -478,9 +486,6 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
         return;
     }
 
-    chirp_load_row_tables<M, THREADS>(twl, tab, tid);
-    __syncthreads();
-
     const LdsRow lds{data + line * LSTR};
     c32* const wrow = a.work + (size_t)slice * wk_slice_stride(a.n1, Hn + 1) + (size_t)ra * 8;   // row a; row b is 8 elements on
     const size_t wblk = (size_t)a.n1 * 8;
@@ -498,15 +503,25 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
             sb += fabsf(vb);
             v[q] = c32{va, vb};
         }
+        chirp_load_row_tables<M, THREADS>(twl, tab, tid);
+        __syncthreads();
     } else {
         const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
         const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);
+        unsigned keep = 0;   // (flags, then loads, then tables: see chirp_row_kernel)
 #pragma unroll
         for (int q = 0; q < H; ++q) {
             const int i = tl + TPL * q;
             const int k = i <= Hn ? i : n - i;
             bool kept = valid && i < n;
             if (nzf && kept) kept = nzf[k >> tsh] != 0;
+            keep |= (kept ? 1u : 0u) << q;
+        }
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            const int i = tl + TPL * q;
+            const int k = i <= Hn ? i : n - i;
+            const bool kept = ((keep >> q) & 1u) != 0;
             c32 r0{0.f, 0.f}, r1{0.f, 0.f};
             if (kept) {
                 const c32* w = wrow + (size_t)(k >> 3) * wblk + (k & 7);
@@ -517,6 +532,8 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
             if (k == 0 || 2 * k == n) { r0.y = 0.f; r1.y = 0.f; }   // self-mirrored columns of a real row are real
             v[q] = c32{r0.x - r1.y, r0.y + r1.x};
         }
+        chirp_load_row_tables<M, THREADS>(twl, tab, tid);
+        __syncthreads();
         constexpr bool EARLY = M < 2048;   // (see chirp_row_kernel)
         float xoa[H], xob[H], mka[H], mkb[H];
         auto fetch = [&] {
@@ -606,7 +623,9 @@ hipError_t launch_chirp_col(int mode, const ColArgs& a, const ChirpTabs& t, hipS
 {
     constexpr int T = ChirpCfg<M>::T;
     const ChirpDev cz{t.chirp, t.bhat, t.n, 1.0f / (float)M};
-    const dim3 grid((a.n2 + T - 1) / T, a.nslices);
+    unsigned gx = (unsigned)((a.n2 + T - 1) / T);
+    if (T < 8 && P3D_XCD_PAIR) { const unsigned g = 8u * (8u / T); gx = (gx + g - 1) / g * g; }   // (see the kernel: surplus workgroups leave at once)
+    const dim3 grid(gx, a.nslices);
     constexpr size_t lds = ChirpCfg<M>::col_lds();
     static_assert(lds >= sizeof(float) * 5 * 16, "scratch of the statistics");
     hipError_t e = hipSuccess;

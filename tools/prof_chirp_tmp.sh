@@ -1,5 +1,2 @@
-for shp in "1009 1013" "1101 1451" "520 530"; do set -- $shp
-python3 tools/pocs_driver.py --nil $1 --nxl $2 --nslices 128 --niter 20 2>&1 | grep colpass
-python3 tools/pocs_driver.py --nil $1 --nxl $2 --nslices 128 --niter 20 --real 2>&1 | grep colpass
-done
-python -m pytest tests/test_gpu_parity.py -q -m gpu -k "flexible or real_cubes or fft2" 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py -q -m gpu -k "flexible or real_cubes or fft2 or time2freq or early_exit or slower" 2>&1 | tail -3
+bash tools/shape_sweep.sh "1001 999" "1009 1013" "1101 1451" "520 530" "999 999" "500 509" "2039 1999" "74 62" "300 331" "1000 1000"
