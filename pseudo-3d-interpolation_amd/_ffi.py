@@ -209,7 +209,9 @@ class Plan:
             lib().p3d_plan_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:   # (module globals are gone while the interpreter shuts down: the process's device memory goes with it)
+            self.close()
 
     def __enter__(self):
         return self
@@ -413,7 +415,9 @@ class WaveletPlan:
             lib().p3d_wavelet_plan_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:   # (module globals are gone while the interpreter shuts down: the process's device memory goes with it)
+            self.close()
 
     def __enter__(self):
         return self
@@ -536,7 +540,9 @@ class ShearletPlan:
             lib().p3d_shearlet_plan_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:   # (module globals are gone while the interpreter shuts down: the process's device memory goes with it)
+            self.close()
 
     def __enter__(self):
         return self

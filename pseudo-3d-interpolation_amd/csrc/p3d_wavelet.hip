@@ -1067,12 +1067,18 @@ __device__ __forceinline__ float im_of(c32 v) { return v.y; }
 __device__ __forceinline__ float re_of(float v) { return v; }
 __device__ __forceinline__ float im_of(float) { return 0.f; }
 
+// statistics of every detail array of every level in ONE launch (grid: level index coarse -> fine, slice, detail array)
+constexpr int WSTAT_MAX_LEVELS = 16;
+struct WStatLevels {
+    size_t off[WSTAT_MAX_LEVELS], count[WSTAT_MAX_LEVELS];   // per level index (0 = coarsest): first detail array and samples per array
+};
 template <typename T>
-__global__ void wstats_kernel(const T* coef, size_t coef_slice, size_t off, size_t count, float* stats, int nlev, int lvl)
+__global__ void wstats_kernel(const T* coef, size_t coef_slice, const WStatLevels lv, float* stats, int nlev)
 {
-    __shared__ float sh[256 * 4];
-    const int s = blockIdx.y, z = blockIdx.z;
-    const T* p = coef + (size_t)s * coef_slice + off + (size_t)z * count;
+    __shared__ float sh[4 * 4];
+    const int lvl = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+    const size_t count = lv.count[lvl];
+    const T* p = coef + (size_t)s * coef_slice + lv.off[lvl] + (size_t)z * count;
     float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY;
     for (size_t i = threadIdx.x; i < count; i += blockDim.x) {
         const T v = p[i];
@@ -1081,11 +1087,20 @@ __global__ void wstats_kernel(const T* coef, size_t coef_slice, size_t off, size
         mx = fmaxf(mx, q);
         mn = fminf(mn, q);
     }
-    float* me = sh + threadIdx.x * 4;
-    me[0] = lr; me[1] = li; me[2] = mx; me[3] = mn;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float orr = __shfl_down(lr, o, 64), oi = __shfl_down(li, o, 64);
+        if (orr > lr || (orr == lr && oi > li)) { lr = orr; li = oi; }
+        mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        mn = fminf(mn, __shfl_down(mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        float* me = sh + (threadIdx.x >> 6) * 4;
+        me[0] = lr; me[1] = li; me[2] = mx; me[3] = mn;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int t = 1; t < (int)blockDim.x; ++t) {
+        for (int t = 1; t < (int)blockDim.x / 64; ++t) {
             const float* o = sh + t * 4;
             if (o[0] > lr || (o[0] == lr && o[1] > li)) { lr = o[0]; li = o[1]; }
             mx = fmaxf(mx, o[2]);
@@ -1112,26 +1127,33 @@ __global__ void wupdate_kernel(const T* rec, size_t rec_ld, size_t rec_slice, T*
             store_out(out, dtype, (size_t)s * per + i, zero_of<T>());
     double acc = 0.0;
     if (dn == 0) {
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
-            const size_t g = (size_t)s * per + i;
-            const int r = (int)(i / n2), c = (int)(i - (size_t)r * n2);
-            const T xo = load_x(x, dtype, g, (T*)nullptr);
-            const float m = mask ? mask[i] : 0.f;
-            const float wgt = 1.0f - alpha * m;
-            T xn;
-            if (mode == 0) {
-                xn = xo;
-            } else {
-                xn = cmulf(rec[(size_t)s * rec_slice + (size_t)r * rec_ld + c], wgt) + cmulf(xo, alpha);
-                if (write_out) store_out(out, dtype, g, xn);
+        // a block walks over rows (no division per sample: the 64-bit one of a flat index cost more than the sample's memory traffic)
+        for (int r = blockIdx.x; r < n1; r += gridDim.x) {
+            const size_t g0 = (size_t)s * per + (size_t)r * n2;
+            const T* const rrow = rec ? rec + (size_t)s * rec_slice + (size_t)r * rec_ld : nullptr;
+            const float* const mrow = mask ? mask + (size_t)r * n2 : nullptr;
+            float racc = 0.f;
+            for (int c = threadIdx.x; c < n2; c += blockDim.x) {
+                const size_t g = g0 + c;
+                const T xo = load_x(x, dtype, g, (T*)nullptr);
+                const float m = mrow ? mrow[c] : 0.f;
+                const float wgt = 1.0f - alpha * m;
+                T xn;
+                if (mode == 0) {
+                    xn = xo;
+                } else {
+                    xn = cmulf(rrow[c], wgt) + cmulf(xo, alpha);
+                    if (write_out) store_out(out, dtype, g, xn);
+                }
+                racc += mag(xn);
+                if (adaptive) {
+                    const T blend = cmulf(xo, alpha) + cmulf(xn, wgt);
+                    feed[g] = blend + cmulf(xo - cmulf(xn, m), 1.0f - alpha);
+                } else {
+                    feed[g] = xn;
+                }
             }
-            acc += (double)mag(xn);
-            if (adaptive) {
-                const T blend = cmulf(xo, alpha) + cmulf(xn, wgt);
-                feed[g] = blend + cmulf(xo - cmulf(xn, m), 1.0f - alpha);
-            } else {
-                feed[g] = xn;
-            }
+            acc += (double)racc;
         }
     }
     sh[threadIdx.x] = acc;
@@ -1188,6 +1210,10 @@ struct p3d_wplan {
     int* done = nullptr;
     float *stats = nullptr, *mask = nullptr;
     void *st_x = nullptr, *st_out = nullptr;
+    // the observed cube and the result of the job in progress: the caller's own device buffers where it passed such (no staging
+    // copies: 0.4 ms each way per 256 MiB), the staging buffers above otherwise
+    const void* cur_x = nullptr;
+    void* cur_out = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool fused = true;              // tile kernels (one launch per level and direction); P3D_WAVELET_UNFUSED=1 selects the per-axis kernels
     int tile_c = 0, tile_r = 0;     // coefficients per tile edge for complex64 / float32 work buffers
@@ -1534,6 +1560,17 @@ static int w_inverse(p3d_wplan* p, int ns)
     return P3D_OK;
 }
 
+// a pointer into the memory of the plan's own device (the entry points take host or device pointers)
+static bool on_plan_device(const p3d_wplan* p, const void* ptr)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+        (void)hipGetLastError();   // ordinary host memory
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice && at.device == p->device;
+}
+
 static int w_check(p3d_wplan* p, int nslices, int dtype)
 {
     if (!p) return wfail(P3D_ERR_INVALID, "NULL plan");
@@ -1546,12 +1583,14 @@ static int w_check(p3d_wplan* p, int nslices, int dtype)
 template <typename T>
 static int w_stats(p3d_wplan* p, int dtype, int nslices)
 {
-    wupdate_kernel<T><<<dim3(blocks_for(p->per()), nslices), 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->st_x, dtype, nullptr, nullptr, p->sums, 0, 0, 0, 1.0f,
+    wupdate_kernel<T><<<dim3(p->nil < 256 ? p->nil : 256, nslices), 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->cur_x, dtype, nullptr, nullptr, p->sums, 0, 0, 0, 1.0f,
                                                                                 p->nil, p->nxl, nullptr, 0);
     int rc = w_forward<T>(p, nslices, nullptr);
     if (rc) return rc;
-    for (int l = p->nlev, i = 0; l >= 1; --l, ++i)
-        wstats_kernel<T><<<dim3(1, nslices, 3), 256, 0, p->stream>>>(as<T>(p->coef), p->ncoef, p->doff[l], (size_t)p->h[l] * p->w[l], p->stats, p->nlev, i);
+    if (p->nlev > WSTAT_MAX_LEVELS) return wfail(P3D_ERR_UNSUPPORTED, "more than %d levels", WSTAT_MAX_LEVELS);
+    WStatLevels lv{};
+    for (int l = p->nlev, i = 0; l >= 1; --l, ++i) { lv.off[i] = p->doff[l]; lv.count[i] = (size_t)p->h[l] * p->w[l]; }
+    wstats_kernel<T><<<dim3(p->nlev, nslices, 3), 256, 0, p->stream>>>(as<T>(p->coef), p->ncoef, lv, p->stats, p->nlev);
     W_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -1561,8 +1600,8 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
 {
     const int niter = prm->niter;
     const bool early = prm->eps > 0.0, adaptive = prm->version == P3D_VER_ADAPTIVE;
-    const dim3 ugrid(blocks_for(p->per()) > 256 ? 256 : blocks_for(p->per()), nslices);
-    wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->st_x, dtype, p->mask, p->st_out, p->sums, 0, adaptive ? 1 : 0, 0,
+    const dim3 ugrid(p->nil < 256 ? p->nil : 256, nslices);   // (a block walks over rows)
+    wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->cur_x, dtype, p->mask, p->cur_out, p->sums, 0, adaptive ? 1 : 0, 0,
                                                    (float)prm->alpha, p->nil, p->nxl, p->done, 0);
     const bool l1fuse = p->fused && (sizeof(T) == sizeof(float) ? p->l1fuse_r : p->l1fuse_c);
     // level-1 details of iteration k live in buffer k % 2 (the level-1 kernel reads one while it writes the other)
@@ -1581,7 +1620,7 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
         if (rc) return rc;
         if (p->fused) {
             Update u{};
-            u.enabled = 1; u.feed = p->feed; u.x = p->st_x; u.dtype = dtype; u.mask = p->mask; u.out = p->st_out;
+            u.enabled = 1; u.feed = p->feed; u.x = p->cur_x; u.dtype = dtype; u.mask = p->mask; u.out = p->cur_out;
             u.sums = p->sums + (size_t)(k + 1) * nslices;
             u.adaptive = (adaptive && !last) ? 1 : 0; u.write_out = (early || last) ? 1 : 0; u.zero_fill = last ? 1 : 0;
             u.alpha = (float)prm->alpha; u.n1 = p->nil; u.n2 = p->nxl; u.done = p->done;
@@ -1608,8 +1647,8 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
             }
         } else {
             if ((rc = w_inverse<T>(p, nslices))) return rc;
-            wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->st_x, dtype, p->mask,
-                                                           p->st_out, p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
+            wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(as<T>(p->rec[0]), (size_t)p->rw[0], (size_t)p->rh[0] * p->rw[0], as<T>(p->feed), p->cur_x, dtype, p->mask,
+                                                           p->cur_out, p->sums + (size_t)(k + 1) * nslices, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
                                                            (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
         }
         if (early) wconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
@@ -1657,7 +1696,12 @@ int p3d_wavelet_stats(p3d_wplan* p, const void* x, int dtype, int nslices, doubl
     if (rc) return rc;
     if (!x || !stats) return wfail(P3D_ERR_INVALID, "NULL buffer");
     const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
-    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));   // x: host or device pointer
+    if (on_plan_device(p, x)) {
+        p->cur_x = x;
+    } else {
+        W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));
+        p->cur_x = p->st_x;
+    }
     if (p->sums_cap < (size_t)nslices) {
         if (p->sums) hipFree(p->sums);
         p->sums = nullptr; p->sums_cap = 0;
@@ -1708,7 +1752,18 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     const bool real_path = dtype == P3D_F32 && real_tau;
     std::vector<int> done_h(nslices, 0);
     if (active) for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;
-    W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));   // x: host or device pointer
+    const size_t cube_bytes = esz * p->per() * nslices;
+    if (on_plan_device(p, x)) {
+        p->cur_x = x;
+    } else {
+        W_TRY(hipMemcpy(p->st_x, x, cube_bytes, hipMemcpyDefault));
+        p->cur_x = p->st_x;
+    }
+    // (the loop reads the observed cube in every iteration: a result buffer that overlaps it goes through the staging buffer)
+    const char* const xb = static_cast<const char*>(x);
+    char* const ob = static_cast<char*>(out);
+    const bool direct_out = on_plan_device(p, out) && (ob + cube_bytes <= xb || xb + cube_bytes <= ob);
+    p->cur_out = direct_out ? out : p->st_out;
     W_TRY(hipMemcpy(p->mask, mask, sizeof(float) * p->per(), hipMemcpyDefault));
     W_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
@@ -1719,7 +1774,7 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     W_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) W_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
     W_TRY(hipStreamSynchronize(p->stream));
-    W_TRY(hipMemcpy(out, p->st_out, esz * p->per() * nslices, hipMemcpyDefault));
+    if (!direct_out) W_TRY(hipMemcpy(out, p->st_out, cube_bytes, hipMemcpyDefault));
     if (niter_done) for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
     if (elapsed_ms) {
         float ms = 0.f;
