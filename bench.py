@@ -549,12 +549,12 @@ def run_leg(ctx, config, K_override, main):
         torch.cuda.synchronize()
 
         def job_real(niter):
-            st = plan.stats_dev(xr.data_ptr(), _ffi.P3D_F32, n_local)
+            st = plan.prime_dev(xr.data_ptr(), _ffi.P3D_F32, mask_t.data_ptr(), n_local)   # (row pairs: the statistics pass is the job's first pass)
             act = st[:, 2] > 0
             st[~act] = 1.0
             tau_r = P._schedule_from_stats(st, nil * nxl, "exponential", niter, 0.99, p_min, "values")
             return plan.run_dev(xr.data_ptr(), _ffi.P3D_F32, mask_t.data_ptr(), tau_r, niter, outr.data_ptr(), n_local,
-                                thresh_op=op, eps=args.eps, alpha=args.alpha, active=act, want_sums=False)
+                                thresh_op=op, eps=args.eps, alpha=args.alpha, active=act, want_sums=False, primed=True)
         job_real(min(W, 3) or 1)
         torch.cuda.synchronize()
         rt = []

@@ -335,7 +335,9 @@ struct p3d_plan {
     float* st_mask = nullptr;
     size_t st_cap = 0;
     // p3d_pocs_prime_dev: the first pass of a job run ahead of it (statistics + work buffer + compact samples of exactly this cube)
-    struct Primed { bool valid = false; const void* x = nullptr; const float* mask = nullptr; int dtype = 0, nslices = 0, nonbinary = 0, violation = 0; unsigned nobs = 0; } primed;
+    struct Primed { bool valid = false; const void* x = nullptr; const float* mask = nullptr; int dtype = 0, nslices = 0, nonbinary = 0, violation = 0; unsigned nobs = 0;
+                    bool real = false;   // the work buffer holds the half spectrum of the row pairs (float32 cube: row_real_kernel<REAL_FIRST>)
+    } primed;
     double* sum0 = nullptr;     // [max_slices] sum |x_obs| of the primed cube
     int sorted_slices = 0;      // p3d_pocs_sorted_spectrum: st_x holds the sorted order keys of that many slices (0: none)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -649,15 +651,16 @@ static int gen_fft2(p3d_plan* p, const c32* in, c32* out, int nslices, int inver
     return P3D_OK;
 }
 
-static int reduce_partials(p3d_plan* p, int nslices, double* stats)
+static int reduce_partials(p3d_plan* p, int nslices, double* stats, int tiles = 0)
 {
-    std::vector<float> part((size_t)STATS_PARTIAL * p->tiles * nslices);
+    if (tiles <= 0) tiles = p->tiles;
+    std::vector<float> part((size_t)STATS_PARTIAL * tiles * nslices);
     HIP_TRY(hipMemcpyAsync(part.data(), p->partials, sizeof(float) * part.size(), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     for (int s = 0; s < nslices; ++s) {
         double lr = -INFINITY, li = -INFINITY, mx = 0.0, mn = INFINITY, sq = 0.0;
-        for (int t = 0; t < p->tiles; ++t) {
-            const float* q = &part[((size_t)s * p->tiles + t) * STATS_PARTIAL];
+        for (int t = 0; t < tiles; ++t) {
+            const float* q = &part[((size_t)s * tiles + t) * STATS_PARTIAL];
             if (q[0] > lr || (q[0] == lr && q[1] > li)) { lr = q[0]; li = q[1]; }
             if (q[2] > mx) mx = q[2];
             if (q[3] < mn) mn = q[3];
@@ -1002,19 +1005,44 @@ int p3d_pocs_prime_dev(p3d_plan* p, const void* x, int dtype, const float* mask,
     r.work = p->work;
     r.sums = p->rowsum;
     r.dtype = dtype;
+    r.real_2048 = sw.real_2048 ? 1 : 0;
     HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
-    HIP_TRY(first_row_pass(p, r));
+    // float32 cubes: the row pairs of the real path (half the transforms, half-spectrum work buffer) and the statistics of the whole
+    // Hermitian spectrum from its stored half (ColArgs::herm_n2).  A run that takes the real path too (hard operator, POCS / FPOCS)
+    // finds its first pass done; any other run starts over with the complex first pass.
+    bool real = dtype == P3D_F32 && !sw.no_real && compact && r.bits64 && r.cbase && p->pipe_wgs > 0 && p->ops_row->row_real != nullptr;
+    if (real) {
+        const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
+        if (re == hipErrorNotSupported) real = false;
+        else HIP_TRY(re);
+    }
+    int violation = 0;
+    if (real) {   // the row pairs live on the compact samples: a cube with energy at unobserved positions takes the complex path
+        HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (violation) {
+            real = false;
+            HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
+        }
+    }
+    if (!real) HIP_TRY(first_row_pass(p, r));
     reduce_rows_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sum0, p->nil);
     ColArgs c = col_args(p, nslices);
     c.in = p->work;
     c.partials = p->partials;
+    int tiles = p->tiles;
+    if (real) {
+        c.n2 = p->nxl / 2 + 1;
+        c.herm_n2 = p->nxl;
+        tiles = (c.n2 + p->ops_col->col_tile - 1) / p->ops_col->col_tile;
+    }
     HIP_TRY(p->ops_col->col(COL_STATS, c, p->stream));
-    int violation = 0;
-    if (compact) HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    if ((rc = reduce_partials(p, nslices, stats))) return rc;   // (synchronises the stream)
+    if (compact && !real) HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if ((rc = reduce_partials(p, nslices, stats, tiles))) return rc;   // (synchronises the stream)
     p->primed.valid = true;
     p->primed.x = x; p->primed.mask = mask; p->primed.dtype = dtype; p->primed.nslices = nslices;
     p->primed.nonbinary = nonbinary; p->primed.nobs = nobs; p->primed.violation = violation;
+    p->primed.real = real;
     return P3D_OK;
 }
 
@@ -1285,13 +1313,16 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // (The flexible-length row pass keeps the pair in LDS and takes any real mask: no compact samples, no tables needed there.)
     bool real_path = dtype == P3D_F32 && base_op == P3D_OP_HARD && !adaptive && !percentile && p->ops_row->row_real != nullptr && !sw.no_real &&
                      (flex_rows ? p->nil % 2 == 0 : (compact && r.bits64 && r.cbase && p->pipe_wgs > 0));
-    if (real_path) {
+    // (a primed real first pass found no energy at unobserved positions -- p3d_pocs_prime_dev falls back to the complex pass otherwise)
+    const bool primed_real = primed_in && primed_state.real && real_path;
+    if (real_path && !primed_real) {
         const hipError_t re = p->ops_row->row_real(REAL_FIRST, r, p->pipe_wgs, p->stream);
         if (re == hipErrorNotSupported) real_path = false;
         else HIP_TRY(re);
     }
-    // The primed first pass is the complex one without the APOCS input mix: work buffer, compact samples and sum |x_obs| are there.
-    const bool primed = primed_in && !real_path && !adaptive;
+    // The primed first pass is the one this run would make itself (row pairs for the real path, the complex one without the APOCS input
+    // mix otherwise): work buffer, compact samples and sum |x_obs| are there.
+    const bool primed = primed_in && !adaptive && (real_path ? primed_real : !primed_state.real);
     if (primed) {
         HIP_TRY(hipMemcpyAsync(p->sums, p->sum0, sizeof(double) * nslices, hipMemcpyDeviceToDevice, p->stream));
         // the primed pass knew nothing of `active`: a slice the caller switched off reports sums[0] = 0, as on the unprimed path

@@ -142,14 +142,19 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
         // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
         float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
         if (valid) {
+            // half-spectrum buffer of a real cube (ColArgs::herm_n2): column k2 stands for column herm_n2 - k2 (its conjugate, mirrored in
+            // k1) as well, unless it is its own mirror image
+            const bool twice = a.herm_n2 > 0 && col != 0 && 2 * col != a.herm_n2;
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
                 const float p = v[q].x * v[q].x + v[q].y * v[q].y;
-                if (lex_greater(v[q].x, v[q].y, lr, li)) { lr = v[q].x; li = v[q].y; }
+                const float vi = twice ? fabsf(v[q].y) : v[q].y;
+                if (lex_greater(v[q].x, vi, lr, li)) { lr = v[q].x; li = vi; }
                 mx = fmaxf(mx, p);
                 mn = fminf(mn, p);
                 sq += p;
             }
+            if (twice) sq += sq;
         }
         // workgroups of short lines have fewer than 64 threads: never combine with an inactive lane
         const int lane = tid & 63;

@@ -207,6 +207,9 @@ struct ColArgs {
     int cus;            // host side only: compute units of the plan's device (0: ask the current device)
     int host_sw;        // host side only: P3D_SW_* experiment switches of the plan
     int flex_over;      // host side only: runs per CU of the persistent flexible-length column pass (P3D_FLEX_COL_OVER, default 8)
+    int herm_n2;        // COL_STATS on the half-spectrum work buffer of a float32 cube (columns 0 ... herm_n2/2 of herm_n2): the statistics
+                        // of the WHOLE Hermitian spectrum -- a column with a mirror image counts twice and offers its conjugates to the
+                        // lexicographic maximum (0: plain)
 };
 
 // |x| for the cost sums: the hardware square root (1 ulp) without the IEEE fix-up sequence the library call expands to (8 more

@@ -203,18 +203,18 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
                 if (h == 0) sa = sh; else sb = sh;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (a.sums != nullptr) {
+            if (a.sums != nullptr) {   // (not for an all-zero slice, dn < 0: it is only handed back -- its work rows hold nothing of this job)
                 double da = (double)sa, db = (double)sb;
                 constexpr int SEG = TPL >= 64 ? 64 : TPL;
 #pragma unroll
                 for (int o = SEG / 2; o > 0; o >>= 1) { da += __shfl_down(da, o, SEG); db += __shfl_down(db, o, SEG); }
                 if constexpr (WAVE) {
-                    if (tl == 0 && on) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
+                    if (tl == 0 && on && dn >= 0) { a.sums[(size_t)slice * a.n1 + ra] = da; a.sums[(size_t)slice * a.n1 + ra + PW] = db; }
                 } else {   // the wavefronts of a pair, in order
                     __syncthreads();
                     if (lane == 0) { red[2 * wave] = da; red[2 * wave + 1] = db; }
                     __syncthreads();
-                    if (tl == 0 && on) {
+                    if (tl == 0 && on && dn >= 0) {
                         double ta = 0.0, tb = 0.0;
                         for (int w = 0; w < WPL; ++w) { ta += red[2 * (uline * WPL + w)]; tb += red[2 * (uline * WPL + w) + 1]; }
                         a.sums[(size_t)slice * a.n1 + ra] = ta;

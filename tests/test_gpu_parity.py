@@ -524,6 +524,7 @@ def test_properties_full_size(P, orc):
 
 @pytest.mark.parametrize("shape,dtype,op,version", [((256, 1024), np.complex64, "hard", "regular"), ((64, 128), np.complex64, "soft", "regular"),
                                                     ((256, 512), np.float32, "soft", "regular"), ((256, 512), np.float32, "hard", "regular"),
+                                                    ((512, 1024), np.float32, "hard", "regular"), ((128, 256), np.float32, "hard", "adaptive"),
                                                     ((128, 256), np.complex64, "hard", "adaptive"), ((90, 50), np.complex64, "hard", "regular"),
                                                     ((64, 64), np.complex64, "hard", "regular")])
 def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
@@ -541,13 +542,21 @@ def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
     with ffi.Plan(nil, nxl, n) as plan:
         x, o, m = plan.alloc(obs.nbytes).upload(obs), plan.alloc(obs.nbytes), plan.alloc(maskf.nbytes).upload(maskf)
 
+        ref_stats = []
+
         def run(primed, spoil=False, switch_off=None):
             st = plan.prime_dev(x.ptr, dt, m.ptr, n) if primed else plan.stats_dev(x.ptr, dt, n)
+            if not ref_stats:
+                ref_stats.append(st.copy())
             active = st[:, 2] > 0
             if switch_off is not None:
                 active[switch_off] = False       # a NON-zero slice the caller does not want processed
             st[~active] = 1.0
-            tau = orc_schedule(st)
+            # (one schedule for every variant: a float32 cube is primed through the row pairs of the real path, whose statistics equal the
+            # complex pass's to rounding only -- with the hard operator that would move decisions, not just bits)
+            sched = ref_stats[0].copy()
+            sched[~active] = 1.0
+            tau = orc_schedule(sched)
             if spoil:
                 plan.fft2(obs[:1].astype(np.complex64))     # anything else on the plan: the primed state is gone
             done, sums, _ = plan.run_dev(x.ptr, dt, m.ptr, tau, niter, o.ptr, n, thresh_op=op, version=version, alpha=0.9 if version == "adaptive" else 1.0,
@@ -563,7 +572,12 @@ def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
         b = run(True)
         c = run(True, spoil=True)
         for other in (b, c):
-            assert np.array_equal(a[0], other[0]) and np.array_equal(a[1], other[1]) and np.array_equal(a[2], other[2]) and np.array_equal(a[3], other[3])
+            if dtype == np.float32:   # statistics of the Hermitian spectrum from its stored half
+                top = a[0][:, 2].max()
+                assert np.allclose(a[0][:, :4], other[0][:, :4], rtol=2e-6, atol=2e-6 * top) and np.allclose(a[0][:, 4], other[0][:, 4], rtol=1e-5)
+            else:
+                assert np.array_equal(a[0], other[0])
+            assert np.array_equal(a[1], other[1]) and np.array_equal(a[2], other[2]) and np.array_equal(a[3], other[3])
         assert not a[1][2].any() and a[2][2] == 0
         # the primed pass knows nothing of `active`: a non-zero slice switched off by the caller must still report sums[0] = 0 and
         # zero iterations, exactly like the unprimed path
@@ -573,6 +587,30 @@ def test_primed_first_pass_changes_nothing(ffi, orc, shape, dtype, op, version):
         assert np.array_equal(d[1][keep], e[1][keep]) and np.array_equal(d[1][keep], a[1][keep])
         for buf in (x, o, m):
             buf.free()
+
+
+@pytest.mark.parametrize("shape", [(64, 128), (256, 1024), (128, 512), (96, 256)])
+def test_primed_statistics_of_a_float32_cube_are_those_of_the_whole_spectrum(ffi, orc, shape):
+    """A float32 cube is primed through the row pairs of the real path: the work buffer holds columns 0 ... N/2 of the Hermitian spectrum
+    and the statistics pass weighs them (ColArgs::herm_n2) -- lexicographic maximum, max |X|, min |X| and sum |X|^2 of numpy's fft2."""
+    nil, nxl = shape
+    n = 3
+    _, mask, obs = orc.synthetic_cube(nil, nxl, n, 0.5, real=True)
+    maskf = mask.astype(np.float32)
+    with ffi.Plan(nil, nxl, n) as plan:
+        x, m = plan.alloc(obs.nbytes).upload(obs), plan.alloc(maskf.nbytes).upload(maskf)
+        st = plan.prime_dev(x.ptr, ffi.P3D_F32, m.ptr, n)
+        x.free(); m.free()
+    X = np.fft.fft2(obs.astype(np.float64))
+    for s in range(n):
+        peak = X[s].max()                      # numpy's complex maximum is lexicographic
+        top = np.abs(X[s]).max()
+        # (a sample and its mirror image have the same real part up to rounding: which of the two wins the tie-break on the imaginary
+        # part is rounding too -- in numpy as much as here; the half-spectrum pass settles it for the positive one)
+        assert abs(st[s, 0] - peak.real) <= 2e-6 * top and abs(abs(st[s, 1]) - abs(peak.imag)) <= 2e-6 * top, (st[s, :2], peak)
+        assert abs(st[s, 2] - top) <= 2e-6 * top
+        assert abs(st[s, 3] - np.abs(X[s]).min()) <= 2e-6 * top
+        assert abs(st[s, 4] - (np.abs(X[s]) ** 2).sum()) <= 1e-5 * (np.abs(X[s]) ** 2).sum()
 
 
 def test_generic_path_early_exit_and_zero_slice(P, orc):
