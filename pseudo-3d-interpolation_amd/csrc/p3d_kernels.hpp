@@ -96,7 +96,8 @@ hipError_t launch_row_pipe64(int pm, const RowArgs& a, int cus, hipStream_t st)
     if constexpr (Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
         constexpr int RPW64 = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0 || a.n1 % RPW64 != 0 || cus < 1) return hipErrorNotSupported;
-        if (a.adaptive || a.write_out || a.only_done || a.plain) return hipErrorNotSupported;   // APOCS, per-iteration store, finalize, fft2 hook
+        if (a.write_out || a.only_done || a.plain) return hipErrorNotSupported;   // per-iteration store, finalize, fft2 hook
+        if (a.adaptive && pm == PIPE_FIRST) return hipErrorNotSupported;          // APOCS: the input mix of the first pass stays with row_kernel (once per job)
         const bool tables = a.bits64 != nullptr && a.cbase != nullptr;
         if (pm == PIPE_FIRST) {
             if (a.x == nullptr || (a.xc != nullptr && !tables)) return hipErrorNotSupported;   // (no tables: the transform only)
@@ -125,6 +126,15 @@ hipError_t launch_row_pipe64(int pm, const RowArgs& a, int cus, hipStream_t st)
         } else if (pm == PIPE_LAST) {
             if (a.dtype == 0) { if (sp) P3D_PIPE64(0, true, PIPE_LAST); else P3D_PIPE64(0, false, PIPE_LAST); }
             else { if (sp) P3D_PIPE64(1, true, PIPE_LAST); else P3D_PIPE64(1, false, PIPE_LAST); }
+        } else if (pm == PIPE_MID && a.adaptive) {   // APOCS (plain stores: the transposed store's two barriers bought nothing measurable there)
+#define P3D_PIPE64_AD(DT, SP)                                                                                          \
+    do {                                                                                                               \
+        if ((e = allow_lds(row_pipe64_kernel<N, DT, SP, PIPE_MID, false, true>, lds64)) != hipSuccess) return e;       \
+        row_pipe64_kernel<N, DT, SP, PIPE_MID, false, true><<<grid64, pipe64_threads<N>(), lds64, st>>>(a);            \
+    } while (0)
+            if (a.dtype == 0) { if (sp) P3D_PIPE64_AD(0, true); else P3D_PIPE64_AD(0, false); }
+            else { if (sp) P3D_PIPE64_AD(1, true); else P3D_PIPE64_AD(1, false); }
+#undef P3D_PIPE64_AD
         } else if (pm == PIPE_MID) {
             bool ts = false;
             if constexpr (pipe64_can_tstore<N>() && LB64 == 16) {

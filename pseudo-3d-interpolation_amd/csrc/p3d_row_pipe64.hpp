@@ -117,7 +117,9 @@ enum PipeMode { PIPE_MID = 0, PIPE_FIRST = 1, PIPE_LAST = 2 };
 // TS (PIPE_MID, rows of one wavefront, n1 a multiple of the 16 rows of a workgroup): the forward transforms are handed round through
 // LDS before they are stored, so that ONE dwordx4 instruction writes the 1-KiB run [16 rows][8 columns] of a column block -- whole
 // 128-byte lines, half the line accesses of sixteen rows' 64-byte pieces and half the store instructions (8 instead of 16).
-template <int N, int DT, bool SPARSE, int PM, bool TS = false>
+// ADAPT (steady state only): APOCS -- the forward transform takes the mix of iterate and observation (POCS.py:574-575) instead of the
+// iterate; the mix needs nothing but the observed sample and the mask bit of the element it replaces, both at hand in the re-insertion loop
+template <int N, int DT, bool SPARSE, int PM, bool TS = false, bool ADAPT = false>
 __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe64_threads<N>() / 64 + 3) / 4)) void row_pipe64_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
@@ -463,7 +465,18 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
             const float w = __builtin_amdgcn_inverse_ballot_w64(mw_cur[q]) ? w_obs : 1.0f;
             xn = axpby(xn, w, raw_c32(bx[q]), a.alpha);        // POCS.py:616-619
             acc += abs_c32(xn);
-            v[q] = xn;
+            if constexpr (ADAPT && PM == PIPE_MID) {
+                // x_input of the next iteration (POCS.py:574-575), the expressions of row_kernel (same bits)
+                c32 xo = raw_c32(bx[q]);
+                asm volatile("" : "+v"(xo.x), "+v"(xo.y), "+v"(xn.x), "+v"(xn.y));   // one element at a time (not gathered into vectors across q: the kernel has no registers for that)
+                const float m = __builtin_amdgcn_inverse_ballot_w64(mw_cur[q]) ? 1.0f : 0.0f;
+                const c32 blend = xo * a.alpha + xn * w;
+                c32 mix = blend + (xo - xn * m) * (1.0f - a.alpha);
+                asm volatile("" : "+v"(mix.x), "+v"(mix.y));
+                v[q] = mix;
+            } else {
+                v[q] = xn;
+            }
         }
 #if P3D_STAMPS
         asm volatile("" : "+v"(acc));

@@ -892,6 +892,48 @@ def test_persistent_column_pass_of_2048_point_columns(monkeypatch):
     assert max(rel_l2(a[s], want[s]) for s in range(3)) <= 2e-3 and np.median([rel_l2(a[s], want[s]) for s in range(3)]) <= 1e-5
 
 
+@pytest.mark.parametrize("nil,nxl,dtype", [(64, 1024, np.complex64), (256, 1024, np.float32), (48, 2048, np.complex64), (64, 512, np.complex64),
+                                           (96, 128, np.complex64), (24, 4096, np.float32)])
+@pytest.mark.parametrize("eps", [0.0, 1e-6])
+def test_apocs_on_the_wave_uniform_row_pass(nil, nxl, dtype, eps, monkeypatch):
+    """APOCS (version='adaptive': the next iteration starts from a mix of iterate and observation, POCS.py:574-575) runs its steady state
+    on the wave-uniform persistent row pass as well (row_pipe64_kernel<..., ADAPT>): the mix is made where the re-insertion already holds
+    the observed sample and the mask bit.  Same bits as the generic passes (P3D_NO_PIPE64=1), with the sparse shortcut and without; with
+    the early exit (eps > 0) APOCS stores every iterate, which only the generic persistent pass does -- the compact samples are then kept
+    in ITS order (no word tables), checked here through the same comparison."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    mask = orc.synthetic_mask(nil, nxl, 0.6)
+    cube = np.stack([orc.synthetic_slice(nil, nxl, 60 + s) for s in range(3)]) * mask
+    cube = (cube.real if dtype == np.float32 else cube).astype(dtype)
+    kw = dict(niter=12, thresh_op="soft", thresh_model="exponential", eps=eps, p_max=0.99, p_min=1e-2, version="adaptive", alpha=0.8)
+    infos, res = [], {}
+    want = orc.pocs_cube(cube.astype(np.float64 if dtype == np.float32 else np.complex128), mask, infos=infos, **kw)
+    its = {}
+    # (float32 cubes: without this the statistics pass takes the row pairs of the real path where the word tables exist and the complex
+    # pass where they do not -- schedules that differ in the last bit, results that differ by rounding; this test compares kernels)
+    monkeypatch.setenv("P3D_NO_REAL", "1")
+    for pipe64 in (True, False):
+        for sparse in (True, False):
+            P.release_plans()
+            for name, on in (("P3D_NO_PIPE64", not pipe64), ("P3D_NO_SPARSE", not sparse)):
+                monkeypatch.setenv(name, "1") if on else monkeypatch.delenv(name, raising=False)
+            info = []
+            try:
+                res[pipe64, sparse] = P.pocs_cube(cube, mask, results=info, **kw)
+                its[pipe64, sparse] = [r["niterations"] for r in info]
+            finally:
+                P.release_plans()
+    first = res[True, True]
+    assert first.dtype == dtype
+    for s in range(len(want)):
+        assert rel_l2(first[s], want[s]) <= 1e-5, (s, rel_l2(first[s], want[s]))
+        assert its[True, True][s] == infos[s]["niterations"]
+    for key, other in res.items():
+        assert np.array_equal(first, other), key
+        assert its[key] == its[True, True]
+
+
 @pytest.mark.parametrize("nil,nxl,dtype", [(64, 1024, np.complex64), (100, 1024, np.complex64), (256, 1024, np.float32),
                                            (1000, 1024, np.complex64), (48, 2048, np.complex64), (50, 2048, np.float32),
                                            (24, 4096, np.complex64), (64, 512, np.complex64), (50, 256, np.complex64),
