@@ -8,6 +8,7 @@
 // 16 wavefronts (rows) per workgroup, one workgroup per CU, no global memory traffic inside the loop.
 // build: hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -I../../pseudo-3d-interpolation_amd/csrc rowpair.hip -o rowpair
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -79,6 +80,79 @@ __global__ __launch_bounds__(1024, 4) void pair_kernel(const c32* tw_g, c32* out
     out[(size_t)blockIdx.x * 1024 + tid] = acc;
 }
 
+// (C) 1024 = 32 x 32: 32 points per thread, a row in HALF a wavefront (two rows per wavefront, 8 wavefronts per CU for the same 16 rows in flight), ONE
+// exchange through LDS per transform instead of two.  A real transform (Stockham, pass 1 without twiddles, pass 2 with the ordered table w^(t j)), results in
+// the canonical layout (register k of lane j = element j + 32 k).  The exchange: lane j stores its 32 outputs contiguously (16 x 128 bits, two padding slots per
+// 32 elements keep the stores 16-byte aligned and spread the lanes over the banks), then reads element j + 32 t with lane stride 1.
+template <int DIR>
+__device__ __forceinline__ void dft32(c32 (&x)[32])
+{
+    constexpr float C[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                             0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                             -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f, 0.83146961230254523708f,
+                             0.92387953251128675613f, 0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                             0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+    c32 e[16], o[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { e[m] = x[2 * m]; o[m] = x[2 * m + 1]; }
+    Dft<16, DIR>::run(e);
+    Dft<16, DIR>::run(o);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const c32 ek = e[digit_rev<16>(k)];
+        c32 ok = o[digit_rev<16>(k)];
+        if (k == 8) ok = mul_i<DIR>(ok);
+        else if (k != 0) ok = ok * c32{C[k], DIR * S[k]};
+        x[k] = ek + ok;
+        x[k + 16] = ek - ok;
+    }
+}
+constexpr int LSTR32 = 1024 + 2 * 32;   // two padding slots per 32 elements
+template <int DIR>
+__device__ __forceinline__ void fft1024_32x32(c32 (&v)[32], c32* row, const c32* tw2, int j)
+{
+    dft32<DIR>(v);                                  // pass 1 (no twiddles): X[k] of butterfly j -> position 32 j + k
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        float4* p = reinterpret_cast<float4*>(row + 34 * j);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) p[m] = float4{v[2 * m].x, v[2 * m].y, v[2 * m + 1].x, v[2 * m + 1].y};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    v[0] = row[j];
+#pragma unroll
+    for (int t = 1; t < 32; ++t) v[t] = row[j + 34 * t] * tw2[(t - 1) * 32 + j];   // pass 2: in[j + 32 t] * w^(t j)
+    dft32<DIR>(v);                                  // X[k] = element j + 32 k: canonical again
+}
+__global__ __launch_bounds__(512, 2) void pair32_kernel(const c32* tw_g, c32* out, int trips)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    c32* twl = reinterpret_cast<c32*>(smem);            // [2][31][32]: forward, inverse
+    c32* data = twl + 2 * 31 * 32;
+    const int tid = threadIdx.x, rowi = tid >> 5, j = tid & 31;
+    for (int i = tid; i < 2 * 31 * 32; i += 512) twl[i] = tw_g[i];
+    __syncthreads();
+    c32* row = data + rowi * LSTR32;
+    c32 v[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) v[q] = c32{(float)(j + 32 * q) * 1e-3f, (float)(rowi + q) * 1e-3f};
+    for (int r = 0; r < trips; ++r) {
+        fft1024_32x32<INV>(v, row, twl + 31 * 32, j);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = v[q] * (1.0f / 1024.0f);
+        fft1024_32x32<FWD>(v, row, twl, j);
+    }
+    c32 acc{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc = acc + v[q];
+    out[(size_t)blockIdx.x * 1024 + tid] = acc;
+    if (trips == 1 && blockIdx.x == 0 && rowi == 0) {   // self-check: one round trip reproduces the input (stored behind the sums)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) out[(size_t)gridDim.x * 1024 + j + 32 * q] = v[q];
+    }
+}
+
 int main()
 {
     std::vector<c32> host(PassTables<N>::slots());
@@ -112,6 +186,41 @@ int main()
         printf("%s: %.3f ms for %d rows per CU (%d per wavefront, 16 wavefronts per CU) = %.3f us per row and CU\n",
                variant == 0 ? "A  LDS Stockham passes (today)            " : "B  cross-lane stages, no LDS (cost model)  ", best, rows_per_wave * ROWS, rows_per_wave,
                best * 1e3f / (rows_per_wave * ROWS));
+    }
+    {   // (C)
+        std::vector<c32> t2(2 * 31 * 32);
+        for (int d = 0; d < 2; ++d)
+            for (int t = 1; t < 32; ++t)
+                for (int j = 0; j < 32; ++j) {
+                    const double ang = (d == 0 ? -1.0 : 1.0) * 6.283185307179586476925286766559 * t * j / 1024.0;
+                    t2[(size_t)d * 31 * 32 + (t - 1) * 32 + j] = c32{(float)cos(ang), (float)sin(ang)};
+                }
+        c32 *tw2, *out2;
+        CK(hipMalloc(&tw2, sizeof(c32) * t2.size()));
+        CK(hipMemcpy(tw2, t2.data(), sizeof(c32) * t2.size(), hipMemcpyHostToDevice));
+        CK(hipMalloc(&out2, sizeof(c32) * 1024 * ((size_t)cus + 1)));
+        const size_t lds2 = sizeof(c32) * (2 * 31 * 32 + (size_t)ROWS * LSTR32);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pair32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        pair32_kernel<<<cus, 512, lds2>>>(tw2, out2, 1);
+        std::vector<c32> back(1024);
+        CK(hipMemcpy(back.data(), out2 + (size_t)cus * 1024, sizeof(c32) * 1024, hipMemcpyDeviceToHost));
+        double err = 0.0;
+        for (int e = 0; e < 1024; ++e) {   // row 0: input element e = (e * 1e-3, (e / 32) * 1e-3), one inverse + scale + forward round trip
+            const double dx = back[e].x - e * 1e-3, dy = back[e].y - (e / 32) * 1e-3;
+            err = fmax(err, sqrt(dx * dx + dy * dy));
+        }
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(e0));
+            pair32_kernel<<<cus, 512, lds2>>>(tw2, out2, rows_per_wave);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("C  32 x 32, one exchange, 32 points per thread : %.3f ms for %d rows per CU (two rows per wavefront, 8 wavefronts per CU) = %.3f us per row and CU; round-trip error %.1e\n",
+               best, rows_per_wave * ROWS, best * 1e3f / (rows_per_wave * ROWS), err);
     }
     return 0;
 }
