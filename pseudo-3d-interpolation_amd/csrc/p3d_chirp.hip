@@ -86,12 +86,14 @@ __device__ __forceinline__ void chirp_dft(c32 (&v)[Plan<M>::PPT], LDS lds, TW tw
 }
 
 // Launch shapes.  A workgroup holds the padded lines of its T columns / LB rows in LDS between the passes of a transform plus the
-// twiddle tables, and a CU should hold TWO workgroups (one covers the other's barriers and table loads; measured on 1009 x 1013:
-// row pass 2.39 -> ... ms): transforms of 2048 points run four lines per workgroup on the half table of p3d_col_shear.hpp (70 + 11 KiB).
+// twiddle tables, and a CU should hold at least TWO workgroups (one covers the other's barriers and table loads): transforms of 2048
+// points run four columns / two rows per workgroup on the half table of p3d_col_shear.hpp (70 + 11 KiB: two per CU; rows 35 + 11: three),
+// transforms of 4096 points one line per workgroup (35 + 20 KiB: two per CU).  Measured on 1009 x 1013 x 128 and 1101 x 1451 x 128:
+// profiles/r03_chirp_shape_sweep.txt.
 template <int M>
 struct ChirpCfg {
     static constexpr bool HALF = M >= 2048;   // ColTablesHalf / TwColHalf in both passes
-    static constexpr int T = M == 2048 ? 4 : col_tile<M>();
+    static constexpr int T = M == 2048 ? 4 : (M == 4096 ? 1 : col_tile<M>());
     static constexpr int LB = M >= 4096 ? 1 : (M == 2048 ? 2 : ROW_THREADS / Plan<M>::TPL);
     static constexpr int ROW_WAVES = M >= 4096 ? 2 : (M >= 1024 ? 3 : 4);   // waves per SIMD the LDS footprint allows anyway: the register budget follows it
     using ColTab = std::conditional_t<HALF, ColTablesHalf<M>, ColTables<M>>;
