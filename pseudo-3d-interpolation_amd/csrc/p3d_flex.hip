@@ -10,8 +10,8 @@
 // Line FFT: mixed-radix Stockham autosort in LDS.  The factor list AND everything a pass derives from it (strides, twiddle step,
 // the multiplier of its one division) are computed on the host and sit behind the line's twiddle table (FlexFactors); radices are
 // in-register butterflies: 2 ... 16 folded from two factors where possible, 11 and 13 on their own (odd radices first: the strided
-// writes of a pass with small stride then have an odd stride in banks); larger primes run in the chirp-z form on a padded length,
-// or as direct O(p^2) passes where that does not fit.  The direction of a transform is a template parameter, the first pass
+// writes of a pass with small stride then have an odd stride in banks); lengths with a larger prime factor run in the chirp-z form on a
+// power of two -- NOT here: flex_row / flex_col hand them to p3d_chirp.hip (round 3) -- or, where that does not apply, as direct O(p^2) passes.  The direction of a transform is a template parameter, the first pass
 // multiplies by no twiddles.  The twiddle table exp(-2 pi i k / n) sits in LDS.
 //   column pass: a workgroup owns T columns (one 64-byte column block for T = 8); element i of column c lives at X[i*T + c],
 //                which is exactly the tile's layout in the work buffer: loads and stores are linear copies.  Long columns (one
@@ -947,15 +947,15 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
 
 // The pass list of a length sits behind its device table (flex_build_table).  It is read through a pointer: as a by-value kernel
 // argument with run-time indexed arrays it was copied to scratch memory by some instantiations (260 bytes, vector loads per pass).
-size_t flex_table_len(const FlexFactors& pl) { return pl.blue ? (size_t)2 * pl.m + pl.n : (size_t)pl.n; }
+size_t flex_table_len(const FlexFactors& pl) { return pl.blue ? (size_t)pl.m + pl.n : (size_t)pl.n; }
 const FlexFactors* device_factors(const c32* table, const FlexFactors& pl) { return reinterpret_cast<const FlexFactors*>(table + flex_table_len(pl)); }
 
-// the tables of a chirp-z length inside its device table (flex_build_table): [exp(-2 pi i k / M) | chirp | spectrum of conj chirp |
-// FlexFactors | tables of the register-resident engine for M]
+// the tables of a chirp-z length inside its device table (flex_build_table): [chirp | spectrum of conj chirp | FlexFactors | tables of the
+// register-resident engine for M]
 ChirpTabs chirp_tabs(const c32* table, const FlexFactors& pl)
 {
     const c32* const tuned = table + flex_table_len(pl) + (sizeof(FlexFactors) + sizeof(c32) - 1) / sizeof(c32);
-    return ChirpTabs{tuned, tuned + chirp_rowtab_slots(pl.m), table + pl.m, table + pl.m + pl.n, pl.n, pl.m};
+    return ChirpTabs{tuned, tuned + chirp_rowtab_slots(pl.m), table, table + pl.n, pl.n, pl.m};
 }
 
 // row-pair passes for float32 cubes (mode = ROW_FIRST / ROW_MID / ROW_LAST)
@@ -1016,8 +1016,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     int tpr = two ? 128 : 64;
     int inpl = 0;
     if (!no_inplace) {
-        // in-place passes want one butterfly per thread: more wavefronts per row where the passes are wide (four for the
-        // 2048-point transforms of the chirp-z form of ~1000-point rows: 20 resident waves per CU instead of 6)
+        // in-place passes want one butterfly per thread: more wavefronts per row where the passes are wide
         // (four only where the passes keep 40 % of the 256 lanes busy: 600 = 15 x 10 x 4 would use a third of them and lost 9 %)
         int butterflies = 0;
         for (int p = 0; p < pl.nf; ++p) butterflies += pl.m / pl.f[p];
@@ -1064,11 +1063,10 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     // Long columns (one workgroup per CU): contiguous runs of tiles, the next tile prefetched.  Short ones share a CU and cover
-    // each other's loads, and the chirp-z form reads its tables from global memory between the passes (a wait for those is a
-    // wait for the prefetch): one tile per workgroup there (measured: 300-point columns 0.23 vs 0.27 ms, 1001-point 2.7 vs 4.0).
+    // each other's loads: one tile per workgroup there (measured: 300-point columns 0.23 vs 0.27 ms).
     const int ntiles = (a.n2 + T - 1) / T, total = ntiles * a.nslices;
     const bool no_persist = (a.host_sw & P3D_SW_FLEX_NO_PERSIST) != 0;
-    const bool persist = !no_persist && !pl.blue && lds + 512 > 80 * 1024;
+    const bool persist = !no_persist && lds + 512 > 80 * 1024;
     // eight workgroups' worth of runs per CU: the hardware hands the next run to the CU that is free (kept tiles cost twice an
     // emptied one and cluster around the low wavenumbers: one run per CU left some CUs with 45 % more work -- 0.90 vs 0.65 ms)
     const int over = a.flex_over > 0 ? a.flex_over : 8;
@@ -1094,8 +1092,8 @@ hipError_t flex_no_pipe(const RowArgs&, int, hipStream_t) { return hipErrorNotSu
 
 }  // namespace
 
-// device table of a line length: exp(-2 pi i k / n), or for the chirp-z form [exp(-2 pi i k / M) | chirp c_k = exp(-i pi k^2 / n) |
-// FFT_M(conj c, wrapped)], computed in double precision and rounded once
+// device table of a line length: exp(-2 pi i k / n), or for the chirp-z form [chirp c_k = exp(-i pi k^2 / n) | FFT_M(conj c, wrapped) | ... the
+// twiddle tables of the register-resident engine for M points], computed in double precision and rounded once
 void flex_build_table(int n, std::vector<c32>& out)
 {
     const FlexFactors pl = flex_factors(n);
@@ -1112,14 +1110,13 @@ void flex_build_table(int n, std::vector<c32>& out)
     }
     const int M = pl.m;
     const double pi = 3.14159265358979323846;
-    out.resize((size_t)2 * M + n);
-    gen_build_twiddles(M, out.data());
+    out.resize((size_t)M + n);
     std::vector<double> cr(n), ci(n), br(M, 0.0), bi(M, 0.0);
     for (int k = 0; k < n; ++k) {
         const long q = ((long)k * k) % (2L * n);   // k^2 mod 2n keeps the angle small
         cr[k] = std::cos(pi * (double)q / n);
         ci[k] = -std::sin(pi * (double)q / n);
-        out[(size_t)M + k] = c32{(float)cr[k], (float)ci[k]};
+        out[(size_t)k] = c32{(float)cr[k], (float)ci[k]};
         br[k] = cr[k]; bi[k] = -ci[k];
         if (k) { br[M - k] = cr[k]; bi[M - k] = -ci[k]; }
     }
@@ -1152,7 +1149,7 @@ void flex_build_table(int n, std::vector<c32>& out)
         br = ar;
         bi = ai;
     }
-    for (int k = 0; k < M; ++k) out[(size_t)M + n + k] = c32{(float)br[k], (float)bi[k]};
+    for (int k = 0; k < M; ++k) out[(size_t)n + k] = c32{(float)br[k], (float)bi[k]};
     append_factors();
     const size_t at = out.size();   // the twiddle tables of the register-resident engine for M points (p3d_chirp.hip)
     out.resize(at + chirp_table_slots(M), c32{0.f, 0.f});
