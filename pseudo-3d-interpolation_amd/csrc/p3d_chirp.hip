@@ -165,12 +165,15 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
     const unsigned blk0 = ((unsigned)(vcol >> 3) * (unsigned)n) * 8 + (vcol & 7);   // column-blocked: + row * 8
     const unsigned in_org = in_std ? (unsigned)vcol : blk0, in_pitch = in_std ? (unsigned)a.n2 : 8u;
     const unsigned out_org = out_std ? (unsigned)vcol : blk0, out_pitch = out_std ? (unsigned)a.n2 : 8u;
+    // element offsets: 32 bits inside the column-blocked buffer (checked by the launcher); 64 bits for the row-major cubes of the fft2 / time-axis
+    // hooks, whose trace count is the caller's (never in the iteration: ITER is compile time)
+    using off_t = std::conditional_t<ITER, unsigned, size_t>;
 
     c32 v[PPT];
 #pragma unroll
     for (int q = 0; q < H; ++q) {
         const int r = tl + TPL * q;
-        v[q] = r < n ? inb[in_org + (unsigned)r * in_pitch] : c32{0.f, 0.f};   // (columns past the edge re-read column 0)
+        v[q] = r < n ? inb[(off_t)in_org + (off_t)r * in_pitch] : c32{0.f, 0.f};   // (columns past the edge re-read column 0)
     }
     chirp_load_col_tables<M, THREADS>(twl, tab, tid);   // (under the latency of the tile's loads)
     __syncthreads();
@@ -196,7 +199,7 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
 #pragma unroll
                         for (int q = 0; q < H; ++q) {
                             const int r = tl + TPL * q;
-                            if (r < n) outb[out_org + (unsigned)r * out_pitch] = c32{0.f, 0.f};
+                            if (r < n) outb[(off_t)out_org + (off_t)r * out_pitch] = c32{0.f, 0.f};
                         }
                     }
                 }
@@ -255,7 +258,7 @@ void chirp_col_kernel(const ColArgs a, const c32* __restrict__ tab, const ChirpD
 #pragma unroll
         for (int q = 0; q < H; ++q) {
             const int r = tl + TPL * q;
-            if (r < n) outb[out_org + (unsigned)r * out_pitch] = v[q];
+            if (r < n) outb[(off_t)out_org + (off_t)r * out_pitch] = v[q];
         }
     }
 }
@@ -736,8 +739,7 @@ void chirp_build_tables(int m, c32* out)
 
 hipError_t chirp_col(int mode, const ColArgs& a, const ChirpTabs& t, hipStream_t st)
 {
-    if (t.n < 2 || 2 * t.n > t.m || (double)wk_slice_stride(t.n, a.n2) >= 4294967296.0 / 8.0) return hipErrorNotSupported;   // 32-bit element offsets
-    if ((a.in_std || a.out_std) && (double)t.n * (double)a.n2 >= 4294967296.0 / 8.0) return hipErrorNotSupported;
+    if (t.n < 2 || 2 * t.n > t.m || (double)wk_slice_stride(t.n, a.n2) >= 4294967296.0) return hipErrorNotSupported;   // 32-bit element offsets inside a work slice
     switch (t.m) {
 #define P3D_CASE(MM) case MM: return launch_chirp_col<MM>(mode, a, t, st);
         P3D_CHIRP_SIZES(P3D_CASE)
@@ -748,7 +750,7 @@ hipError_t chirp_col(int mode, const ColArgs& a, const ChirpTabs& t, hipStream_t
 
 hipError_t chirp_row(int mode, const RowArgs& a, const ChirpTabs& t, hipStream_t st)
 {
-    if (t.n < 2 || 2 * t.n > t.m || (double)wk_slice_stride(a.n1, t.n) >= 4294967296.0 / 8.0) return hipErrorNotSupported;
+    if (t.n < 2 || 2 * t.n > t.m || (double)wk_slice_stride(a.n1, t.n) >= 4294967296.0) return hipErrorNotSupported;   // (32-bit element offsets inside a work slice)
     switch (t.m) {
 #define P3D_CASE(MM) case MM: return launch_chirp_row<MM, false>(mode, a, t, st);
         P3D_CHIRP_SIZES(P3D_CASE)

@@ -737,7 +737,8 @@ def test_compact_observed_samples_path_is_exact(ffi, orc, monkeypatch):
 # steps 12 / 14: time <-> frequency helpers (closed form with numpy.fft; the xrft fork is not on disk)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nt,shape,up,real_only", [(64, (5, 7), 1, False), (100, (3, 4), 1, True), (90, (6,), 2, True),
-                                                   (250, (4, 4), 1, False), (512, (16, 8), 1, True), (37, (2, 3), 1, False)])
+                                                   (250, (4, 4), 1, False), (512, (16, 8), 1, True), (37, (2, 3), 1, False),
+                                                   (1009, (3, 5), 1, True), (530, (7,), 2, False)])   # (37, 1009, 1060 = 20 x 53: chirp-z along the time axis)
 def test_time2freq_closed_form_and_round_trip(ffi, nt, shape, up, real_only):
     rng = np.random.default_rng(nt)
     x = rng.standard_normal((nt,) + shape).astype(np.float32)
