@@ -824,8 +824,8 @@ def test_skipping_emptied_spectrum_tiles_changes_nothing(shape, missing, monkeyp
         assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143), (48, 999), (330, 52), (1009, 34), (17, 1101)])
-# (74, 62, 999 = 27 x 37, 1009, 34, 17, 1101 = 3 x 367: chirp-z on 256 ... 4096 points, p3d_chirp.hip; 143 = 11 x 13, 330 = 30 x 11, 52 = 4 x 13: in-register
+@pytest.mark.parametrize("shape", [(60, 100), (96, 75), (35, 64), (64, 35), (250, 120), (74, 62), (128, 143), (48, 999), (330, 52), (1009, 34), (17, 1101), (331, 40), (48, 131)])
+# (74, 62, 999 = 27 x 37, 1009, 34, 17, 1101 = 3 x 367, 331, 131: chirp-z on 64 ... 4096 points -- every instantiated length --, p3d_chirp.hip; 143 = 11 x 13, 330 = 30 x 11, 52 = 4 x 13: in-register
 # prime butterflies)
 @pytest.mark.parametrize("kw", [
     dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2),
