@@ -721,7 +721,9 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
         ve[i] = eo.first();
         vo[i] = eo.second();
     }
-    double acc = 0.0;
+    // per-thread partial sums in float (a thread adds at most 2 NR samples), combined in double: a convert and a double add per sample
+    // were 3 % of the vector instructions of these issue-bound kernels, and the sums only feed the convergence test (POCS.py:622)
+    float facc = 0.f;
     const int n = n0 + 2 * tx;
     if (!u.enabled) {
 #pragma unroll
@@ -773,13 +775,14 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
                 const float wgt = 1.0f - u.alpha * mk[i][e];
                 const T xn = cmulf(e ? vo[i] : ve[i], wgt) + cmulf(xo[i][e], u.alpha);
                 if (u.write_out) store_out(u.out, u.dtype, g, xn);
-                acc += (double)mag(xn);
+                facc += mag(xn);
                 if (u.adaptive) feed[g] = (cmulf(xo[i][e], u.alpha) + cmulf(xn, wgt)) + cmulf(xo[i][e] - cmulf(xn, mk[i][e]), 1.0f - u.alpha);
                 else feed[g] = xn;
             }
         }
     }
     if (u.enabled) {   // tile sum: shuffle tree per wavefront, then the four wavefronts through LDS
+        double acc = (double)facc;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     }
     __syncthreads();
     // ---- undo axis 1 + crop + re-insertion: samples (m_lo + m, n_lo + 2 ii), + 1 -> the tile's image of the iterate ----
-    double acc = 0.0;
+    float facc = 0.f;   // (float per thread, double across threads: see idwt2_tile_kernel)
     {
         T* feed_img = s_in + (m_lo - r0) * IW + (n_lo - c0);
         const int core_m0 = 2 * or0, core_n0 = 2 * oc0;   // the tile OWNS rows core_m0 ... + 2 TILE - 1 (cost sum, `out`)
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
                 const T xn = cmulf(ee ? eo.second() : eo.first(), wgt) + cmulf(xo2[ee], u.alpha);
                 if (mine_m && (unsigned)(gn - core_n0) < (unsigned)(2 * TILE)) {   // the tile's own core: cost sum, `out`
                     if (u.write_out) store_out(u.out, u.dtype, (size_t)s * per + (size_t)gm * u.n2 + gn, xn);
-                    acc += (double)mag(xn);
+                    facc += mag(xn);
                 }
                 T fd = xn;
                 if (u.adaptive) fd = (cmulf(xo2[ee], u.alpha) + cmulf(xn, wgt)) + cmulf(xo2[ee] - cmulf(xn, mk2[ee]), 1.0f - u.alpha);
@@ -1054,6 +1057,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
         }
     }
     // ---- cost sum of the core ----
+    double acc = (double)facc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = acc;

@@ -345,8 +345,10 @@ def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypa
         for sw in switches:
             monkeypatch.delenv(sw)
         assert np.array_equal(a[0], b[0]) and [n for n, _ in a[1]] == [n for n, _ in b[1]], switches
-        for (_, ca), (_, cb) in zip(a[1], b[1]):      # (the cost sums add their per-tile partial sums atomically: last bits vary run to run)
-            np.testing.assert_allclose(ca, cb, rtol=1e-9)
+        # (the cost is a difference of two nearly equal sums of |x|; a thread adds its few samples in float -- which samples differs between the
+        # kernels -- and the tiles' partial sums arrive atomically: the sums agree to 1e-7, the costs to that over their own size)
+        for (_, ca), (_, cb) in zip(a[1], b[1]):
+            np.testing.assert_allclose(ca, cb, rtol=5e-3, atol=1e-7 * float(np.max(ca)))
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     P.release_plans()
     with ffi.WaveletPlan(nil, nxl, 2, wavelet=wavelet) as plan:   # and the decomposition is PyWavelets' (the oracle's)
