@@ -356,3 +356,34 @@ def test_coarse_levels_in_one_workgroup_equal_the_tile_kernels(ffi, wo, monkeypa
         got = plan.unpack(a[2][0])
         scale = np.abs(ref[0]).max()
         assert np.abs(got[0] - ref[0]).max() <= 2e-5 * scale     # (30-tap filters over four levels: ~1e-5 of the peak in float32)
+
+
+@pytest.mark.parametrize("dtype,op,eps", [(np.float32, "soft", 0.0), (np.complex64, "hard", 1e-6), (np.float32, "hard", 1e-7)])
+def test_device_buffers_are_used_in_place(ffi, dtype, op, eps):
+    """The entry points take host or device pointers.  Device cubes are read and written where they are (no staging copies of the
+    observed cube and of the result); a result buffer that overlaps the observed cube goes through the staging buffer, because the
+    loop reads the observations in every iteration.  Same bits either way, with and without the early exit, all-zero slices included."""
+    from oracle import pocs_oracle as po
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    nil, nxl, n, K = 96, 80, 4, 9
+    mask = po.synthetic_mask(nil, nxl, 0.5).astype(np.float32)
+    cube = np.stack([po.synthetic_slice(nil, nxl, 10 + s, real=dtype == np.float32) for s in range(n)]) * mask
+    cube[2] = 0
+    cube = cube.astype(dtype)
+    dt = ffi.P3D_F32 if dtype == np.float32 else ffi.P3D_C64
+    with ffi.WaveletPlan(nil, nxl, n, wavelet="db4") as plan, ffi.Plan(nil, nxl, n) as mem:   # (the second plan only hands out device memory)
+        stats = plan.stats(cube)
+        tau = P._wavelet_schedule_from_stats(stats, "exponential", K, 0.99, 1e-2, "values")
+        active = np.abs(cube).reshape(n, -1).max(axis=1) > 0
+        want, done_h, sums_h, _ = plan.run(cube, mask, tau, K, thresh_op=op, eps=eps, active=active)
+        x, m, out = mem.alloc(cube.nbytes).upload(cube), mem.alloc(mask.nbytes).upload(mask), mem.alloc(cube.nbytes).upload(np.full_like(cube, 7))
+        assert np.array_equal(plan.stats_dev(x.ptr, dt, n), stats)
+        done, sums, _ = plan.run_dev(x.ptr, dt, m.ptr, tau, K, out.ptr, n, thresh_op=op, eps=eps, active=active)
+        assert np.array_equal(out.download(cube.shape, dtype), want) and np.array_equal(done, done_h)
+        assert np.array_equal(x.download(cube.shape, dtype), cube)                      # the observed cube is untouched
+        np.testing.assert_allclose(sums, sums_h, rtol=1e-9, atol=0)                     # (per-tile partial sums arrive atomically)
+        # in place: result over the observed cube
+        done2, _, _ = plan.run_dev(x.ptr, dt, m.ptr, tau, K, x.ptr, n, thresh_op=op, eps=eps, active=active)
+        assert np.array_equal(x.download(cube.shape, dtype), want) and np.array_equal(done2, done_h)
+        for b in (x, m, out):
+            b.free()
