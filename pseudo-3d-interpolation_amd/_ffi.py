@@ -1,7 +1,9 @@
 """ctypes binding of include/p3d.h (libp3d_hip.so).  No fallback: if the library is missing or no
 GPU is visible, every compute entry point raises."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -101,6 +103,22 @@ PROTOTYPES = {
 }
 
 
+def _preload_torch_hip():
+    """PyTorch-ROCm wheels bring their own HIP runtime.  When THIS library's runtime (the system's, /opt/rocm) is the first to initialise
+    in a process, a later ``torch.cuda`` call finds no device ("No HIP GPUs are available", measured on the MI355X boxes); the other
+    order works.  Loading torch's runtime library ahead of ours -- a dlopen, torch itself is not imported -- makes both orders work.
+    Nothing happens without torch, when torch is already imported, or with P3D_NO_TORCH_HIP_PRELOAD=1."""
+    if os.environ.get("P3D_NO_TORCH_HIP_PRELOAD") or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+        if path and os.path.isfile(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def lib():
     """Load libp3d_hip.so once.  Raises ``ImportError`` if it has not been built."""
     global _lib
@@ -109,6 +127,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        _preload_torch_hip()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
