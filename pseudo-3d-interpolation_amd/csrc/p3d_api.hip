@@ -1280,11 +1280,9 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     r.mask = nonbinary ? mask : nullptr;
     r.bits = nonbinary ? nullptr : p->bits;
     // APOCS runs the wave-uniform persistent pass too (round 3): the first pass, row_kernel with the input mix, writes the compact array
-    // in the word order when it is handed the tables.  Not with the early exit: APOCS then stores every iterate (write_out below), which
-    // only the generic persistent pass does -- and that one counts the compact samples row by row: no word tables then.
-    const bool word_tables = !nonbinary && !(adaptive && early);
-    r.bits64 = word_tables ? p->bits64 : nullptr;
-    r.cbase = word_tables ? p->cbase : nullptr;
+    // in the word order when it is handed the tables; with the early exit it stores every iterate there (write_out below).
+    r.bits64 = nonbinary ? nullptr : p->bits64;
+    r.cbase = nonbinary ? nullptr : p->cbase;
     r.xc = compact ? p->xc : nullptr;
     r.rowbase = p->rowbase;
     r.nobs = nobs;

@@ -96,7 +96,8 @@ hipError_t launch_row_pipe64(int pm, const RowArgs& a, int cus, hipStream_t st)
     if constexpr (Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
         constexpr int RPW64 = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0 || a.n1 % RPW64 != 0 || cus < 1) return hipErrorNotSupported;
-        if (a.write_out || a.only_done || a.plain) return hipErrorNotSupported;   // per-iteration store, finalize, fft2 hook
+        if (a.only_done || a.plain) return hipErrorNotSupported;                  // finalize, fft2 hook
+        if (a.write_out && !(a.adaptive && pm == PIPE_MID)) return hipErrorNotSupported;   // the per-iteration store exists for APOCS' steady state only
         if (a.adaptive && pm == PIPE_FIRST) return hipErrorNotSupported;          // APOCS: the input mix of the first pass stays with row_kernel (once per job)
         const bool tables = a.bits64 != nullptr && a.cbase != nullptr;
         if (pm == PIPE_FIRST) {

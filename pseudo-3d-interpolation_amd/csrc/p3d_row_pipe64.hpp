@@ -459,6 +459,16 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
 #pragma unroll
         for (int q = 0; q < PPT; ++q) asm volatile("" : "+v"(bx[q]));
         float acc = 0.f;
+        // (ADAPT + write_out: the row's place in the result cube, as store_cube addresses it)
+        __amdgpu_buffer_rsrc_t wo_srd = sums_srd;
+        unsigned wo_so = 0u, wo_vo = BUF_OOB;
+        if constexpr (ADAPT && PM == PIPE_MID) {
+            if (a.write_out) {
+                wo_srd = buf_srd(reinterpret_cast<const char*>(a.out) + (size_t)cur.slice * cube_slice_bytes, cube_slice_bytes);
+                wo_so = cube_soff(cur);
+                wo_vo = cur.on ? lane_c : BUF_OOB;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             c32 xn = v[q] * a.scale;
@@ -466,6 +476,12 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
             xn = axpby(xn, w, raw_c32(bx[q]), a.alpha);        // POCS.py:616-619
             acc += abs_c32(xn);
             if constexpr (ADAPT && PM == PIPE_MID) {
+                // APOCS with the early exit keeps every iterate (RowArgs::write_out): a slice that converges is simply left alone afterwards
+                if (a.write_out) {
+                    if (DT == 0) buf_store_c32(wo_srd, wo_vo, wo_so, xn);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn.x), wo_srd, (int)wo_vo, (int)wo_so, 0);
+                    wo_so += qc;
+                }
                 // x_input of the next iteration (POCS.py:574-575), the expressions of row_kernel (same bits)
                 c32 xo = raw_c32(bx[q]);
                 asm volatile("" : "+v"(xo.x), "+v"(xo.y), "+v"(xn.x), "+v"(xn.y));   // one element at a time (not gathered into vectors across q: the kernel has no registers for that)

@@ -900,8 +900,8 @@ def test_apocs_on_the_wave_uniform_row_pass(nil, nxl, dtype, eps, monkeypatch):
     """APOCS (version='adaptive': the next iteration starts from a mix of iterate and observation, POCS.py:574-575) runs its steady state
     on the wave-uniform persistent row pass as well (row_pipe64_kernel<..., ADAPT>): the mix is made where the re-insertion already holds
     the observed sample and the mask bit.  Same bits as the generic passes (P3D_NO_PIPE64=1), with the sparse shortcut and without; with
-    the early exit (eps > 0) APOCS stores every iterate, which only the generic persistent pass does -- the compact samples are then kept
-    in ITS order (no word tables), checked here through the same comparison."""
+    the early exit (eps > 0: the reference's default) APOCS stores every iterate, which the wave-uniform pass does as well
+    (RowArgs::write_out); a slice that converges is left alone from then on."""
     import pseudo_3d_interpolation_amd.functions.POCS as P
     from oracle import pocs_oracle as orc
     mask = orc.synthetic_mask(nil, nxl, 0.6)
