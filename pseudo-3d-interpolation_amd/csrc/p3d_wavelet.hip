@@ -113,6 +113,7 @@ __device__ __forceinline__ T smooth_at(const T* line, int n, size_t st, int k)
 struct Thresh {
     const c32* tau;  // [slice][niter][nlev][3]
     int niter, iter, nlev, lvl, op, z_lo, z_hi;
+    const int* done;   // early exit: per-slice state, != 0 = leave the slice's arrays alone (its iterate is rebuilt from them after the loop); nullptr: all slices
 };
 
 // forward step along one axis of a batch of 2-D arrays.
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     const int tx = threadIdx.x % LX, ty = threadIdx.x / LX;
     int s, tile;
     if (!xcd_decode(ntiles, ns, s, tile)) return;
+    if (th.done != nullptr && th.done[s] != 0) return;   // (uniform over the workgroup)
     const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int or0 = by * TILE, oc0 = bx * TILE, r0 = 2 * or0 - L + 2, c0 = 2 * oc0 - L + 2;
     // the last tile of an axis holds Ho mod TILE (Wo mod TILE) outputs -- 3 of 32 for a 512-point axis and db4 -- and needs
@@ -425,6 +427,7 @@ __global__ __launch_bounds__(COARSE_THREADS) void wcoarse_kernel(CoarseArgs a, F
     const int L = LT ? LT : f.len, HL = L / 2;
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= a.ns) return;
+    if (th.done != nullptr && th.done[s] != 0) return;
     T* X = reinterpret_cast<T*>(w_smem);
     T* Y = X + a.x_elems;
     if (tid < HL) {
@@ -563,6 +566,10 @@ struct Update {
     float alpha;
     int n1, n2;
     const int* done;
+    // "finalize" launch of the early exit (after the loop): only the slices that converged before the last iteration, done in 1 ... only_below - 1, and of
+    // those the ones whose level-1 details sit in the buffer at hand: only_parity - 1 = (done - 1) & 1 (3: either).  Their iterate is rebuilt from the
+    // coefficients they stopped at and stored -- the loop itself then stores the iterate in its last iteration only.  0: an ordinary pass
+    int only_parity, only_below;
 };
 
 __device__ __forceinline__ c32 load_x(const void* x, int dtype, size_t g, c32*)
@@ -604,7 +611,10 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
     if (!xcd_decode(ntiles, ns, s, tile)) return;
     const int by = tile / tiles_x, bx = tile - by * tiles_x;
     const int m0 = by * OH, n0 = bx * OW, kr0 = m0 / 2, kc0 = n0 / 2;
-    const int dn = u.enabled && u.done ? u.done[s] : 0;
+    const int dn = u.done ? u.done[s] : 0;
+    if (!u.enabled && dn != 0) return;   // a level above the first of a finished slice (early exit): its arrays stay as they are
+    const bool fin = u.enabled && u.only_parity != 0;
+    if (fin && !(dn > 0 && dn < u.only_below && (u.only_parity == 3 || ((dn - 1) & 1) == u.only_parity - 1))) return;   // (uniform over the workgroup)
     const size_t cnt = (size_t)Ho * Wo;
     const T* pa = a + (size_t)s * a_slice;
     const T* pd = det + (size_t)s * det_slice;
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
             if (n < RW) o[0] = ve[i];
             if (n + 1 < RW) o[1] = vo[i];
         }
-    } else if (dn != 0) {
+    } else if (dn != 0 && !fin) {
         if (dn < 0 && u.zero_fill) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
@@ -776,6 +786,7 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
                 const T xn = cmulf(e ? vo[i] : ve[i], wgt) + cmulf(xo[i][e], u.alpha);
                 if (u.write_out) store_out(u.out, u.dtype, g, xn);
                 facc += mag(xn);
+                if (fin) continue;   // (the slice is finished: nothing feeds on it)
                 if (u.adaptive) feed[g] = (cmulf(xo[i][e], u.alpha) + cmulf(xn, wgt)) + cmulf(xo[i][e] - cmulf(xn, mk[i][e]), 1.0f - u.alpha);
                 else feed[g] = xn;
             }
@@ -1218,6 +1229,7 @@ struct p3d_wplan {
     // copies: 0.4 ms each way per 256 MiB), the staging buffers above otherwise
     const void* cur_x = nullptr;
     void* cur_out = nullptr;
+    const int* loop_done = nullptr;   // the loop with the early exit: the per-slice states, for the passes that have no Update / Thresh of the caller's
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool fused = true;              // tile kernels (one launch per level and direction); P3D_WAVELET_UNFUSED=1 selects the per-axis kernels
     int tile_c = 0, tile_r = 0;     // coefficients per tile edge for complex64 / float32 work buffers
@@ -1421,8 +1433,9 @@ static int w_coarse(p3d_wplan* p, int ns, const Thresh* th, bool fwd, bool inv)
     a.nlev = p->nlev; a.LC = lc; a.do_fwd = fwd ? 1 : 0; a.do_inv = inv ? 1 : 0; a.ns = ns;
     a.x_elems = sizeof(T) == sizeof(float) ? p->cx_r : p->cx_c;
     const size_t lds = sizeof(T) == sizeof(float) ? p->clds_r : p->clds_c;
-    Thresh t{nullptr, 0, 0, 0, 0, 0, -1, -1};
+    Thresh t{nullptr, 0, 0, 0, 0, 0, -1, -1, nullptr};
     if (th) t = *th;
+    t.done = p->loop_done;
     const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
     if (lt == 8) wcoarse_kernel<T, 8><<<ns, COARSE_THREADS, lds, p->stream>>>(a, p->f, t);
     else if (lt == 4) wcoarse_kernel<T, 4><<<ns, COARSE_THREADS, lds, p->stream>>>(a, p->f, t);
@@ -1483,6 +1496,7 @@ static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u, bool coarse_do
         const size_t a_ld = l == p->nlev ? (size_t)Wo : (size_t)p->rw[l];
         const size_t a_slice = l == p->nlev ? p->ncoef : (size_t)p->rh[l] * p->rw[l];
         Update none{};
+        none.done = p->loop_done;
         const Update& up = (l == 1 && u) ? *u : none;
         // with the re-insertion fused only the nil x nxl crop of the level-0 reconstruction is needed
         const int OHt = up.enabled ? up.n1 : RH, OWt = up.enabled ? up.n2 : RW;
@@ -1604,6 +1618,10 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
 {
     const int niter = prm->niter;
     const bool early = prm->eps > 0.0, adaptive = prm->version == P3D_VER_ADAPTIVE;
+    // early exit on the fused kernels: a finished slice's arrays are left alone by EVERY pass from the iteration after its last one, and its iterate is
+    // rebuilt from them after the loop (below)
+    struct LoopDone { p3d_wplan* p; ~LoopDone() { p->loop_done = nullptr; } } loop_done_guard{p};
+    p->loop_done = (early && p->fused) ? p->done : nullptr;
     const dim3 ugrid(p->nil < 256 ? p->nil : 256, nslices);   // (a block walks over rows)
     wupdate_kernel<T><<<ugrid, 256, 0, p->stream>>>(nullptr, 0, 0, as<T>(p->feed), p->cur_x, dtype, p->mask, p->cur_out, p->sums, 0, adaptive ? 1 : 0, 0,
                                                    (float)prm->alpha, p->nil, p->nxl, p->done, 0);
@@ -1613,20 +1631,22 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
     T* const det1[2] = {as<T>(p->coef) + p->doff[1], as<T>(p->det1_alt)};
     const size_t det1_slice[2] = {p->ncoef, 3 * cnt1};
     if (l1fuse) {
-        const Thresh th0{p->tau, niter, 0, p->nlev, 0, prm->thresh_op, -1, -1};
+        const Thresh th0{p->tau, niter, 0, p->nlev, 0, prm->thresh_op, -1, -1, p->loop_done};
         const int rc = w_forward_fused<T>(p, nslices, &th0, false, 1, 1, det1[0], det1_slice[0]);
         if (rc) return rc;
     }
     for (int k = 0; k < niter; ++k) {
         const bool last = k + 1 == niter;
-        const Thresh th{p->tau, niter, k, p->nlev, 0, prm->thresh_op, -1, -1};
+        const Thresh th{p->tau, niter, k, p->nlev, 0, prm->thresh_op, -1, -1, p->loop_done};
         int rc = l1fuse ? w_forward_fused<T>(p, nslices, &th, true, 2) : (p->fused ? w_forward_fused<T>(p, nslices, &th, true) : w_forward<T>(p, nslices, &th));
         if (rc) return rc;
         if (p->fused) {
             Update u{};
             u.enabled = 1; u.feed = p->feed; u.x = p->cur_x; u.dtype = dtype; u.mask = p->mask; u.out = p->cur_out;
             u.sums = p->sums + (size_t)(k + 1) * nslices;
-            u.adaptive = (adaptive && !last) ? 1 : 0; u.write_out = (early || last) ? 1 : 0; u.zero_fill = last ? 1 : 0;
+            // (early exit: the iterate of a slice that converges is rebuilt once, after the loop, from the coefficients it stopped at -- storing every
+            // iterate of every slice instead cost 7 % of a configs[3] job)
+            u.adaptive = (adaptive && !last) ? 1 : 0; u.write_out = last ? 1 : 0; u.zero_fill = last ? 1 : 0;
             u.alpha = (float)prm->alpha; u.n1 = p->nil; u.n2 = p->nxl; u.done = p->done;
             if (!l1fuse) {
                 if ((rc = w_inverse_fused<T>(p, nslices, &u, true))) return rc;
@@ -1656,6 +1676,18 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
                                                            (float)prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0);
         }
         if (early) wconv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+    }
+    if (early && p->fused) {
+        Update uf{};
+        uf.enabled = 1; uf.feed = p->feed; uf.x = p->cur_x; uf.dtype = dtype; uf.mask = p->mask; uf.out = p->cur_out;
+        uf.sums = p->sums;   // (not added to: the slices are finished)
+        uf.write_out = 1; uf.alpha = (float)prm->alpha; uf.n1 = p->nil; uf.n2 = p->nxl; uf.done = p->done;
+        uf.only_below = niter;
+        for (int par = 0; par < (l1fuse ? 2 : 1); ++par) {
+            uf.only_parity = l1fuse ? par + 1 : 3;
+            const int rc = l1fuse ? w_inverse_fused<T>(p, nslices, &uf, true, 1, 1, det1[par], det1_slice[par]) : w_inverse_fused<T>(p, nslices, &uf, true, 1, 1);
+            if (rc) return rc;
+        }
     }
     W_TRY(hipGetLastError());
     return P3D_OK;

@@ -387,3 +387,45 @@ def test_device_buffers_are_used_in_place(ffi, dtype, op, eps):
         assert np.array_equal(x.download(cube.shape, dtype), want) and np.array_equal(done2, done_h)
         for b in (x, m, out):
             b.free()
+
+
+@pytest.mark.parametrize("real", [True, False])
+def test_early_exit_rebuilds_a_finished_slice_from_its_coefficients(wo, monkeypatch, real):
+    """With the convergence test on (eps > 0, the reference's default) the fused loop no longer stores every iterate of every slice: a slice that
+    converges is left alone by every pass from then on, and its iterate is rebuilt once, after the loop, from the coefficients it stopped at
+    (level-1 details in the buffer of its last iteration's parity).  Slices that stop at different iterations -- odd and even --, one that never does,
+    an all-zero one: same iteration counts as the oracle, results to 1e-5, and the same bits as the unfused variants behind the switches."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    shape = (200, 180)
+    mask = po.synthetic_mask(*shape, 0.5)
+    rng = np.random.default_rng(5)
+    slices = []
+    for s in range(7):
+        x = po.synthetic_slice(*shape, 20 + s, real=real)
+        x = x + (0.02 * s) * (rng.standard_normal(shape) + (0 if real else 1j * rng.standard_normal(shape)))   # more noise: later convergence
+        slices.append(x)
+    slices[3] = np.zeros(shape)
+    cube = (np.stack(slices) * mask).astype(np.float32 if real else np.complex64)
+    kw = dict(thresh_op="soft", thresh_model="exponential", niter=30, p_max=0.99, p_min=0.05, eps=2e-5)
+    infos, res = [], []
+    want = wo.pocs_cube_wavelet(cube.astype(np.float64 if real else np.complex128), mask, infos=infos, wavelet="db4", **kw)
+    got = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet="db4", results=res, **kw)
+    its = [r["niterations"] for r in res]
+    assert its == [i["niterations"] for i in infos], (its, [i["niterations"] for i in infos])
+    early = [n for n in its if 0 < n < 30]
+    assert early and its[3] == 0 and 30 in its, its                       # slices that stop early, the empty one, one that runs to the end
+    if not real:
+        assert len(set(n % 2 for n in early)) == 2, its                   # both parities of the level-1 details' ping-pong
+    for s in range(7):
+        err = rel_l2(got[s], want[s]) if its[s] else float(np.abs(got[s]).max())
+        assert err <= 2e-5, (s, its[s], err)       # (noisy slices: 1e-5 is the level of the unfused loop as well)
+    for switches in (("P3D_WAVELET_NO_L1FUSE",), ("P3D_WAVELET_NO_COARSE",), ("P3D_WAVELET_NO_L1FUSE", "P3D_WAVELET_NO_COARSE")):
+        P.release_plans()
+        for sw in switches:
+            monkeypatch.setenv(sw, "1")
+        other = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet="db4", **kw)
+        for sw in switches:
+            monkeypatch.delenv(sw)
+        assert np.array_equal(got, other), switches
+    P.release_plans()
