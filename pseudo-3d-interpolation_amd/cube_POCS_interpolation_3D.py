@@ -157,17 +157,34 @@ def main(argv=sys.argv, return_dataset=False):
         return ds
 
     merged = np.empty_like(data)
+    # `batch_chunk` is the unit of the OUTPUT (one file and one runtime record per batch, as the reference writes them); the GPU is handed several
+    # consecutive batches per call -- a 20-slice batch of the documented example is a fraction of what keeps the device and the host link busy
+    # (pocs_cube overlaps upload, loop and download of ~128-MiB portions on several plans inside ONE call, not across calls)
+    group_bytes = float(os.environ.get('P3D_CLI_GROUP_GIB', '4')) * 2.0 ** 30
+    per_slice = data[0].nbytes if len(data) else 1
+    groups, cur, cur_bytes = [], [], 0
     for sl in batches:
+        nb = (sl.stop - sl.start) * per_slice
+        if cur and cur_bytes + nb > group_bytes:
+            groups.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(sl)
+        cur_bytes += nb
+    if cur:
+        groups.append(cur)
+    for group in groups:
+        span = slice(group[0].start, group[-1].stop)
         results = []
         aux = Psi if TRANSFORM == 'SHEARLET' else None      # :307
-        block = pocs_cube(data[sl], mask, results=results, auxiliary_data=aux, **kwargs)
-        merged[sl] = block
-        save_cube(wrap(block, sl), create_file_path(coord[sl], prefix=prefix, root_path=out_path, suffix=suffix))
-        if cfg.get('output_runtime_results'):
-            with open(os.path.join(out_path, f"slice-{sl.start:04d}-{sl.stop:04d}.out"), mode='a', newline='\n') as f:
-                for info in results:   # one line per slice: niter;runtime;cost_1;...  (POCS.py:649-651)
-                    f.write(';'.join([str(i) for i in [info['niterations'], info['runtime']] + info['costs']]) + '\n')
-        xprint(f'batch {sl.start}-{sl.stop} done', kind='info', verbosity=verbose)
+        merged[span] = pocs_cube(data[span], mask, results=results, auxiliary_data=aux, **kwargs)
+        for sl in group:
+            block = merged[sl]
+            save_cube(wrap(block, sl), create_file_path(coord[sl], prefix=prefix, root_path=out_path, suffix=suffix))
+            if cfg.get('output_runtime_results'):
+                with open(os.path.join(out_path, f"slice-{sl.start:04d}-{sl.stop:04d}.out"), mode='a', newline='\n') as f:
+                    for info in results[sl.start - span.start:sl.stop - span.start]:   # one line per slice: niter;runtime;cost_1;...  (POCS.py:649-651)
+                        f.write(';'.join([str(i) for i in [info['niterations'], info['runtime']] + info['costs']]) + '\n')
+            xprint(f'batch {sl.start}-{sl.stop} done', kind='info', verbosity=verbose)
 
     if cfg.get('output_runtime_results'):
         combine_runtime_results(out_path, prefix=prefix)
