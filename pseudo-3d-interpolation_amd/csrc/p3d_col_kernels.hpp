@@ -47,9 +47,7 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     const int col = tile * T + cbl * CW + c_lo;
     const bool valid = col < a.n2;
 
-    // a finished slice is skipped -- but its flag is only ASKED for here and looked at behind the tile's loads (below): a `return` in front of them
-    // would put the flag's latency in front of every workgroup's first load (the early exit cost both passes 5 % that way)
-    const int slice_done = a.done ? a.done[slice] : 0;
+    if (a.done && a.done[slice] != 0) return;
 
     for (int i = tid; i < ColTables<N>::slots(); i += THREADS) twl[i] = a.tw[i];
     __syncthreads();
@@ -73,7 +71,6 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
     };
     c32 v[PPT];
     if (MODE == COL_SHRINK) {
-        if (slice_done != 0) return;
         // coefficients of shearlet s of slice b (grid.y = b*nsh + s): back to the space domain, threshold (POCS.py:598 with a
         // per-shearlet tau), forward again; in place on the work buffer
         const int b = slice / a.sh.nsh, s = slice - b * a.sh.nsh;
@@ -104,7 +101,6 @@ __global__ __launch_bounds__(T* Plan<N>::TPL, (T * Plan<N>::TPL >= 1024 ? 4 : P3
 #pragma unroll
     for (int q = 0; q < PPT; ++q)   // scalar base + 32-bit byte offset (a slice is far below 4 GiB); columns past the edge re-read column 0
         v[q] = *reinterpret_cast<const c32*>(reinterpret_cast<const char*>(inb) + (in_org + (unsigned)(tl + TPL * q) * in_pitch) * 8u);
-    if (slice_done != 0) return;   // (uniform over the workgroup)
 
     if (MODE != COL_INV) line_fft<N, FWD, false>(v, lds, tw, tl);
 

@@ -175,9 +175,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
     // row: the unit's index inside its slice (= the row itself when RPW == 1); on: the unit is computed and stored; zero (PIPE_LAST):
     // the unit belongs to an all-zero slice, which is handed back untouched (POCS.py:515-521)
     struct Where { unsigned slice, row; bool on, zero; };
-    // state of the slice of unit g (0 where there is no table or no such unit)
-    auto done_of = [&](unsigned g) -> int { return (k_done != nullptr && g < total) ? k_done[g / upslice] : 0; };
-    auto locate_with = [&](unsigned g, int dn) -> Where {
+    auto locate = [&](unsigned g) -> Where {
         Where w;
         w.on = g < total;
         w.zero = false;
@@ -185,6 +183,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
         w.slice = gg / upslice;
         w.row = gg - w.slice * upslice;
         if (k_done != nullptr && w.on) {
+            const int dn = k_done[w.slice];
             if (PM == PIPE_LAST) {   // converged earlier (dn > 0): `out` already holds that iterate
                 w.zero = dn < 0;
                 w.on = dn <= 0;
@@ -194,7 +193,6 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
         }
         return w;
     };
-    auto locate = [&](unsigned g) -> Where { return locate_with(g, done_of(g)); };
     auto work_srd = [&](const Where& w) { return buf_srd(reinterpret_cast<const char*>(a.work) + w.slice * wstride * 8, slice_bytes); };
     auto work_soff = [&](const Where& w) -> unsigned { return w.row * (unsigned)(RPW * 64) + (unsigned)wsub * qs64; };
     // by[] <- the unit's elements of the work buffer; emptied column blocks (SPARSE) read as zero without a memory access
@@ -441,12 +439,8 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
     unsigned st_acc[STAMP_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
-    // The early exit's per-slice flag of the NEXT unit is a scalar load, and scalar loads share their counter with the LDS operations: one of them in flight
-    // across a transform turns every wait of that transform's exchanges into a wait for everything (the early exit cost this pass 5 % that way).  It is
-    // requested two units ahead, next to the mask words -- the scalar loads the loop already has, with their wait where it is cheap -- and carried.
-    int dn_nxt = done_of(g + step);
     for (unsigned g0 = wg * UPB; g0 < total; g0 += step) {
-        const Where nxt = locate_with(g + step, dn_nxt);
+        const Where nxt = locate(g + step);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = raw_c32(by[q]);
@@ -515,7 +509,6 @@ __global__ __launch_bounds__((pipe64_threads<N>()), (P3D_EXP_HALFWG ? 4 : (pipe6
         unsigned long long mw_nxt[PPT];
         unsigned cbs_n[PPT];
         obs_tables(mw_nxt, cbs_n, nxt);
-        dn_nxt = done_of(g + 2 * step);
         P3D_STAMP(4);   // requests for the next row's work-buffer elements (scalar tables first)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PM == PIPE_MID) {
