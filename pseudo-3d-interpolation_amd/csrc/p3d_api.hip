@@ -1404,6 +1404,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     }
 
     HIP_TRY(stamp());
+    int last_finalized = 0;   // early exit: slices with done <= last_finalized have been handed to `out`
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
         if (percentile) {
@@ -1469,12 +1470,17 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             conv_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
             // slices that just finished are skipped from now on: their rows must read as zero afterwards
             HIP_TRY(hipMemsetAsync(p->rowsum, 0, sizeof(double) * (size_t)p->nil * nslices, p->stream));
-            if (finalize && k + 1 < niter) {
+            // (the finalize launch -- mostly workgroups that find nothing to do -- runs every FIN_EVERY iterations and before the last pass: a slice that has
+            // converged keeps its work rows, nothing touches them any more)
+            constexpr int FIN_EVERY = 8;
+            if (finalize && k + 1 < niter && (k + 1 - last_finalized >= FIN_EVERY || k + 2 >= niter)) {
                 RowArgs f = r;
                 f.nzm = nullptr;  // the rows it reads were written by the row pass: all there
                 f.nzl = nullptr;
                 f.nzflag = nullptr;
+                f.only_done_lo = last_finalized;
                 f.only_done = k + 1;
+                last_finalized = k + 1;
                 f.plain = 0;      // the observed samples are needed (exact hand-back at observed traces)
                 f.sums = nullptr;
                 f.done = p->done;

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
 
     const int dn = a.done ? a.done[slice] : 0;
     if (MODE == ROW_LAST && a.only_done) {
-        if (dn != a.only_done) return;
+        if (dn <= a.only_done_lo || dn > a.only_done) return;
     } else if (MODE == ROW_LAST) {
         if (dn > 0) return;   // converged earlier: `out` already holds that iterate
         if (dn < 0) {         // all-zero slice is handed back untouched (POCS.py:515-521)
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(chirp_row_threads<M>(), chirp_row_waves<M>()) void 
 
     const int dn = a.done ? a.done[slice] : 0;
     if (MODE == ROW_LAST && a.only_done) {
-        if (dn != a.only_done) return;
+        if (dn <= a.only_done_lo || dn > a.only_done) return;
     } else if (MODE == ROW_LAST) {
         if (dn > 0) return;
         if (dn < 0) {

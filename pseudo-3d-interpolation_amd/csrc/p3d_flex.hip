@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void flex_row_kernel(const RowArgs a, const Fl
     const int dn = a.done ? a.done[slice] : 0;
     const size_t sbase = ((size_t)slice * a.n1 + vrow) * n;   // row-major cubes (x, out)
     if (mode == ROW_LAST && a.only_done) {
-        if (dn != a.only_done) return;
+        if (dn <= a.only_done_lo || dn > a.only_done) return;
     } else if (mode == ROW_LAST) {
         if (dn > 0) return;   // converged earlier: `out` already holds that iterate
         if (dn < 0) {         // all-zero slice is handed back untouched (POCS.py:515-521)
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(256) void flex_row_real_kernel(const RowArgs a, con
     const float* const xa = reinterpret_cast<const float*>(a.x) + sbase;
     float* const oa = reinterpret_cast<float*>(a.out) + sbase;
     if (mode == ROW_LAST && a.only_done) {
-        if (dn != a.only_done) return;
+        if (dn <= a.only_done_lo || dn > a.only_done) return;
     } else if (mode == ROW_LAST) {
         if (dn > 0) return;
         if (dn < 0) {

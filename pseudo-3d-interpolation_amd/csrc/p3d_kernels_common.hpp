@@ -171,7 +171,8 @@ struct RowArgs {
     const uint8_t* nzflag; // the flexible row pass (p3d_flex.hip) reads the column pass's tile flags directly: [nslices][nz_tiles],
     int nz_tiles;          //   a tile spans nz_col_t columns
     int nz_col_t;
-    int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done == only_done; their work
+    int only_done_lo;      // LAST, only_done > 0: the finalize launch takes the slices with only_done_lo < done <= only_done (it runs every few iterations)
+    int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done is in (only_done_lo, only_done]; their work
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
     const unsigned long long* bits64;  // rows of whole wavefronts: the mask as lane masks, word pipe64_word(row, TPL/64, wsub, q) bit l =
                                        // mask[row][64*wsub + l + TPL*q]

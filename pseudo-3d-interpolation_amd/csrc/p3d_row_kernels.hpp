@@ -52,7 +52,7 @@ __global__ __launch_bounds__((row_threads<N, MODE>()), (row_threads<N, MODE>() >
 
     const int dn = a.done ? a.done[slice] : 0;
     if (MODE == ROW_LAST && a.only_done) {
-        if (dn != a.only_done) return;
+        if (dn <= a.only_done_lo || dn > a.only_done) return;
     } else if (MODE == ROW_LAST) {
         if (dn > 0) return;  // converged earlier: `out` already holds that iterate
         if (dn < 0) {        // all-zero slice is handed back untouched (POCS.py:515-521)

@@ -79,7 +79,7 @@ __global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(cons
         if (k_done != nullptr) dn = k_done[slice];
         bool on = in_range;
         if (MODE == REAL_MID) on = on && dn == 0;
-        if (MODE == REAL_LAST) on = on && (a.only_done ? dn == a.only_done : dn <= 0);
+        if (MODE == REAL_LAST) on = on && (a.only_done ? (dn > a.only_done_lo && dn <= a.only_done) : dn <= 0);
         if (MODE == REAL_FIRST) on = on && dn == 0;
         // lock-step (adjacent row pairs complete the 128-byte lines of a column block) -- and a trip in which NONE of the workgroup's units has anything
         // to do is skipped as a whole: the "finalize" launch of the early exit (only_done) touches the few slices that have just converged, and ran a full
