@@ -82,14 +82,16 @@ static __global__ void rowbase_kernel(const uint16_t* bits, unsigned* rowbase, i
 static __global__ void nz_count_kernel(const uint8_t* flags, unsigned long long* count, int nslices, int tiles, int col_t, int nblocks, const int* done)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nslices * nblocks) return;
-    const int s = i / nblocks, b = i - s * nblocks;
-    if (done && done[s] != 0) return;
-    const uint8_t* f = flags + (size_t)s * tiles;
+    const bool live = i < nslices * nblocks;
+    const int s = live ? i / nblocks : 0, b = live ? i - s * nblocks : 0;
     unsigned any = 0;
-    if (col_t >= 8) any = f[b / (col_t / 8)];
-    else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
-    if (any) atomicAdd(count, 1ull);
+    if (live && !(done && done[s] != 0)) {
+        const uint8_t* f = flags + (size_t)s * tiles;
+        if (col_t >= 8) any = f[b / (col_t / 8)];
+        else for (int t = 0; t < 8 / col_t; ++t) { const int ti = b * (8 / col_t) + t; if (ti < tiles) any |= f[ti]; }
+    }
+    const unsigned long long kept = __ballot(any != 0);   // one atomic per wavefront, not one per kept block (all on one address)
+    if ((threadIdx.x & 63u) == 0 && kept) atomicAdd(count, (unsigned long long)__popcll(kept));
 }
 
 static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsigned long long* count, int nslices, int tiles, int col_t, int groups,
@@ -112,7 +114,12 @@ static __global__ void nz_pack_kernel(const uint8_t* flags, uint16_t* nzm, unsig
             kept += any ? 1u : 0u;
         }
         nzm[i] = (uint16_t)word;
-        if (kept) atomicAdd(count, (unsigned long long)kept);
+    }
+    {   // kept blocks of the launch: one atomic per wavefront (one per thread -- a few thousand on one address -- was most of this kernel's 10 us)
+        unsigned wsum = kept;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o, 64);
+        if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(count, (unsigned long long)wsum);
     }
     // rows of whole wavefronts (groups = 8, 16, 32): the same flags as 64-bit lane masks, word (slice, wavefront, q) bit l = the
     // flag word of thread group 8 * wavefront + l / 8, bit q; those 8 threads are neighbours in the wave and build two words each
