@@ -585,7 +585,7 @@ static RunSwitches read_switches()
     s.no_compact = getenv("P3D_NO_COMPACT") != nullptr;
     s.no_real = getenv("P3D_NO_REAL") != nullptr;
     s.no_sparse = getenv("P3D_NO_SPARSE") != nullptr;
-    s.real_2048 = getenv("P3D_REAL_2048") != nullptr;
+    s.real_2048 = getenv("P3D_NO_REAL_2048") == nullptr;   // rows of 2048 samples in pairs: on since the kernel got the registers its occupancy allows (round 3)
     s.no_resident = getenv("P3D_NO_RESIDENT") != nullptr;
     s.no_tstore = getenv("P3D_NO_TSTORE") != nullptr;
     s.force_colpipe = getenv("P3D_FORCE_COLPIPE") != nullptr;

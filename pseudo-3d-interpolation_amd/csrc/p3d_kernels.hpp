@@ -215,9 +215,10 @@ hipError_t launch_row_real(int mode, const RowArgs& a, int cus, hipStream_t st)
 {
     if constexpr ((64 % Plan<N>::TPL == 0 || Plan<N>::TPL % 64 == 0) && Plan<N>::TPL >= 8 && Plan<N>::TPL <= 256 && Plan<N>::PPT == 16) {
         constexpr int PW = Plan<N>::TPL >= 64 ? 1 : 64 / Plan<N>::TPL, WPL = Plan<N>::TPL >= 64 ? Plan<N>::TPL / 64 : 1;
-        // Rows of 2048 samples (two wavefronts per pair: workgroup barriers around the split and the sums on top of those of the
-        // transforms, 8 waves per CU) lose what the half spectrum gains: 1024 x 2048 x 256 float32, 20 iterations, 71.3 ms against
-        // 68.4 on the complex path; 4096 samples: 37.1 against 43.0.  The kernel handles both; only the latter is switched on.
+        // Rows of 2048 samples (two wavefronts per pair: workgroup barriers around the split and the sums on top of those of the transforms, 8 waves
+        // per CU) used to lose what the half spectrum gains (round 2: 71.3 ms against 68.4 on the complex path for 1024 x 2048 x 256 float32, 20
+        // iterations) -- at a register budget meant for 16 waves per CU, with 27 registers spilled.  With the budget its LDS-bound occupancy allows
+        // (round 3) the pair form wins there too: 16.8 against 17.7 ms on 1024 x 2048 x 64; 4096 samples: 17.7 against 19.5.  P3D_NO_REAL_2048=1: off.
         if (WPL == 2 && !a.real_2048) return hipErrorNotSupported;
         if (a.n1 % (2 * PW) != 0 || a.bits64 == nullptr || a.cbase == nullptr || a.dtype != 1) return hipErrorNotSupported;
         if ((double)a.nslices * (double)wk_slice_stride(a.n1, N / 2 + 1) >= 4294967296.0) return hipErrorNotSupported;

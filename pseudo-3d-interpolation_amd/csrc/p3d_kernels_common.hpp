@@ -181,7 +181,7 @@ struct RowArgs {
     float alpha;
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)
-    int real_2048;         // host side only: the row-pair path for rows of 2048 samples is switched on (experiment switch P3D_REAL_2048)
+    int real_2048;         // host side only: the row-pair path for rows of 2048 samples is on (off: experiment switch P3D_NO_REAL_2048)
     int tstore;            // host side only: rows of one wavefront hand their transforms round through LDS and store 1-KiB runs (P3D_NO_TSTORE unset)
     int host_sw;           // host side only: P3D_SW_* experiment switches of the plan (read from the environment once per plan)
     ShearArgs sh;          // ROW_SPREAD_INV, ROW_GATHER_FWD

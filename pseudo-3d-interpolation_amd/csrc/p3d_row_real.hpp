@@ -21,7 +21,9 @@ namespace p3d {
 enum RealMode { REAL_FIRST = 0, REAL_MID = 1, REAL_LAST = 2 };
 
 template <int N, int MODE, bool SPARSE>
-__global__ __launch_bounds__((pipe64_threads<N>()), 4) void row_real_kernel(const RowArgs a)
+// (register budget = what the workgroup's own wavefronts need per SIMD, as in row_pipe64_kernel: rows of 2048 / 4096 samples leave one or two 256- / 512-thread
+// workgroups per CU for their LDS anyway -- at a flat "4 waves per SIMD" the 4096-sample kernel spilled 17 registers for an occupancy it cannot have)
+__global__ __launch_bounds__((pipe64_threads<N>()), ((pipe64_threads<N>() / 64 + 3) / 4)) void row_real_kernel(const RowArgs a)
 {
     using PL = Plan<N>;
     constexpr int TPL = PL::TPL, PPT = PL::PPT;

@@ -1051,7 +1051,7 @@ def test_real_cubes_share_one_transform_per_row_pair(nil, nxl, kw, monkeypatch):
     cube = cube.astype(np.float32)
     kw = dict(kw, thresh_op="hard")
     res = {}
-    monkeypatch.setenv("P3D_REAL_2048", "1")   # rows of 2048 samples: implemented and tested, switched off by default (slower there)
+    # (rows of 2048 samples run in pairs by default since round 3: the kernel got the register budget its occupancy allows)
     for real in (True, False):
         for sparse in (True, False):
             P.release_plans()

@@ -22,8 +22,7 @@ KNOWN_SCRATCH = {
     r"resident_kernel<128, 128, \d>": "128 x 128 slices are NOT routed to the single-kernel path (p3d_resident.hpp: RESIDENT_MAX_POINTS); kept for the record of why",
     r"row_pipe_kernel<\d+, true, \d, (true|false), true>": "generic per-lane persistent row pass (APOCS with the early exit on short rows, odd row counts): 168-register budget, not a default path",
     r"row_real_kernel<(256|512|1024), 1, false>": "row-pair steady state WITHOUT the sparse shortcut (P3D_NO_SPARSE / dense spectra): the sparse form, the default, is clean",
-    r"row_real_kernel<2048, \d, (true|false)>": "row pairs at 2048 samples: implemented, switched off by default (slower than the complex path, DESIGN.md section 3)",
-    r"row_real_kernel<4096, \d, (true|false)>": "row pairs at 4096 samples, four wavefronts per pair at 128 registers: 15-17 spilled registers, still faster than the complex path there",
+    r"row_real_kernel<(2048|4096), \d, (true|false)>": "row pairs at 2048 / 4096 samples: no VGPR spills since their register budget follows their LDS-bound occupancy; 80 B of scratch for spilled SCALAR registers (the mask / base tables of two units)",
     r"row_pipe64_kernel<128, 1, false, 0, false, false>": "float32 cube through the complex passes at 128-sample rows, dense form",
     r"col_pipe_kernel<256, 32, \d, false>": "persistent column pass at 256 points (an experiment behind P3D_FORCE_COLPIPE)",
     r"flex_col_kernel<false, false>": "SGPR spills of the run-time radix dispatch (one tile per workgroup form)",
