@@ -220,18 +220,43 @@ def fill_random_spectrum(torch, out, nil, nxl, first, pool, m, plan):
 # slice through scipy.fft's threads instead
 # ---------------------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
-    kind, x, mask, niter, op, extra = job
+    kind, x, mask, niter, op, extra = job[:6]
+    keep = len(job) > 6 and job[6]
     t0 = time.perf_counter()
+    res = None
     if kind == "FFT":
         from oracle import pocs_oracle as orc
-        orc.pocs_slice(x, mask, niter=niter, thresh_op=op, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
+        res = orc.pocs_slice(x, mask, niter=niter, thresh_op=op, thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3)
     elif kind == "WAVELET":
         from oracle import wavelet_oracle as wo
-        wo.pocs_slice_wavelet(x, mask, wavelet=extra, niter=niter, thresh_op=op, thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-3)
-    return time.perf_counter() - t0
+        res = wo.pocs_slice_wavelet(x, mask, wavelet=extra, niter=niter, thresh_op=op, thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-3)
+    wall = time.perf_counter() - t0
+    return (wall, res) if keep else wall
 
 
-def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None):
+def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None):
+    """rel-L2 per slice between the GPU result of the TIMED job (the first slices of its output cube) and the oracle run on the
+    same observed slices for the same number of iterations -- fed in double precision (BASELINE's yardstick), and once more in the
+    cube's own precision: NumPy's float32-vs-float64 spread on these very slices, which is what the reference itself gives up."""
+    wide = np.complex128 if np.iscomplexobj(obs_slices[0]) else np.float64
+    narrow = np.complex64 if np.iscomplexobj(obs_slices[0]) else np.float32
+    # (the GPU was fed the float32 / complex64 casts of these slices: the oracle gets exactly those values, widened or not)
+    ref64 = [r for _, r in pool.map(_cpu_worker, [(kind, s.astype(narrow).astype(wide), mask, niter, op, extra, True) for s in obs_slices])]
+    ref32 = [r for _, r in pool.map(_cpu_worker, [(kind, s.astype(narrow), mask, niter, op, extra, True) for s in obs_slices])]
+    rel = [float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(gpu_result, ref64)]
+    spread = [float(np.linalg.norm(a.astype(wide) - r) / np.linalg.norm(r)) for a, r in zip(ref32, ref64)]
+    return {
+        "rel_l2_max": max(rel), "rel_l2_median": float(np.median(rel)), "slices": len(rel), "niter": int(niter),
+        "against": "oracle (NumPy restatement of the reference, pinned on its golden vectors) fed the same observed slices in double precision",
+        "what": "out[:slices] of the TIMED job (same cube, same K, same schedule) vs the oracle, ||gpu - ref|| / ||ref|| per slice",
+        "reference_own_float32_spread_max": max(spread), "reference_own_float32_spread_median": float(np.median(spread)),
+        "spread_note": "the oracle fed the cube's own precision (what NumPy executes for such a cube) vs the oracle fed double precision, same slices",
+        "tolerance": 1e-5,
+    }
+
+
+def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None, parity_of=None, parity_niter=None):
+    """(cpu_baseline record, parity record or None).  parity_of: the GPU result on exactly these slices after parity_niter iterations."""
     import multiprocessing as mp
 
     workers = len(obs_slices)
@@ -239,14 +264,17 @@ def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None)
     per_it = {"FFT": 93.3e-3, "WAVELET": 0.35}[kind] * pts / (1024 * 1024)   # s per slice-iteration on one core (measured)
     niter = int(max(4, min(100, budget_s / max(per_it, 1e-6))))
     ctx = mp.get_context("spawn")
+    parity = None
     with ctx.Pool(workers) as pool:
         tiny = (kind, obs_slices[0][:16, :16].copy(), mask[:16, :16].copy(), 2, op, extra)
         pool.map(_cpu_worker, [tiny] * workers)  # spin up
         t0 = time.perf_counter()
         pool.map(_cpu_worker, [(kind, s, mask, niter, op, extra) for s in obs_slices])
         wall = time.perf_counter() - t0
+        if parity_of is not None:
+            parity = cpu_parity(pool, kind, obs_slices, mask, op, parity_niter, parity_of, extra)
     slice_iters_per_s = workers * niter / wall
-    return {
+    return parity, {
         "value": slice_iters_per_s / nslices_cube,
         "unit": "iterations/s",
         "cores": workers,
@@ -449,8 +477,34 @@ def run_leg(ctx, config, K_override, main):
         times.append(sec)
         dev_times.append(dms)
     seconds = float(np.median(times))
+    # the timed job's result on the slices the CPU leg also computes (parity figure of the line; nothing below may overwrite it)
+    gpu_first = out[:len(cpu_slices)].cpu().numpy() if (cpu_slices is not None and kind != "SHEARLET" and args.eps == 0) else None
 
     nz_fraction = plan.last_sparsity() if kind == "FFT" else -1.0
+
+    # ---- strong scaling without the hardware: the SAME job on 1/8 of this rank's slices (the block a GPU gets at N = 8) -------
+    block8 = None
+    if rank == 0 and world == 1 and main and kind == "FFT" and n_local % 8 == 0 and n_local >= 8:
+        nl_full = n_local
+        n_local = nl_full // 8          # (job() reads n_local; the plan was created for nl_full slices)
+        try:
+            job(min(W, 3) or 1)
+            bt = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                b0 = time.perf_counter()
+                job(K)
+                torch.cuda.synchronize()
+                bt.append(time.perf_counter() - b0)
+        finally:
+            n_local = nl_full
+        b_s = float(np.median(bt))
+        block8 = {"slices": nl_full // 8, "job_s_median": b_s, "predicted_speedup_8": seconds / b_s,
+                  "note": "the whole job (statistics, schedule round trip, K iterations, last pass) on the first 1/8 of the slices, on this one GPU: "
+                          "what each of 8 ranks would run; seconds(all slices) / seconds(1/8) is the strong-scaling speed-up the job's own fixed costs "
+                          "allow BEFORE launch skew between ranks (no collective inside the timed region).  A prediction, not a measurement: unmeasured on 8 GPUs"}
+        job(min(W, 3) or 1)             # leave `out` holding the full result again for the legs below
+        job(K)
 
     # ---- per-kernel durations of the same job, HIP events on the plan's stream --------------------
     alg_bytes = ALG_BYTES[kind](nsh) * pts_local
@@ -627,6 +681,7 @@ def run_leg(ctx, config, K_override, main):
                           "rank 0 -- the 'trivial gather' of north_star; device tensors over RCCL/xGMI, no host round trip")
 
     cpu = None
+    parity = None
     if rank == 0 and cpu_slices is not None:
         plan.close()
         del x_obs, out
@@ -636,7 +691,7 @@ def run_leg(ctx, config, K_override, main):
             cpu = cpu_baseline_shearlet(cpu_slices[0], mask, psi, op, cube_slices)
         else:
             cs = cpu_slices if not cfg["real"] else cpu_slices.real.astype(np.float64)
-            cpu = cpu_baseline(kind, list(cs), mask, op, budget, cube_slices, extra=cfg.get("wavelet"))
+            parity, cpu = cpu_baseline(kind, cs, mask, op, budget, cube_slices, extra=cfg.get("wavelet"), parity_of=gpu_first, parity_niter=K)
     else:
         plan.close()
         del x_obs, out
@@ -668,7 +723,10 @@ def run_leg(ctx, config, K_override, main):
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": f"{dtype_s} (f32 arithmetic)",
-        "data": ("synthetic: 6 plane waves + 1% Gaussian noise per slice (seeded; NumPy noise pool, no torch RNG), random trace mask"
+        "data": ("synthetic: 6 plane waves (SURVEY 8d's per-slice seeds) + 1% Gaussian noise per slice, random trace mask.  The noise of slice s is "
+                 f"slice s % {NOISE_POOL} of a pool of {NOISE_POOL} NumPy-drawn slices rolled by a shift that depends on s // {NOISE_POOL} -- POOLED, not 8d's per-slice "
+                 f"generator (no torch RNG kernels: counter collection); the first slices (those the cpu_baseline / parity leg computes) ARE 8d's "
+                 f"oracle.synthetic_slice, noise included"
                  if density == 0 else
                  f"synthetic: {density} random spectral coefficients + 1% Gaussian noise per slice (seeded), random trace mask"),
         "config": {
@@ -706,13 +764,15 @@ def run_leg(ctx, config, K_override, main):
         "end_to_end": e2e,
         "roofline": roof,
         "cpu_baseline": cpu,
+        "parity": parity,
+        "strong_scaling_model": block8,
     }
 
 
 def compact(rec):
     """What an `other_configs` entry keeps of a leg's record: enough to recompute its rate and roofline fraction."""
     keep = ("value", "unit", "steps", "ms_per_step", "dtype", "steady_state_iterations_per_s", "fixed_ms_per_job", "slice_iterations_per_s",
-            "interpolated_traces_per_s", "end_to_end", "roofline", "cpu_baseline")
+            "interpolated_traces_per_s", "end_to_end", "roofline", "cpu_baseline", "parity")
     out = {"workload": rec["config"]["workload"], "slices_per_gpu": rec["config"]["slices_per_gpu"]}
     out.update({k: rec[k] for k in keep})
     out["repeats"] = {k: rec["repeats"][k] for k in ("n", "job_s_median", "job_s_min", "job_s_max")}

@@ -3,8 +3,9 @@ CPU oracle for the kx-ky slice filters of step 15 -- 
 
 Restates remove_acquisition_footprint (cube_postprocessing_3D.py:179-260), spatial_antialiasing (:263-347) and
 gaussian_kernel_2d (:127-176) with the same SciPy calls the reference makes (scipy.signal.fftconvolve, scipy.signal.windows.gaussian)
-and NumPy's FFT.  **Parity unpinned against the reference itself**: its module imports xarray at the top, which no interpreter of this
-image has, so no fixtures could be generated from it; what pins this file is SciPy / NumPy (the reference's own dependencies).
+and NumPy's FFT.  **Pinned** (round 4): tests/golden/make_golden_helpers.py imported the reference's module in the build container (conda interpreter,
+inert stand-ins for the absent xarray / xrft that raise on any use) and recorded its functions' outputs on seeded arrays;
+tests/test_helpers_golden.py holds every function below to them.
 """
 import numpy as np
 from scipy import ndimage, signal
@@ -14,6 +15,8 @@ def rescale(a, vmin=0, vmax=1):
     """functions/utils.py:413-441."""
     a = np.asarray(a)
     amin, amax = np.nanmin(a), np.nanmax(a)
+    vmin = amin if vmin is None else vmin   # (None: keep the array's own extremum, utils.py:435-436)
+    vmax = amax if vmax is None else vmax
     if amin == amax:
         return a
     return vmin + (a - amin) * ((vmax - vmin) / (amax - amin))

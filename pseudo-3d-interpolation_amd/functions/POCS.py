@@ -436,6 +436,27 @@ def _result_rows(done, sums, runtime):
     return rows
 
 
+def _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps, p_max, alpha, p_min):
+    """Argument checks of the batched entry points (``pocs_cube``, ``sharding.pocs_block_on_device``), made BEFORE anything is
+    uploaded: the kernels read ``nil * nxl`` mask entries whatever the caller handed over.  Returns the normalised
+    ``(cube, mask, kind, niter, eps, p_max, alpha, p_min)`` (POCS.py:488-508 for the scalar conversions)."""
+    cube = np.asarray(cube)
+    if cube.ndim != 3:
+        raise ValueError(f'cube must be (nslices, iline, xline), got shape {cube.shape}')
+    mask = np.asarray(mask)
+    if mask.shape != cube.shape[1:]:
+        raise ValueError(f'mask shape {mask.shape} does not match slice shape {cube.shape[1:]}')
+    kind = _check_common(mask, transform_kind, thresh_op)
+    if version not in _ffi.P3D_VER:
+        raise ValueError(f'Unknown POCS version {version!r}')
+    niter, eps, p_max, alpha = int(niter), float(eps), float(p_max), float(alpha)
+    if isinstance(p_min, str) and p_min != 'adaptive':
+        p_min = float(p_min)  # YAML 1.1 reads 1e-4 as a string
+    if niter < 1 and cube.shape[0] > 0:  # the reference's loop body never runs and it then fails on `iiter`; be explicit
+        raise ValueError('niter must be >= 1')
+    return cube, mask, kind, niter, eps, p_max, alpha, p_min
+
+
 def pocs_cube(
     cube,
     mask,
@@ -470,25 +491,12 @@ def pocs_cube(
 
     Returns an array with the shape and dtype of ``cube``.
     """
-    cube = np.asarray(cube)
-    if cube.ndim != 3:
-        raise ValueError(f'cube must be (nslices, iline, xline), got shape {cube.shape}')
-    mask = np.asarray(mask)
-    if mask.shape != cube.shape[1:]:
-        raise ValueError(f'mask shape {mask.shape} does not match slice shape {cube.shape[1:]}')
-    kind = _check_common(mask, transform_kind, thresh_op)
-    if version not in _ffi.P3D_VER:
-        raise ValueError(f'Unknown POCS version {version!r}')
-    niter, eps, p_max, alpha = int(niter), float(eps), float(p_max), float(alpha)
-    if isinstance(p_min, str) and p_min != 'adaptive':
-        p_min = float(p_min)  # YAML 1.1 reads 1e-4 as a string
-
+    cube, mask, kind, niter, eps, p_max, alpha, p_min = _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps,
+                                                                         p_max, alpha, p_min)
     nslices, nil, nxl = cube.shape
     out = np.empty_like(cube)
     if nslices == 0:
         return out
-    if niter < 1:  # the reference's loop body never runs and it then fails on `iiter`; be explicit
-        raise ValueError('niter must be >= 1')
     step = int(batch_slices) if batch_slices else nslices
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
     if kind == 'SHEARLET':

@@ -79,44 +79,79 @@ def gather_blocks_to_root(local, nslices, group=None, root=0):
 
 def pocs_block_on_device(block, mask, device=0, **params):
     """``functions.POCS.pocs_cube`` for one rank's block with the RESULT LEFT ON THE GPU: the block is uploaded once into a torch
-    tensor, statistics / schedule / iterations run on raw device pointers (``Plan.prime_dev`` + ``run_dev``) and the result comes
-    back as a device tensor (complex64 or float32) -- what the gather collective wants.  FFT transform with a statistics-driven
-    schedule; everything else is computed by ``pocs_cube`` (host arrays) and uploaded."""
+    tensor, statistics / schedule / iterations run on raw device pointers and the result comes back as a device tensor (complex64 or
+    float32) -- what the gather collective wants.  Covers the FFT transform with a statistics-driven schedule (``Plan.prime_dev`` +
+    ``run_dev``) and the WAVELET / SHEARLET transforms (``WaveletPlan`` / ``ShearletPlan.stats_dev`` + ``run_dev``; BASELINE
+    configs[4] is the 8-GPU SHEARLET configuration).  The arguments are checked exactly as ``pocs_cube`` checks them, before
+    anything is uploaded.  ``results`` / ``batch_slices`` (per-slice records, caller-chosen chunks), the data-driven schedule and
+    cubes that are neither complex64 nor float32 go through ``pocs_cube`` itself (host arrays) and are uploaded afterwards."""
     import torch
 
     from . import _ffi
     from .functions import POCS as P
 
-    block = np.asarray(block)
+    thresh_op = params.get("thresh_op", "hard")
+    version = params.get("version", "regular")
+    block, mask, kind, niter, eps, p_max, alpha, p_min = P._check_cube_args(
+        block, mask, params.get("transform_kind", "FFT"), thresh_op, version, params.get("niter", 50), params.get("eps", 1e-9),
+        params.get("p_max", 0.99), params.get("alpha", 1.0), params.get("p_min", 1e-5))
     dev = torch.device("cuda", int(device))
-    kind = str(params.get("transform_kind", "FFT")).upper()
     model = params.get("thresh_model", "exponential")
-    fast = (kind == "FFT" and model != "data-driven" and block.ndim == 3 and block.shape[0] > 0 and
-            block.dtype in (np.complex64, np.float32) and params.get("thresh_op", "hard") in _ffi.P3D_OP)
+    decay_kind = params.get("decay_kind", "values")
+    n, nil, nxl = block.shape
+    psi = params.get("auxiliary_data")
+    fast = (n > 0 and block.dtype in (np.complex64, np.float32) and params.get("results") is None and not params.get("batch_slices"))
+    if kind == "FFT":
+        fast = fast and model != "data-driven" and thresh_op in _ffi.P3D_OP
+    else:
+        fast = fast and thresh_op in P._WAVELET_OPS and not (kind == "SHEARLET" and psi is None)
+        if kind == "WAVELET" and decay_kind == "factors" and not all(s in model for s in ["inverse", "proportional"]):
+            fast = False   # (pocs_cube raises the reference's IndexError there)
     if not fast:
         res = np.ascontiguousarray(P.pocs_cube(block, mask, device=int(device), **params))
         return torch.from_numpy(res).to(dev)
-    P._check_common(np.asarray(mask), kind, params.get("thresh_op", "hard"))
-    n, nil, nxl = block.shape
-    niter = int(params.get("niter", 50))
-    p_min = params.get("p_min", 1e-5)
-    if isinstance(p_min, str) and p_min != "adaptive":
-        p_min = float(p_min)
     x = torch.from_numpy(np.ascontiguousarray(block)).to(dev)
     out = torch.empty_like(x)
     m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32)).to(dev)
     dt = _ffi.P3D_C64 if np.iscomplexobj(block) else _ffi.P3D_F32
-    torch.cuda.synchronize(dev)      # the plan works on its own stream
-    plan = P._get_plan(nil, nxl, n, int(device), slot=14)
-    stats = plan.prime_dev(x.data_ptr(), dt, m.data_ptr(), n)
-    active = ~(stats[:, 2] == 0)
-    stats[~active] = 1.0
-    tau = P._schedule_from_stats(stats, nil * nxl, model, niter, float(params.get("p_max", 0.99)), p_min, params.get("decay_kind", "values"))
-    if params.get("sqrt_decay", False):
-        tau = np.sqrt(tau)
-    plan.run_dev(x.data_ptr(), dt, m.data_ptr(), tau, niter, out.data_ptr(), n, thresh_op=params.get("thresh_op", "hard"),
-                 version=params.get("version", "regular"), eps=float(params.get("eps", 1e-9)), alpha=float(params.get("alpha", 1.0)),
-                 active=active, primed=True, want_sums=False)
+    esz = 8 if dt == _ffi.P3D_C64 else 4
+    torch.cuda.synchronize(dev)      # the plans work on their own streams
+    common = dict(thresh_op=thresh_op, version=version, eps=eps, alpha=alpha)
+    if kind == "FFT":
+        plan = P._get_plan(nil, nxl, n, int(device), slot=14)
+        stats = plan.prime_dev(x.data_ptr(), dt, m.data_ptr(), n)
+        active = ~(stats[:, 2] == 0)
+        stats[~active] = 1.0
+        tau = P._schedule_from_stats(stats, nil * nxl, model, niter, p_max, p_min, decay_kind)
+        if params.get("sqrt_decay", False):
+            tau = np.sqrt(tau)
+        plan.run_dev(x.data_ptr(), dt, m.data_ptr(), tau, niter, out.data_ptr(), n, active=active, primed=True, want_sums=False, **common)
+        return out
+    # WAVELET / SHEARLET: the same statistics -> schedule -> loop as pocs_cube, batch by batch on device pointers
+    if kind == "SHEARLET":
+        psi = np.asarray(psi)
+        if psi.ndim != 3 or psi.shape[:2] != (nil, nxl):
+            raise ValueError(f"Psi must be ({nil}, {nxl}, nshearlets), got shape {psi.shape}")
+        step = max(1, min(int((8 << 30) // (psi.shape[2] * nil * nxl * 8)), 65535 // psi.shape[2], n))
+        plan = P._get_shearlet_plan(psi, step, int(device))
+    else:
+        step = n
+        plan = P._get_wavelet_plan(nil, nxl, n, P._wavelet_name(params.get("transform"), params.get("wavelet")), int(device))
+    per = nil * nxl * esz
+    for lo in range(0, n, step):
+        nb = min(step, n - lo)
+        xp, op = x.data_ptr() + lo * per, out.data_ptr() + lo * per
+        stats = plan.stats_dev(xp, dt, nb)
+        active = (x[lo:lo + nb].reshape(nb, -1) != 0).any(dim=1).cpu().numpy()   # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+        stats[~active] = 1.0
+        stats[~active, ..., 1] = 0.0
+        if kind == "WAVELET":
+            tau = P._wavelet_schedule_from_stats(stats, model, niter, p_max, p_min, decay_kind)
+        else:
+            tau = P._shearlet_schedule_from_stats(stats, (nil, nxl), model, niter, p_max, p_min, decay_kind)
+        if params.get("sqrt_decay", False):
+            tau = np.sqrt(tau)
+        plan.run_dev(xp, dt, m.data_ptr(), tau, niter, op, nb, active=active, **common)
     return out
 
 
@@ -137,7 +172,7 @@ def pocs_cube_sharded(cube, mask, group=None, compute=None, gather="root", **par
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = slice_block(cube.shape[0], world, rank)
     on_gpu = dist.get_backend(group) == "nccl"
-    local_dev = int(os.environ.get("LOCAL_RANK", rank))
+    local_dev = int(params.pop("device", os.environ.get("LOCAL_RANK", rank)))   # (a caller's device=... wins over LOCAL_RANK)
     if compute is None:
         block = pocs_block_on_device(np.asarray(cube[lo:hi]), mask, device=local_dev, **params)
         if not on_gpu:

@@ -19,6 +19,7 @@ import numpy as np
 import torch.distributed as dist
 from oracle import pocs_oracle as orc
 from pseudo_3d_interpolation_amd.functions import POCS as P
+from pseudo_3d_interpolation_amd.functions import shearlets
 from pseudo_3d_interpolation_amd.sharding import pocs_block_on_device, pocs_cube_sharded
 os.environ["LOCAL_RANK"] = "0"          # every rank of this test shares the one GPU
 dist.init_process_group("gloo")
@@ -27,7 +28,10 @@ n = int(os.environ["P3D_NSLICES"])
 for real, shape, prm in ((False, (64, 128), dict(niter=9, thresh_op="hard", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)),
                          (True, (128, 128), dict(niter=7, thresh_op="hard", thresh_model="linear", eps=1e-7, p_max=0.9, p_min=1e-2)),
                          (False, (60, 50), dict(niter=5, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2, version="adaptive", alpha=0.8)),
-                         (True, (64, 64), dict(niter=4, thresh_op="soft", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.1, transform_kind="WAVELET", wavelet="db2"))):
+                         (True, (64, 64), dict(niter=4, thresh_op="soft", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.1, transform_kind="WAVELET", wavelet="db2")),
+                         (False, (64, 64), dict(niter=3, thresh_op="hard", thresh_model="exponential", eps=0.0, p_max=0.9, p_min=0.1, transform_kind="WAVELET", wavelet="db4")),
+                         (True, (64, 64), dict(niter=4, thresh_op="soft", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.1, transform_kind="SHEARLET",
+                                               auxiliary_data=shearlets.scalesShearsAndSpectra((64, 64))))):
     _, mask, obs = orc.synthetic_cube(shape[0], shape[1], n, 0.6, real=real)
     obs[n // 2] = 0                                          # an all-zero slice passes through untouched
     want = P.pocs_cube(obs, mask, **prm)
@@ -35,8 +39,23 @@ for real, shape, prm in ((False, (64, 128), dict(niter=9, thresh_op="hard", thre
     assert everywhere.dtype == obs.dtype and np.array_equal(everywhere, want), (rank, shape)
     root = pocs_cube_sharded(obs, mask, **prm)
     assert (root is None) == (rank != 0) and (rank != 0 or np.array_equal(root, want))
-dev = pocs_block_on_device(obs[:2], mask, device=0, **prm)
+dev = pocs_block_on_device(obs[:2], mask, device=0, **prm)      # (the SHEARLET case: the device-resident branch of configs[4])
 assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), want[:2])
+# the argument checks of pocs_cube come before any upload (a short mask would be read out of bounds by the kernels)
+for bad in (dict(mask=mask[:-1]), dict(niter=0), dict(version="nope"), dict(thresh_op="nope")):
+    kw = dict(prm, **{k: v for k, v in bad.items() if k != "mask"})
+    try:
+        pocs_block_on_device(obs[:2], bad.get("mask", mask), device=0, **kw)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError(f"no ValueError for {list(bad)}")
+# per-slice records and caller-chosen chunks are honoured (through pocs_cube), and device= may be passed explicitly
+rows = []
+dev = pocs_block_on_device(obs[:3], mask, device=0, results=rows, batch_slices=2, **prm)
+assert len(rows) == 3 and np.array_equal(dev.cpu().numpy(), want[:3])
+again = pocs_cube_sharded(obs, mask, gather="all", device=0, **prm)
+assert np.array_equal(again, want)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
