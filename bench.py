@@ -230,6 +230,21 @@ def _cpu_worker(job):
     elif kind == "WAVELET":
         from oracle import wavelet_oracle as wo
         res = wo.pocs_slice_wavelet(x, mask, wavelet=extra, niter=niter, thresh_op=op, thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-3)
+    elif kind == "WAVELET32":
+        # the WAVELET loop CARRIED in float32 -- what PyWavelets executes for a float32 cube (its C kernels are typed), i.e. the
+        # reference's own arithmetic for configs[3]; the schedule from the double-precision decomposition, as the oracle's
+        # (tests/test_gpu_wavelet.py::test_wavelet_long_run_tracks_float32_reference has the same loop)
+        from oracle import pocs_oracle as orc
+        from oracle import wavelet_oracle as wo
+        n0, n1 = x.shape
+        bank32 = tuple(b.astype(np.float32) for b in wo.filter_bank(extra))
+        tau = wo.wavelet_schedule("exponential", niter, 0.99, 1e-3, wo.wavedec2(x.astype(np.float64), wo.filter_bank(extra))[1:])
+        x32 = x.astype(np.float32)
+        res = x32
+        for k in range(niter):
+            c = wo.wavedec2(res, bank32)
+            shr = [tuple(orc.apply_threshold(c[l + 1][d], np.float32(tau[k, l, d]), kind=op) for d in range(3)) for l in range(len(c) - 1)]
+            res = (wo.waverec2([c[0]] + shr, bank32)[:n0, :n1] * (1 - mask) + x32).astype(np.float32)
     wall = time.perf_counter() - t0
     return (wall, res) if keep else wall
 
@@ -242,7 +257,8 @@ def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None):
     narrow = np.complex64 if np.iscomplexobj(obs_slices[0]) else np.float32
     # (the GPU was fed the float32 / complex64 casts of these slices: the oracle gets exactly those values, widened or not)
     ref64 = [r for _, r in pool.map(_cpu_worker, [(kind, s.astype(narrow).astype(wide), mask, niter, op, extra, True) for s in obs_slices])]
-    ref32 = [r for _, r in pool.map(_cpu_worker, [(kind, s.astype(narrow), mask, niter, op, extra, True) for s in obs_slices])]
+    kind32 = "WAVELET32" if (kind == "WAVELET" and narrow is np.float32) else kind   # (the wavelet oracle promotes to double whatever it is fed)
+    ref32 = [r for _, r in pool.map(_cpu_worker, [(kind32, s.astype(narrow), mask, niter, op, extra, True) for s in obs_slices])]
     rel = [float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(gpu_result, ref64)]
     spread = [float(np.linalg.norm(a.astype(wide) - r) / np.linalg.norm(r)) for a, r in zip(ref32, ref64)]
     return {
@@ -252,6 +268,10 @@ def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None):
         "reference_own_float32_spread_max": max(spread), "reference_own_float32_spread_median": float(np.median(spread)),
         "spread_note": "the oracle fed the cube's own precision (what NumPy executes for such a cube) vs the oracle fed double precision, same slices",
         "tolerance": 1e-5,
+        "note": None if kind != "WAVELET" else
+        "the WAVELET iteration with 'smooth' boundaries is expansive on decimated data (the iterate grows by orders of magnitude over the schedule, "
+        "DESIGN.md section 4): rounding noise grows with it, in the reference's own float32 run as in the device's -- compare rel_l2 with "
+        "reference_own_float32_spread, not with the tolerance; short / well-conditioned runs are held to 1e-5 by tests/test_gpu_wavelet.py",
     }
 
 

@@ -405,7 +405,10 @@ int p3d_shearlet_stats(p3d_splan* p, const void* x, int dtype, int nslices, doub
     S_RC(s_check(p, nslices, dtype));
     if (!x || !stats) return sfail(P3D_ERR_INVALID, "NULL buffer");
     const size_t esz = dtype == P3D_C64 ? sizeof(c32) : sizeof(float);
-    S_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));   // x: host or device pointer
+    // x: host or device pointer.  On the plan's stream: a device-to-device hipMemcpy runs on the null stream and need not have finished when it
+    // returns, and the plan's stream does not wait for the null stream -- the kernels below would read st_x early (seen as wrong statistics
+    // when several processes share the GPU)
+    S_TRY(hipMemcpyAsync(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault, p->stream));
     if (p->sums_cap < (size_t)nslices) {
         if (p->sums) hipFree(p->sums);
         p->sums = nullptr; p->sums_cap = 0;
@@ -465,8 +468,8 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
     }
     std::vector<int> done_h(nslices, 0);
     if (active) for (int s = 0; s < nslices; ++s) done_h[s] = active[s] ? 0 : -1;
-    S_TRY(hipMemcpy(p->st_x, x, esz * per * nslices, hipMemcpyDefault));   // x, mask, out: host or device pointers
-    S_TRY(hipMemcpy(p->mask, mask, sizeof(float) * per, hipMemcpyDefault));
+    S_TRY(hipMemcpyAsync(p->st_x, x, esz * per * nslices, hipMemcpyDefault, p->stream));   // x, mask, out: host or device pointers (on the plan's stream, see p3d_shearlet_stats)
+    S_TRY(hipMemcpyAsync(p->mask, mask, sizeof(float) * per, hipMemcpyDefault, p->stream));
     S_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
     S_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     S_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
@@ -501,7 +504,8 @@ int p3d_shearlet_run(p3d_splan* p, const void* x, int dtype, const float* mask, 
     S_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) S_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
     S_TRY(hipStreamSynchronize(p->stream));
-    S_TRY(hipMemcpy(out, p->st_out, esz * per * nslices, hipMemcpyDefault));
+    S_TRY(hipMemcpyAsync(out, p->st_out, esz * per * nslices, hipMemcpyDefault, p->stream));
+    S_TRY(hipStreamSynchronize(p->stream));   // (the caller may read `out` on any stream once this returns)
     if (niter_done) for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
     if (elapsed_ms) {
         float ms = 0.f;

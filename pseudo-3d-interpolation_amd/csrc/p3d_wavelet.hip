@@ -1735,7 +1735,7 @@ int p3d_wavelet_stats(p3d_wplan* p, const void* x, int dtype, int nslices, doubl
     if (on_plan_device(p, x)) {
         p->cur_x = x;
     } else {
-        W_TRY(hipMemcpy(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault));
+        W_TRY(hipMemcpyAsync(p->st_x, x, esz * p->per() * nslices, hipMemcpyDefault, p->stream));   // (ordered with the plan's stream: p3d_wavelet_run)
         p->cur_x = p->st_x;
     }
     if (p->sums_cap < (size_t)nslices) {
@@ -1792,7 +1792,7 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     if (on_plan_device(p, x)) {
         p->cur_x = x;
     } else {
-        W_TRY(hipMemcpy(p->st_x, x, cube_bytes, hipMemcpyDefault));
+        W_TRY(hipMemcpyAsync(p->st_x, x, cube_bytes, hipMemcpyDefault, p->stream));
         p->cur_x = p->st_x;
     }
     // (the loop reads the observed cube in every iteration: a result buffer that overlaps it goes through the staging buffer)
@@ -1800,7 +1800,9 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     char* const ob = static_cast<char*>(out);
     const bool direct_out = on_plan_device(p, out) && (ob + cube_bytes <= xb || xb + cube_bytes <= ob);
     p->cur_out = direct_out ? out : p->st_out;
-    W_TRY(hipMemcpy(p->mask, mask, sizeof(float) * p->per(), hipMemcpyDefault));
+    // the mask may be a device pointer: a device-to-device hipMemcpy runs on the null stream, need not have finished when it returns, and the plan's
+    // (non-blocking) stream does not wait for it -- every copy of this entry point goes onto the plan's stream
+    W_TRY(hipMemcpyAsync(p->mask, mask, sizeof(float) * p->per(), hipMemcpyDefault, p->stream));
     W_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
@@ -1810,7 +1812,10 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     W_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) W_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
     W_TRY(hipStreamSynchronize(p->stream));
-    if (!direct_out) W_TRY(hipMemcpy(out, p->st_out, cube_bytes, hipMemcpyDefault));
+    if (!direct_out) {
+        W_TRY(hipMemcpyAsync(out, p->st_out, cube_bytes, hipMemcpyDefault, p->stream));
+        W_TRY(hipStreamSynchronize(p->stream));
+    }
     if (niter_done) for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
     if (elapsed_ms) {
         float ms = 0.f;

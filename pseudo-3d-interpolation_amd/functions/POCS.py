@@ -331,6 +331,7 @@ def _check_common(mask, transform_kind, thresh_op):
 
 
 _copy_pool = None
+_timeline = None     # a list while tools/e2e_timeline.py records the phases of the chunk workers (None: no recording)
 
 
 def _slab_copy(dst, src):
@@ -390,6 +391,11 @@ class _FFTWorker:
     def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha):
         n = chunk.shape[0]
         t0 = time.perf_counter()
+        marks = [('start', t0)] if _timeline is not None else None   # tools/e2e_timeline.py: where a chunk's wall time goes
+
+        def mark(name):
+            if marks is not None:
+                marks.append((name, time.perf_counter()))
         if n > self.capacity or chunk.shape[1:] != (self.plan.nil, self.plan.nxl):
             raise ValueError(f'chunk {chunk.shape} does not fit the worker ({self.capacity}, {self.plan.nil}, {self.plan.nxl})')
         dt, dtype = (_ffi.P3D_C64, np.complex64) if np.iscomplexobj(chunk) else (_ffi.P3D_F32, np.float32)
@@ -405,18 +411,25 @@ class _FFTWorker:
             xin = self.hx.view(chunk.shape, dtype)
             _slab_copy(xin, chunk)
             self.x.upload(xin)                         # one upload serves the statistics and the loop
+        mark('h2d')
         stats = self.plan.prime_dev(self.x.ptr, dt, self.m.ptr, n)   # the statistics pass doubles as the first pass of the job
+        mark('prime')
         active = ~(stats[:, 2] == 0)                   # max|fft2(x)| == 0 <=> np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         stats[~active] = 1.0                           # keep NaNs of empty slices out of the (unused) schedule rows
         tau = sched(stats)
+        mark('schedule')
         done, sums, _ = self.plan.run_dev(self.x.ptr, dt, self.m.ptr, tau, niter, self.o.ptr, n, thresh_op=thresh_op,
                                           version=version, eps=eps, alpha=alpha, active=active, primed=True)
+        mark('loop')
         if direct:
             self.o.download_into(dst)
         else:
             xout = self.ho.view(chunk.shape, dtype)
             self.o.download_into(xout)
             _slab_copy(dst, xout)                      # e.g. a float64 cube: results are cast on assignment, as before
+        mark('d2h')
+        if marks is not None:
+            _timeline.append((id(self), marks))
         return done, sums, time.perf_counter() - t0
 
 
