@@ -100,6 +100,12 @@ int p3d_memcpy_d2h(p3d_plan* plan, void* dst_host, const void* src_dev, size_t b
  * quarter of it); the chunk pipeline of pocs_cube keeps its staging buffers here */
 int p3d_host_alloc(void** hptr, size_t bytes);
 int p3d_host_free(void* hptr);
+/* page-lock a caller's array IN PLACE for the duration of a job (the host-buffer entry point of the Python mirror,
+ * functions/POCS.py pocs_cube, does this with the cube it is handed and the result it returns -- the stand-in for the dask workers'
+ * netCDF chunks of cube_POCS_interpolation_3D.py:314-340): transfers to / from it are DMA both ways at once.
+ * P3D_ERR_UNSUPPORTED when the runtime refuses the range (the caller then simply goes on with pageable memory). */
+int p3d_host_register(void* hptr, size_t bytes);
+int p3d_host_unregister(void* hptr);
 
 /* Batched 2-D FFT of complex64 slices, numpy.fft.fft2 / ifft2 conventions (unnormalised forward,
  * 1/(nil*nxl) inverse).  Replaces the callables injected at cube_POCS_interpolation_3D.py:255-257;

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "p3d_fft2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "p3d_fft2_shrink_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "p3d_host_unregister": (C.c_int, [C.c_void_p]),
     "p3d_pocs_prime_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "p3d_pocs_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_pocs_sorted_spectrum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -189,6 +191,18 @@ class DeviceBuffer:
         if self.ptr:
             check(lib().p3d_free(self.plan.handle, self.ptr))
             self.ptr = None
+
+
+def host_register(arr):
+    """Page-lock a C-contiguous NumPy array in place (p3d_host_register).  True when it is registered now (and must be handed to
+    :func:`host_unregister` later), False when the runtime refused -- the array is usable either way."""
+    if not arr.flags.c_contiguous or arr.nbytes == 0:
+        return False
+    return lib().p3d_host_register(_ptr(arr), arr.nbytes) == P3D_OK
+
+
+def host_unregister(arr):
+    check(lib().p3d_host_unregister(_ptr(arr)))
 
 
 class PinnedBuffer:

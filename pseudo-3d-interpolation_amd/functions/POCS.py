@@ -351,6 +351,62 @@ def _slab_copy(dst, src):
 
 
 _COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_PIN_MIN_BYTES = int(os.environ.get('P3D_PIN_MIN_MIB', 256)) << 20   # cubes from this size on are page-locked in place for the call (0 MiB: always; huge: never)
+
+
+def _touch_pages(arr):
+    """Write one byte into every 4-KiB page of a freshly allocated C-contiguous array from a few threads (its contents are about to
+    be overwritten): the kernel hands out the pages in parallel instead of one by one under the first download."""
+    global _copy_pool
+    flat = arr.reshape(-1).view(np.uint8)
+    parts = max(1, min(_COPY_THREADS, flat.size >> 22))
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(_COPY_THREADS)
+    cuts = [flat.size * i // parts for i in range(parts + 1)]
+
+    def touch(i):
+        flat[cuts[i]:cuts[i + 1]:4096] = 0
+    return [_copy_pool.submit(touch, i) for i in range(parts)]
+
+
+class _HostPins:
+    """The caller's cube and the result array of one ``pocs_cube`` call, page-locked in place (``_ffi.host_register``) and released
+    at the end of the call.  The cube is registered at once (touched memory: ~2 ms per GiB); the result is touched in the
+    background, then registered -- ``result_ready()`` blocks until that has happened.  A refused registration (already page-locked
+    by the caller, a read-only mapping ...) is not an error: that array simply stays pageable."""
+
+    def __init__(self, cube, out):
+        import threading
+        self._regs = []
+        self._lock = threading.Lock()
+        self._done = threading.Event()
+        if _ffi.host_register(cube):
+            self._regs.append(cube)
+        self._out = out
+        self._touching = _touch_pages(out)
+        self._thread = threading.Thread(target=self._finish, daemon=True)
+        self._thread.start()
+
+    def _finish(self):
+        try:
+            for f in self._touching:
+                f.result()
+            if _ffi.host_register(self._out):
+                with self._lock:
+                    self._regs.append(self._out)
+        finally:
+            self._done.set()
+
+    def result_ready(self):
+        self._done.wait()
+
+    def release(self):
+        self._done.wait()
+        with self._lock:
+            regs, self._regs = self._regs, []
+        for a in regs:
+            _ffi.host_unregister(a)
 _CHUNK_WORKERS = int(os.environ.get('P3D_CHUNK_WORKERS', 4))   # chunks in flight (slots 0.. of the plan cache; slot 15 belongs to the unchunked path)
 
 
@@ -388,7 +444,7 @@ class _FFTWorker:
             if b is not None:
                 b.free()
 
-    def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha):
+    def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha, before_download=None):
         n = chunk.shape[0]
         t0 = time.perf_counter()
         marks = [('start', t0)] if _timeline is not None else None   # tools/e2e_timeline.py: where a chunk's wall time goes
@@ -421,6 +477,8 @@ class _FFTWorker:
         done, sums, _ = self.plan.run_dev(self.x.ptr, dt, self.m.ptr, tau, niter, self.o.ptr, n, thresh_op=thresh_op,
                                           version=version, eps=eps, alpha=alpha, active=active, primed=True)
         mark('loop')
+        if before_download is not None:
+            before_download()                          # (the result array's pages are there and page-locked)
         if direct:
             self.o.download_into(dst)
         else:
@@ -546,16 +604,31 @@ def pocs_cube(
             tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
             return np.sqrt(tau) if sqrt_decay else tau  # POCS.py:595
 
-        def lane(w):
-            return [(lo, workers[w].run(cube[lo:lo + step], out[lo:lo + step], sched, niter, thresh_op, version, eps, alpha))
-                    for lo in starts[w::len(workers)]]
+        # Large cubes: page-lock the caller's cube and the result IN PLACE for the duration of the call, so that the chunk transfers are
+        # DMA on the workers' own streams, uploads and downloads at the same time (profiles/r04_pcie_probe.txt: 96 GB/s both ways
+        # together against 56 GB/s for pageable memory, whose copies take turns; a download into FRESH pages runs at 17 GB/s).  The
+        # result array is brand new: its pages are touched by a few threads first (24 ms for 4 GiB; the driver alone takes 176 ms),
+        # while the first chunks are already uploading -- a worker waits for that only before its first download.
+        pin = _HostPins(cube, out) if (len(starts) > 1 and cube.nbytes >= _PIN_MIN_BYTES and cube.dtype == out.dtype
+                                       and cube.dtype in (np.complex64, np.float32) and cube.flags.c_contiguous) else None
 
-        if len(workers) == 1:
-            done_rows = lane(0)
-        else:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(len(workers)) as pool:
-                done_rows = [r for part in pool.map(lane, range(len(workers))) for r in part]
+        def lane(w):
+            rows = []
+            for lo in starts[w::len(workers)]:
+                rows.append((lo, workers[w].run(cube[lo:lo + step], out[lo:lo + step], sched, niter, thresh_op, version, eps, alpha,
+                                                before_download=None if pin is None else pin.result_ready)))
+            return rows
+
+        try:
+            if len(workers) == 1:
+                done_rows = lane(0)
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(len(workers)) as pool:
+                    done_rows = [r for part in pool.map(lane, range(len(workers))) for r in part]
+        finally:
+            if pin is not None:
+                pin.release()
         if results is not None:
             for _, (done, sums, runtime) in sorted(done_rows, key=lambda r: r[0]):
                 results.extend(_result_rows(done, sums, runtime))
