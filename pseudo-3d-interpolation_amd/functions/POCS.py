@@ -373,7 +373,9 @@ def _touch_pages(arr):
 class _HostPins:
     """The caller's cube and the result array of one ``pocs_cube`` call, page-locked in place (``_ffi.host_register``) and released
     at the end of the call.  The cube is registered at once (touched memory: ~2 ms per GiB); the result is touched in the
-    background, then registered -- ``result_ready()`` blocks until that has happened.  A refused registration (already page-locked
+    background, then registered -- ``result_ready()`` blocks until that has happened.  (Registering chunk by chunk from the workers
+    was tried: hipHostRegister / Unregister beside running transfers cost more than they hide -- 215 against 155 ms per call on
+    BASELINE configs[2], profiles/r04_pcie_probe.txt.)  A refused registration (already page-locked
     by the caller, a read-only mapping ...) is not an error: that array simply stays pageable."""
 
     def __init__(self, cube, out):
