@@ -559,8 +559,8 @@ def run_leg(ctx, config, K_override, main):
                 "kernel": (f"resident_kernel<{nil},{nxl}>: one workgroup per slice, all {K} iterations in registers / LDS -- the iterations "
                            f"move NO HBM bytes (16 B/point per job), so `achieved` (algorithmic bytes over time) may exceed the HBM peak"
                            if resident else
-                           f"col_kernel<{nil},COL_ITER> + the persistent row pass (row_pipe64_kernel<{nxl}> for rows of whole "
-                           f"wavefronts, row_pipe_kernel otherwise) = one POCS iteration of {n_local} slices"),
+                           f"col_kernel<{nil},COL_ITER> + the persistent row pass (row_pipe32_kernel for rows of 1024 samples, row_pipe64_kernel<{nxl}> "
+                           f"for other rows of whole wavefronts, row_pipe_kernel otherwise) = one POCS iteration of {n_local} slices"),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_from": traffic_from, "traffic_last_measured": last,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -646,16 +646,36 @@ def run_leg(ctx, config, K_override, main):
         host = x_obs.cpu().numpy()
         kw = dict(transform_kind=kind, thresh_op=op, thresh_model="exponential", eps=args.eps, alpha=args.alpha, p_max=0.99, p_min=p_min,
                   device=dev_index, wavelet=cfg.get("wavelet"))
-        P.pocs_cube(host[:min(n_local, 64)], mask, niter=2, **kw)     # plans, device buffers, page-locked staging of the chunk pipeline
+        # plans, device buffers and streams of ALL chunk workers (four chunks of the size the timed call will use), not the cube's page-locking
+        warm = min(n_local, 64)
+        P.pocs_cube(host[:warm], mask, niter=2, batch_slices=max(1, min(warm // 4, (128 << 20) // (nil * nxl * esz))) if kind == "FFT" else None, **kw)
         ctx.fence()
+        P._timeline = [] if kind == "FFT" else None      # phases of the chunk workers (rank 0's block)
         t0 = time.perf_counter()
         res_host = P.pocs_cube(host, mask, niter=K, **kw)
         ctx.fence()
-        e_s = ctx.max_over_ranks(time.perf_counter() - t0)
+        t1 = time.perf_counter()
+        e_s = ctx.max_over_ranks(t1 - t0)
+        tl, P._timeline = P._timeline, None
+        phases = None
+        if tl:
+            setup = [m for wid, m in tl if wid == 'setup']
+            tl = [(wid, m) for wid, m in tl if wid != 'setup']
+            tot = {}
+            for _, marks in tl:
+                for (_, a_), (name, b_) in zip(marks[:-1], marks[1:]):
+                    tot[name] = tot.get(name, 0.0) + (b_ - a_)
+            nw = len({wid for wid, _ in tl})
+            phases = {"workers": nw, "chunks": len(tl), "first_lane_starts_after_ms": 1e3 * (min(m[0][1] for m in setup) - t0) if setup else None,
+                      "first_chunk_starts_after_ms": 1e3 * (min(m[0][1] for _, m in tl) - t0),
+                      "last_chunk_ends_before_return_ms": 1e3 * (t1 - max(m[-1][1] for _, m in tl)),
+                      "summed_over_chunks_ms": {k: 1e3 * v for k, v in tot.items()},
+                      "note": "h2d / d2h: copies on the worker's own stream between the caller's page-locked-in-place arrays and the device; prime: statistics pass = first pass; "
+                              "loop: the K iterations; the workers run side by side, so the wall share of a phase is its sum / workers"}
         same = bool(np.array_equal(res_host, out.cpu().numpy())) if args.eps == 0 else None
         e2e = {"iterations_per_s": K / e_s, "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / e_s, "seconds": e_s,
                "host_bytes_in_plus_out": 2 * host.nbytes * world if world == 1 else 2 * host.nbytes,
-               "equals_resident_result": same,
+               "equals_resident_result": same, "phases": phases,
                "what": f"functions.POCS.pocs_cube(host cube, mask, niter={K}) per rank on its block: pageable NumPy array in, NumPy array "
                        f"out, statistics + schedule + iterations + PCIe both ways (FFT: chunks of ~128 MiB, four in flight); max over ranks"}
         del host, res_host

@@ -272,6 +272,21 @@ static __global__ void pack_cbase_kernel(const unsigned long long* bits64, const
     }
 }
 
+// Lane-mask table of row_pipe32_kernel (rows of 1024 samples, a row pair per wavefront): word (unit u, register k) bit l =
+// mask[2u + (l >> 5)][(l & 31) + 32 k], from the 16-bit words of the 64-thread layout (bits[row][tl] bit q = mask[row][tl + 64 q])
+static __global__ void pack_mask32_kernel(const uint16_t* bits, unsigned long long* bits32, int n1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (n1 / 2) * 32) return;
+    const int k = i & 31, u = i >> 5;
+    unsigned long long w = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int row = 2 * u + (l >> 5), c = (l & 31) + 32 * k;
+        w |= (unsigned long long)((bits[(size_t)row * 64 + (c & 63)] >> (c >> 6)) & 1u) << l;
+    }
+    bits32[i] = w;
+}
+
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...)
@@ -318,6 +333,12 @@ struct p3d_plan {
     unsigned long long* bits64 = nullptr;       // tpl = 64, 128, 256: the same as lane masks (row_pipe64_kernel, pipe64_word)
     unsigned long long* nzl = nullptr;          // ... nzm as lane masks, per slice
     unsigned* cbase = nullptr;                  // ... observed traces before each word of bits64
+    // rows of 1024 samples: the one-exchange persistent row passes (row_pipe32_kernel).  use32 is fixed when the plan is created: the
+    // first pass of EVERY job and of every statistics call is then that kernel's (its forward transform rounds differently from
+    // line_fft<1024>; statistics and first iteration must see the same bits), whatever kernels the rest of a job takes
+    bool use32 = false;
+    unsigned long long* bits32 = nullptr;       // [nil / 2][32] lane masks of the row pairs (RowArgs::bits32)
+    c32* tw32 = nullptr;                        // P32::build_tw
     int* flag = nullptr;                        // device int[2]: mask not binary / x non-zero at a missing trace
     unsigned* rowbase = nullptr;                // [nil+1] observed positions before each row
     void* xc = nullptr;                         // compact observed samples [nslices][nobs]
@@ -398,7 +419,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->cbase, p->bits64, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->sum0, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
+    void* bufs[] = {p->cbase, p->bits64, p->bits32, p->tw32, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->sum0, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -508,6 +529,15 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
             TRY_OR_BAIL(hipMalloc((void**)&p->nzl, sizeof(unsigned long long) * 16 * wpl * (size_t)max_slices));
         }
         TRY_OR_BAIL(hipMalloc((void**)&p->rowbase, sizeof(unsigned) * ((size_t)nil + 1)));
+        if (orow->row_pipe32 != nullptr && p->bits64 != nullptr && p->pipe_wgs > 0 && nil % 2 == 0 && nil <= 4096 && (double)welems < 4294967296.0 &&
+            !getenv("P3D_NO_PIPE32")) {
+            std::vector<c32> host((size_t)orow->row_tw32_slots);
+            orow->build_row_tw32(host.data());
+            TRY_OR_BAIL(hipMalloc((void**)&p->tw32, sizeof(c32) * host.size()));
+            TRY_OR_BAIL(hipMemcpy(p->tw32, host.data(), sizeof(c32) * host.size(), hipMemcpyHostToDevice));
+            TRY_OR_BAIL(hipMalloc((void**)&p->bits32, sizeof(unsigned long long) * 32 * (size_t)(nil / 2)));
+            p->use32 = true;
+        }
     }
     TRY_OR_BAIL(hipMalloc((void**)&p->flag, 2 * sizeof(int)));
     TRY_OR_BAIL(hipMalloc((void**)&p->rowsum, sizeof(double) * (size_t)nil * max_slices));
@@ -635,6 +665,7 @@ static RowArgs row_args(p3d_plan* p, int nslices)
 {
     RowArgs r{};
     r.tw = p->tw_row;
+    r.tw32 = p->tw32;
     r.n1 = p->nil;
     r.nslices = nslices;
     r.alpha = 1.0f;
@@ -707,6 +738,8 @@ static int reduce_partials(p3d_plan* p, int nslices, double* stats, int tiles = 
     return P3D_OK;
 }
 
+static hipError_t first_row_pass(p3d_plan* p, const RowArgs& r);
+
 static int fft2_enqueue(p3d_plan* p, const void* in, void* out, int nslices, int inverse)
 {
     int rc = check_batch(p, nslices);
@@ -721,7 +754,7 @@ static int fft2_enqueue(p3d_plan* p, const void* in, void* out, int nslices, int
         r.x = in;
         r.work = p->work;
         r.dtype = P3D_C64;
-        HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+        HIP_TRY(first_row_pass(p, r));   // (every forward transform of a plan takes the same row pass: the same bits as the statistics and the loop)
         ColArgs c = col_args(p, nslices);
         c.in = p->work;
         c.out = (c32*)out;
@@ -942,7 +975,7 @@ int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, 
     r.x = p->st_x;
     r.work = p->work;
     r.dtype = P3D_C64;
-    HIP_TRY(p->ops_row->row(ROW_FIRST, r, p->stream));
+    HIP_TRY(first_row_pass(p, r));
     ColArgs c = col_args(p, nslices);
     c.in = p->work;
     c.out = (c32*)p->st_out;
@@ -961,6 +994,10 @@ int p3d_fft2_shrink_c64(p3d_plan* p, const void* in, const double* tau, int op, 
 // (rows of 128 ... 4096 samples, P3D_NO_PIPE64 unset), the one-launch-per-pass kernels otherwise
 static hipError_t first_row_pass(p3d_plan* p, const RowArgs& r)
 {
+    if (p->use32) {   // rows of 1024 samples: always this first pass where the plan has it (see p3d_plan::use32)
+        const hipError_t e = p->ops_row->row_pipe32(PIPE_FIRST, r, p->pipe_wgs, p->stream);
+        if (e != hipErrorNotSupported) return e;   // (not supported: APOCS on a non-binary mask -- the input mix needs the mask bits)
+    }
     if (p->pipe_wgs > 0 && p->bits64 != nullptr && p->ops_row->row_pipe64 != nullptr) {
         const hipError_t e = p->ops_row->row_pipe64(PIPE_FIRST, r, p->pipe_wgs, p->stream);
         if (e != hipErrorNotSupported) return e;
@@ -985,6 +1022,7 @@ static int pack_mask(p3d_plan* p, const float* mask, int* nonbinary, unsigned* n
         pack_mask64_kernel<<<(p->nil * wpl * 16 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits64, p->nil, tpl);
         pack_cbase_kernel<<<(p->nil + 255) / 256, 256, 0, p->stream>>>(p->bits64, p->rowbase, p->cbase, p->nil, tpl);
     }
+    if (p->use32) pack_mask32_kernel<<<((p->nil / 2) * 32 + 255) / 256, 256, 0, p->stream>>>(p->bits, p->bits32, p->nil);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(nonbinary, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
     if (p->nil <= 4096) HIP_TRY(hipMemcpyAsync(nobs, p->rowbase + p->nil, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
@@ -1033,6 +1071,7 @@ int p3d_pocs_prime_dev(p3d_plan* p, const void* x, int dtype, const float* mask,
     r.bits = nonbinary ? nullptr : p->bits;
     r.bits64 = nonbinary ? nullptr : p->bits64;
     r.cbase = nonbinary ? nullptr : p->cbase;
+    r.bits32 = (nonbinary || !p->use32) ? nullptr : p->bits32;
     r.xc = compact ? p->xc : nullptr;
     r.rowbase = p->rowbase;
     r.nobs = nobs;
@@ -1318,6 +1357,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     // in the word order when it is handed the tables; with the early exit it stores every iterate there (write_out below).
     r.bits64 = nonbinary ? nullptr : p->bits64;
     r.cbase = nonbinary ? nullptr : p->cbase;
+    r.bits32 = (nonbinary || !p->use32) ? nullptr : p->bits32;
     r.xc = compact ? p->xc : nullptr;
     r.rowbase = p->rowbase;
     r.nobs = nobs;
@@ -1485,8 +1525,16 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         HIP_TRY(stamp());
         r.sum_row = k + 1;
         bool piped = false;
+        // rows of 1024 samples whose first pass wrote the compact samples in row_pipe32_kernel's order: that family all the way
+        // (r.xc is null whenever the first pass wrote none: non-binary mask, no compact samples wanted, energy at unobserved traces)
+        const bool fam32 = !real_path && p->use32 && r.xc != nullptr && r.bits32 != nullptr;
         if (real_path) {
             HIP_TRY(p->ops_row->row_real(k + 1 < niter ? REAL_MID : REAL_LAST, r, p->pipe_wgs, p->stream));
+            piped = true;
+        } else if (fam32) {
+            const hipError_t fe = p->ops_row->row_pipe32(k + 1 < niter ? PIPE_MID : PIPE_LAST, r, p->pipe_wgs, p->stream);
+            if (fe == hipErrorNotSupported) return fail(P3D_ERR_HIP, "row_pipe32_kernel refused a job its first pass had accepted");
+            HIP_TRY(fe);
             piped = true;
         } else if (k + 1 < niter && p->pipe_wgs > 0) {  // steady state: persistent, software-pipelined row pass
             const hipError_t pe = p->ops_row->row_pipe(r, p->pipe_wgs, p->stream);

@@ -15,7 +15,8 @@ const LineOps* P3D_CAT(get_line_ops_, P3D_N)()
                                 &launch_row<P3D_N>, &launch_col<P3D_N>, &launch_row_pipe<P3D_N>, row_lds_bytes<P3D_N>(),
                                 PassTables<P3D_N>::slots(), &PassTables<P3D_N>::build,
                                 ColTables<P3D_N>::slots(),  &ColTables<P3D_N>::build,
-                                &launch_row_real<P3D_N>, &launch_row_pipe64<P3D_N>, &launch_col_pipe<P3D_N>, &launch_col_shear_pair<P3D_N>};
+                                &launch_row_real<P3D_N>, &launch_row_pipe64<P3D_N>, &launch_col_pipe<P3D_N>, &launch_col_shear_pair<P3D_N>,
+                                P3D_N == P32::N ? &launch_row_pipe32<P3D_N> : nullptr, P3D_N == P32::N ? P32::TW : 0, P3D_N == P32::N ? &P32::build_tw : nullptr};
     return &ops;
 }
 }  // namespace p3d

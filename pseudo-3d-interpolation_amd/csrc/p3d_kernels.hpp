@@ -28,6 +28,7 @@
 #include "p3d_kernels_common.hpp"
 #include "p3d_row_kernels.hpp"
 #include "p3d_row_pipe64.hpp"
+#include "p3d_row_pipe32.hpp"
 #include "p3d_row_real.hpp"
 #include "p3d_col_kernels.hpp"
 #include "p3d_col_shear.hpp"
@@ -159,6 +160,54 @@ hipError_t launch_row_pipe64(int pm, const RowArgs& a, int cus, hipStream_t st)
             return hipErrorInvalidValue;
         }
 #undef P3D_PIPE64
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+// one launch of the one-exchange persistent row pass of 1024-sample rows (row_pipe32_kernel) in mode `pm`; hipErrorNotSupported where
+// the kernel does not apply.  What it needs is decided per PLAN (p3d_api.hip: use32) except the tables a mode reads, which the caller
+// checks before it commits a job to this kernel family (the compact samples are ordered differently from the other kernels').
+template <int N>
+hipError_t launch_row_pipe32(int pm, const RowArgs& a, int cus, hipStream_t st)
+{
+    if constexpr (N == P32::N) {
+        if ((double)a.nslices * (double)wk_slice_stride(a.n1, N) >= 4294967296.0 || a.n1 % 2 != 0 || cus < 1 || a.tw32 == nullptr) return hipErrorNotSupported;
+        if (a.only_done || a.plain) return hipErrorNotSupported;                  // finalize, fft2 hook
+        if (a.write_out && !a.adaptive) return hipErrorNotSupported;   // the per-iteration store exists for APOCS only (the last pass stores anyway)
+        const bool tables = a.bits32 != nullptr && a.rowbase != nullptr;
+        if (pm == PIPE_FIRST) {
+            if (a.x == nullptr || (a.xc != nullptr && !tables) || (a.adaptive && !tables)) return hipErrorNotSupported;
+        } else {
+            if (a.xc == nullptr || !tables) return hipErrorNotSupported;
+        }
+        const long groups = ((long)a.nslices * (a.n1 / 2) + P32::UPB - 1) / P32::UPB;
+        const dim3 grid((unsigned)(groups < cus ? groups : cus));   // one 147-KiB workgroup per CU
+        constexpr size_t lds = P32::lds_bytes();
+        hipError_t e = hipSuccess;
+#define P3D_PIPE32(DT, SP, PM, AD)                                                                              \
+    do {                                                                                                        \
+        if ((e = allow_lds(row_pipe32_kernel<DT, SP, PM, AD>, lds)) != hipSuccess) return e;                    \
+        row_pipe32_kernel<DT, SP, PM, AD><<<grid, P32::THREADS, lds, st>>>(a);                                  \
+    } while (0)
+        const bool sp = a.nzl != nullptr, c64 = a.dtype == 0;
+        if (pm == PIPE_FIRST) {
+            if (a.adaptive) { if (c64) P3D_PIPE32(0, false, PIPE_FIRST, true); else P3D_PIPE32(1, false, PIPE_FIRST, true); }
+            else { if (c64) P3D_PIPE32(0, false, PIPE_FIRST, false); else P3D_PIPE32(1, false, PIPE_FIRST, false); }
+        } else if (pm == PIPE_LAST) {
+            if (c64) { if (sp) P3D_PIPE32(0, true, PIPE_LAST, false); else P3D_PIPE32(0, false, PIPE_LAST, false); }
+            else { if (sp) P3D_PIPE32(1, true, PIPE_LAST, false); else P3D_PIPE32(1, false, PIPE_LAST, false); }
+        } else if (pm == PIPE_MID && a.adaptive) {
+            if (c64) { if (sp) P3D_PIPE32(0, true, PIPE_MID, true); else P3D_PIPE32(0, false, PIPE_MID, true); }
+            else { if (sp) P3D_PIPE32(1, true, PIPE_MID, true); else P3D_PIPE32(1, false, PIPE_MID, true); }
+        } else if (pm == PIPE_MID) {
+            if (c64) { if (sp) P3D_PIPE32(0, true, PIPE_MID, false); else P3D_PIPE32(0, false, PIPE_MID, false); }
+            else { if (sp) P3D_PIPE32(1, true, PIPE_MID, false); else P3D_PIPE32(1, false, PIPE_MID, false); }
+        } else {
+            return hipErrorInvalidValue;
+        }
+#undef P3D_PIPE32
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;
@@ -344,6 +393,9 @@ struct LineOps {
     hipError_t (*row_pipe64)(int pm, const RowArgs&, int cus, hipStream_t);   // PIPE_FIRST / PIPE_MID / PIPE_LAST (hipErrorNotSupported where absent)
     hipError_t (*col_pipe)(const ColArgs&, int cus, hipStream_t);             // persistent COL_ITER (hipErrorNotSupported where absent)
     hipError_t (*col_shear_pair)(const ColArgs&, hipStream_t);                // SHEARLET column pass of float32 cubes, two columns per transform
+    hipError_t (*row_pipe32)(int pm, const RowArgs&, int cus, hipStream_t);   // rows of 1024 samples: the one-exchange persistent passes (nullptr elsewhere)
+    int row_tw32_slots;                                                       // ... their twiddle table
+    void (*build_row_tw32)(c32* out);
 };
 
 }  // namespace p3d

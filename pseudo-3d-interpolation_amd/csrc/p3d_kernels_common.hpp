@@ -178,6 +178,9 @@ struct RowArgs {
                                        // mask[row][64*wsub + l + TPL*q]
     const unsigned long long* nzl;     // the same for nzm, per slice (pipe64_word); nullptr: dense
     const unsigned* cbase;             // observed traces of the slice before the first column of each word (pipe64_word)
+    const unsigned long long* bits32;  // row_pipe32_kernel (rows of 1024 samples, a row pair per wavefront): word (unit u, register k) bit l =
+                                       // mask[2u + (l >> 5)][(l & 31) + 32 k]; [n1 / 2][32]
+    const c32* tw32;                   // ... and its twiddles (P32::build_tw, device)
     float alpha;
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)

@@ -371,44 +371,58 @@ def _touch_pages(arr):
 
 
 class _HostPins:
-    """The caller's cube and the result array of one ``pocs_cube`` call, page-locked in place (``_ffi.host_register``) and released
-    at the end of the call.  The cube is registered at once (touched memory: ~2 ms per GiB); the result is touched in the
-    background, then registered -- ``result_ready()`` blocks until that has happened.  (Registering chunk by chunk from the workers
-    was tried: hipHostRegister / Unregister beside running transfers cost more than they hide -- 215 against 155 ms per call on
-    BASELINE configs[2], profiles/r04_pcie_probe.txt.)  A refused registration (already page-locked
-    by the caller, a read-only mapping ...) is not an error: that array simply stays pageable."""
+    """The caller's cube and the result array of one ``pocs_cube`` call, page-locked in place (``_ffi.host_register``) for the
+    duration of the call.  Both are registered in the background from the start of the call, CHUNK BY CHUNK in the order the workers
+    take them (the cube at once; the result behind a few threads that touch its fresh pages): a worker waits for the slab it is about to
+    move -- ``input_ready(i)`` / ``result_ready(i)`` -- not for the whole array.  That matters the first time memory is pinned:
+    hipHostRegister of 4 GiB that never was takes ~90 ms and holds a lock of the runtime that every other HIP call of the process
+    waits for; slab by slab the lock is held ~3 ms at a time and the uploads follow the registration front.  Everything is released
+    at the end of the call.  A refused registration (memory the caller page-locked itself, a read-only mapping ...) is not an error:
+    that slab simply stays pageable.  (Registering AND releasing chunk by chunk from the workers themselves was tried: it costs
+    more than it hides -- 215 against 155 ms per call on BASELINE configs[2], profiles/r04_pcie_probe.txt.)"""
 
-    def __init__(self, cube, out):
+    def __init__(self, cube, out, starts, step):
         import threading
         self._regs = []
         self._lock = threading.Lock()
-        self._done = threading.Event()
-        if _ffi.host_register(cube):
-            self._regs.append(cube)
-        self._out = out
+        self._slabs = [(lo, lo + step) for lo in starts]
+        self._in_done = [threading.Event() for _ in self._slabs]
+        self._out_done = [threading.Event() for _ in self._slabs]
         self._touching = _touch_pages(out)
-        self._thread = threading.Thread(target=self._finish, daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._pin, args=(cube, (), self._in_done), daemon=True),
+                         threading.Thread(target=self._pin, args=(out, self._touching, self._out_done), daemon=True)]
+        for t in self._threads:
+            t.start()
 
-    def _finish(self):
+    def _pin(self, arr, after, done):
         try:
-            for f in self._touching:
+            for f in after:
                 f.result()
-            if _ffi.host_register(self._out):
-                with self._lock:
-                    self._regs.append(self._out)
+            for (lo, hi), ev in zip(self._slabs, done):
+                slab = arr[lo:hi]
+                if _ffi.host_register(slab):
+                    with self._lock:
+                        self._regs.append(slab)
+                ev.set()
         finally:
-            self._done.set()
+            for ev in done:
+                ev.set()
 
-    def result_ready(self):
-        self._done.wait()
+    def input_ready(self, i):
+        self._in_done[i].wait()
+
+    def result_ready(self, i):
+        self._out_done[i].wait()
 
     def release(self):
-        self._done.wait()
+        for t in self._threads:
+            t.join()
         with self._lock:
             regs, self._regs = self._regs, []
         for a in regs:
             _ffi.host_unregister(a)
+
+
 _CHUNK_WORKERS = int(os.environ.get('P3D_CHUNK_WORKERS', 4))   # chunks in flight (slots 0.. of the plan cache; slot 15 belongs to the unchunked path)
 
 
@@ -446,7 +460,7 @@ class _FFTWorker:
             if b is not None:
                 b.free()
 
-    def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha, before_download=None):
+    def run(self, chunk, dst, sched, niter, thresh_op, version, eps, alpha, before_upload=None, before_download=None):
         n = chunk.shape[0]
         t0 = time.perf_counter()
         marks = [('start', t0)] if _timeline is not None else None   # tools/e2e_timeline.py: where a chunk's wall time goes
@@ -460,6 +474,8 @@ class _FFTWorker:
         # cubes that already have the device dtype move straight between the caller's arrays and the device (the runtime reaches
         # the PCIe rate from pageable memory here); others are converted through page-locked staging buffers in parallel slabs
         direct = chunk.dtype == dtype and chunk.flags.c_contiguous and dst.dtype == dtype and dst.flags.c_contiguous
+        if before_upload is not None:
+            before_upload()                            # (the caller's cube is page-locked, or will not be)
         if direct:
             self.x.upload(chunk)
         else:
@@ -600,7 +616,8 @@ def pocs_cube(
             step = max(1, (int(os.environ.get('P3D_CHUNK_MIB', 128)) << 20) // slice_bytes)   # ~128 MiB per chunk, four in flight
         step = min(step, nslices)
         starts = list(range(0, nslices, step))
-        workers = [_FFTWorker.get(nil, nxl, step, device, slot, maskf) for slot in range(min(_CHUNK_WORKERS, len(starts)))]
+        nworkers = min(_CHUNK_WORKERS, len(starts))
+        workers = [None] * nworkers      # (each lane creates / fetches its own worker: plans and device buffers of a first call are set up side by side)
 
         def sched(stats):
             tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
@@ -610,24 +627,30 @@ def pocs_cube(
         # DMA on the workers' own streams, uploads and downloads at the same time (profiles/r04_pcie_probe.txt: 96 GB/s both ways
         # together against 56 GB/s for pageable memory, whose copies take turns; a download into FRESH pages runs at 17 GB/s).  The
         # result array is brand new: its pages are touched by a few threads first (24 ms for 4 GiB; the driver alone takes 176 ms),
-        # while the first chunks are already uploading -- a worker waits for that only before its first download.
-        pin = _HostPins(cube, out) if (len(starts) > 1 and cube.nbytes >= _PIN_MIN_BYTES and cube.dtype == out.dtype
+        # while the first chunks are already uploading.  Registration runs in the background, slab by slab ahead of the workers (_HostPins).
+        pin = _HostPins(cube, out, starts, step) if (len(starts) > 1 and cube.nbytes >= _PIN_MIN_BYTES and cube.dtype == out.dtype
                                        and cube.dtype in (np.complex64, np.float32) and cube.flags.c_contiguous) else None
 
         def lane(w):
+            t_lane = time.perf_counter()
+            workers[w] = _FFTWorker.get(nil, nxl, step, device, w, maskf)
+            if _timeline is not None:
+                _timeline.append(('setup', [('lane starts', t_lane), ('worker ready', time.perf_counter())]))
             rows = []
-            for lo in starts[w::len(workers)]:
+            for i in range(w, len(starts), nworkers):
+                lo = starts[i]
                 rows.append((lo, workers[w].run(cube[lo:lo + step], out[lo:lo + step], sched, niter, thresh_op, version, eps, alpha,
-                                                before_download=None if pin is None else pin.result_ready)))
+                                                before_upload=None if pin is None else (lambda i=i: pin.input_ready(i)),
+                                                before_download=None if pin is None else (lambda i=i: pin.result_ready(i)))))
             return rows
 
         try:
-            if len(workers) == 1:
+            if nworkers == 1:
                 done_rows = lane(0)
             else:
                 from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(len(workers)) as pool:
-                    done_rows = [r for part in pool.map(lane, range(len(workers))) for r in part]
+                with ThreadPoolExecutor(nworkers) as pool:
+                    done_rows = [r for part in pool.map(lane, range(nworkers)) for r in part]
         finally:
             if pin is not None:
                 pin.release()

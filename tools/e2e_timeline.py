@@ -25,6 +25,7 @@ for rep in range(3):
     out = P.pocs_cube(cube, mask, **params)
     wall = time.perf_counter() - t0
     tl, P._timeline = P._timeline, None
+    tl = [(w, m) for w, m in tl if w != 'setup']
     first = min(m[0][1] for _, m in tl)
     last = max(m[-1][1] for _, m in tl)
     tot = {}
