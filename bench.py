@@ -640,6 +640,29 @@ def run_leg(ctx, config, K_override, main):
         real_its = K / float(np.median(rt))
         del xr, outr
 
+    # ---- the same loop in the reference's double precision (p3d_f64.hip), a sample of the cube (rank 0, N = 1, config 2 only) ----
+    ref_prec = None
+    if side and world == 1 and config == 2 and not cfg["real"]:
+        n64 = min(32, n_local)
+        plan64 = _ffi.Plan64(nil, nxl, n64, device=dev_index)
+        host64 = x_obs[:n64].cpu().numpy()
+        st64 = plan64.stats(host64)
+        st64[st64[:, 2] == 0] = 1.0
+        tau64 = P._schedule_from_stats(st64, nil * nxl, "exponential", K, 0.99, p_min, "values")
+        ms64 = [plan64.run(host64, mask, tau64, K, thresh_op=op, eps=args.eps, alpha=args.alpha)[3] for _ in range(3)]
+        plan64.close()
+        it64 = float(np.median(ms64)) / K            # ms per iteration of the n64-slice sample (device time of the loop)
+        ref_prec = {
+            "what": f"the same job with precision='reference': the loop in double precision (the reference's arithmetic for soft / garrote / FPOCS / APOCS and "
+                    f"for every run under NumPy < 2), unfused -- a sample of {n64} slices of the cube, complex64 in and out, device time of the {K}-iteration loop",
+            "slice_iterations_per_s": n64 / (it64 * 1e-3), "iterations_per_s_of_the_cube": n64 / (it64 * 1e-3) / cube_slices,
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": 56.0, "achieved": 56.0 * nil * nxl * n64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": 56.0 * nil * nxl * n64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "note": "28 B/point of the float32 accounting, doubled; the six unfused passes move ~210 B/point (four line-transform passes at 16 + 16, "
+                                 "threshold 32, re-insertion ~50)"},
+        }
+        del host64
+
     # ---- end to end: host NumPy cube in -> host NumPy cube out through the host-buffer entry point (every rank its block) ----
     e2e = None
     if not args.only_main and not args.no_end_to_end and kind != "SHEARLET" and density == 0:
@@ -806,6 +829,7 @@ def run_leg(ctx, config, K_override, main):
         "cpu_baseline": cpu,
         "parity": parity,
         "strong_scaling_model": block8,
+        "reference_precision": ref_prec,
     }
 
 

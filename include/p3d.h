@@ -42,6 +42,8 @@ extern "C" {
 /* element type of the observed cube `x` and of the result (np.iscomplexobj(x), POCS.py:511, 653-656) */
 #define P3D_C64 0 /* complex64: frequency-domain cube (dim 'freq_twt') */
 #define P3D_F32 1 /* float32 : time-domain cube (dim 'twt'); result is np.real() of the iterate */
+#define P3D_C128 2 /* complex128 and */
+#define P3D_F64 3  /* float64 cubes: the double-precision entry points only (p3d_pocs64_*) */
 
 /* thresh_op (POCS.py:91-102 -> threshold_operator.py:9-112) */
 #define P3D_OP_HARD 0
@@ -172,6 +174,20 @@ int p3d_multi_stats(int ndev, const int* devices, int nil, int nxl, const void* 
 int p3d_multi_run(int ndev, const int* devices, int nil, int nxl, const void* x_host, int dtype, const float* mask_host,
                   const double* tau, const uint8_t* active, const p3d_pocs_params* params, void* out_host, int nslices,
                   int32_t* niter_done, double* sums);
+
+/* The same loop in the REFERENCE's precision.  POCS_algorithm computes in complex128 / float64 whenever its input is, under NumPy < 2 for every
+ * input, and under NumPy >= 2 for the soft / garrote operators, FPOCS and APOCS on complex64 / float32 input as well (threshold_operator.py:37-39,
+ * 76-78; POCS.py:566-575, 616: tau, the momentum scalar and the weights 1 - alpha * mask are float64 / complex128).  A plan64 runs
+ * fft2 -> threshold -> ifft2 -> re-insertion -> cost in double precision for any slice extents up to 5120, unfused (a precision path: six passes
+ * over the cube per iteration).  dtype of x and out: P3D_C128, P3D_F64, or P3D_C64 / P3D_F32 (converted on load / store: what the reference's final
+ * cast to the input dtype does, cube_POCS_interpolation_3D.py:324); x, out, mask may be host or device pointers; mask is DOUBLE [nil][nxl];
+ * tau [nslices][niter][2], stats, sums and the error behaviour as p3d_pocs_stats / p3d_pocs_run; thresh_op: hard, soft, garrote. */
+typedef struct p3d_plan64 p3d_plan64;
+int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_slices);
+int p3d_plan64_destroy(p3d_plan64* plan);
+int p3d_pocs64_stats(p3d_plan64* plan, const void* x, int dtype, int nslices, double* stats_host);
+int p3d_pocs64_run(p3d_plan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
+                   const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);
 
 /* Steps 12 / 14 of the workflow: transform every trace of a (nt, ntraces) time-domain cube (ntraces = nil*nxl, the
  * slice-major layout: sample index slowest) to the frequency domain and back, with the conventions of

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("P3D_LIB_PATH") or os.path.join(_HERE, "libp3d_hip.so"
 P3D_OK = 0
 P3D_ERR_INVALID, P3D_ERR_UNSUPPORTED, P3D_ERR_HIP = -1, -2, -3
 P3D_C64, P3D_F32 = 0, 1
+P3D_C128, P3D_F64 = 2, 3      # the double-precision entry points only (Plan64)
 P3D_OP = {"hard": 0, "soft": 1, "garrote": 2, "garotte": 2}
 P3D_OP_PERCENTILE = 16
 P3D_OP.update({f"{k}-percentile": v | P3D_OP_PERCENTILE for k, v in list(P3D_OP.items())})
@@ -57,6 +58,11 @@ PROTOTYPES = {
     "p3d_fft2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "p3d_fft2_shrink_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_plan64_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "p3d_plan64_destroy": (C.c_int, [C.c_void_p]),
+    "p3d_pocs64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_pocs64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams), C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "p3d_host_unregister": (C.c_int, [C.c_void_p]),
     "p3d_pocs_prime_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -543,6 +549,69 @@ class WaveletPlan:
         check(lib().p3d_wavelet_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
                                     C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return done, sums, ms.value
+
+
+# ---- the loop in the reference's precision ---------------------------------------------------
+class Plan64:
+    """p3d_plan64 wrapper: the FFT POCS loop in double precision (include/p3d.h) for complex128 / float64 cubes, and for complex64 /
+    float32 cubes whose reference run is a double-precision one (soft / garrote / FPOCS / APOCS, or any run under NumPy < 2)."""
+    _DT = {np.dtype(np.complex128): P3D_C128, np.dtype(np.float64): P3D_F64, np.dtype(np.complex64): P3D_C64, np.dtype(np.float32): P3D_F32}
+
+    def __init__(self, nil, nxl, max_slices, device=0):
+        self.nil, self.nxl, self.max_slices, self.device = int(nil), int(nxl), int(max_slices), int(device)
+        h = C.c_void_p()
+        check(lib().p3d_plan64_create(C.byref(h), self.device, self.nil, self.nxl, self.max_slices))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().p3d_plan64_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        if lib is not None:
+            self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _cube(self, x):
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[None]
+        if x.ndim != 3 or x.shape[1:] != (self.nil, self.nxl) or x.shape[0] > self.max_slices:
+            raise ValueError(f"expected (<= {self.max_slices}, {self.nil}, {self.nxl}), got {x.shape}")
+        if x.dtype not in self._DT:
+            x = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+        return np.ascontiguousarray(x), self._DT[x.dtype]
+
+    def stats(self, x):
+        """(nslices, 6) float64, the layout of ``Plan.stats``: statistics of the double-precision ``fft2(x)``."""
+        xc, dt = self._cube(x)
+        st = np.empty((xc.shape[0], 6), np.float64)
+        check(lib().p3d_pocs64_stats(self.handle, _ptr(xc), dt, xc.shape[0], _ptr(st)))
+        return st
+
+    def run(self, x, mask, tau, niter, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """Host arrays in, host arrays out (dtype of ``x``).  Returns (out, niter_done, sums, elapsed_ms)."""
+        xc, dt = self._cube(x)
+        n = xc.shape[0]
+        m = np.ascontiguousarray(mask, dtype=np.float64)
+        if m.shape != (self.nil, self.nxl):
+            raise ValueError(f"mask shape {m.shape} != {(self.nil, self.nxl)}")
+        t = Plan._tau(tau, n, niter)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        out = np.empty_like(xc)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_pocs64_run(self.handle, _ptr(xc), dt, _ptr(m), _ptr(t), None if act is None else _ptr(act), C.byref(prm), _ptr(out), n,
+                                   _ptr(done), _ptr(sums), C.byref(ms)))
+        return out, done, sums, ms.value
 
 
 # ---- SHEARLET variant ----------------------------------------------------------------------

@@ -525,6 +525,48 @@ def _result_rows(done, sums, runtime):
     return rows
 
 
+def _get_plan64(nil, nxl, nslices, device):
+    key = ('f64', nil, nxl, device)
+    plan = _plans.get(key)
+    if plan is None or plan.max_slices < nslices:
+        if plan is not None:
+            plan.close()
+        plan = _ffi.Plan64(nil, nxl, max(nslices, 1), device)
+        _plans[key] = plan
+    return plan
+
+
+def _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results, device,
+                      batch_slices):
+    """``pocs_cube`` through the double-precision loop (``_ffi.Plan64``): statistics of the double-precision ``fft2`` -> the schedule
+    (host, complex128, as always) -> the iterations, batch by batch.  The data-driven schedule takes its picks from the float32
+    plan's device sort (positions in the sorted spectrum; the values differ from a double sort's by float32 rounding)."""
+    nslices, nil, nxl = cube.shape
+    step = int(batch_slices) if batch_slices else max(1, min(nslices, (2 << 30) // (nil * nxl * 16)))   # work + staging: 48 B per point and slice
+    plan = _get_plan64(nil, nxl, min(step, nslices), device)
+    mask64 = np.ascontiguousarray(mask, dtype=np.float64)
+    for lo in range(0, nslices, step):
+        chunk = cube[lo:lo + step]
+        n = chunk.shape[0]
+        active = chunk.reshape(n, -1).any(axis=1)   # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+        t0 = time.perf_counter()
+        if thresh_model == 'data-driven':
+            narrow = chunk.astype(np.complex64 if np.iscomplexobj(chunk) else np.float32)
+            tau = _data_driven_batch(_get_plan(nil, nxl, n, device, slot=15), narrow, active, niter, p_max, p_min)
+        else:
+            stats = plan.stats(chunk)
+            stats[~active] = 1.0
+            tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
+        if sqrt_decay:
+            tau = np.sqrt(tau)
+        res, done, sums, _ = plan.run(chunk, mask64, tau, niter, thresh_op=thresh_op, version=version, eps=eps, alpha=alpha, active=active)
+        runtime = time.perf_counter() - t0
+        out[lo:lo + n] = res
+        if results is not None:
+            results.extend(_result_rows(done, sums, runtime))
+    return out
+
+
 def _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps, p_max, alpha, p_min):
     """Argument checks of the batched entry points (``pocs_cube``, ``sharding.pocs_block_on_device``), made BEFORE anything is
     uploaded: the kernels read ``nil * nxl`` mask entries whatever the caller handed over.  Returns the normalised
@@ -565,6 +607,7 @@ def pocs_cube(
     batch_slices=None,
     wavelet=None,
     auxiliary_data=None,
+    precision=None,
     **ignored,
 ):
     """
@@ -578,6 +621,14 @@ def pocs_cube(
     callables in ``**ignored`` are accepted for signature compatibility and not called: the transform
     is selected by ``transform_kind``.
 
+    ``precision`` (FFT transform; default: the environment variable ``P3D_PRECISION``, else ``None``) -- the arithmetic of the loop:
+    ``None``: that of the cube -- float32 kernels for complex64 / float32 cubes, the double-precision loop for complex128 / float64
+    cubes (the reference computes such cubes in double precision; POCS.py:371-656 never narrows its input); ``'reference'``: double
+    precision also for complex64 / float32 cubes, the result cast back (what the reference itself executes for the soft / garrote
+    operators, FPOCS and APOCS, and for every run under NumPy < 2 -- SURVEY appendix A.16); ``'float32'``: the float32 kernels whatever the
+    cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loop is an unfused
+    precision path, has the hard / soft / garrote operators and slice extents up to 5120.
+
     Returns an array with the shape and dtype of ``cube``.
     """
     cube, mask, kind, niter, eps, p_max, alpha, p_min = _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps,
@@ -588,6 +639,14 @@ def pocs_cube(
         return out
     step = int(batch_slices) if batch_slices else nslices
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
+    if precision is None:
+        precision = os.environ.get('P3D_PRECISION') or None
+    if precision not in (None, 'reference', 'float32'):
+        raise ValueError(f"precision must be None, 'reference' or 'float32', got {precision!r}")
+    wide = cube.dtype in (np.complex128, np.float64)
+    if kind == 'FFT' and thresh_op in _WAVELET_OPS and max(nil, nxl) <= 5120 and (precision == 'reference' or (wide and precision is None)):
+        return _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results,
+                                 device, batch_slices)
     if kind == 'SHEARLET':
         if auxiliary_data is None:
             raise ValueError(f'{kind} requires pre-computed shearlets in Fourier domain (Psi)')

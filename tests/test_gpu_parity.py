@@ -695,16 +695,63 @@ def test_batching_is_transparent(P, orc):
 
 
 def test_double_precision_cubes_are_converted_on_their_way_in(P, orc):
-    """complex128 / float64 cubes go through the page-locked staging buffers of the chunk pipeline (parallel slab copies with the
-    dtype conversion folded in); the result is the single-precision cube's, cast back, and keeps the caller's dtype."""
+    """precision='float32': complex128 / float64 cubes go through the page-locked staging buffers of the chunk pipeline (parallel slab
+    copies with the dtype conversion folded in); the result is the single-precision cube's, cast back, and keeps the caller's dtype.
+    (By default such cubes run the double-precision loop: the tests below.)"""
     _, mask, obs = orc.synthetic_cube(1024, 512, 9, 0.6)          # 9 x 4 MiB: two slabs per copy, chunks of 4 slices
     params = dict(niter=5, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2, batch_slices=4)
     a = P.pocs_cube(obs, mask, **params)
-    b = P.pocs_cube(obs.astype(np.complex128), mask, **params)
+    b = P.pocs_cube(obs.astype(np.complex128), mask, precision="float32", **params)
     assert b.dtype == np.complex128 and np.array_equal(b, a.astype(np.complex128))
-    r = P.pocs_cube(obs.real.astype(np.float64), mask, **dict(params, thresh_op="hard"))
+    r = P.pocs_cube(obs.real.astype(np.float64), mask, precision="float32", **dict(params, thresh_op="hard"))
     r32 = P.pocs_cube(obs.real.astype(np.float32), mask, **dict(params, thresh_op="hard"))
     assert r.dtype == np.float64 and np.array_equal(r, r32.astype(np.float64))
+    with pytest.raises(ValueError):
+        P.pocs_cube(obs[:1], mask, precision="half", **params)
+
+
+REFERENCE_PRECISION = [
+    # the three regimes the float32 kernels hold to 2e-4 only (ILL_CONDITIONED above): the reference itself computes them in double precision
+    dict(nil=512, nxl=512, n=1, missing=0.7, niter=12, thresh_op="soft"),
+    dict(nil=64, nxl=1024, n=2, missing=0.8, niter=10, thresh_op="garrote"),
+    dict(nil=128, nxl=128, n=2, missing=0.5, niter=10, thresh_op="garrote"),
+    dict(nil=1024, nxl=1024, n=1, missing=0.8, niter=10, thresh_op="hard"),
+    # BASELINE configs[1]'s slice with the soft operator over its 50 iterations
+    dict(nil=512, nxl=512, n=1, missing=0.7, niter=50, thresh_op="soft"),
+    dict(nil=60, nxl=100, n=3, missing=0.5, niter=8, thresh_op="soft", version="adaptive", alpha=0.8),
+    dict(nil=96, nxl=50, n=3, missing=0.5, niter=8, thresh_op="soft", version="fast", thresh_model="inverse_proportional"),
+    dict(nil=96, nxl=50, n=3, missing=0.5, niter=8, thresh_op="hard", version="regular", thresh_model="linear"),
+    dict(nil=64, nxl=64, n=4, missing=0.5, niter=30, thresh_op="soft", eps=1e-7, real=True),
+]
+
+
+@pytest.mark.parametrize("cfg", REFERENCE_PRECISION)
+def test_reference_precision_loop(P, orc, cfg):
+    """precision='reference' (and, by default, every complex128 / float64 cube): the loop in double precision (p3d_f64.hip) -- what the
+    reference itself executes for soft / garrote / FPOCS / APOCS and for every cube under NumPy < 2.  BASELINE's 1e-5 against the float64
+    oracle holds there with five orders of magnitude to spare, in the regimes where float32 decisions at |X| = Re tau cost the float32
+    kernels 1e-4; iteration counts of the early exit agree; a complex64 / float32 cube comes back in its own dtype."""
+    cfg = dict(cfg)
+    nil, nxl, n, missing, real = cfg.pop("nil"), cfg.pop("nxl"), cfg.pop("n"), cfg.pop("missing"), cfg.pop("real", False)
+    params = dict(dict(thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-3), **cfg)
+    _, mask, obs = orc.synthetic_cube(nil, nxl, n, missing, real=real)
+    if n > 2:
+        obs[1] = 0                                                   # an all-zero slice passes through
+    wide = obs.astype(np.float64 if real else np.complex128)
+    infos = []
+    want = orc.pocs_cube(wide, mask, infos=infos, **params)
+    res64, res32 = [], []
+    got64 = P.pocs_cube(wide, mask, results=res64, **params)                           # a double cube: double loop by default
+    got32 = P.pocs_cube(obs, mask, precision="reference", results=res32, **params)   # a single cube on request, cast back
+    assert got64.dtype == wide.dtype and got32.dtype == obs.dtype
+    for s in range(n):
+        if n > 2 and s == 1:
+            assert not got64[s].any() and not got32[s].any()
+            continue
+        assert rel_l2(got64[s], want[s]) <= 1e-10, (s, rel_l2(got64[s], want[s]))
+        assert rel_l2(got32[s], want[s]) <= 2e-7, (s, rel_l2(got32[s], want[s]))   # (the final cast to float32)
+        assert res64[s]["niterations"] == infos[s]["niterations"] == res32[s]["niterations"]
+        assert np.allclose(res64[s]["costs"], infos[s]["costs"], rtol=1e-6, atol=1e-18)   # (a cost is a squared difference of two nearly equal sums)
 
 
 @pytest.mark.parametrize("family", ["one-exchange (row_pipe32_kernel)", "row_pipe64_kernel"])
