@@ -877,6 +877,8 @@ def main():
             line["other_configs"] = others
     if ctx.rank == 0:
         line["kernel_source_hash"] = kernel_source_hash()
+        from pseudo_3d_interpolation_amd import _ffi as _f
+        line["hip_runtime"] = _f.runtime_info()
         line["bench_wall_s"] = time.perf_counter() - t_all
         print(json.dumps(line), flush=True)
     if ctx.world > 1:

@@ -85,6 +85,9 @@ typedef struct p3d_pocs_params {
 
 int p3d_abi_version(void);
 const char* p3d_last_error(void);
+/* HIP_VERSION this library was compiled against and the version of the HIP runtime the process bound (they differ when another copy of
+ * libamdhip64 was mapped first; the Python binding warns when major.minor disagree) */
+int p3d_runtime_info(int* compiled_hip_version, int* runtime_hip_version);
 int p3d_device_count(int* n);
 
 /* 1 when the HIP kernels cover an (nil, nxl) slice shape, else 0 */

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "p3d_fft2_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "p3d_fft2_shrink_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "p3d_pocs_stats_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_runtime_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "p3d_plan64_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "p3d_plan64_destroy": (C.c_int, [C.c_void_p]),
     "p3d_pocs64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -142,7 +143,44 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        _check_runtime(handle)
     return _lib
+
+
+_runtime = None
+
+
+def _check_runtime(handle):
+    """Which HIP runtime did the process bind?  libp3d_hip.so is built against /opt/rocm; when a PyTorch wheel's copy of libamdhip64 (same
+    SONAME) is mapped first -- `_preload_torch_hip` does that on purpose, see there -- the library runs on THAT runtime.  Record both
+    versions and the file, and warn when major.minor differ (an unchecked ABI / code-object skew otherwise)."""
+    global _runtime
+    comp, run = C.c_int(0), C.c_int(0)
+    path = None
+    try:
+        if handle.p3d_runtime_info(C.byref(comp), C.byref(run)) != P3D_OK:
+            return
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+    except OSError:
+        pass
+
+    def split(v):
+        return v // 10000000, (v // 100000) % 100, v % 100000
+    _runtime = {"compiled_hip_version": "%d.%d.%d" % split(comp.value), "runtime_hip_version": "%d.%d.%d" % split(run.value), "runtime_library": path}
+    if split(comp.value)[:2] != split(run.value)[:2]:
+        import warnings
+        warnings.warn(f"libp3d_hip.so was compiled against HIP {_runtime['compiled_hip_version']} but the process runs HIP "
+                      f"{_runtime['runtime_hip_version']} ({path}); set P3D_NO_TORCH_HIP_PRELOAD=1 to keep PyTorch's runtime out", RuntimeWarning, stacklevel=3)
+
+
+def runtime_info():
+    """{'compiled_hip_version', 'runtime_hip_version', 'runtime_library'} of the loaded library (bench.py records it)."""
+    lib()
+    return dict(_runtime or {})
 
 
 def check(code):

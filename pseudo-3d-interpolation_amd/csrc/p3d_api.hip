@@ -201,6 +201,25 @@ static __global__ void reduce_rows_kernel(const double* rowsum, double* sums_row
     if (threadIdx.x == 0) sums_row[s] = sh[0];
 }
 
+// ---- debug (P3D_CHECK_DONE_ROWS=1): checksum of the work slice of every converged slice that still waits for its finalize launch ----
+// The early exit hands a converged slice's iterate back from its WORK ROWS up to FIN_EVERY iterations later (p3d_pocs_run_dev), so every
+// pass must leave the work slice of a slice with done != 0 alone.  sum[s] = wrap-around sum of the slice's 64-bit words, 0 for the others.
+static __global__ void done_rows_checksum_kernel(const unsigned long long* work, size_t words_per_slice, const int* done, int lo, unsigned long long* sum)
+{
+    __shared__ unsigned long long sh[256];
+    const int s = blockIdx.x;
+    unsigned long long t = 0;
+    if (done[s] > lo)
+        for (size_t i = threadIdx.x; i < words_per_slice; i += 256) t += work[(size_t)s * words_per_slice + i] * (2 * i + 1);
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sum[s] = sh[0];
+}
+
 // ---- sums[0] of slices that are switched off from the start (done < 0) reads as zero --------------------------
 static __global__ void zero_off_sums_kernel(double* sums0, const int* done, int nslices)
 {
@@ -396,6 +415,16 @@ extern "C" {
 int p3d_abi_version(void) { return P3D_ABI_VERSION; }
 
 const char* p3d_last_error(void) { return g_err.c_str(); }
+
+// HIP_VERSION the library was compiled against and the version of the runtime the process actually bound (the two differ when another
+// copy of libamdhip64 was mapped first, e.g. the one a PyTorch wheel brings: _ffi.py compares them)
+int p3d_runtime_info(int* compiled_hip_version, int* runtime_hip_version)
+{
+    if (!compiled_hip_version || !runtime_hip_version) return fail(P3D_ERR_INVALID, "NULL argument");
+    *compiled_hip_version = HIP_VERSION;
+    HIP_TRY(hipRuntimeGetVersion(runtime_hip_version));
+    return P3D_OK;
+}
 
 int p3d_device_count(int* n)
 {
@@ -1480,6 +1509,14 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
 
     HIP_TRY(stamp());
     int last_finalized = 0;   // early exit: slices with done <= last_finalized have been handed to `out`
+    // Debug mode of the invariant the deferred finalize rests on (RowArgs::only_done_lo, ColArgs::done): the work slice of a converged slice
+    // that has not been handed back yet must not change.  One blocking round trip per iteration: tests only (tests/test_gpu_parity.py).
+    const bool check_done_rows = finalize && getenv("P3D_CHECK_DONE_ROWS") != nullptr;
+    std::vector<unsigned long long> done_sum_first(check_done_rows ? nslices : 0, 0ull), done_sum_now(check_done_rows ? nslices : 0, 0ull);
+    std::vector<char> done_sum_seen(check_done_rows ? nslices : 0, 0);
+    unsigned long long* done_sum_d = nullptr;
+    if (check_done_rows) HIP_TRY(hipMalloc((void**)&done_sum_d, sizeof(unsigned long long) * nslices));
+    struct FreeSum { unsigned long long* p; ~FreeSum() { if (p) hipFree(p); } } free_sum{done_sum_d};
     for (int k = 0; k < niter; ++k) {
         c.iter = k;
         if (percentile) {
@@ -1556,6 +1593,20 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
             // (the finalize launch -- mostly workgroups that find nothing to do -- runs every FIN_EVERY iterations and before the last pass: a slice that has
             // converged keeps its work rows, nothing touches them any more)
             constexpr int FIN_EVERY = 8;
+            if (check_done_rows) {
+                done_rows_checksum_kernel<<<nslices, 256, 0, p->stream>>>(reinterpret_cast<const unsigned long long*>(p->work), wk_slice_stride(p->nil, n2_work),
+                                                                         p->done, last_finalized, done_sum_d);
+                HIP_TRY(hipMemcpyAsync(done_sum_now.data(), done_sum_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                for (int s = 0; s < nslices; ++s) {
+                    if (done_h[s] <= last_finalized) continue;   // running, empty or already handed back
+                    if (!done_sum_seen[s]) { done_sum_seen[s] = 1; done_sum_first[s] = done_sum_now[s]; }
+                    else if (done_sum_first[s] != done_sum_now[s])
+                        return fail(P3D_ERR_HIP, "P3D_CHECK_DONE_ROWS: the work rows of slice %d (converged at iteration %d) changed before its finalize launch (iteration %d)", s,
+                                    done_h[s], k + 1);
+                }
+            }
             if (finalize && k + 1 < niter && (k + 1 - last_finalized >= FIN_EVERY || k + 2 >= niter)) {
                 RowArgs f = r;
                 f.nzm = nullptr;  // the rows it reads were written by the row pass: all there

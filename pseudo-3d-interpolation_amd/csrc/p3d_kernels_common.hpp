@@ -171,7 +171,11 @@ struct RowArgs {
     const uint8_t* nzflag; // the flexible row pass (p3d_flex.hip) reads the column pass's tile flags directly: [nslices][nz_tiles],
     int nz_tiles;          //   a tile spans nz_col_t columns
     int nz_col_t;
-    int only_done_lo;      // LAST, only_done > 0: the finalize launch takes the slices with only_done_lo < done <= only_done (it runs every few iterations)
+    int only_done_lo;      // LAST, only_done > 0: the finalize launch takes the slices with only_done_lo < done <= only_done (it runs every few iterations).
+                           // INVARIANT every pass of the loop must keep (row, column, flexible, chirp-z, percentile-fused ...): a slice with done != 0 is
+                           // left ALONE -- its work rows hold the forward row transform of its converged iterate until the finalize launch reads them,
+                           // up to 8 iterations later.  A pass that ignores `done` corrupts exactly the eps > 0 jobs whose slices converge at different
+                           // iterations; P3D_CHECK_DONE_ROWS=1 (p3d_pocs_run_dev) checksums those rows every iteration, tests/test_gpu_parity.py runs it
     int only_done;         // LAST, > 0: "finalize" launch of the early exit -- only slices whose done is in (only_done_lo, only_done]; their work
                            // rows hold the forward row transform of the converged iterate, which is handed to `out`
     const unsigned long long* bits64;  // rows of whole wavefronts: the mask as lane masks, word pipe64_word(row, TPL/64, wsub, q) bit l =
@@ -195,7 +199,7 @@ struct ColArgs {
     c32* out;           // may alias `in`
     const c32* tw;      // the column pass's twiddle tables (ColTables<N>, device)
     const c32* tau;     // [nslices][niter] (COL_ITER, optional for COL_FWD)
-    const int* done;
+    const int* done;    // per slice: != 0 -> the column pass must not touch the slice (see RowArgs::only_done_lo for the invariant)
     float* partials;    // [nslices][tiles][STATS_PARTIAL] (COL_STATS)
     int n2;
     int nslices;

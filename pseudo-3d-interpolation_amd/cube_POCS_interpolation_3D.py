@@ -160,7 +160,13 @@ def main(argv=sys.argv, return_dataset=False):
     # `batch_chunk` is the unit of the OUTPUT (one file and one runtime record per batch, as the reference writes them); the GPU is handed several
     # consecutive batches per call -- a 20-slice batch of the documented example is a fraction of what keeps the device and the host link busy
     # (pocs_cube overlaps upload, loop and download of ~128-MiB portions on several plans inside ONE call, not across calls)
-    group_bytes = float(os.environ.get('P3D_CLI_GROUP_GIB', '4')) * 2.0 ** 30
+    try:
+        group_gib = float(os.environ.get('P3D_CLI_GROUP_GIB', '4'))
+    except ValueError:
+        raise ValueError(f"P3D_CLI_GROUP_GIB must be a number of GiB, got {os.environ['P3D_CLI_GROUP_GIB']!r}") from None
+    if not group_gib >= 0:
+        raise ValueError(f'P3D_CLI_GROUP_GIB must be >= 0, got {group_gib}')
+    group_bytes = group_gib * 2.0 ** 30
     per_slice = data[0].nbytes if len(data) else 1
     groups, cur, cur_bytes = [], [], 0
     for sl in batches:
@@ -176,7 +182,9 @@ def main(argv=sys.argv, return_dataset=False):
         span = slice(group[0].start, group[-1].stop)
         results = []
         aux = Psi if TRANSFORM == 'SHEARLET' else None      # :307
-        merged[span] = pocs_cube(data[span], mask, results=results, auxiliary_data=aux, **kwargs)
+        # (straight into the merged cube: no second group-sized result array.  `runtime` of a slice's record is its GROUP's wall time divided by
+        # the group's slices -- the reference records a batch's time / its slices; INTEGRATION.md says so)
+        pocs_cube(data[span], mask, results=results, auxiliary_data=aux, out=merged[span], **kwargs)
         for sl in group:
             block = merged[sl]
             save_cube(wrap(block, sl), create_file_path(coord[sl], prefix=prefix, root_path=out_path, suffix=suffix))

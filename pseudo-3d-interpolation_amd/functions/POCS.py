@@ -608,6 +608,7 @@ def pocs_cube(
     wavelet=None,
     auxiliary_data=None,
     precision=None,
+    out=None,
     **ignored,
 ):
     """
@@ -629,12 +630,18 @@ def pocs_cube(
     cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loop is an unfused
     precision path, has the hard / soft / garrote operators and slice extents up to 5120.
 
-    Returns an array with the shape and dtype of ``cube``.
+    ``out`` (optional): an array of the shape and dtype of ``cube`` to write the result into (e.g. a slab of the merged cube of the
+    step-13 driver) instead of a new one.
+
+    Returns an array with the shape and dtype of ``cube`` (``out`` when given).
     """
     cube, mask, kind, niter, eps, p_max, alpha, p_min = _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps,
                                                                          p_max, alpha, p_min)
     nslices, nil, nxl = cube.shape
-    out = np.empty_like(cube)
+    if out is None:
+        out = np.empty_like(cube)
+    elif not isinstance(out, np.ndarray) or out.shape != cube.shape or out.dtype != cube.dtype:
+        raise ValueError(f'out must be a NumPy array of shape {cube.shape} and dtype {cube.dtype}')
     if nslices == 0:
         return out
     step = int(batch_slices) if batch_slices else nslices

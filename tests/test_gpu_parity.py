@@ -710,6 +710,36 @@ def test_double_precision_cubes_are_converted_on_their_way_in(P, orc):
         P.pocs_cube(obs[:1], mask, precision="half", **params)
 
 
+@pytest.mark.parametrize("shape,dtype,op", [((64, 1024), np.complex64, "hard"), ((64, 512), np.complex64, "soft"), ((48, 100), np.complex64, "hard"),
+                                            ((61, 67), np.complex64, "hard"), ((64, 128), np.float32, "hard"), ((64, 256), np.complex64, "hard-percentile"),
+                                            ((32, 2048), np.complex64, "hard")])
+def test_converged_slices_keep_their_work_rows_until_they_are_handed_back(P, orc, monkeypatch, shape, dtype, op):
+    """The early exit (eps > 0, the reference's default) hands a converged slice's iterate back from its WORK ROWS, up to eight
+    iterations after it converged (one finalize launch per eight iterations): every pass of the loop -- tuned, one-exchange, flexible,
+    chirp-z, row pairs, percentile-fused -- has to leave a slice with done != 0 alone.  P3D_CHECK_DONE_ROWS=1 checksums those rows after
+    every iteration inside p3d_pocs_run_dev and fails the job on a change; the slices here converge at different iterations."""
+    nil, nxl = shape
+    n = 6
+    mask = orc.synthetic_mask(nil, nxl, 0.5)
+    full = np.stack([orc.synthetic_slice(nil, nxl, 300 + s) for s in range(n)])
+    il, xl = np.arange(nil)[:, None] / nil, np.arange(nxl)[None, :] / nxl
+    for s in (1, 4):                                   # noise-free single plane waves: these converge early
+        full[s] = (2.0 + s) * np.exp(2j * np.pi * (3 * il + (2 + s) * xl))
+    cube = full * mask
+    cube = (cube.real if dtype == np.float32 else cube).astype(dtype)
+    kw = dict(niter=40, thresh_op=op, thresh_model="exponential", eps=1e-7, p_max=0.99 if "percentile" not in op else 99.0,
+              p_min=1e-2 if "percentile" not in op else 50.0)
+    plain, checked = [], []
+    a = P.pocs_cube(cube, mask, results=plain, **kw)
+    monkeypatch.setenv("P3D_CHECK_DONE_ROWS", "1")
+    b = P.pocs_cube(cube, mask, results=checked, **kw)
+    monkeypatch.delenv("P3D_CHECK_DONE_ROWS")
+    its = [r["niterations"] for r in plain]
+    assert its == [r["niterations"] for r in checked] and np.array_equal(a, b)
+    # (the check had converged slices to watch -- with the hard operator finishing at different iterations)
+    assert min(its) < 40 - 8 and (len(set(its)) >= 2 or op != "hard"), its
+
+
 REFERENCE_PRECISION = [
     # the three regimes the float32 kernels hold to 2e-4 only (ILL_CONDITIONED above): the reference itself computes them in double precision
     dict(nil=512, nxl=512, n=1, missing=0.7, niter=12, thresh_op="soft"),

@@ -25,7 +25,7 @@ cfg = bench.CONFIGS[config]
 kind = cfg["kind"]
 # (pattern of the loop's kernels, pattern of the one that runs once per iteration and rank)
 LOOP = {
-    "FFT": (r"col_kernel<\d+, \d+, (0|4|5)>|col_pipe_kernel|row_pipe64_kernel<\d+, \d, (true|false), 0,|row_pipe_kernel|row_real_kernel|resident_kernel",
+    "FFT": (r"col_kernel<\d+, \d+, (0|4|5)>|col_pipe_kernel|row_pipe64_kernel<\d+, \d, (true|false), 0,|row_pipe32_kernel<\d, (true|false), 0,|row_pipe_kernel|row_real_kernel|resident_kernel",
             r"col_kernel<\d+, \d+, (0|4|5)>|col_pipe_kernel|resident_kernel"),
     "WAVELET": (r"dwt2_tile_kernel|idwt2_tile_kernel|wcoarse_kernel|wfuse1_kernel", r"wcoarse_kernel"),
     "SHEARLET": (r"p3d::row_kernel|p3d::col_kernel|col_pipe_kernel|col_shear_pair_kernel|supdate_kernel|mirror_rows_kernel", r"col_shear_pair_kernel|col_pipe_kernel"),
