@@ -504,7 +504,7 @@ def run_leg(ctx, config, K_override, main):
 
     # ---- strong scaling without the hardware: the SAME job on 1/8 of this rank's slices (the block a GPU gets at N = 8) -------
     block8 = None
-    if rank == 0 and world == 1 and main and kind == "FFT" and n_local % 8 == 0 and n_local >= 8:
+    if rank == 0 and world == 1 and main and kind == "FFT" and n_local % 8 == 0 and n_local >= 8 and not args.only_main:   # (not under a profiler: launches of ONE size there)
         nl_full = n_local
         n_local = nl_full // 8          # (job() reads n_local; the plan was created for nl_full slices)
         try:
