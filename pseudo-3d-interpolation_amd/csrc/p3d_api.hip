@@ -932,7 +932,7 @@ int p3d_pocs_sorted_spectrum(p3d_plan* p, const void* x, int nslices, float* pea
     if (!x || !peaks) return fail(P3D_ERR_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(p->device));
     const size_t per = p->slice_elems(), bytes = sizeof(c32) * per * nslices;
-    if (per * (size_t)nslices > 0xffffffffull) return fail(P3D_ERR_UNSUPPORTED, "%zu samples per batch: the segmented sort indexes with 32 bits", per * (size_t)nslices);
+    if (per > 0xffffffffull) return fail(P3D_ERR_UNSUPPORTED, "%zu samples per slice: the segmented sort indexes a slice with 32 bits", per);
     if ((rc = ensure_staging(p, sizeof(c32) * per * p->max_slices))) return rc;
     HIP_TRY(hipMemcpyAsync(p->st_x, x, bytes, hipMemcpyDefault, p->stream));   // (x may be a device pointer: ordered with the plan's stream)
     if ((rc = fft2_enqueue(p, p->st_x, p->st_out, nslices, 0))) return rc;

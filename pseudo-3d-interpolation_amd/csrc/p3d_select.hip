@@ -5,15 +5,14 @@
 //     idx = (x_fwd > tau_min) & (x_fwd < tau_max);  v = np.sort(x_fwd[idx])[::-1]
 //     tau[0] = v[0];  tau[i] = v[ceil(i (Nv - 1) / (niter - 1))]
 // x_fwd is COMPLEX: NumPy orders complex numbers lexicographically (real part, then imaginary part), in the comparisons and in the
-// sort.  (re, im) -> one 64-bit key whose unsigned order is that order; the keys of every slice are sorted once (rocPRIM segmented
-// radix sort, descending), the two bounds are found by bisection, the niter picks are reads.  The host used to download the
+// sort.  (re, im) -> one 64-bit key whose unsigned order is that order; the keys of every slice are sorted once (a hand-written segmented
+// least-significant-digit radix sort, descending: sixteen 4-bit passes of histogram / scan / stable scatter -- round 4; rocPRIM's
+// segmented sort before), the two bounds are found by bisection, the niter picks are reads.  The host used to download the
 // spectrum and sort it per slice (80 ms per 1024 x 1024 slice).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <cstring>
-
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "p3d_select.hpp"
 
@@ -41,10 +40,78 @@ __global__ void lex_keys_kernel(uint64_t* inout, size_t count)
     }
 }
 
-__global__ void offsets_kernel(unsigned* off, unsigned per, int nslices)
+// ---- segmented radix sort, descending, one segment per slice ---------------------------------------------------------------------------
+// 4 bits per pass (bucket = 15 - digit: the largest digit first), tiles of 4096 keys (256 threads x 16 consecutive keys: a thread's keys,
+// then the threads, then the tiles are in index order, so ranks counted that way keep the pass stable).  Off the iteration loop, once per
+// job of the 'data-driven' model: clarity over speed (48 launches, ~50 ms for 512 slices of 2^20 keys).
+constexpr int SORT_T = 256, SORT_K = 16, SORT_TILE = SORT_T * SORT_K;
+__device__ __forceinline__ unsigned sort_bucket(uint64_t k, int shift) { return 15u - (unsigned)((k >> shift) & 15ull); }
+
+// hist[(slice * 16 + bucket) * tiles + tile] = keys of the tile in the bucket
+__global__ void sort_hist_kernel(const uint64_t* src, unsigned* hist, size_t per, int tiles, int shift)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= nslices) off[i] = (unsigned)i * per;
+    __shared__ unsigned cnt[16];
+    const int tile = blockIdx.x, slice = blockIdx.y;
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t* s = src + (size_t)slice * per;
+    const size_t lo = (size_t)tile * SORT_TILE;
+    for (int j = 0; j < SORT_K; ++j) {
+        const size_t i = lo + (size_t)j * SORT_T + threadIdx.x;   // (any order will do for counting: coalesced)
+        if (i < per) atomicAdd(&cnt[sort_bucket(s[i], shift)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) hist[((size_t)slice * 16 + threadIdx.x) * tiles + tile] = cnt[threadIdx.x];
+}
+// exclusive prefix of a slice's counts in (bucket, tile) order, in place: where the tile's keys of that bucket start in the sorted slice
+__global__ void sort_scan_kernel(unsigned* hist, int tiles)
+{
+    __shared__ unsigned total[16];
+    const int slice = blockIdx.x, b = threadIdx.x;   // 16 threads
+    unsigned* h = hist + ((size_t)slice * 16 + b) * tiles;
+    unsigned t = 0;
+    for (int i = 0; i < tiles; ++i) t += h[i];
+    total[b] = t;
+    __syncthreads();
+    unsigned run = 0;
+    for (int q = 0; q < b; ++q) run += total[q];
+    for (int i = 0; i < tiles; ++i) { const unsigned c = h[i]; h[i] = run; run += c; }
+}
+__global__ __launch_bounds__(SORT_T) void sort_scatter_kernel(const uint64_t* src, uint64_t* dst, const unsigned* offs, size_t per, int tiles, int shift)
+{
+    __shared__ unsigned cnt[16][SORT_T];   // [bucket][thread]: keys of the thread in the bucket, then their exclusive prefix over the threads
+    const int tile = blockIdx.x, slice = blockIdx.y, t = threadIdx.x;
+    const uint64_t* s = src + (size_t)slice * per;
+    uint64_t* d = dst + (size_t)slice * per;
+    const size_t i0 = (size_t)tile * SORT_TILE + (size_t)t * SORT_K;   // a thread's 16 CONSECUTIVE keys
+#pragma unroll
+    for (int b = 0; b < 16; ++b) cnt[b][t] = 0u;
+    uint64_t key[SORT_K];
+    unsigned rank[SORT_K];
+#pragma unroll
+    for (int j = 0; j < SORT_K; ++j) {
+        key[j] = i0 + j < per ? s[i0 + j] : 0ull;
+        if (i0 + j < per) {
+            const unsigned b = sort_bucket(key[j], shift);
+            rank[j] = cnt[b][t];          // keys of this thread, of this bucket, before this one (the thread owns its column: no race)
+            cnt[b][t] = rank[j] + 1u;
+        } else {
+            rank[j] = 0u;
+        }
+    }
+    __syncthreads();
+    if (t < 16) {   // thread b: exclusive prefix of its bucket's row over the 256 threads
+        unsigned run = 0;
+        for (int i = 0; i < SORT_T; ++i) { const unsigned c = cnt[t][i]; cnt[t][i] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SORT_K; ++j) {
+        if (i0 + j < per) {
+            const unsigned b = sort_bucket(key[j], shift);
+            d[offs[((size_t)slice * 16 + b) * tiles + tile] + cnt[b][t] + rank[j]] = key[j];
+        }
+    }
 }
 
 __global__ void peaks_kernel(const uint64_t* sorted, size_t per, int nslices, float* peaks)
@@ -98,29 +165,31 @@ __global__ void pick_kernel(const uint64_t* sorted, size_t per, int niter, const
 
 hipError_t lex_sort_desc(c32* spectrum, void* sorted, size_t per, int nslices, float* peaks_dev, hipStream_t st)
 {
+    if (per > 0xffffffffull || nslices < 1) return hipErrorInvalidValue;
     const size_t count = per * (size_t)nslices;
-    if (count > 0xffffffffull || per > 0xffffffffull) return hipErrorInvalidValue;
     uint64_t* keys = reinterpret_cast<uint64_t*>(spectrum);
+    uint64_t* other = reinterpret_cast<uint64_t*>(sorted);
     lex_keys_kernel<<<4096, 256, 0, st>>>(keys, count);
-    unsigned* off = nullptr;
-    hipError_t e = hipMalloc((void**)&off, sizeof(unsigned) * (nslices + 1));
+    const int tiles = (int)((per + SORT_TILE - 1) / SORT_TILE);
+    unsigned* hist = nullptr;
+    hipError_t e = hipMalloc((void**)&hist, sizeof(unsigned) * 16 * (size_t)tiles * nslices);
     if (e != hipSuccess) return e;
-    offsets_kernel<<<(nslices + 256) / 256, 256, 0, st>>>(off, (unsigned)per, nslices);
-    size_t tmp_bytes = 0;
-    void* tmp = nullptr;
-    e = rocprim::segmented_radix_sort_keys_desc(nullptr, tmp_bytes, keys, reinterpret_cast<uint64_t*>(sorted), (unsigned)count, (unsigned)nslices,
-                                                off, off + 1, 0, 64, st);
-    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 8);
-    if (e == hipSuccess)
-        e = rocprim::segmented_radix_sort_keys_desc(tmp, tmp_bytes, keys, reinterpret_cast<uint64_t*>(sorted), (unsigned)count, (unsigned)nslices,
-                                                    off, off + 1, 0, 64, st);
+    const dim3 grid((unsigned)tiles, (unsigned)nslices);
+    for (int pass = 0; pass < 16; ++pass) {   // 16 passes: the sorted keys end where they started; a copy puts them into `sorted`
+        const uint64_t* src = (pass & 1) ? other : keys;
+        uint64_t* dst = (pass & 1) ? keys : other;
+        sort_hist_kernel<<<grid, SORT_T, 0, st>>>(src, hist, per, tiles, 4 * pass);
+        sort_scan_kernel<<<nslices, 16, 0, st>>>(hist, tiles);
+        sort_scatter_kernel<<<grid, SORT_T, 0, st>>>(src, dst, hist, per, tiles, 4 * pass);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(other, keys, sizeof(uint64_t) * count, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) {
         peaks_kernel<<<(nslices + 255) / 256, 256, 0, st>>>(reinterpret_cast<const uint64_t*>(sorted), per, nslices, peaks_dev);
         e = hipGetLastError();
     }
     const hipError_t es = hipStreamSynchronize(st);
-    if (tmp) hipFree(tmp);
-    hipFree(off);
+    hipFree(hist);
     return e != hipSuccess ? e : es;
 }
 
