@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "p3d_fft.hpp"
+#include "p3d_fft32.hpp"
 
 using namespace p3d;
 using cd = std::complex<double>;
@@ -87,6 +88,49 @@ double check_dft()
     return err;
 }
 
+// the one-exchange 1024-point transform of row_pipe32_kernel (p3d_fft32.hpp): 32 lanes, 32 points each, first half -> exchange buffer -> second half
+template <int DIR>
+double check_32x32()
+{
+    constexpr int N = P32::N;
+    std::vector<cd> x(N);
+    for (int i = 0; i < N; ++i) x[i] = cd(std::sin(0.37 * i * i + 0.1) + 0.25, std::cos(1.3 * i) - 0.5 * (i % 3));
+    std::vector<c32> tab(P32::TW), row(P32::LSTR);
+    P32::build_tw(tab.data());
+    std::vector<std::vector<c32>> regs(32, std::vector<c32>(32));
+    for (int j = 0; j < 32; ++j)
+        for (int k = 0; k < 32; ++k) regs[j][k] = c32{float(x[j + 32 * k].real()), float(x[j + 32 * k].imag())};
+    for (int j = 0; j < 32; ++j) p32_half1<DIR>(*reinterpret_cast<c32(*)[32]>(regs[j].data()), row.data(), j);
+    for (int j = 0; j < 32; ++j) p32_half2<DIR>(*reinterpret_cast<c32(*)[32]>(regs[j].data()), row.data(), tab.data(), j);
+    double err = 0, nrm = 0;
+    for (int k = 0; k < N; ++k) {
+        cd acc = 0;
+        for (int n = 0; n < N; ++n) acc += x[n] * std::polar(1.0, DIR * 2 * M_PI * double((long long)n * k % N) / N);
+        const c32 g = regs[k % 32][k / 32];   // canonical layout again: register k2 of lane k1 = element k1 + 32 k2
+        err += std::norm(acc - cd(g.x, g.y));
+        nrm += std::norm(acc);
+    }
+    return std::sqrt(err / nrm);
+}
+template <int DIR>
+double check_dft32()
+{
+    c32 a[32];
+    cd x[32];
+    for (int i = 0; i < 32; ++i) {
+        x[i] = cd(0.3 * i - 1.0 + 0.01 * i * i, 0.7 - 0.11 * i);
+        a[i] = c32{float(x[i].real()), float(x[i].imag())};
+    }
+    dft32<DIR>(a);
+    double err = 0;
+    for (int k = 0; k < 32; ++k) {
+        cd acc = 0;
+        for (int n = 0; n < 32; ++n) acc += x[n] * std::polar(1.0, DIR * 2 * M_PI * n * k / 32);
+        err = std::fmax(err, std::abs(acc - cd(a[k].x, a[k].y)));   // natural order in and out
+    }
+    return err;
+}
+
 int fails = 0;
 void report(const char* what, int n, int dir, double e, double tol)
 {
@@ -116,6 +160,10 @@ int main()
     report("dft16", 16, INV, check_dft<16, INV>(), 1e-5);
     sweep<2>(); sweep<4>(); sweep<8>(); sweep<16>(); sweep<32>(); sweep<64>(); sweep<128>();
     sweep<256>(); sweep<512>(); sweep<1024>(); sweep<2048>(); sweep<4096>();
+    report("dft32", 32, FWD, check_dft32<FWD>(), 1e-4);
+    report("dft32", 32, INV, check_dft32<INV>(), 1e-4);
+    report("32x32", 1024, FWD, check_32x32<FWD>(), 1e-6);
+    report("32x32", 1024, INV, check_32x32<INV>(), 1e-6);
     std::printf(fails ? "FAILED %d\n" : "ALL OK\n", fails);
     return fails ? 1 : 0;
 }
