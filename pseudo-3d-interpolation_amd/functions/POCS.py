@@ -388,7 +388,8 @@ class _HostPins:
         self._slabs = [(lo, lo + step) for lo in starts]
         self._in_done = [threading.Event() for _ in self._slabs]
         self._out_done = [threading.Event() for _ in self._slabs]
-        self._touching = _touch_pages(out)
+        # (a caller's `out` that IS the cube -- an in-place call -- holds the input: its pages exist already and must not be written to)
+        self._touching = [] if np.may_share_memory(cube, out) else _touch_pages(out)
         self._threads = [threading.Thread(target=self._pin, args=(cube, (), self._in_done), daemon=True),
                          threading.Thread(target=self._pin, args=(out, self._touching, self._out_done), daemon=True)]
         for t in self._threads:
