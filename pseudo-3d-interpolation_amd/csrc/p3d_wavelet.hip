@@ -817,14 +817,27 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
 template <int TILE>
 __host__ __device__ constexpr size_t wfuse1_lds_elems(int L) { return (size_t)4 * (TILE + L - 2) * (TILE + L - 2) + (size_t)2 * (2 * TILE + L - 2) * (TILE + L - 2); }
 
+// Threads of a workgroup (a multiple of 256, at most 1024).  The tile's LDS image (44 KiB of float, 88 KiB of complex samples) allows three
+// / one workgroups per CU whatever their size, so the size sets how many wavefronts cover each other's LDS and memory waits between the
+// five barriers of a tile.  BASELINE configs[3] (float32), 256 / 512 / 1024 threads: 0.574 / 0.535 / 0.595 ms per iteration (12 / 24 / 32
+// wavefronts per CU; at 1024 the barriers of sixteen wavefronts cost more than the occupancy returns); a 512 x 512 x 128 complex64
+// cube (one workgroup per CU): 0.90 / 0.73 / 0.69 ms (profiles/r04_wavelet_workgroup_size.txt).
+#ifndef P3D_WFUSE1_THREADS
+#define P3D_WFUSE1_THREADS 512
+#endif
+#ifndef P3D_WFUSE1_THREADS_COMPLEX
+#define P3D_WFUSE1_THREADS_COMPLEX 1024
+#endif
+template <typename T> constexpr int WFUSE1_NT = sizeof(T) == sizeof(float) ? P3D_WFUSE1_THREADS : P3D_WFUSE1_THREADS_COMPLEX;
 template <typename T, int TILE, int LT>
-__global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det_in, size_t det_in_slice, T* det_out, size_t det_out_slice,
+__global__ __launch_bounds__(WFUSE1_NT<T>) void wfuse1_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det_in, size_t det_in_slice, T* det_out, size_t det_out_slice,
                                                      int Ho, int Wo, T* cA, size_t cA_slice, Filters f, int tiles_x, int ntiles, int ns, Update u, Thresh th)
 {
     extern __shared__ __align__(16) unsigned char w_smem[];
-    __shared__ double red[4];
+    constexpr int NT = WFUSE1_NT<T>;
+    __shared__ double red[NT / 64];
     __shared__ float4 s_dec[MAXL / 2], s_rec[MAXL / 2];
-    constexpr int LX = TILE, LY = 256 / TILE, R = TILE / LY;
+    constexpr int LX = TILE, LY = NT / TILE, R = TILE / LY;
     const int L = LT ? LT : f.len, HL = L / 2, IH = 2 * TILE + L - 2, IW = IH, KH = TILE + L - 2, KW = KH;
     T* s_a = reinterpret_cast<T*>(w_smem);           // synthesis: four coefficient arrays [KH][KW] ...
     T* s_h = s_a + (size_t)KH * KW;
@@ -857,7 +870,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     //      and mask weights of the region: all requests of a thread are in flight together (a load per loop trip would pay the
     //      memory latency once per trip -- ten trips per tile) ----
     constexpr int IHc = 2 * TILE + (LT ? LT : 2) - 2, KHc = TILE + (LT ? LT : 2) - 2;
-    constexpr int NE = LT ? (KHc * KHc + 255) / 256 : 1, NIT = LT ? (IHc * (IHc / 2) + 255) / 256 : 1;
+    constexpr int NE = LT ? (KHc * KHc + NT - 1) / NT : 1, NIT = LT ? (IHc * (IHc / 2) + NT - 1) / NT : 1;
     const size_t per = (size_t)u.n1 * u.n2;
     const T* const pd1 = pd + cnt;
     const T* const pd2 = pd + 2 * cnt;
@@ -868,7 +881,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
         T va[NE], vh_[NE], vv[NE], vd[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i, kr = e / KHc, kc = e - kr * KHc, gr = kr0 + kr, gc = kc0 + kc;
+            const int e = tid + NT * i, kr = e / KHc, kc = e - kr * KHc, gr = kr0 + kr, gc = kc0 + kc;
             va[i] = vh_[i] = vv[i] = vd[i] = zero_of<T>();
             if (e < KHc * KHc && kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
                 // (32-bit element offsets from wave-uniform bases: one level of one slice is far below 2^32 samples)
@@ -881,7 +894,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int e = tid + 256 * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+            const int e = tid + NT * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
 #pragma unroll
             for (int ee = 0; ee < 2; ++ee) {
                 xo[it][ee] = zero_of<T>();
@@ -896,11 +909,11 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int e = tid + 256 * i, kr = e / KHc, kc = e - kr * KHc;
+            const int e = tid + NT * i, kr = e / KHc, kc = e - kr * KHc;
             if (e < KHc * KHc && kr < KHv && kc < KWv) { s_a[e] = va[i]; s_h[e] = vh_[i]; s_v[e] = vv[i]; s_d[e] = vd[i]; }
         }
     } else {
-        for (int e = tid; e < KH * KW; e += 256) {
+        for (int e = tid; e < KH * KW; e += NT) {
             const int kr = e / KW, kc = e - kr * KW, gr = kr0 + kr, gc = kc0 + kc;
             if (kr < KHv && kc < KWv) {
                 T va = zero_of<T>(), vh_ = zero_of<T>(), vv = zero_of<T>(), vd = zero_of<T>();
@@ -917,7 +930,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     }
     __syncthreads();
     // ---- undo axis 0: rows m_lo + 2 ip, + 1 from coefficient rows ip ... ip + L/2 - 1 (local) ----
-    for (int e = tid; e < (IH / 2) * KW; e += 256) {
+    for (int e = tid; e < (IH / 2) * KW; e += NT) {
         const int ip = e / KW, kc = e - ip * KW;
         if (2 * ip < nm && kc < KWv) {
             Acc<T> lo, hi;
@@ -970,11 +983,11 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
         if constexpr (LT != 0) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int e = tid + 256 * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+                const int e = tid + NT * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
                 if (e < IHc * (IHc / 2) && m < nm && 2 * ii < nn) sample(m, ii, xo[it], mk[it]);
             }
         } else {
-            for (int e = tid; e < IH * (IW / 2); e += 256) {
+            for (int e = tid; e < IH * (IW / 2); e += NT) {
                 const int m = e / (IW / 2), ii = e - m * (IW / 2);
                 if (m >= nm || 2 * ii >= nn) continue;
                 T x2[2];
@@ -997,7 +1010,7 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     __syncthreads();
     // ---- 'smooth' extension where the region leaves the slice (smooth2_at on the image: along axis 0, then along axis 1) ----
     if (r0 < 0 || c0 < 0 || r0 + IHv > u.n1 || c0 + IWv > u.n2) {
-        for (int e = tid; e < IH * IW; e += 256) {
+        for (int e = tid; e < IH * IW; e += NT) {
             const int lr = e / IW, lc = e - lr * IW;
             if (lr >= IHv || lc >= IWv) continue;
             const int r = r0 + lr, c = c0 + lc;
@@ -1073,7 +1086,11 @@ __global__ __launch_bounds__(256) void wfuse1_kernel(const T* a, size_t a_ld, si
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) atomicAdd(u.sums + s, (red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) {
+        double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        for (int w = 4; w < NT / 64; w += 4) tot += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+        atomicAdd(u.sums + s, tot);
+    }
 }
 
 // per (slice, level, detail): lexicographic max, max |d|, min |d| -> stats[((s*nlev + lvl)*3 + z)*4 ..]; one block each
@@ -1662,7 +1679,7 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
                     // (both detail buffers are addressed with ONE slice stride inside the kernel: hand the larger-stride buffer its own launch form)
                     const T* din = det1[k & 1];
                     T* dout = det1[(k + 1) & 1];
-#define P3D_W_FUSE1(LT) wfuse1_kernel<T, 32, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(as<T>(p->rec[1]), (size_t)p->rw[1], (size_t)p->rh[1] * p->rw[1], din, det1_slice[k & 1], \
+#define P3D_W_FUSE1(LT) wfuse1_kernel<T, 32, LT><<<tx * ty * ns8, WFUSE1_NT<T>, lds, p->stream>>>(as<T>(p->rec[1]), (size_t)p->rw[1], (size_t)p->rh[1] * p->rw[1], din, det1_slice[k & 1], \
                                                                                        dout, det1_slice[(k + 1) & 1], Ho, Wo, as<T>(p->approx[1]), cnt1, p->f, tx, tx * ty, nslices, u, tn)
                     const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
                     if (lt == 8) P3D_W_FUSE1(8); else if (lt == 4) P3D_W_FUSE1(4); else P3D_W_FUSE1(0);

@@ -13,9 +13,10 @@ K = int(os.environ.get("K", 50))
 ncheck = int(os.environ.get("NCHECK", 2))
 wavelet = os.environ.get("WAVELET", "db4")
 mask = po.synthetic_mask(nil, nxl, 0.7)
-base = np.stack([po.synthetic_slice(nil, nxl, s, real=True) for s in range(8)])
+cplx = bool(int(os.environ.get("COMPLEX", 0)))   # COMPLEX=1: a complex64 cube (frequency slices) instead of configs[3]'s float32 one
+base = np.stack([po.synthetic_slice(nil, nxl, s, real=not cplx) for s in range(8)])
 cube = np.concatenate([np.roll(base, 7 * r, axis=2) for r in range((ns + 7) // 8)])[:ns] * mask
-cube = cube.astype(np.float32)
+cube = cube.astype(np.complex64 if cplx else np.float32)
 kw = dict(thresh_op="soft", thresh_model="exponential", niter=K, p_max=0.99, p_min=1e-2, eps=0.0)
 plan = P._get_wavelet_plan(nil, nxl, ns, wavelet, 0)
 stats = plan.stats(cube)
@@ -28,9 +29,9 @@ for rep in range(3):
     best = ms if best is None else min(best, ms)
 err = []
 for s in range(ncheck):
-    want = wo.pocs_slice_wavelet(cube[s].astype(np.float64), mask, wavelet=wavelet, **kw)
+    want = wo.pocs_slice_wavelet(cube[s].astype(np.complex128 if cplx else np.float64), mask, wavelet=wavelet, **kw)
     err.append(float(np.linalg.norm(out[s] - want) / np.linalg.norm(want)))
 pts = ns * nil * nxl
-print(json.dumps({"workload": f"{nil}x{nxl}x{ns} float32 cube, {wavelet}, soft, {K} iterations (BASELINE configs[3])", "nlev": plan.nlev,
+print(json.dumps({"workload": f"{nil}x{nxl}x{ns} {cube.dtype} cube, {wavelet}, soft, {K} iterations (BASELINE configs[3])", "nlev": plan.nlev,
                   "iterations_per_s": K / (best * 1e-3), "ms_per_iteration": best / K, "wall_s_incl_pcie": wall,
                   "rel_l2_vs_oracle": err, "points_per_s": pts * K / (best * 1e-3)}))
