@@ -654,12 +654,14 @@ def run_leg(ctx, config, K_override, main):
         it64 = float(np.median(ms64)) / K            # ms per iteration of the n64-slice sample (device time of the loop)
         ref_prec = {
             "what": f"the same job with precision='reference': the loop in double precision (the reference's arithmetic for soft / garrote / FPOCS / APOCS and "
-                    f"for every run under NumPy < 2), unfused -- a sample of {n64} slices of the cube, complex64 in and out, device time of the {K}-iteration loop",
+                    f"for every run under NumPy < 2), two fused kernels per iteration on LDS-resident tiles (col64_kernel / row64_kernel) -- a sample of {n64} slices of the cube, "
+                    f"complex64 in and out, device time of the {K}-iteration loop",
             "slice_iterations_per_s": n64 / (it64 * 1e-3), "iterations_per_s_of_the_cube": n64 / (it64 * 1e-3) / cube_slices,
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": 56.0, "achieved": 56.0 * nil * nxl * n64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": 56.0 * nil * nxl * n64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "note": "28 B/point of the float32 accounting, doubled; the six unfused passes move ~210 B/point (four line-transform passes at 16 + 16, "
-                                 "threshold 32, re-insertion ~50)"},
+                         "note": "28 B/point of the float32 accounting, doubled; the two fused passes move ~80 B/point (16 + 16 per pass, observed sample and weight "
+                                 "in the row pass) and are bound by their double-precision butterflies in LDS, not by memory (round 4 first cut, six unfused "
+                                 "passes: ~210 B/point, half this rate)"},
         }
         del host64
 

@@ -6,16 +6,20 @@
 // APOCS and every alpha-weighted update through the float64 weight array 1 - alpha * mask (POCS.py:572-575, 616).  The float32 kernels of
 // this library reproduce those runs to float32 rounding only, and the operators are discontinuous at |X| = Re tau (soft and garrote jump by
 // |Im tau| there): 1e-4 instead of 1e-5 on ill-conditioned slices.  This file is the same loop in double precision.
-// It is built from the plain pieces of the any-length pipeline (p3d_generic.hip) -- an LDS-resident mixed-radix Stockham line transform with
-// run-time factors and element-wise passes, six passes over the cube per iteration instead of two fused ones: a precision path, not a
-// fast one (rates in DESIGN.md section 5).  Any line length up to 5120 (two double-precision copies of a line in 160 KiB of LDS).
+// Two fused kernels per iteration like the float32 path (col64_kernel: forward transform, threshold, inverse transform of a tile of columns;
+// row64_kernel: inverse transform, re-insertion, cost sum, forward transform of a tile of rows), on LDS-resident mixed-radix Stockham transforms
+// with run-time factors -- a precision path, bound by its double-precision butterflies (rates in DESIGN.md section 5).  Any line length up to 5120;
+// lines whose tile does not fit LDS (beyond ~4600 points) take the first cut of this file, six plain passes over the cube per iteration built
+// from the pieces of the any-length pipeline (p3d_generic.hip), which P3D_F64_UNFUSED=1 selects for every shape.
 //
 // Entry points (include/p3d.h): p3d_plan64_create / _destroy, p3d_pocs64_stats, p3d_pocs64_run.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -215,14 +219,16 @@ __global__ void update64_kernel(c64* w, const void* x, int dtype, const double* 
     if (threadIdx.x == 0) partial[(size_t)s * gridDim.x + blockIdx.x] = tot;
 }
 
-// per slice: sums[s] = the blocks' partial sums added in order
+// per slice: sums[s] = the blocks' partial sums in a FIXED order (reproducible costs): one wavefront per slice, lane l adds blocks l, l + 64, ...
+// in order, the 64 lane sums are combined by a fixed tree
 __global__ void fold64_kernel(const double* partial, double* sums, int nslices, int blocks)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nslices) return;
+    const int s = blockIdx.x, lane = threadIdx.x;
     double t = 0.0;
-    for (int b = 0; b < blocks; ++b) t += partial[(size_t)s * blocks + b];
-    sums[s] = t;
+    for (int b = lane; b < blocks; b += 64) t += partial[(size_t)s * blocks + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if (lane == 0) sums[s] = t;
 }
 
 __global__ void conv64_kernel(const double* sums, int* done, int nslices, int iter, double eps)
@@ -264,6 +270,421 @@ __global__ void stats64_kernel(const c64* w, double* partial, size_t per_slice)
     }
 }
 
+
+// ==================================================================================================================================
+// Fused passes (round 4): the loop as TWO kernels per iteration, like the float32 path -- a column pass (forward transform, threshold,
+// inverse transform of a tile of adjacent columns) and a row pass (inverse transform, re-insertion, cost sum, forward transform of a
+// few rows) -- instead of six passes over the cube with one line per workgroup (whose column transforms read 16 bytes per 16-KiB
+// stride).  Lines live in LDS (two buffers, Stockham passes with in-register butterflies of 2, 3, 4, 5, 7, 8 and 9 points -- other
+// prime factors as direct sums spread over the threads), the twiddle table exp(-2 pi i k / n) beside them when it fits.  The unfused
+// kernels above remain the path of lines too long for that (two buffers + table > 160 KiB) and of P3D_F64_UNFUSED=1.
+// ==================================================================================================================================
+constexpr int F64_MAX_PASSES = 16;
+struct Fft64 {
+    int n, nf;
+    int f[F64_MAX_PASSES];    // radices; 2, 3, 4, 5, 7, 8, 9: in-register butterflies, anything else: direct sums
+    int ns[F64_MAX_PASSES];   // product of the earlier radices = distance of a butterfly's outputs
+    unsigned mg[F64_MAX_PASSES];   // j / ns = umulhi(j, mg) for j < 2^16 (ns > 1)
+};
+
+Fft64 make_fft64(int n)
+{
+    Fft64 p{};
+    p.n = n;
+    int r = n, k = 0;
+    auto push = [&](int R) { if (k < F64_MAX_PASSES) p.f[k] = R; ++k; };
+    // odd radices first: the scattered writes of an early pass (small output stride) then have an odd stride
+    while (r % 9 == 0) { push(9); r /= 9; }
+    for (int q : {3, 5, 7}) while (r % q == 0) { push(q); r /= q; }
+    for (int q = 11; (long)q * q <= r; q += 2) while (r % q == 0) { push(q); r /= q; }
+    { int odd = r; while (odd % 2 == 0) odd /= 2; if (odd > 1) { push(odd); r /= odd; } }
+    while (r % 8 == 0) { push(8); r /= 8; }
+    while (r % 4 == 0) { push(4); r /= 4; }
+    while (r % 2 == 0) { push(2); r /= 2; }
+    p.nf = k <= F64_MAX_PASSES ? k : -1;
+    int ns = 1;
+    for (int i = 0; i < k && i < F64_MAX_PASSES; ++i) {
+        p.ns[i] = ns;
+        p.mg[i] = ns > 1 ? (unsigned)((0x100000000ull + (unsigned)ns - 1) / (unsigned)ns) : 0u;   // ceil(2^32 / ns): exact for j ns < 2^32
+        ns *= p.f[i];
+    }
+    return p;
+}
+
+template <int R> struct Roots64;
+template <> struct Roots64<3> {
+    static constexpr double c[3] = {1.0, -0.5, -0.5};
+    static constexpr double s[3] = {0.0, 0.86602540378443864676, -0.86602540378443864676};
+};
+template <> struct Roots64<5> {
+    static constexpr double c[5] = {1.0, 0.3090169943749474241, -0.8090169943749474241, -0.8090169943749474241, 0.3090169943749474241};
+    static constexpr double s[5] = {0.0, 0.95105651629515357212, 0.58778525229247312917, -0.58778525229247312917, -0.95105651629515357212};
+};
+template <> struct Roots64<7> {
+    static constexpr double c[7] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624, -0.90096886790241912624, -0.22252093395631440429, 0.62348980185873353053};
+    static constexpr double s[7] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048, -0.43388373911755812048, -0.97492791218182360702, -0.78183148246802980871};
+};
+template <> struct Roots64<8> {
+    static constexpr double c[8] = {1.0, 0.7071067811865475244, 0.0, -0.7071067811865475244, -1.0, -0.7071067811865475244, 0.0, 0.7071067811865475244};
+    static constexpr double s[8] = {0.0, 0.7071067811865475244, 1.0, 0.7071067811865475244, 0.0, -0.7071067811865475244, -1.0, -0.7071067811865475244};
+};
+template <> struct Roots64<9> {
+    static constexpr double c[9] = {1.0, 0.7660444431189780352, 0.17364817766693034885, -0.5, -0.93969262078590838405, -0.93969262078590838405, -0.5, 0.17364817766693034885, 0.7660444431189780352};
+    static constexpr double s[9] = {0.0, 0.64278760968653932632, 0.98480775301220805937, 0.86602540378443864676, 0.34202014332566873304, -0.34202014332566873304, -0.86602540378443864676, -0.98480775301220805937, -0.64278760968653932632};
+};
+
+// entry k of the twiddle table; `half` != 0: the table holds k < half = n / 2 only, exp(-2 pi i (k + n/2) / n) = -exp(-2 pi i k / n)
+// (half the LDS: what lets two workgroups with a table each share a CU at 1024 points)
+__device__ __forceinline__ c64 tw_at(const c64* tw, int k, int half)
+{
+    if (half == 0) return tw[k];
+    const bool hi = k >= half;
+    const c64 w = tw[hi ? k - half : k];
+    return hi ? c64{-w.x, -w.y} : w;
+}
+// a * w (forward) or a * conj(w) (inverse): the table holds exp(-2 pi i k / n)
+template <int DIR> __device__ __forceinline__ c64 twmul(c64 a, c64 w) { return DIR > 0 ? c64{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y} : a * w; }
+// a +- i b
+__device__ __forceinline__ c64 add_i(c64 a, c64 b) { return {a.x - b.y, a.y + b.x}; }
+__device__ __forceinline__ c64 sub_i(c64 a, c64 b) { return {a.x + b.y, a.y - b.x}; }
+
+// X[k] = sum_t x[t] W^(t k), W = exp(DIR 2 pi i / R), natural order in and out
+template <int R, int DIR>
+__device__ __forceinline__ void dft_small64(c64 (&x)[R])
+{
+    if constexpr (R == 2) {
+        const c64 a = x[0] + x[1], b = x[0] - x[1];
+        x[0] = a; x[1] = b;
+    } else if constexpr (R == 4) {
+        const c64 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], t = x[1] - x[3];
+        x[0] = a + s; x[2] = a - s;
+        x[1] = DIR > 0 ? add_i(b, t) : sub_i(b, t);
+        x[3] = DIR > 0 ? sub_i(b, t) : add_i(b, t);
+    } else {
+        // odd prime: X[k], X[R-k] = A_k +- i B_k, A_k = x0 + sum_q cos(2 pi q k / R) (x[q] + x[R-q]), B_k = DIR sum_q sin(2 pi q k / R) (x[q] - x[R-q])
+        constexpr int H = (R - 1) / 2;
+        c64 sp[H], dm[H];
+        c64 x0 = x[0];
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            sp[q - 1] = x[q] + x[R - q];
+            dm[q - 1] = x[q] - x[R - q];
+            x0 = x0 + sp[q - 1];
+        }
+        const c64 xin = x[0];
+        x[0] = x0;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            c64 A = xin, B{0.0, 0.0};
+#pragma unroll
+            for (int q = 1; q <= H; ++q) {
+                const double cq = Roots64<R>::c[(q * k) % R], sq = DIR > 0 ? Roots64<R>::s[(q * k) % R] : -Roots64<R>::s[(q * k) % R];
+                A = A + sp[q - 1] * cq;
+                B = B + dm[q - 1] * sq;
+            }
+            x[k] = add_i(A, B);
+            x[R - k] = sub_i(A, B);
+        }
+    }
+}
+
+// R = R1 R2 in registers (t = R2 t1 + t2, k = k1 + R1 k2)
+template <int R1, int R2, int DIR>
+__device__ __forceinline__ void radix64(c64 (&v)[R1 * R2])
+{
+    constexpr int R = R1 * R2;
+    if constexpr (R2 == 1) {
+        dft_small64<R, DIR>(v);
+    } else {
+        c64 u[R];
+#pragma unroll
+        for (int t2 = 0; t2 < R2; ++t2) {
+            c64 a[R1];
+#pragma unroll
+            for (int t1 = 0; t1 < R1; ++t1) a[t1] = v[R2 * t1 + t2];
+            dft_small64<R1, DIR>(a);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                constexpr int dummy = 0; (void)dummy;
+                const int q = (k1 * t2) % R;
+                u[k1 * R2 + t2] = q == 0 ? a[k1] : a[k1] * c64{Roots64<R>::c[q], DIR > 0 ? Roots64<R>::s[q] : -Roots64<R>::s[q]};
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            c64 b[R2];
+#pragma unroll
+            for (int t2 = 0; t2 < R2; ++t2) b[t2] = u[k1 * R2 + t2];
+            dft_small64<R2, DIR>(b);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = b[k2];
+        }
+    }
+}
+
+// Addressing of a tile of LN lines in LDS.  COLS: the lines interleaved, element i of line l at X[i' * LN + l] (a tile of adjacent
+// columns: a row of the tile is contiguous, as in memory); else line after line, element i of line l at X[l * pad64(n) + i'] (rows);
+// i' = i + i / 16.
+// One padding slot per 16 elements of a line keeps the strided Stockham writes (stride R ns elements of 16 bytes) off a single group of banks.
+#ifndef P3D_F64_PAD
+#define P3D_F64_PAD 0   // measured: padded lines are 30 % SLOWER here (16-byte elements; profiles/r04_f64_fused.txt)
+#endif
+#if P3D_F64_PAD
+__host__ __device__ __forceinline__ int pad64(int n) { return n + (n >> 4) + 1; }   // slots of a padded line
+template <bool COLS> __device__ __forceinline__ int at64(int i, int l, int n, int LN) { return COLS ? (i + (i >> 4)) * LN + l : l * pad64(n) + i + (i >> 4); }
+#else
+__host__ __device__ __forceinline__ int pad64(int n) { return n; }
+template <bool COLS> __device__ __forceinline__ int at64(int i, int l, int n, int LN) { return COLS ? i * LN + l : l * n + i; }
+#endif
+
+// one Stockham pass of radix R = R1 R2 over the tile: butterfly j of line l reads in[j + t nb], multiplies by w^(t jm ts), writes
+// out[j0 + k ns] (jq = j / ns, jm = j mod ns, j0 = jq ns R + jm)
+// (LN and the thread count are powers of two: a thread's line and its first butterfly come from shifts -- lsh = log2 LN --, the
+// quotient by ns from a multiplication; integer divisions were a third of the instructions of a pass)
+template <int R1, int R2, int DIR, bool COLS>
+__device__ __forceinline__ void pass64(const c64* A, c64* B, const c64* tw, int half, int n, int ns, unsigned mg, int LN, int lsh, int tid, int nthr)
+{
+    constexpr int R = R1 * R2;
+    const int nb = n / R, ts = n / (ns * R);
+    const int tpl = nthr >> lsh;                                   // threads per line
+    const int l = COLS ? tid & (LN - 1) : tid >> (31 - __clz(tpl));
+    for (int j = COLS ? tid >> lsh : tid & (tpl - 1); j < nb; j += tpl) {
+        const int jq = ns > 1 ? (int)__umulhi((unsigned)j, mg) : j, jm = j - jq * ns, j0 = jq * ns * R + jm;
+        c64 v[R];
+        v[0] = A[at64<COLS>(j, l, n, LN)];
+        if (ns == 1) {
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = A[at64<COLS>(j + t * nb, l, n, LN)];
+        } else {
+            const int twi = jm * ts;
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = twmul<DIR>(A[at64<COLS>(j + t * nb, l, n, LN)], tw_at(tw, t * twi, half));
+        }
+        radix64<R1, R2, DIR>(v);
+#pragma unroll
+        for (int k = 0; k < R; ++k) B[at64<COLS>(j0 + k * ns, l, n, LN)] = v[k];
+    }
+}
+
+// any other (prime) radix: every OUTPUT of every butterfly is a direct sum, spread over the threads
+template <int DIR, bool COLS>
+__device__ __forceinline__ void pass64_direct(const c64* A, c64* B, const c64* tw, int half, int n, int R, int ns, int LN, int tid, int nthr)
+{
+    const int nb = n / R, ts = n / (ns * R), total = n * LN;
+    for (int o = tid; o < total; o += nthr) {
+        int rest = o;
+        const int l = COLS ? rest % LN : rest / n;
+        rest = COLS ? rest / LN : rest % n;          // (k, j): output k of butterfly j
+        const int k = rest / nb, j = rest - k * nb;
+        const int jq = j / ns, jm = j - jq * ns, j0 = jq * ns * R + jm;
+        c64 acc{0.0, 0.0};
+        for (int t = 0; t < R; ++t) {
+            const long idx = ((long)t * jm * ts + (long)((long)t * k % R) * nb) % n;
+            acc = acc + twmul<DIR>(A[at64<COLS>(j + t * nb, l, n, LN)], tw_at(tw, (int)idx, half));
+        }
+        B[at64<COLS>(j0 + k * ns, l, n, LN)] = acc;
+    }
+}
+
+// all passes of the tile; returns the buffer that holds the result (every thread of the workgroup calls this)
+template <int DIR, bool COLS>
+__device__ __forceinline__ c64* tile_fft64(c64* A, c64* B, const c64* tw, int half, const Fft64& pl, int LN, int tid, int nthr)
+{
+    const int lsh = 31 - __clz(LN);
+    for (int p = 0; p < pl.nf; ++p) {
+        const int ns = pl.ns[p];
+        switch (pl.f[p]) {
+            case 2: pass64<2, 1, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            case 3: pass64<3, 1, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            case 4: pass64<4, 1, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            case 5: pass64<5, 1, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            case 7: pass64<7, 1, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            case 8: pass64<2, 4, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            case 9: pass64<3, 3, DIR, COLS>(A, B, tw, half, pl.n, ns, pl.mg[p], LN, lsh, tid, nthr); break;
+            default: pass64_direct<DIR, COLS>(A, B, tw, half, pl.n, pl.f[p], ns, LN, tid, nthr);
+        }
+        __syncthreads();
+        c64* t = A; A = B; B = t;
+    }
+    return A;
+}
+
+constexpr int F64_THREADS = 512;
+enum { C64_ITER = 0, C64_STATS = 1, C64_FWD = 2 };
+
+// Column pass of one tile of LN adjacent columns of a slice.  C64_ITER: forward transform, threshold (tau of the slice and iteration),
+// inverse transform, 1 / n1, in place on the work buffer.  C64_STATS: forward transform, then the tile's statistics (lexicographic
+// maximum, max |X|, min |X|, sum |X|^2) -> partial[(slice, tile)][8].  C64_FWD: forward transform only.
+// grid (tiles, slices); dynamic LDS: [table n1 if tw_lds][2 x LN n1]
+template <int MODE>
+__global__ __launch_bounds__(F64_THREADS) void col64_kernel(c64* work, const c64* tw_g, Fft64 pl, int n2, int LN, int tw_lds, const c64* tau, int niter, int iter, int op,
+                                                            double* partial, const int* done)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[(F64_THREADS / 64) * 5];
+    const int tid = threadIdx.x, nthr = blockDim.x, n = pl.n, s = blockIdx.y, c0 = blockIdx.x * LN;
+    if (done && done[s] != 0) return;
+    c64* twl = reinterpret_cast<c64*>(smem_raw);
+    const int half = tw_lds == 2 ? n / 2 : 0, tw_n = tw_lds == 2 ? n / 2 : (tw_lds ? n : 0);   // tw_lds: 0 the table stays in memory, 1 in LDS, 2 its first half in LDS
+    c64* A = twl + tw_n;
+    c64* B = A + (size_t)LN * pad64(n);
+    c64* const base = work + (size_t)s * n * n2;
+    const int lsh = 31 - __clz(LN);
+    const int lv = min(LN, n2 - c0);   // valid columns of the tile
+    for (int e = tid; e < n * LN; e += nthr) {
+        const int i = e >> lsh, l = e & (LN - 1);
+        A[at64<true>(i, l, n, LN)] = l < lv ? base[(size_t)i * n2 + c0 + l] : c64{0.0, 0.0};
+    }
+    for (int k = tid; k < tw_n; k += nthr) twl[k] = tw_g[k];
+    const c64* tw = tw_lds ? twl : tw_g;
+    __syncthreads();
+    c64* X = tile_fft64<-1, true>(A, B, tw, half, pl, LN, tid, nthr);
+    c64* Y = X == A ? B : A;
+    if (MODE == C64_STATS) {
+        double lr = -INFINITY, li = -INFINITY, mx = 0.0, mn = INFINITY, sq = 0.0;
+        for (int e = tid; e < n * LN; e += nthr) {
+            if ((e & (LN - 1)) >= lv) continue;
+            const c64 v = X[at64<true>(e >> lsh, e & (LN - 1), n, LN)];
+            const double a = hypot(v.x, v.y);
+            if (v.x > lr || (v.x == lr && v.y > li)) { lr = v.x; li = v.y; }
+            mx = fmax(mx, a);
+            mn = fmin(mn, a);
+            sq += v.x * v.x + v.y * v.y;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double orr = __shfl_down(lr, o, 64), oi = __shfl_down(li, o, 64);
+            if (orr > lr || (orr == lr && oi > li)) { lr = orr; li = oi; }
+            mx = fmax(mx, __shfl_down(mx, o, 64));
+            mn = fmin(mn, __shfl_down(mn, o, 64));
+            sq += __shfl_down(sq, o, 64);
+        }
+        if ((tid & 63) == 0) { double* r = red + (tid >> 6) * 5; r[0] = lr; r[1] = li; r[2] = mx; r[3] = mn; r[4] = sq; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < (nthr + 63) / 64; ++w) {
+                const double* r = red + w * 5;
+                if (r[0] > lr || (r[0] == lr && r[1] > li)) { lr = r[0]; li = r[1]; }
+                mx = fmax(mx, r[2]);
+                mn = fmin(mn, r[3]);
+                sq += r[4];
+            }
+            double* q = partial + ((size_t)s * gridDim.x + blockIdx.x) * 8;
+            q[0] = lr; q[1] = li; q[2] = mx; q[3] = mn; q[4] = sq;
+        }
+        return;
+    }
+    double scale = 1.0;
+    if (MODE == C64_ITER) {
+        const c64 t = tau[(size_t)s * niter + iter];
+        for (int e = tid; e < n * LN; e += nthr) {
+            c64& v = X[at64<true>(e >> lsh, e & (LN - 1), n, LN)];
+            v = shrink64(v, t, op);
+        }
+        __syncthreads();
+        X = tile_fft64<+1, true>(X, Y, tw, half, pl, LN, tid, nthr);
+        scale = 1.0 / n;
+    }
+    for (int e = tid; e < n * LN; e += nthr) {
+        const int i = e >> lsh, l = e & (LN - 1);
+        if (l < lv) base[(size_t)i * n2 + c0 + l] = X[at64<true>(i, l, n, LN)] * scale;
+    }
+}
+
+enum { R64_FIRST = 0, R64_MID = 1, R64_LAST = 2 };
+
+// Row pass of LN consecutive rows of a slice (n = n2 samples each; n1 rows per slice).
+//   R64_FIRST: w = x (adaptive: the APOCS mix of the first input, POCS.py:574-575 with x_old = x), sum |x| -> partial, forward transform.
+//   R64_MID:   inverse transform, 1 / n2, re-insertion (POCS.py:616-619), sum |x_new| -> partial, the iterate to `out` if asked, APOCS mix,
+//              forward transform.     R64_LAST: the same without the forward transform (nothing feeds on the iterate any more).
+// partial[(slice, workgroup)]: the host-side fold adds a slice's workgroups in order (reproducible costs).
+// dynamic LDS as in col64_kernel
+template <int MODE>
+__global__ __launch_bounds__(F64_THREADS) void row64_kernel(c64* work, const c64* tw_g, Fft64 pl, int n1, int LN, int tw_lds, const void* x, int dtype, const double* mask,
+                                                            void* out, double* partial, int adaptive, int write_out, double alpha, const int* done, int zero_fill)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[F64_THREADS / 64];
+    const int tid = threadIdx.x, nthr = blockDim.x, n = pl.n, s = blockIdx.y, r0 = blockIdx.x * LN;
+    const int dn = done ? done[s] : 0;
+    const size_t per = (size_t)n1 * n;
+    const int lv = min(LN, n1 - r0);   // valid rows of the tile
+    auto put = [&](size_t g, c64 v) {
+        if (dtype == P3D_C128) reinterpret_cast<c64*>(out)[g] = v;
+        else if (dtype == P3D_F64) reinterpret_cast<double*>(out)[g] = v.x;
+        else if (dtype == P3D_C64) reinterpret_cast<float2*>(out)[g] = float2{(float)v.x, (float)v.y};
+        else reinterpret_cast<float*>(out)[g] = (float)v.x;
+    };
+    if (MODE != R64_FIRST && zero_fill && dn < 0) {   // an empty slice is handed back untouched (zeros), POCS.py:515-521
+        for (int e = tid; e < n * lv; e += nthr) put((size_t)s * per + (size_t)r0 * n + e, c64{0.0, 0.0});
+    }
+    if (dn != 0) {
+        if (tid == 0) partial[(size_t)s * gridDim.x + blockIdx.x] = 0.0;
+        return;
+    }
+    c64* twl = reinterpret_cast<c64*>(smem_raw);
+    const int half = tw_lds == 2 ? n / 2 : 0, tw_n = tw_lds == 2 ? n / 2 : (tw_lds ? n : 0);
+    c64* A = twl + tw_n;
+    c64* B = A + (size_t)LN * pad64(n);
+    c64* const base = work + (size_t)s * per + (size_t)r0 * n;   // the tile's rows are one contiguous range
+    for (int k = tid; k < tw_n; k += nthr) twl[k] = tw_g[k];
+    const c64* tw = tw_lds ? twl : tw_g;
+    c64* X = A;
+    if (MODE != R64_FIRST) {
+        for (int l = 0; l < LN; ++l)
+            for (int i = tid; i < n; i += nthr) A[at64<false>(i, l, n, LN)] = l < lv ? base[(size_t)l * n + i] : c64{0.0, 0.0};
+        __syncthreads();
+        X = tile_fft64<+1, false>(A, B, tw, half, pl, LN, tid, nthr);
+    } else {
+        __syncthreads();   // (the table)
+    }
+    c64* Y = X == A ? B : A;
+    // ---- re-insertion / first input, element by element; the tile's samples are one contiguous range of the slice ----
+    double acc = 0.0;
+    const double inv = 1.0 / n;
+    for (int l = 0; l < LN; ++l) {
+        for (int i = tid; i < n; i += nthr) {
+            c64& slot = X[at64<false>(i, l, n, LN)];
+            if (l >= lv) { slot = c64{0.0, 0.0}; continue; }
+            const size_t li = (size_t)(r0 + l) * n + i, g = (size_t)s * per + li;
+            c64 xo;
+            if (dtype == P3D_C128) xo = reinterpret_cast<const c64*>(x)[g];
+            else if (dtype == P3D_F64) xo = c64{reinterpret_cast<const double*>(x)[g], 0.0};
+            else if (dtype == P3D_C64) { const float2 t = reinterpret_cast<const float2*>(x)[g]; xo = c64{(double)t.x, (double)t.y}; }
+            else xo = c64{(double)reinterpret_cast<const float*>(x)[g], 0.0};
+            const double m = mask ? mask[li] : 0.0;
+            const double wgt = 1.0 - alpha * m;
+            c64 xn;
+            if (MODE == R64_FIRST) {
+                xn = xo;
+            } else {
+                xn = (slot * inv) * wgt + xo * alpha;
+                if (write_out) put(g, xn);
+            }
+            acc += hypot(xn.x, xn.y);
+            if (adaptive) {   // POCS.py:574-575
+                const c64 tmp = xo * alpha + xn * wgt;
+                slot = tmp + (xo - xn * m) * (1.0 - alpha);
+            } else {
+                slot = xn;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();   // (also: the tile is complete for the forward transform)
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (nthr + 63) / 64; ++w) tot += red[w];
+        partial[(size_t)s * gridDim.x + blockIdx.x] = tot;
+    }
+    if (MODE == R64_LAST) return;
+    X = tile_fft64<-1, false>(X, Y, tw, half, pl, LN, tid, nthr);
+    for (int l = 0; l < lv; ++l)
+        for (int i = tid; i < n; i += nthr) base[(size_t)l * n + i] = X[at64<false>(i, l, n, LN)];
+}
+
 }  // namespace
 
 struct p3d_plan64 {
@@ -278,6 +699,13 @@ struct p3d_plan64 {
     size_t tau_cap = 0, sums_cap = 0;
     static constexpr int BLOCKS = 64;
     size_t per() const { return (size_t)nil * nxl; }
+    // fused passes (col64_kernel / row64_kernel): tiles of ln_col columns / ln_row rows, the twiddle table in LDS where it fits
+    bool fused = false;
+    Fft64 fcol{}, frow{};
+    int ln_col = 0, ln_row = 0, tw_col_lds = 0, tw_row_lds = 0, thr_col = F64_THREADS, thr_row = F64_THREADS;
+    size_t lds_col = 0, lds_row = 0;
+    int tiles_col() const { return (nxl + ln_col - 1) / ln_col; }
+    int tiles_row() const { return (nil + ln_row - 1) / ln_row; }
 };
 
 namespace {
@@ -308,6 +736,49 @@ int fft2_64(p3d_plan64* p, int nslices, bool inverse, const int* done)
     return fft_pass(p, p->work, p->work, nslices, true, +1, 1.0 / p->nxl, done);
 }
 
+// tile of the fused passes for lines of n points: the largest of 4, 2, 1 lines whose two buffers (+ the table, where another 32 KiB allow it)
+// stay below `budget` bytes of LDS; 0: none
+int pick_tile64(int n, size_t budget, int want, int* tw_lds, size_t* lds)
+{
+    for (int ln : {8, 4, 2, 1}) {
+        if (ln > want) continue;
+        const size_t buf = sizeof(c64) * 2 * (size_t)ln * pad64(n), tab = sizeof(c64) * (size_t)n;
+        if (buf > budget) continue;
+        *tw_lds = 0;
+        if (!getenv("P3D_F64_TW_GLOBAL")) {
+            if (tab <= 32 * 1024 && buf + tab <= budget) *tw_lds = 1;
+            else if (n % 2 == 0 && tab / 2 <= 32 * 1024 && buf + tab / 2 <= budget && !getenv("P3D_F64_NO_HALF_TABLE")) *tw_lds = 2;
+        }
+        *lds = buf + (*tw_lds == 1 ? tab : (*tw_lds == 2 ? tab / 2 : 0));
+        return ln;
+    }
+    return 0;
+}
+
+template <int MODE>
+int col_pass64(p3d_plan64* p, int nslices, int niter, int iter, int op, const int* done)
+{
+    const void* k = reinterpret_cast<const void*>(col64_kernel<MODE>);
+    if (p->lds_col > 64 * 1024) F_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_col));
+    col64_kernel<MODE><<<dim3(p->tiles_col(), nslices), p->thr_col, p->lds_col, p->stream>>>(p->work, p->tw_col, p->fcol, p->nxl, p->ln_col, p->tw_col_lds, p->tau, niter, iter, op,
+                                                                                            p->partial, done);
+    F_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
+template <int MODE>
+int row_pass64(p3d_plan64* p, int dtype, double* sums_row, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill)
+{
+    const void* k = reinterpret_cast<const void*>(row64_kernel<MODE>);
+    if (p->lds_row > 64 * 1024) F_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_row));
+    row64_kernel<MODE><<<dim3(p->tiles_row(), nslices), p->thr_row, p->lds_row, p->stream>>>(p->work, p->tw_row, p->frow, p->nil, p->ln_row, p->tw_row_lds, p->st_x, dtype,
+                                                                                            (MODE == R64_FIRST && !adaptive) ? nullptr : p->mask, p->st_out, p->spart, adaptive,
+                                                                                            write_out, alpha, done, zero_fill);
+    fold64_kernel<<<nslices, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p->tiles_row());
+    F_TRY(hipGetLastError());
+    return P3D_OK;
+}
+
 size_t esize(int dtype) { return dtype == P3D_C128 ? 16 : (dtype == P3D_F64 || dtype == P3D_C64 ? 8 : 4); }
 
 int check64(p3d_plan64* p, int nslices, int dtype)
@@ -323,7 +794,7 @@ int update(p3d_plan64* p, int dtype, double* sums_row, int mode, int adaptive, i
 {
     update64_kernel<<<dim3(p3d_plan64::BLOCKS, nslices), 256, 0, p->stream>>>(p->work, p->st_x, dtype, mode == 0 && !adaptive ? nullptr : p->mask, p->st_out, p->spart, mode,
                                                                               adaptive, write_out, alpha, p->per(), done, zero_fill);
-    fold64_kernel<<<(nslices + 63) / 64, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p3d_plan64::BLOCKS);
+    fold64_kernel<<<nslices, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p3d_plan64::BLOCKS);
     F_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -383,14 +854,32 @@ int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_sl
         if ((e = hipMalloc((void**)dst, sizeof(c64) * n)) != hipSuccess) return bail("twiddles", e);
         if ((e = hipMemcpy(*dst, host.data(), sizeof(c64) * n, hipMemcpyHostToDevice)) != hipSuccess) return bail("twiddles", e);
     }
+    // the fused passes where two buffers of a tile fit LDS (rows: two workgroups per CU if that leaves a tile of two rows)
+    p->fcol = make_fft64(nil);
+    p->frow = make_fft64(nxl);
+    {
+        const size_t whole = 160 * 1024 - 1024, half = 80 * 1024 - 1024;
+        auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v && atoi(v) > 0 ? atoi(v) : dflt; };
+        const size_t first = getenv("P3D_F64_ONE_PER_CU") ? whole : half;
+        p->ln_col = pick_tile64(nil, first, knob("P3D_F64_COL_TILE", 2), &p->tw_col_lds, &p->lds_col);
+        if (p->ln_col == 0) p->ln_col = pick_tile64(nil, whole, knob("P3D_F64_COL_TILE", 2), &p->tw_col_lds, &p->lds_col);
+        p->ln_row = pick_tile64(nxl, first, knob("P3D_F64_ROW_TILE", 2), &p->tw_row_lds, &p->lds_row);
+        if (p->ln_row == 0) p->ln_row = pick_tile64(nxl, whole, knob("P3D_F64_ROW_TILE", 2), &p->tw_row_lds, &p->lds_row);
+        auto pow2 = [](int v) { int t = 64; while (2 * t <= v && 2 * t <= F64_THREADS) t *= 2; return t; };   // (the passes split threads by shifts)
+        p->thr_col = pow2(knob("P3D_F64_COL_THREADS", F64_THREADS));
+        p->thr_row = pow2(knob("P3D_F64_ROW_THREADS", F64_THREADS));
+        p->fused = p->ln_col > 0 && p->ln_row > 0 && p->fcol.nf > 0 && p->frow.nf > 0 && !getenv("P3D_F64_UNFUSED");
+        if (!p->fused) p->ln_col = p->ln_row = 1;
+    }
     const size_t S = (size_t)max_slices, per = p->per();
+    const size_t nparts = (size_t)std::max(std::max(p3d_plan64::BLOCKS, p->tiles_col()), p->tiles_row());
 #define ALLOC64(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(#ptr, e)
     ALLOC64(p->work, sizeof(c64) * per * S);
     ALLOC64(p->st_x, sizeof(c64) * per * S);
     ALLOC64(p->st_out, sizeof(c64) * per * S);
     ALLOC64(p->mask, sizeof(double) * per);
-    ALLOC64(p->partial, sizeof(double) * 8 * p3d_plan64::BLOCKS * S);
-    ALLOC64(p->spart, sizeof(double) * p3d_plan64::BLOCKS * S);
+    ALLOC64(p->partial, sizeof(double) * 8 * nparts * S);
+    ALLOC64(p->spart, sizeof(double) * nparts * S);
     ALLOC64(p->done, sizeof(int) * S);
 #undef ALLOC64
     *out = p;
@@ -404,17 +893,23 @@ int p3d_pocs64_stats(p3d_plan64* p, const void* x, int dtype, int nslices, doubl
     if (rc) return rc;
     if (!x || !stats) return f64fail(P3D_ERR_INVALID, "NULL buffer");
     F_TRY(hipMemcpyAsync(p->st_x, x, esize(dtype) * p->per() * nslices, hipMemcpyDefault, p->stream));
-    if ((rc = update(p, dtype, p->partial, 0, 0, 0, 1.0, nslices, nullptr, 0))) return rc;   // w = x (its sums go to a scratch row)
-    if ((rc = fft2_64(p, nslices, false, nullptr))) return rc;
-    stats64_kernel<<<dim3(p3d_plan64::BLOCKS, nslices), 256, 0, p->stream>>>(p->work, p->partial, p->per());
-    F_TRY(hipGetLastError());
-    std::vector<double> host((size_t)nslices * p3d_plan64::BLOCKS * 8);
+    const int nblocks = p->fused ? p->tiles_col() : p3d_plan64::BLOCKS;
+    if (p->fused) {
+        if ((rc = row_pass64<R64_FIRST>(p, dtype, p->partial, 0, 0, 1.0, nslices, nullptr, 0))) return rc;   // rows of x (its sums go to a scratch row)
+        if ((rc = col_pass64<C64_STATS>(p, nslices, 0, 0, 0, nullptr))) return rc;
+    } else {
+        if ((rc = update(p, dtype, p->partial, 0, 0, 0, 1.0, nslices, nullptr, 0))) return rc;   // w = x (its sums go to a scratch row)
+        if ((rc = fft2_64(p, nslices, false, nullptr))) return rc;
+        stats64_kernel<<<dim3(p3d_plan64::BLOCKS, nslices), 256, 0, p->stream>>>(p->work, p->partial, p->per());
+        F_TRY(hipGetLastError());
+    }
+    std::vector<double> host((size_t)nslices * nblocks * 8);
     F_TRY(hipMemcpyAsync(host.data(), p->partial, sizeof(double) * host.size(), hipMemcpyDeviceToHost, p->stream));
     F_TRY(hipStreamSynchronize(p->stream));
     for (int s = 0; s < nslices; ++s) {
         double lr = -INFINITY, li = -INFINITY, mx = 0.0, mn = INFINITY, sq = 0.0;
-        for (int b = 0; b < p3d_plan64::BLOCKS; ++b) {
-            const double* q = &host[((size_t)s * p3d_plan64::BLOCKS + b) * 8];
+        for (int b = 0; b < nblocks; ++b) {
+            const double* q = &host[((size_t)s * nblocks + b) * 8];
             if (q[0] > lr || (q[0] == lr && q[1] > li)) { lr = q[0]; li = q[1]; }
             mx = std::fmax(mx, q[2]);
             mn = std::fmin(mn, q[3]);
@@ -462,6 +957,19 @@ int p3d_pocs64_run(p3d_plan64* p, const void* x, int dtype, const double* mask, 
     F_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     F_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
     F_TRY(hipEventRecord(p->ev0, p->stream));
+    if (p->fused) {
+        // two kernels per iteration: rows (inverse transform, re-insertion, forward transform), columns (forward, threshold, inverse)
+        if ((rc = row_pass64<R64_FIRST>(p, dtype, p->sums, adaptive ? 1 : 0, 0, prm->alpha, nslices, done_d, 0))) return rc;
+        for (int k = 0; k < niter; ++k) {
+            const bool last = k + 1 == niter;
+            if ((rc = col_pass64<C64_ITER>(p, nslices, niter, k, prm->thresh_op, done_d))) return rc;
+            double* srow = p->sums + (size_t)(k + 1) * nslices;
+            if (last) rc = row_pass64<R64_LAST>(p, dtype, srow, 0, 1, prm->alpha, nslices, p->done, 1);
+            else rc = row_pass64<R64_MID>(p, dtype, srow, adaptive ? 1 : 0, early ? 1 : 0, prm->alpha, nslices, p->done, 0);
+            if (rc) return rc;
+            if (early) conv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+        }
+    } else {
     if ((rc = update(p, dtype, p->sums, 0, adaptive ? 1 : 0, 0, prm->alpha, nslices, done_d, 0))) return rc;
     for (int k = 0; k < niter; ++k) {
         const bool last = k + 1 == niter;
@@ -472,6 +980,7 @@ int p3d_pocs64_run(p3d_plan64* p, const void* x, int dtype, const double* mask, 
                          last ? 1 : 0)))
             return rc;
         if (early) conv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+    }
     }
     F_TRY(hipGetLastError());
     F_TRY(hipEventRecord(p->ev1, p->stream));

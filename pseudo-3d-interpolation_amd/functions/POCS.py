@@ -628,8 +628,8 @@ def pocs_cube(
     cubes (the reference computes such cubes in double precision; POCS.py:371-656 never narrows its input); ``'reference'``: double
     precision also for complex64 / float32 cubes, the result cast back (what the reference itself executes for the soft / garrote
     operators, FPOCS and APOCS, and for every run under NumPy < 2 -- SURVEY appendix A.16); ``'float32'``: the float32 kernels whatever the
-    cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loop is an unfused
-    precision path, has the hard / soft / garrote operators and slice extents up to 5120.
+    cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loop is a
+    precision path (about a tenth of the float32 rate), has the hard / soft / garrote operators and slice extents up to 5120.
 
     ``out`` (optional): an array of the shape and dtype of ``cube`` to write the result into (e.g. a slab of the merged cube of the
     step-13 driver) instead of a new one.

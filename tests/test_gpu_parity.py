@@ -783,6 +783,13 @@ REFERENCE_PRECISION = [
     dict(nil=96, nxl=50, n=3, missing=0.5, niter=8, thresh_op="soft", version="fast", thresh_model="inverse_proportional"),
     dict(nil=96, nxl=50, n=3, missing=0.5, niter=8, thresh_op="hard", version="regular", thresh_model="linear"),
     dict(nil=64, nxl=64, n=4, missing=0.5, niter=30, thresh_op="soft", eps=1e-7, real=True),
+    # every butterfly of the fused double passes: 9, 7, 5, 3, 2 (630 = 9 x 7 x 5 x 2), 8 and 4 (2048 = 8^3 x 4), prime factors as direct sums (61, 67, 11)
+    dict(nil=63, nxl=90, n=3, missing=0.5, niter=8, thresh_op="soft"),
+    dict(nil=2048, nxl=24, n=2, missing=0.6, niter=6, thresh_op="hard"),
+    dict(nil=61, nxl=67, n=3, missing=0.5, niter=8, thresh_op="garrote", eps=1e-9),
+    dict(nil=22, nxl=630, n=3, missing=0.5, niter=8, thresh_op="hard", version="adaptive", alpha=0.7),
+    # columns too long for two LDS buffers of a tile: the unfused kernels
+    dict(nil=5000, nxl=16, n=1, missing=0.5, niter=4, thresh_op="hard"),
 ]
 
 
@@ -813,6 +820,35 @@ def test_reference_precision_loop(P, orc, cfg):
         assert rel_l2(got32[s], want[s]) <= 2e-7, (s, rel_l2(got32[s], want[s]))   # (the final cast to float32)
         assert res64[s]["niterations"] == infos[s]["niterations"] == res32[s]["niterations"]
         assert np.allclose(res64[s]["costs"], infos[s]["costs"], rtol=1e-6, atol=1e-18)   # (a cost is a squared difference of two nearly equal sums)
+
+
+@pytest.mark.parametrize("shape", [(128, 96), (1024, 50), (45, 77)])
+def test_fused_double_precision_passes_equal_the_unfused_ones(ffi, orc, monkeypatch, shape):
+    """The double-precision loop runs as two fused kernels per iteration (col64_kernel / row64_kernel, p3d_f64.hip); P3D_F64_UNFUSED=1
+    keeps the six plain passes (one line per workgroup), which remain the path of lines too long for a tile in LDS.  Same arithmetic up
+    to the order of the butterflies: the iterates agree to double rounding, statistics and cost sums to 1e-12, iteration counts exactly."""
+    from pseudo_3d_interpolation_amd.functions.POCS import _schedule_from_stats
+    nil, nxl = shape
+    _, mask, obs = orc.synthetic_cube(nil, nxl, 3, 0.6)
+    obs = obs.astype(np.complex128)
+    obs[1] = 0
+    K = 12
+    act = np.array([1, 0, 1], np.uint8)
+
+    def run():
+        with ffi.Plan64(nil, nxl, 3) as plan:
+            st = plan.stats(obs)
+            st[1] = 1.0
+            tau = _schedule_from_stats(st, nil * nxl, "exponential", K, 0.99, 1e-3, "values")
+            return (st,) + plan.run(obs, mask, tau, K, thresh_op="soft", version="adaptive", alpha=0.9, eps=1e-6, active=act)[:3]
+
+    st_f, out_f, done_f, sums_f = run()
+    monkeypatch.setenv("P3D_F64_UNFUSED", "1")
+    st_u, out_u, done_u, sums_u = run()
+    assert np.allclose(st_f[[0, 2]], st_u[[0, 2]], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(done_f, done_u) and done_f[1] == 0 and not out_f[1].any()
+    assert max(rel_l2(out_f[s], out_u[s]) for s in (0, 2)) <= 1e-13
+    assert np.allclose(sums_f, sums_u, rtol=1e-12)
 
 
 @pytest.mark.parametrize("family", ["one-exchange (row_pipe32_kernel)", "row_pipe64_kernel"])
