@@ -34,6 +34,8 @@ for case in range(ncases):
     cube = (cube.real if dtype == np.float32 else cube).astype(dtype)
     if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):
         continue   # (FUZZ_ONLY=<case>: that case alone, with the float32-fed oracle beside the float64 one)
+    if os.environ.get("FUZZ_SAVE"):   # the case's inputs for a closer look (tools/diag_f64_case.py)
+        np.savez(os.environ["FUZZ_SAVE"], cube=cube, mask=mask, kw=np.array([repr(kw)]))
     res, infos = [], []
     try:
         got = P.pocs_cube(cube, mask, results=res, **kw)
