@@ -422,47 +422,46 @@ __device__ __forceinline__ void radix64(c64 (&v)[R1 * R2])
     }
 }
 
-// Addressing of a tile of LN lines in LDS.  COLS: the lines interleaved, element i of line l at X[i' * LN + l] (a tile of adjacent
-// columns: a row of the tile is contiguous, as in memory); else line after line, element i of line l at X[l * pad64(n) + i'] (rows);
-// i' = i + i / 16.
-// One padding slot per 16 elements of a line keeps the strided Stockham writes (stride R ns elements of 16 bytes) off a single group of banks.
-#ifndef P3D_F64_PAD
-#define P3D_F64_PAD 0   // measured: padded lines are 30 % SLOWER here (16-byte elements; profiles/r04_f64_fused.txt)
-#endif
-#if P3D_F64_PAD
-__host__ __device__ __forceinline__ int pad64(int n) { return n + (n >> 4) + 1; }   // slots of a padded line
-template <bool COLS> __device__ __forceinline__ int at64(int i, int l, int n, int LN) { return COLS ? (i + (i >> 4)) * LN + l : l * pad64(n) + i + (i >> 4); }
-#else
-__host__ __device__ __forceinline__ int pad64(int n) { return n; }
+// Addressing of a tile of LN lines in LDS.  COLS: the lines interleaved, element i of line l at X[i * LN + l] (a tile of adjacent
+// columns: a row of the tile is contiguous, as in memory); else line after line, element i of line l at X[l * n + i] (rows).
+// (one padding slot per 16 elements of a line, the recipe of the float32 engine against the strided Stockham writes, made these passes 30 %
+// SLOWER -- 16-byte elements; profiles/r04_f64_fused.txt -- : the lines are not padded)
 template <bool COLS> __device__ __forceinline__ int at64(int i, int l, int n, int LN) { return COLS ? i * LN + l : l * n + i; }
-#endif
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }   // a wave-uniform value: into a scalar register
 
 // one Stockham pass of radix R = R1 R2 over the tile: butterfly j of line l reads in[j + t nb], multiplies by w^(t jm ts), writes
-// out[j0 + k ns] (jq = j / ns, jm = j mod ns, j0 = jq ns R + jm)
+// out[j0 + k ns] (jq = j / ns, jm = j mod ns, j0 = jq ns R + jm).  A, B: the two buffers of the tile.
 // (LN and the thread count are powers of two: a thread's line and its first butterfly come from shifts -- lsh = log2 LN --, the
-// quotient by ns from a multiplication; integer divisions were a third of the instructions of a pass)
+// quotient by ns from a multiplication; what a pass derives from its run-time constants -- the strides of a butterfly's inputs and
+// outputs -- is pinned to scalar registers: as vector values they cost a quarter-rate 32-bit multiplication per LDS access)
 template <int R1, int R2, int DIR, bool COLS>
 __device__ __forceinline__ void pass64(const c64* A, c64* B, const c64* tw, int half, int n, int ns, unsigned mg, int LN, int lsh, int tid, int nthr)
 {
     constexpr int R = R1 * R2;
-    const int nb = n / R, ts = n / (ns * R);
-    const int tpl = nthr >> lsh;                                   // threads per line
+    n = uni(n); ns = uni(ns); LN = uni(LN); lsh = uni(lsh); half = uni(half);
+    const int nb = uni(n / R), ts = uni(n / (ns * R));
+    const int tpl = uni(nthr >> lsh);                              // threads per line
+    const int sa = COLS ? nb << lsh : nb, sb = COLS ? ns << lsh : ns;   // element distance of a butterfly's inputs / outputs
     const int l = COLS ? tid & (LN - 1) : tid >> (31 - __clz(tpl));
+    const int lb = COLS ? l : l * n;                               // the thread's line
     for (int j = COLS ? tid >> lsh : tid & (tpl - 1); j < nb; j += tpl) {
         const int jq = ns > 1 ? (int)__umulhi((unsigned)j, mg) : j, jm = j - jq * ns, j0 = jq * ns * R + jm;
+        const c64* in = A + (lb + (COLS ? j << lsh : j));
+        c64* out = B + (lb + (COLS ? j0 << lsh : j0));
         c64 v[R];
-        v[0] = A[at64<COLS>(j, l, n, LN)];
+        v[0] = in[0];
         if (ns == 1) {
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = A[at64<COLS>(j + t * nb, l, n, LN)];
+            for (int t = 1; t < R; ++t) v[t] = in[t * sa];
         } else {
             const int twi = jm * ts;
 #pragma unroll
-            for (int t = 1; t < R; ++t) v[t] = twmul<DIR>(A[at64<COLS>(j + t * nb, l, n, LN)], tw_at(tw, t * twi, half));
+            for (int t = 1; t < R; ++t) v[t] = twmul<DIR>(in[t * sa], tw_at(tw, t * twi, half));
         }
         radix64<R1, R2, DIR>(v);
 #pragma unroll
-        for (int k = 0; k < R; ++k) B[at64<COLS>(j0 + k * ns, l, n, LN)] = v[k];
+        for (int k = 0; k < R; ++k) out[k * sb] = v[k];
     }
 }
 
@@ -516,7 +515,8 @@ enum { C64_ITER = 0, C64_STATS = 1, C64_FWD = 2 };
 // inverse transform, 1 / n1, in place on the work buffer.  C64_STATS: forward transform, then the tile's statistics (lexicographic
 // maximum, max |X|, min |X|, sum |X|^2) -> partial[(slice, tile)][8].  C64_FWD: forward transform only.
 // grid (tiles, slices); dynamic LDS: [table n1 if tw_lds][2 x LN n1]
-template <int MODE>
+// TWL: the twiddle table (or its first half) sits in LDS -- a template parameter, so that its loads are LDS instructions and not flat ones
+template <int MODE, bool TWL>
 __global__ __launch_bounds__(F64_THREADS) void col64_kernel(c64* work, const c64* tw_g, Fft64 pl, int n2, int LN, int tw_lds, const c64* tau, int niter, int iter, int op,
                                                             double* partial, const int* done)
 {
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(F64_THREADS) void col64_kernel(c64* work, const c64
     const int tid = threadIdx.x, nthr = blockDim.x, n = pl.n, s = blockIdx.y, c0 = blockIdx.x * LN;
     if (done && done[s] != 0) return;
     c64* twl = reinterpret_cast<c64*>(smem_raw);
-    const int half = tw_lds == 2 ? n / 2 : 0, tw_n = tw_lds == 2 ? n / 2 : (tw_lds ? n : 0);   // tw_lds: 0 the table stays in memory, 1 in LDS, 2 its first half in LDS
+    const int half = TWL && tw_lds == 2 ? n / 2 : 0, tw_n = !TWL ? 0 : (tw_lds == 2 ? n / 2 : n);   // tw_lds: 0 the table stays in memory, 1 in LDS, 2 its first half in LDS
     c64* A = twl + tw_n;
-    c64* B = A + (size_t)LN * pad64(n);
+    c64* B = A + (size_t)LN * n;
     c64* const base = work + (size_t)s * n * n2;
     const int lsh = 31 - __clz(LN);
     const int lv = min(LN, n2 - c0);   // valid columns of the tile
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(F64_THREADS) void col64_kernel(c64* work, const c64
         A[at64<true>(i, l, n, LN)] = l < lv ? base[(size_t)i * n2 + c0 + l] : c64{0.0, 0.0};
     }
     for (int k = tid; k < tw_n; k += nthr) twl[k] = tw_g[k];
-    const c64* tw = tw_lds ? twl : tw_g;
+    const c64* tw = TWL ? twl : tw_g;
     __syncthreads();
     c64* X = tile_fft64<-1, true>(A, B, tw, half, pl, LN, tid, nthr);
     c64* Y = X == A ? B : A;
@@ -599,7 +599,7 @@ enum { R64_FIRST = 0, R64_MID = 1, R64_LAST = 2 };
 //              forward transform.     R64_LAST: the same without the forward transform (nothing feeds on the iterate any more).
 // partial[(slice, workgroup)]: the host-side fold adds a slice's workgroups in order (reproducible costs).
 // dynamic LDS as in col64_kernel
-template <int MODE>
+template <int MODE, bool TWL>
 __global__ __launch_bounds__(F64_THREADS) void row64_kernel(c64* work, const c64* tw_g, Fft64 pl, int n1, int LN, int tw_lds, const void* x, int dtype, const double* mask,
                                                             void* out, double* partial, int adaptive, int write_out, double alpha, const int* done, int zero_fill)
 {
@@ -623,12 +623,12 @@ __global__ __launch_bounds__(F64_THREADS) void row64_kernel(c64* work, const c64
         return;
     }
     c64* twl = reinterpret_cast<c64*>(smem_raw);
-    const int half = tw_lds == 2 ? n / 2 : 0, tw_n = tw_lds == 2 ? n / 2 : (tw_lds ? n : 0);
+    const int half = TWL && tw_lds == 2 ? n / 2 : 0, tw_n = !TWL ? 0 : (tw_lds == 2 ? n / 2 : n);
     c64* A = twl + tw_n;
-    c64* B = A + (size_t)LN * pad64(n);
+    c64* B = A + (size_t)LN * n;
     c64* const base = work + (size_t)s * per + (size_t)r0 * n;   // the tile's rows are one contiguous range
     for (int k = tid; k < tw_n; k += nthr) twl[k] = tw_g[k];
-    const c64* tw = tw_lds ? twl : tw_g;
+    const c64* tw = TWL ? twl : tw_g;
     c64* X = A;
     if (MODE != R64_FIRST) {
         for (int l = 0; l < LN; ++l)
@@ -742,7 +742,7 @@ int pick_tile64(int n, size_t budget, int want, int* tw_lds, size_t* lds)
 {
     for (int ln : {8, 4, 2, 1}) {
         if (ln > want) continue;
-        const size_t buf = sizeof(c64) * 2 * (size_t)ln * pad64(n), tab = sizeof(c64) * (size_t)n;
+        const size_t buf = sizeof(c64) * 2 * (size_t)ln * n, tab = sizeof(c64) * (size_t)n;
         if (buf > budget) continue;
         *tw_lds = 0;
         if (!getenv("P3D_F64_TW_GLOBAL")) {
@@ -758,10 +758,9 @@ int pick_tile64(int n, size_t budget, int want, int* tw_lds, size_t* lds)
 template <int MODE>
 int col_pass64(p3d_plan64* p, int nslices, int niter, int iter, int op, const int* done)
 {
-    const void* k = reinterpret_cast<const void*>(col64_kernel<MODE>);
-    if (p->lds_col > 64 * 1024) F_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_col));
-    col64_kernel<MODE><<<dim3(p->tiles_col(), nslices), p->thr_col, p->lds_col, p->stream>>>(p->work, p->tw_col, p->fcol, p->nxl, p->ln_col, p->tw_col_lds, p->tau, niter, iter, op,
-                                                                                            p->partial, done);
+    auto kern = p->tw_col_lds ? col64_kernel<MODE, true> : col64_kernel<MODE, false>;
+    if (p->lds_col > 64 * 1024) F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_col));
+    kern<<<dim3(p->tiles_col(), nslices), p->thr_col, p->lds_col, p->stream>>>(p->work, p->tw_col, p->fcol, p->nxl, p->ln_col, p->tw_col_lds, p->tau, niter, iter, op, p->partial, done);
     F_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -769,11 +768,11 @@ int col_pass64(p3d_plan64* p, int nslices, int niter, int iter, int op, const in
 template <int MODE>
 int row_pass64(p3d_plan64* p, int dtype, double* sums_row, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill)
 {
-    const void* k = reinterpret_cast<const void*>(row64_kernel<MODE>);
-    if (p->lds_row > 64 * 1024) F_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_row));
-    row64_kernel<MODE><<<dim3(p->tiles_row(), nslices), p->thr_row, p->lds_row, p->stream>>>(p->work, p->tw_row, p->frow, p->nil, p->ln_row, p->tw_row_lds, p->st_x, dtype,
-                                                                                            (MODE == R64_FIRST && !adaptive) ? nullptr : p->mask, p->st_out, p->spart, adaptive,
-                                                                                            write_out, alpha, done, zero_fill);
+    auto kern = p->tw_row_lds ? row64_kernel<MODE, true> : row64_kernel<MODE, false>;
+    if (p->lds_row > 64 * 1024) F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_row));
+    kern<<<dim3(p->tiles_row(), nslices), p->thr_row, p->lds_row, p->stream>>>(p->work, p->tw_row, p->frow, p->nil, p->ln_row, p->tw_row_lds, p->st_x, dtype,
+                                                                              (MODE == R64_FIRST && !adaptive) ? nullptr : p->mask, p->st_out, p->spart, adaptive, write_out, alpha,
+                                                                              done, zero_fill);
     fold64_kernel<<<nslices, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p->tiles_row());
     F_TRY(hipGetLastError());
     return P3D_OK;
