@@ -219,12 +219,24 @@ __device__ __forceinline__ T smooth2_at(const T* a, size_t ld, int H, int W, int
 // lane, conflict-free) and axis 0 slides a window down a column, every loaded sample feeding all outputs it belongs to.
 // LT: the filter length at compile time (0: read from `f`).  With it the tile geometry is constant, the tap loops unroll and
 // their coefficients stay in registers -- these kernels are bound by instruction issue, not by memory.
+// Threads of a tile kernel's workgroup: a tile's LDS image decides how many workgroups share a CU (four / two for float / complex samples), the
+// workgroup size how many wavefronts then cover each other between its barriers (see wfuse1_kernel).  512 instead of 256 threads: configs[3]
+// 0.535 -> 0.520 ms per iteration, a complex64 cube 0.688 -> 0.648 (1024: no further gain).  32-point tiles only; the 16-point tiles of the
+// coarse levels stay at 256.
+#ifndef P3D_WTILE_THREADS
+#define P3D_WTILE_THREADS 512
+#endif
+#ifndef P3D_WTILE_THREADS_COMPLEX
+#define P3D_WTILE_THREADS_COMPLEX 512
+#endif
+template <typename T, int TILE> constexpr int WTILE_NT = TILE != 32 ? 256 : (sizeof(T) == sizeof(float) ? P3D_WTILE_THREADS : P3D_WTILE_THREADS_COMPLEX);
 template <typename T, int TILE, int LT>
-__global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_slice, int H, int W, T* cA, size_t cA_slice, T* det, size_t det_slice, int Ho, int Wo,
+__global__ __launch_bounds__((WTILE_NT<T, TILE>)) void dwt2_tile_kernel(const T* in, size_t in_slice, int H, int W, T* cA, size_t cA_slice, T* det, size_t det_slice, int Ho, int Wo,
                                                         Filters f, int tiles_x, int ntiles, int ns, Thresh th)
 {
     extern __shared__ __align__(16) unsigned char w_smem[];
-    constexpr int LX = TILE, LY = 256 / TILE, R = TILE / LY > 0 ? TILE / LY : 1;
+    constexpr int NT = WTILE_NT<T, TILE>;
+    constexpr int LX = TILE, LY = NT / TILE, R = TILE / LY > 0 ? TILE / LY : 1;
     const int L = LT ? LT : f.len, IH = 2 * TILE + L - 2, IW = IH;  // L is even: IW is even, rows of s_in start 8-byte aligned for float
     T* s_in = reinterpret_cast<T*>(w_smem);
     T* s_lo = s_in + (size_t)IH * IW;
@@ -252,18 +264,18 @@ __global__ __launch_bounds__(256) void dwt2_tile_kernel(const T* in, size_t in_s
     if (LT != 0 && inside && vh == TILE && vw == TILE) {
         // a whole interior tile with the filter length known: its IH x IW samples as ONE index range over the 256 threads
         // (20 loads per thread for db4 where the row / column-step batches below issue 27), LDS index = that index
-        constexpr int IHc = 2 * TILE + LT - 2, IWc = IHc, NE = (IHc * IWc + 255) / 256;
+        constexpr int IHc = 2 * TILE + LT - 2, IWc = IHc, NE = (IHc * IWc + NT - 1) / NT;
         const T* g = src + (size_t)r0 * W + c0;
         T v[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = (int)threadIdx.x + k * 256, r = e / IWc, c = e - r * IWc;
+            const int e = (int)threadIdx.x + k * NT, r = e / IWc, c = e - r * IWc;
             v[k] = zero_of<T>();
             if (e < IHc * IWc) v[k] = g[(unsigned)r * (unsigned)W + (unsigned)c];
         }
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = (int)threadIdx.x + k * 256;
+            const int e = (int)threadIdx.x + k * NT;
             if (e < IHc * IWc) s_in[e] = v[k];
         }
     } else if (inside) {
@@ -593,12 +605,13 @@ __device__ __forceinline__ void store_out(void* out, int, size_t g, float v) { r
 // synthesis of one level: (a, cH, cV, cD) (Ho x Wo valid samples each; a may sit in a larger array) -> rec (RH x RW).
 // Workgroup = 2 TILE x 2 TILE output samples; same thread layout and LDS economy as the analysis kernel.
 template <typename T, int TILE, int LT>
-__global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det, size_t det_slice, int Ho, int Wo, T* rec,
+__global__ __launch_bounds__((WTILE_NT<T, TILE>)) void idwt2_tile_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det, size_t det_slice, int Ho, int Wo, T* rec,
                                                          size_t rec_slice, int RH, int RW, Filters f, int tiles_x, int ntiles, int ns, Update u)
 {
     extern __shared__ __align__(16) unsigned char w_smem[];
-    __shared__ double red[4];
-    constexpr int LX = TILE, LY = 256 / TILE, OH = 2 * TILE, OW = 2 * TILE, R = OH / LY;   // R output rows per thread along axis 0
+    constexpr int NT = WTILE_NT<T, TILE>;
+    __shared__ double red[NT / 64];
+    constexpr int LX = TILE, LY = NT / TILE, OH = 2 * TILE, OW = 2 * TILE, R = OH / LY;   // R output rows per thread along axis 0
     const int L = LT ? LT : f.len, HL = L / 2, KH = TILE + HL - 1, KW = KH;
     T* s_a = reinterpret_cast<T*>(w_smem);
     T* s_h = s_a + (size_t)KH * KW;
@@ -629,11 +642,11 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
     if constexpr (LT != 0) {
         // the KH x KW coefficients of the tile as ONE index range over the 256 threads (5 loads per array and thread for db4
         // instead of 5 x 2, half of them for the three columns beyond the lanes' own); LDS index = that index (pitch KW)
-        constexpr int KHc = TILE + LT / 2 - 1, KWc = KHc, NE = (KHc * KWc + 255) / 256;
+        constexpr int KHc = TILE + LT / 2 - 1, KWc = KHc, NE = (KHc * KWc + NT - 1) / NT;
         T va[NE], vh[NE], vv[NE], vd[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = (int)threadIdx.x + k * 256, kr = e / KWc, kc = e - kr * KWc, gr = kr0 + kr, gc = kc0 + kc;
+            const int e = (int)threadIdx.x + k * NT, kr = e / KWc, kc = e - kr * KWc, gr = kr0 + kr, gc = kc0 + kc;
             va[k] = vh[k] = vv[k] = vd[k] = zero_of<T>();
             if (kr < KHv && kc < KWv && gr < Ho && gc < Wo) {
                 const size_t o = (size_t)gr * Wo + gc;
@@ -645,7 +658,7 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
         }
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = (int)threadIdx.x + k * 256, kr = e / KWc, kc = e - kr * KWc;
+            const int e = (int)threadIdx.x + k * NT, kr = e / KWc, kc = e - kr * KWc;
             if (kr < KHv && kc < KWv) { s_a[e] = va[k]; s_h[e] = vh[k]; s_v[e] = vv[k]; s_d[e] = vd[k]; }
         }
     } else {
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
     // a second sweep `kc += LX` cost every wavefront a full pass for three active lanes
     {
         const int extra = KWv - LX;
-        for (int it = threadIdx.x; it < extra * LY; it += 256) {
+        for (int it = threadIdx.x; it < extra * LY; it += NT) {
             const int tyg = it / extra, kc = LX + (it - tyg * extra);
             if (tyg * R < nvh) undo_axis0(kc, tyg);
         }
@@ -798,7 +811,11 @@ __global__ __launch_bounds__(256) void idwt2_tile_kernel(const T* a, size_t a_ld
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
-        if (threadIdx.x == 0 && dn == 0) atomicAdd(u.sums + s, (red[0] + red[1]) + (red[2] + red[3]));
+        if (threadIdx.x == 0 && dn == 0) {
+            double tot = (red[0] + red[1]) + (red[2] + red[3]);
+            for (int w = 4; w < NT / 64; w += 4) tot += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+            atomicAdd(u.sums + s, tot);
+        }
     }
 }
 
@@ -1482,7 +1499,7 @@ static int w_forward_fused(p3d_wplan* p, int ns, const Thresh* th, bool fuse_inv
         const int tx = (Wo + tile - 1) / tile, ty = (Ho + tile - 1) / tile;
         T* const det = (l == 1 && det1) ? det1 : coef + p->doff[l];
         const size_t det_slice = (l == 1 && det1) ? det1_slice : p->ncoef;
-#define P3D_W_DWT(TL, LT) dwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, det, det_slice, Ho, Wo, p->f, tx, tx * ty, ns, t)
+#define P3D_W_DWT(TL, LT) dwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, WTILE_NT<T, TL>, lds, p->stream>>>(src, (size_t)H * W, H, W, cA, cA_slice, det, det_slice, Ho, Wo, p->f, tx, tx * ty, ns, t)
         const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;   // db4 / sym4 and db2 have kernels of their own
         if (tile == 32) { if (lt == 8) P3D_W_DWT(32, 8); else if (lt == 4) P3D_W_DWT(32, 4); else P3D_W_DWT(32, 0); }
         else { if (lt == 8) P3D_W_DWT(16, 8); else if (lt == 4) P3D_W_DWT(16, 4); else P3D_W_DWT(16, 0); }
@@ -1520,7 +1537,7 @@ static int w_inverse_fused(p3d_wplan* p, int ns, const Update* u, bool coarse_do
         const int tx = (OWt + 2 * tile - 1) / (2 * tile), ty = (OHt + 2 * tile - 1) / (2 * tile);
         const T* const det = (l == 1 && det1) ? det1 : coef + p->doff[l];
         const size_t det_slice = (l == 1 && det1) ? det1_slice : p->ncoef;
-#define P3D_W_IDWT(TL, LT) idwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, 256, lds, p->stream>>>(a, a_ld, a_slice, det, det_slice, Ho, Wo, as<T>(p->rec[l - 1]), \
+#define P3D_W_IDWT(TL, LT) idwt2_tile_kernel<T, TL, LT><<<tx * ty * ns8, WTILE_NT<T, TL>, lds, p->stream>>>(a, a_ld, a_slice, det, det_slice, Ho, Wo, as<T>(p->rec[l - 1]), \
                                                                                      (size_t)RH * RW, RH, RW, p->f, tx, tx * ty, ns, up)
         const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
         if (tile == 32) { if (lt == 8) P3D_W_IDWT(32, 8); else if (lt == 4) P3D_W_IDWT(32, 4); else P3D_W_IDWT(32, 0); }
