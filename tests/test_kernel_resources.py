@@ -67,5 +67,40 @@ def test_no_new_kernel_spills_registers():
     assert not stale, "no kernel matches these entries of KNOWN_SCRATCH any more (take them off the list): %r" % (sorted(stale),)
     # the kernels of the metric's configuration and of the other BASELINE configurations, by name: every instantiation of them is clean
     hot = ("row_pipe32_kernel", "row_pipe64_kernel<1024", "col_kernel<1024, 8", "row_pipe64_kernel<512", "col_kernel<512, 16", "row_real_kernel<1024, 1, true", "col_shear_pair_kernel<2048",
-           "row_kernel<1024, 3", "row_kernel<1024, 4", "wfuse1_kernel", "wcoarse_kernel", "dwt2_tile_kernel", "idwt2_tile_kernel", "chirp_row_kernel")
+           "row_kernel<1024, 3", "row_kernel<1024, 4", "wfuse1_kernel", "wcoarse_kernel", "dwt2_tile_kernel", "idwt2_tile_kernel", "chirp_row_kernel",
+           "col64_kernel", "row64_kernel")
     assert not [n for n in dirty if n.startswith(hot)], [n for n in dirty if n.startswith(hot)]
+
+
+# kernels whose speed rests on a number of workgroups per CU that their LDS image allows and their registers must not take away again:
+# (pattern of the demangled name, threads per workgroup, workgroups per CU) -> at most 512 / (wavefronts per SIMD) registers, in steps of 8
+OCCUPANCY = [
+    (r"wfuse1_kernel<float, 32, (4|8)>", 512, 3),            # three 44-KiB tiles per CU: 24 wavefronts (profiles/r04_wavelet_workgroup_size.txt)
+    (r"wfuse1_kernel<p3d::c32, 32, (4|8)>", 1024, 1),
+    (r"dwt2_tile_kernel<float, 32, (4|8)>", 512, 4),
+    (r"idwt2_tile_kernel<float, 32, (4|8)>", 512, 4),
+    (r"row_pipe32_kernel<.*>", 512, 1),
+    (r"col_kernel<1024, 8, \d+>", 512, 2),
+    (r"col64_kernel<\d, (true|false)>", 512, 2),
+    (r"row64_kernel<\d, (true|false)>", 512, 2),
+]
+
+
+@pytest.mark.skipif(not glob.glob(os.path.join(BUILD, "*.o")) or not os.path.exists(f"{LLVM}/clang-offload-bundler") or not shutil.which("c++filt"),
+                    reason="needs the object files of the library build and the ROCm LLVM tools")
+def test_register_budgets_of_the_occupancy_bound_kernels():
+    seen = set()
+    for obj in sorted(glob.glob(os.path.join(BUILD, "*.o"))):
+        if os.path.basename(obj) not in ("wavelet.o", "f64.o", "inst_1024.o"):
+            continue
+        for mangled, res in _kernels(obj).items():
+            name = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
+            short = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "")).replace("void ", "")
+            short = short.replace("p3d::row", "row").replace("p3d::col", "col")
+            for pat, threads, per_cu in OCCUPANCY:
+                if re.fullmatch(pat, short):
+                    seen.add(pat)
+                    waves_per_simd = threads // 64 * per_cu / 4
+                    budget = int(512 // waves_per_simd) // 8 * 8
+                    assert res["vgpr_count"] <= min(budget, 512), (short, res["vgpr_count"], budget)
+    assert seen == {pat for pat, _, _ in OCCUPANCY}, sorted({pat for pat, _, _ in OCCUPANCY} - seen)
