@@ -114,6 +114,22 @@ template <int EXTRA> __global__ __launch_bounds__(256) void rowblk(float2* p, co
     #pragma unroll
     for (int q = 0; q < 16; ++q) { const int e = lane + 64 * q; v[q].x *= 1.0001f; sb[((size_t)(e >> 3) * N1 + row) * 8 + (e & 7)] = v[q]; }
 }
+// read-only / write-only streams, each WG a contiguous 64 KiB chunk (what the column pass of a sparse spectrum / the row pass's store side look like to the memory)
+__global__ void read4(const float4* a, float* sink, size_t n) {
+    const size_t base = (size_t)blockIdx.x * 4096;
+    float4 v[16];
+    #pragma unroll
+    for (int k = 0; k < 16; ++k) { const size_t i = base + k * 256 + threadIdx.x; v[k] = i < n ? a[i] : float4{0.f, 0.f, 0.f, 0.f}; }
+    float s = 0.f;
+    #pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k].x + v[k].w;
+    if (s == 123.456f) sink[0] = s;   // (never: keeps the loads)
+}
+__global__ void write4(float4* b, size_t n, float val) {
+    const size_t base = (size_t)blockIdx.x * 4096;
+    #pragma unroll
+    for (int k = 0; k < 16; ++k) { const size_t i = base + k * 256 + threadIdx.x; if (i < n) b[i] = float4{val, val, val, val}; }
+}
 __global__ void copy4(const float4* a, float4* b, size_t n) {   // each WG a contiguous 64 KiB chunk
     const size_t base = (size_t)blockIdx.x * 4096;
     #pragma unroll
@@ -184,6 +200,8 @@ int main(int argc, char** argv) {
     col(colpat<8, 0, 1>, 8, 512, 36, "col T=8  8B/lane  4 WG/CU (36 KiB LDS)  64-B segments");
     col(colpat<16, 0, 1>, 16, 1024, 1, "col T=16 8B/lane  no LDS limit");
     col(colpat<16, 1, 1>, 16, 1024, 1, "col T=16 16B/lane no LDS limit");
+    rep("read only float4, WG-contiguous 64 KiB", timeit([&] { read4<<<(unsigned)((n / 2 + 4095) / 4096), 256>>>((const float4*)x, (float*)p, n / 2); }, 5), gb);
+    rep("write only float4, WG-contiguous 64 KiB", timeit([&] { write4<<<(unsigned)((n / 2 + 4095) / 4096), 256>>>((float4*)p, n / 2, 1.5f); }, 5), gb);
     rep("copy float4 a->b, WG-contiguous 64 KiB (r+w)", timeit([&] { copy4<<<(unsigned)((n / 2 + 4095) / 4096), 256>>>((const float4*)x, (float4*)p, n / 2); }, 5), 2 * gb);
     auto col8 = [&](auto kern, int ldskb, const char* name) {
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldskb * 1024));
