@@ -287,7 +287,7 @@ def release_plans():
     for w in _workers.values():
         w.close()
     _workers.clear()
-    for cache in (_plans, _shearlet_plans):
+    for cache in (_plans, _shearlet_plans, _holders):
         for plan in cache.values():
             plan.close()
         cache.clear()
@@ -351,6 +351,31 @@ def _slab_copy(dst, src):
 
 
 _COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_holders = {}
+
+
+def _holder(device):
+    """A minimal FFT plan per device: owner of the device buffers and copies of the WAVELET / SHEARLET batches (``p3d_malloc`` / ``p3d_memcpy_*`` go
+    through a plan's device and stream)."""
+    h = _holders.get(device)
+    if h is None or h.handle is None:
+        h = _holders[device] = _ffi.Plan(4, 4, 1, device=device)
+    return h
+
+
+def _active_slices(chunk):
+    """``np.count_nonzero(x) != 0`` per slice (POCS.py:515-521), the slices spread over a few threads (NumPy's reductions release the GIL; one thread
+    takes ~25 ms per 256 MiB)."""
+    global _copy_pool
+    n = chunk.shape[0]
+    parts = max(1, min(_COPY_THREADS, n, chunk.nbytes >> 22))
+    if parts == 1:
+        return chunk.reshape(n, -1).any(axis=1)
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_pool = ThreadPoolExecutor(_COPY_THREADS)
+    cuts = [n * i // parts for i in range(parts + 1)]
+    return np.concatenate(list(_copy_pool.map(lambda i: chunk[cuts[i]:cuts[i + 1]].reshape(cuts[i + 1] - cuts[i], -1).any(axis=1), range(parts))))
 _PIN_MIN_BYTES = int(os.environ.get('P3D_PIN_MIN_MIB', 256)) << 20   # cubes from this size on are page-locked in place for the call (0 MiB: always; huge: never)
 
 
@@ -728,22 +753,61 @@ def pocs_cube(
     else:
         plan = _get_plan(nil, nxl, min(step, nslices), device, slot=15)   # the low slots belong to the chunk workers
 
+    if kind in ('WAVELET', 'SHEARLET'):
+        # One upload per batch, statistics and loop on the device-resident copy, the result downloaded straight into `out` (whose fresh
+        # pages a few threads touch while the batch iterates: a download into untouched pages runs at a third of the link's rate).
+        # configs[3]'s cube: 0.10 -> 0.04 s per call (tools/wv_e2e.py); the entry points took host pointers before: two uploads,
+        # a result array of their own and a copy of it.
+        holder = _holder(device)
+        narrow = np.complex64 if np.iscomplexobj(cube) else np.float32
+        per = nil * nxl * np.dtype(narrow).itemsize
+        cap = min(step, nslices)
+        xd, od, md = holder.alloc(per * cap), holder.alloc(per * cap), holder.alloc(maskf.nbytes)
+        touching = [] if (np.may_share_memory(cube, out) or not out.flags.c_contiguous) else _touch_pages(out)
+        try:
+            md.upload(maskf)
+            for lo in range(0, nslices, step):
+                chunk = cube[lo:lo + step]
+                n = chunk.shape[0]
+                t0 = time.perf_counter()
+                xc, dt = plan._cube(chunk)
+                xd.upload(xc)
+                active = _active_slices(chunk)  # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+                stats = plan.stats_dev(xd.ptr, dt, n)
+                stats[~active] = 1.0      # keep NaNs of empty slices out of the (unused) schedule rows ...
+                stats[~active, ..., 1] = 0.0  # ... without making them complex
+                if kind == 'WAVELET':
+                    tau = _wavelet_schedule_from_stats(stats, thresh_model, niter, p_max, p_min, decay_kind)
+                else:
+                    tau = _shearlet_schedule_from_stats(stats, (nil, nxl), thresh_model, niter, p_max, p_min, decay_kind)
+                if sqrt_decay:
+                    tau = np.sqrt(tau)  # POCS.py:595
+                done, sums, _ = plan.run_dev(xd.ptr, dt, md.ptr, tau, niter, od.ptr, n, thresh_op=thresh_op, version=version, eps=eps, alpha=alpha,
+                                             active=active)
+                for f in touching:
+                    f.result()
+                touching = []
+                dst = out[lo:lo + n]
+                if dst.dtype == xc.dtype and dst.flags.c_contiguous:
+                    od.download_into(dst)
+                else:
+                    dst[...] = od.download(xc.shape, xc.dtype)   # (a double-precision cube: the reference's final cast, the other way round)
+                runtime = time.perf_counter() - t0
+                if results is not None:
+                    results.extend(_result_rows(done, sums, runtime))
+        finally:
+            for f in touching:
+                f.result()
+            for b in (xd, od, md):
+                b.free()
+        return out
+
     for lo in range(0, nslices, step):
         chunk = cube[lo:lo + step]
         n = chunk.shape[0]
         active = chunk.reshape(n, -1).any(axis=1)  # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         t0 = time.perf_counter()
-        if kind == 'WAVELET':
-            stats = plan.stats(chunk)
-            stats[~active] = 1.0      # keep NaNs of empty slices out of the (unused) schedule rows ...
-            stats[~active, ..., 1] = 0.0  # ... without making them complex
-            tau = _wavelet_schedule_from_stats(stats, thresh_model, niter, p_max, p_min, decay_kind)
-        elif kind == 'SHEARLET':
-            stats = plan.stats(chunk)
-            stats[~active] = 1.0
-            stats[~active, ..., 1] = 0.0
-            tau = _shearlet_schedule_from_stats(stats, (nil, nxl), thresh_model, niter, p_max, p_min, decay_kind)
-        elif thresh_model == 'data-driven':
+        if thresh_model == 'data-driven':
             tau = _data_driven_batch(plan, chunk, active, niter, p_max, p_min)
         else:
             stats = plan.stats(chunk)
