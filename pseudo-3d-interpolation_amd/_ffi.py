@@ -651,6 +651,24 @@ class Plan64:
                                    _ptr(done), _ptr(sums), C.byref(ms)))
         return out, done, sums, ms.value
 
+    def stats_dev(self, x_ptr, dtype, n):
+        """`stats` for a cube resident on the device (raw pointer; dtype P3D_C128 / P3D_F64 / P3D_C64 / P3D_F32)."""
+        st = np.empty((n, 6), np.float64)
+        check(lib().p3d_pocs64_stats(self.handle, C.c_void_p(x_ptr), dtype, n, _ptr(st)))
+        return st
+
+    def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, n, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """`run` on device-resident buffers (raw pointers; the mask is DOUBLE [nil][nxl]).  Returns (niter_done, sums, device ms of the loop)."""
+        t = Plan._tau(tau, n, niter)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_pocs64_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act), C.byref(prm),
+                                   C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return done, sums, ms.value
+
 
 # ---- SHEARLET variant ----------------------------------------------------------------------
 class ShearletPlan:

@@ -571,25 +571,49 @@ def _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alph
     step = int(batch_slices) if batch_slices else max(1, min(nslices, (2 << 30) // (nil * nxl * 16)))   # work + staging: 48 B per point and slice
     plan = _get_plan64(nil, nxl, min(step, nslices), device)
     mask64 = np.ascontiguousarray(mask, dtype=np.float64)
-    for lo in range(0, nslices, step):
-        chunk = cube[lo:lo + step]
-        n = chunk.shape[0]
-        active = chunk.reshape(n, -1).any(axis=1)   # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
-        t0 = time.perf_counter()
-        if thresh_model == 'data-driven':
-            narrow = chunk.astype(np.complex64 if np.iscomplexobj(chunk) else np.float32)
-            tau = _data_driven_batch(_get_plan(nil, nxl, n, device, slot=15), narrow, active, niter, p_max, p_min)
-        else:
-            stats = plan.stats(chunk)
-            stats[~active] = 1.0
-            tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
-        if sqrt_decay:
-            tau = np.sqrt(tau)
-        res, done, sums, _ = plan.run(chunk, mask64, tau, niter, thresh_op=thresh_op, version=version, eps=eps, alpha=alpha, active=active)
-        runtime = time.perf_counter() - t0
-        out[lo:lo + n] = res
-        if results is not None:
-            results.extend(_result_rows(done, sums, runtime))
+    # one upload per batch into device buffers, statistics and loop on the resident copy, the result downloaded straight into `out` (whose fresh
+    # pages a few threads touch meanwhile): a 2-GiB batch of complex128 slices used to be uploaded twice, downloaded into an array of the
+    # wrapper's own and copied once more on the host -- more wall time than its loop
+    holder = _holder(device)
+    cap = min(step, nslices)
+    itemsize = cube.dtype.itemsize if cube.dtype in _ffi.Plan64._DT else (16 if np.iscomplexobj(cube) else 8)
+    xd, od, md = holder.alloc(nil * nxl * itemsize * cap), holder.alloc(nil * nxl * itemsize * cap), holder.alloc(mask64.nbytes)
+    touching = [] if (np.may_share_memory(cube, out) or not out.flags.c_contiguous) else _touch_pages(out)
+    try:
+        md.upload(mask64)
+        for lo in range(0, nslices, step):
+            chunk = cube[lo:lo + step]
+            n = chunk.shape[0]
+            t0 = time.perf_counter()
+            xc, dt = plan._cube(chunk)
+            xd.upload(xc)
+            active = _active_slices(chunk)   # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+            if thresh_model == 'data-driven':
+                narrow = chunk.astype(np.complex64 if np.iscomplexobj(chunk) else np.float32)
+                tau = _data_driven_batch(_get_plan(nil, nxl, n, device, slot=15), narrow, active, niter, p_max, p_min)
+            else:
+                stats = plan.stats_dev(xd.ptr, dt, n)
+                stats[~active] = 1.0
+                tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
+            if sqrt_decay:
+                tau = np.sqrt(tau)
+            done, sums, _ = plan.run_dev(xd.ptr, dt, md.ptr, tau, niter, od.ptr, n, thresh_op=thresh_op, version=version, eps=eps, alpha=alpha, active=active)
+            for f in touching:
+                f.result()
+            touching = []
+            dst = out[lo:lo + n]
+            if dst.dtype == xc.dtype and dst.flags.c_contiguous:
+                od.download_into(dst)
+            else:
+                dst[...] = od.download(xc.shape, xc.dtype)
+            runtime = time.perf_counter() - t0
+            if results is not None:
+                results.extend(_result_rows(done, sums, runtime))
+    finally:
+        for f in touching:
+            f.result()
+        for b in (xd, od, md):
+            b.free()
     return out
 
 
