@@ -287,6 +287,10 @@ def release_plans():
     for w in _workers.values():
         w.close()
     _workers.clear()
+    for bufs in _batch_bufs.values():
+        for b in bufs:
+            b.free()
+    _batch_bufs.clear()
     for cache in (_plans, _shearlet_plans, _holders):
         for plan in cache.values():
             plan.close()
@@ -361,6 +365,22 @@ def _holder(device):
     if h is None or h.handle is None:
         h = _holders[device] = _ffi.Plan(4, 4, 1, device=device)
     return h
+
+
+_batch_bufs = {}
+
+
+def _batch_buffers(device, cube_bytes, mask_bytes):
+    """Device buffers (observed batch, result batch, mask) of the resident WAVELET / SHEARLET / double-precision batches, kept per device and grown
+    on demand: a per-slice caller (``POCS_algorithm`` under ``xr.apply_ufunc``) does not pay three hipMalloc / hipFree pairs per call."""
+    holder = _holder(device)
+    have = _batch_bufs.get(device)
+    if have is None or have[0].nbytes < cube_bytes or have[2].nbytes < mask_bytes or have[0].plan is not holder:
+        if have is not None:
+            for b in have:
+                b.free()
+        have = _batch_bufs[device] = (holder.alloc(cube_bytes), holder.alloc(cube_bytes), holder.alloc(mask_bytes))
+    return have
 
 
 def _active_slices(chunk):
@@ -574,10 +594,9 @@ def _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alph
     # one upload per batch into device buffers, statistics and loop on the resident copy, the result downloaded straight into `out` (whose fresh
     # pages a few threads touch meanwhile): a 2-GiB batch of complex128 slices used to be uploaded twice, downloaded into an array of the
     # wrapper's own and copied once more on the host -- more wall time than its loop
-    holder = _holder(device)
     cap = min(step, nslices)
     itemsize = cube.dtype.itemsize if cube.dtype in _ffi.Plan64._DT else (16 if np.iscomplexobj(cube) else 8)
-    xd, od, md = holder.alloc(nil * nxl * itemsize * cap), holder.alloc(nil * nxl * itemsize * cap), holder.alloc(mask64.nbytes)
+    xd, od, md = _batch_buffers(device, nil * nxl * itemsize * cap, mask64.nbytes)
     touching = [] if (np.may_share_memory(cube, out) or not out.flags.c_contiguous) else _touch_pages(out)
     try:
         md.upload(mask64)
@@ -612,8 +631,6 @@ def _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alph
     finally:
         for f in touching:
             f.result()
-        for b in (xd, od, md):
-            b.free()
     return out
 
 
@@ -782,11 +799,10 @@ def pocs_cube(
         # pages a few threads touch while the batch iterates: a download into untouched pages runs at a third of the link's rate).
         # configs[3]'s cube: 0.10 -> 0.04 s per call (tools/wv_e2e.py); the entry points took host pointers before: two uploads,
         # a result array of their own and a copy of it.
-        holder = _holder(device)
         narrow = np.complex64 if np.iscomplexobj(cube) else np.float32
         per = nil * nxl * np.dtype(narrow).itemsize
         cap = min(step, nslices)
-        xd, od, md = holder.alloc(per * cap), holder.alloc(per * cap), holder.alloc(maskf.nbytes)
+        xd, od, md = _batch_buffers(device, per * cap, maskf.nbytes)
         touching = [] if (np.may_share_memory(cube, out) or not out.flags.c_contiguous) else _touch_pages(out)
         try:
             md.upload(maskf)
@@ -822,8 +838,6 @@ def pocs_cube(
         finally:
             for f in touching:
                 f.result()
-            for b in (xd, od, md):
-                b.free()
         return out
 
     for lo in range(0, nslices, step):
