@@ -355,6 +355,12 @@ class Plan:
         check(lib().p3d_pocs_sorted_spectrum(self.handle, _ptr(xc), xc.shape[0], _ptr(peaks)))
         return peaks.view(np.complex64)[:, 0]
 
+    def sorted_spectrum_dev(self, x_ptr, n):
+        """`sorted_spectrum` of a complex64 batch resident on the device (raw pointer)."""
+        peaks = np.empty((n, 2), np.float32)
+        check(lib().p3d_pocs_sorted_spectrum(self.handle, C.c_void_p(x_ptr), n, _ptr(peaks)))
+        return peaks.view(np.complex64)[:, 0]
+
     def data_driven_pick(self, tau_min, tau_max, niter):
         """Second half: per slice the number of coefficients strictly between the bounds (complex64, NumPy's order) and the
         niter thresholds picked from them (POCS.py:359-362); must follow sorted_spectrum directly."""

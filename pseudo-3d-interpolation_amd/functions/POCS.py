@@ -112,7 +112,7 @@ def _data_driven(x_fwd, niter, p_max, p_min):
     return tau
 
 
-def _data_driven_batch(plan, chunk, active, niter, p_max, p_min):
+def _data_driven_batch(plan, chunk, active, niter, p_max, p_min, x_dev=None):
     """'data-driven' schedules of a batch of slices (POCS.py:356-362).  The spectrum stays on the device: sorted there in NumPy's
     complex order, the bounds formed here exactly as the reference forms them (p * x_fwd.max(): a Python float times a complex64
     scalar), the picks read back.  p_min='adaptive' takes its bound from np.linalg.norm of the spectrum: that one is computed on
@@ -127,7 +127,8 @@ def _data_driven_batch(plan, chunk, active, niter, p_max, p_min):
         for s in live:
             tau[s] = _data_driven(X0[s], niter, p_max, p_min)
         return tau
-    peaks = plan.sorted_spectrum(chunk)                      # x_fwd.max() per slice, complex64
+    # x_fwd.max() per slice, complex64 (x_dev: the batch is on the device already, as complex64)
+    peaks = plan.sorted_spectrum(chunk) if x_dev is None else plan.sorted_spectrum_dev(x_dev, n)
     lo = np.asarray([p_min * pk for pk in peaks])            # weak Python scalar times complex64 scalar -> complex64 (POCS.py:293-294)
     hi = np.asarray([p_max * pk for pk in peaks])
     picks, count = plan.data_driven_pick(lo, hi, niter)
@@ -840,23 +841,33 @@ def pocs_cube(
                 f.result()
         return out
 
+    # FFT, the schedules that need the sorted spectrum (or a result array that is not contiguous): one batch at a time, resident between one
+    # upload and one download like the WAVELET / SHEARLET batches above
+    narrow = np.complex64 if np.iscomplexobj(cube) else np.float32
+    xd, od, md = _batch_buffers(device, nil * nxl * np.dtype(narrow).itemsize * min(step, nslices), maskf.nbytes)
+    md.upload(maskf)
     for lo in range(0, nslices, step):
         chunk = cube[lo:lo + step]
         n = chunk.shape[0]
-        active = chunk.reshape(n, -1).any(axis=1)  # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         t0 = time.perf_counter()
+        xc, dt = plan._cube(chunk)
+        xd.upload(xc)
+        active = _active_slices(chunk)  # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
         if thresh_model == 'data-driven':
-            tau = _data_driven_batch(plan, chunk, active, niter, p_max, p_min)
+            tau = _data_driven_batch(plan, chunk, active, niter, p_max, p_min, x_dev=xd.ptr if dt == _ffi.P3D_C64 else None)
         else:
-            stats = plan.stats(chunk)
+            stats = plan.stats_dev(xd.ptr, dt, n)
             stats[~active] = 1.0  # keep NaNs of empty slices out of the (unused) schedule rows
             tau = _schedule_from_stats(stats, nil * nxl, thresh_model, niter, p_max, p_min, decay_kind)
         if sqrt_decay:
             tau = np.sqrt(tau)  # POCS.py:595
-        res, done, sums, _ = plan.run(chunk, maskf, tau, niter, thresh_op=thresh_op, version=version, eps=eps,
-                                      alpha=alpha, active=active)
+        done, sums, _ = plan.run_dev(xd.ptr, dt, md.ptr, tau, niter, od.ptr, n, thresh_op=thresh_op, version=version, eps=eps, alpha=alpha, active=active)
+        dst = out[lo:lo + n]
+        if dst.dtype == xc.dtype and dst.flags.c_contiguous:
+            od.download_into(dst)
+        else:
+            dst[...] = od.download(xc.shape, xc.dtype)
         runtime = time.perf_counter() - t0
-        out[lo:lo + n] = res
         if results is not None:
             results.extend(_result_rows(done, sums, runtime))
     return out

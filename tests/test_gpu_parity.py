@@ -710,6 +710,34 @@ def test_double_precision_cubes_are_converted_on_their_way_in(P, orc):
         P.pocs_cube(obs[:1], mask, precision="half", **params)
 
 
+@pytest.mark.parametrize("kind", ["FFT", "WAVELET", "FFT-data-driven", "FFT-double"])
+def test_result_arrays_of_the_caller(P, orc, kind):
+    """``out=``: a result array of the caller's -- contiguous (downloaded into directly), a strided view (the batch comes back through a temporary),
+    and the cube itself (in place: nothing may be written to it before it has been uploaded; the page-touching of fresh result arrays must stay away)."""
+    nil, nxl, n = 64, 96, 5
+    _, mask, obs = orc.synthetic_cube(nil, nxl, n, 0.5, real=(kind == "WAVELET"))
+    obs[2] = 0
+    kw = dict(niter=6, thresh_op="hard", eps=0.0, p_max=0.99, p_min=1e-2)
+    if kind == "WAVELET":
+        kw.update(transform_kind="WAVELET", wavelet="db2")
+    elif kind == "FFT-data-driven":
+        kw.update(thresh_model="data-driven", p_min=1e-3)
+    elif kind == "FFT-double":
+        obs = obs.astype(np.complex128)
+    want = P.pocs_cube(obs, mask, **kw)
+    assert want.dtype == obs.dtype and not want[2].any()
+    mine = np.full_like(obs, 7)
+    assert P.pocs_cube(obs, mask, out=mine, **kw) is mine and np.array_equal(mine, want)
+    wide = np.full((n, nil, 2 * nxl), 7, obs.dtype)
+    view = wide[:, :, ::2]
+    assert not view.flags.c_contiguous
+    assert P.pocs_cube(obs, mask, out=view, **kw) is view and np.array_equal(view, want) and (wide[:, :, 1::2] == 7).all()
+    inplace = obs.copy()
+    assert P.pocs_cube(inplace, mask, out=inplace, **kw) is inplace and np.array_equal(inplace, want)
+    with pytest.raises(ValueError):
+        P.pocs_cube(obs, mask, out=np.empty((n, nil, nxl + 1), obs.dtype), **kw)
+
+
 @pytest.mark.parametrize("shape,dtype,op", [((64, 1024), np.complex64, "hard"), ((64, 512), np.complex64, "soft"), ((48, 100), np.complex64, "hard"),
                                             ((61, 67), np.complex64, "hard"), ((64, 128), np.float32, "hard"), ((64, 256), np.complex64, "hard-percentile"),
                                             ((32, 2048), np.complex64, "hard")])
