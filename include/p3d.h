@@ -182,7 +182,7 @@ int p3d_multi_run(int ndev, const int* devices, int nil, int nxl, const void* x_
  * input, and under NumPy >= 2 for the soft / garrote operators, FPOCS and APOCS on complex64 / float32 input as well (threshold_operator.py:37-39,
  * 76-78; POCS.py:566-575, 616: tau, the momentum scalar and the weights 1 - alpha * mask are float64 / complex128).  A plan64 runs
  * fft2 -> threshold -> ifft2 -> re-insertion -> cost in double precision for any slice extents up to 5120: two fused kernels per iteration on tiles
- * of lines in LDS (extents beyond ~4600, whose tiles do not fit: six plain passes over the cube).  A precision path, bound by its double-precision
+ * of lines in LDS (extents beyond 5088, whose tiles do not fit: six plain passes over the cube).  A precision path, bound by its double-precision
  * butterflies: about a tenth of the float32 rate.  dtype of x and out: P3D_C128, P3D_F64, or P3D_C64 / P3D_F32 (converted on load / store: what the reference's final
  * cast to the input dtype does, cube_POCS_interpolation_3D.py:324); x, out, mask may be host or device pointers; mask is DOUBLE [nil][nxl];
  * tau [nslices][niter][2], stats, sums and the error behaviour as p3d_pocs_stats / p3d_pocs_run; thresh_op: hard, soft, garrote. */

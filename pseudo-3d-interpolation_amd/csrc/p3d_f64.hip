@@ -9,7 +9,7 @@
 // Two fused kernels per iteration like the float32 path (col64_kernel: forward transform, threshold, inverse transform of a tile of columns;
 // row64_kernel: inverse transform, re-insertion, cost sum, forward transform of a tile of rows), on LDS-resident mixed-radix Stockham transforms
 // with run-time factors -- a precision path, bound by its double-precision butterflies (rates in DESIGN.md section 5).  Any line length up to 5120;
-// lines whose tile does not fit LDS (beyond ~4600 points) take the first cut of this file, six plain passes over the cube per iteration built
+// lines whose tile does not fit LDS (beyond 5088 points) take the first cut of this file, six plain passes over the cube per iteration built
 // from the pieces of the any-length pipeline (p3d_generic.hip), which P3D_F64_UNFUSED=1 selects for every shape.
 //
 // Entry points (include/p3d.h): p3d_plan64_create / _destroy, p3d_pocs64_stats, p3d_pocs64_run.
