@@ -565,6 +565,26 @@ __global__ __launch_bounds__(COARSE_THREADS) void wcoarse_kernel(CoarseArgs a, F
     }
 }
 
+// mask [n1][n2] (float weights) -> one bit per sample, rows of `words` 32-bit words; *binary is cleared when a weight is neither 0 nor 1 (the bits are not
+// used then).  One thread per word.
+__global__ void wmask_pack_kernel(const float* mask, unsigned* bits, int n1, int n2, int words, int* binary)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1 * words) return;
+    const int r = i / words, w = i - r * words;
+    unsigned v = 0;
+    bool ok = true;
+    for (int b = 0; b < 32; ++b) {
+        const int c = w * 32 + b;
+        if (c >= n2) break;
+        const float m = mask[(size_t)r * n2 + c];
+        ok = ok && (m == 0.f || m == 1.f);
+        v |= (m != 0.f ? 1u : 0u) << b;
+    }
+    bits[i] = v;
+    if (!ok) *binary = 0;
+}
+
 // what the last synthesis step (level 1) does with its output instead of storing it: crop + re-insertion (POCS.py:609, 616-619)
 struct Update {
     int enabled;
@@ -572,6 +592,8 @@ struct Update {
     const void* x;      // observed slices (dtype)
     int dtype;
     const float* mask;
+    const unsigned* mask_bits;   // the same as one bit per sample, rows of mask_words words -- NULL unless every weight is 0 or 1 (wfuse1_kernel)
+    int mask_words;
     void* out;
     double* sums;       // [nslices] of this iteration
     int adaptive, write_out, zero_fill;
@@ -846,7 +868,9 @@ __host__ __device__ constexpr size_t wfuse1_lds_elems(int L) { return (size_t)4 
 #define P3D_WFUSE1_THREADS_COMPLEX 1024
 #endif
 template <typename T> constexpr int WFUSE1_NT = sizeof(T) == sizeof(float) ? P3D_WFUSE1_THREADS : P3D_WFUSE1_THREADS_COMPLEX;
-template <typename T, int TILE, int LT>
+// MBITS (LT != 0): the mask weights of the tile come as bits (Update::mask_bits: every weight is 0 or 1) -- 280 words per tile through LDS instead of ten
+// float loads per thread, a quarter of the tile's load instructions
+template <typename T, int TILE, int LT, bool MBITS>
 __global__ __launch_bounds__(WFUSE1_NT<T>) void wfuse1_kernel(const T* a, size_t a_ld, size_t a_slice, const T* det_in, size_t det_in_slice, T* det_out, size_t det_out_slice,
                                                      int Ho, int Wo, T* cA, size_t cA_slice, Filters f, int tiles_x, int ntiles, int ns, Update u, Thresh th)
 {
@@ -854,6 +878,8 @@ __global__ __launch_bounds__(WFUSE1_NT<T>) void wfuse1_kernel(const T* a, size_t
     constexpr int NT = WFUSE1_NT<T>;
     __shared__ double red[NT / 64];
     __shared__ float4 s_dec[MAXL / 2], s_rec[MAXL / 2];
+    constexpr int MBW = 4;   // words of a tile row: 2 TILE + L - 2 <= 126 columns from any bit offset
+    __shared__ unsigned s_mb[MBITS ? (2 * TILE + (LT ? LT : 2) - 2) * MBW : 1];
     constexpr int LX = TILE, LY = NT / TILE, R = TILE / LY;
     const int L = LT ? LT : f.len, HL = L / 2, IH = 2 * TILE + L - 2, IW = IH, KH = TILE + L - 2, KW = KH;
     T* s_a = reinterpret_cast<T*>(w_smem);           // synthesis: four coefficient arrays [KH][KW] ...
@@ -909,18 +935,38 @@ __global__ __launch_bounds__(WFUSE1_NT<T>) void wfuse1_kernel(const T* a, size_t
                 vd[i] = pd2[o];
             }
         }
+        // observed samples (m, 2 ii), (m, 2 ii + 1) of a thread: ONE load of the pair where rows have an even number of samples (n_lo is even: the pair
+        // is aligned then and never straddles the region's right edge) and the cube's samples have the kernel's own type; else sample by sample
+        const bool pairs = MBITS && (u.n2 & 1) == 0 && (u.dtype == 0) == (sizeof(T) == sizeof(c32)) && (reinterpret_cast<size_t>(xs) & (2 * sizeof(T) - 1)) == 0;
+        if (pairs) {
+            struct alignas(2 * sizeof(T)) XPair { T a, b; };
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + NT * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
-#pragma unroll
-            for (int ee = 0; ee < 2; ++ee) {
-                xo[it][ee] = zero_of<T>();
-                mk[it][ee] = 0.f;
-                const int gm = m_lo + m, gn = n_lo + 2 * ii + ee;
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + NT * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+                xo[it][0] = xo[it][1] = zero_of<T>();
+                mk[it][0] = mk[it][1] = 0.f;
+                const int gm = m_lo + m, gn = n_lo + 2 * ii;
                 if (e < IHc * (IHc / 2) && m < nm && gn <= n_hi) {
                     const unsigned li = (unsigned)gm * (unsigned)u.n2 + (unsigned)gn;
-                    xo[it][ee] = load_xs(xs, u.dtype, li, (T*)nullptr);
-                    mk[it][ee] = u.mask[li];
+                    const XPair v = *reinterpret_cast<const XPair*>(reinterpret_cast<const T*>(xs) + li);
+                    xo[it][0] = v.a;
+                    xo[it][1] = v.b;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + NT * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
+#pragma unroll
+                for (int ee = 0; ee < 2; ++ee) {
+                    xo[it][ee] = zero_of<T>();
+                    mk[it][ee] = 0.f;
+                    const int gm = m_lo + m, gn = n_lo + 2 * ii + ee;
+                    if (e < IHc * (IHc / 2) && m < nm && gn <= n_hi) {
+                        const unsigned li = (unsigned)gm * (unsigned)u.n2 + (unsigned)gn;
+                        xo[it][ee] = load_xs(xs, u.dtype, li, (T*)nullptr);
+                        if constexpr (!MBITS) mk[it][ee] = u.mask[li];
+                    }
                 }
             }
         }
@@ -928,6 +974,12 @@ __global__ __launch_bounds__(WFUSE1_NT<T>) void wfuse1_kernel(const T* a, size_t
         for (int i = 0; i < NE; ++i) {
             const int e = tid + NT * i, kr = e / KHc, kc = e - kr * KHc;
             if (e < KHc * KHc && kr < KHv && kc < KWv) { s_a[e] = va[i]; s_h[e] = vh_[i]; s_v[e] = vv[i]; s_d[e] = vd[i]; }
+        }
+        if constexpr (MBITS) {   // rows m_lo ... of the region, words (n_lo / 32) ... + 3 of each
+            for (int e = tid; e < nm * MBW; e += NT) {
+                const int row = e / MBW, wi = (n_lo >> 5) + (e - row * MBW);
+                s_mb[e] = wi < u.mask_words ? u.mask_bits[(unsigned)(m_lo + row) * (unsigned)u.mask_words + (unsigned)wi] : 0u;
+            }
         }
     } else {
         for (int e = tid; e < KH * KW; e += NT) {
@@ -1001,7 +1053,15 @@ __global__ __launch_bounds__(WFUSE1_NT<T>) void wfuse1_kernel(const T* a, size_t
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int e = tid + NT * it, m = e / (IHc / 2), ii = e - m * (IHc / 2);
-                if (e < IHc * (IHc / 2) && m < nm && 2 * ii < nn) sample(m, ii, xo[it], mk[it]);
+                if (e < IHc * (IHc / 2) && m < nm && 2 * ii < nn) {
+                    if constexpr (MBITS) {   // samples (m, 2 ii), (m, 2 ii + 1): n_lo is even, so both bits sit in one word
+                        const int rel = (n_lo & 31) + 2 * ii;
+                        const unsigned wv = s_mb[m * MBW + (rel >> 5)] >> (rel & 31);
+                        mk[it][0] = (float)(wv & 1u);
+                        mk[it][1] = (float)((wv >> 1) & 1u);
+                    }
+                    sample(m, ii, xo[it], mk[it]);
+                }
             }
         } else {
             for (int e = tid; e < IH * (IW / 2); e += NT) {
@@ -1258,6 +1318,8 @@ struct p3d_wplan {
     size_t sums_cap = 0, tau_cap = 0;
     int* done = nullptr;
     float *stats = nullptr, *mask = nullptr;
+    unsigned* mask_bits = nullptr;   // one bit per sample of the mask, rows of mask_words words, + one int behind them: 1 = every weight is 0 or 1
+    int mask_words = 0, mask_binary = 0;
     void *st_x = nullptr, *st_out = nullptr;
     // the observed cube and the result of the job in progress: the caller's own device buffers where it passed such (no staging
     // copies: 0.4 ms each way per 256 MiB), the staging buffers above otherwise
@@ -1315,7 +1377,7 @@ extern "C" int p3d_wavelet_plan_destroy(p3d_wplan* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->det1_alt, p->coef, p->feed, p->lo, p->hi, p->tau, p->sums, p->done, p->stats, p->mask, p->st_x, p->st_out};
+    void* bufs[] = {p->det1_alt, p->coef, p->feed, p->lo, p->hi, p->tau, p->sums, p->done, p->stats, p->mask, p->mask_bits, p->st_x, p->st_out};
     for (void* b : bufs) if (b) hipFree(b);
     for (c32* b : p->approx) if (b) hipFree(b);
     for (c32* b : p->rec) if (b) hipFree(b);
@@ -1385,6 +1447,8 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
     ALLOC(p->done, sizeof(int) * S);
     ALLOC(p->stats, sizeof(float) * 4 * 3 * (size_t)level * S);
     ALLOC(p->mask, sizeof(float) * p->per());
+    p->mask_words = (nxl + 31) / 32;
+    ALLOC(p->mask_bits, sizeof(unsigned) * ((size_t)nil * p->mask_words + 1));
     ALLOC(p->st_x, sizeof(c32) * p->per() * S);
     ALLOC(p->st_out, sizeof(c32) * p->per() * S);
     p->tile_c = pick_tile(flen, sizeof(c32));
@@ -1409,8 +1473,10 @@ extern "C" int p3d_wavelet_plan_create(p3d_wplan** out, int device, int nil, int
         p->l1fuse_r = geom && p->tile_r == 32 && wfuse1_lds_elems<32>(flen) * sizeof(float) <= 150 * 1024;
         if (p->l1fuse_c || p->l1fuse_r) {
             ALLOC(p->det1_alt, sizeof(c32) * 3 * (size_t)p->h[1] * p->w[1] * S);
-            const void* fk[] = {(const void*)wfuse1_kernel<c32, 32, 0>, (const void*)wfuse1_kernel<c32, 32, 4>, (const void*)wfuse1_kernel<c32, 32, 8>,
-                                (const void*)wfuse1_kernel<float, 32, 0>, (const void*)wfuse1_kernel<float, 32, 4>, (const void*)wfuse1_kernel<float, 32, 8>};
+            const void* fk[] = {(const void*)wfuse1_kernel<c32, 32, 0, false>, (const void*)wfuse1_kernel<c32, 32, 4, false>, (const void*)wfuse1_kernel<c32, 32, 8, false>,
+                                (const void*)wfuse1_kernel<float, 32, 0, false>, (const void*)wfuse1_kernel<float, 32, 4, false>, (const void*)wfuse1_kernel<float, 32, 8, false>,
+                                (const void*)wfuse1_kernel<c32, 32, 4, true>, (const void*)wfuse1_kernel<c32, 32, 8, true>,
+                                (const void*)wfuse1_kernel<float, 32, 4, true>, (const void*)wfuse1_kernel<float, 32, 8, true>};
             for (const void* k : fk)
                 if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) != hipSuccess) return bail("hipFuncSetAttribute", e);
         }
@@ -1677,6 +1743,7 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
         if (p->fused) {
             Update u{};
             u.enabled = 1; u.feed = p->feed; u.x = p->cur_x; u.dtype = dtype; u.mask = p->mask; u.out = p->cur_out;
+            u.mask_bits = p->mask_binary ? p->mask_bits : nullptr; u.mask_words = p->mask_words;
             u.sums = p->sums + (size_t)(k + 1) * nslices;
             // (early exit: the iterate of a slice that converges is rebuilt once, after the loop, from the coefficients it stopped at -- storing every
             // iterate of every slice instead cost 7 % of a configs[3] job)
@@ -1696,10 +1763,13 @@ static int w_loop(p3d_wplan* p, int dtype, int nslices, const p3d_pocs_params* p
                     // (both detail buffers are addressed with ONE slice stride inside the kernel: hand the larger-stride buffer its own launch form)
                     const T* din = det1[k & 1];
                     T* dout = det1[(k + 1) & 1];
-#define P3D_W_FUSE1(LT) wfuse1_kernel<T, 32, LT><<<tx * ty * ns8, WFUSE1_NT<T>, lds, p->stream>>>(as<T>(p->rec[1]), (size_t)p->rw[1], (size_t)p->rh[1] * p->rw[1], din, det1_slice[k & 1], \
+#define P3D_W_FUSE1(LT, MB) wfuse1_kernel<T, 32, LT, MB><<<tx * ty * ns8, WFUSE1_NT<T>, lds, p->stream>>>(as<T>(p->rec[1]), (size_t)p->rw[1], (size_t)p->rh[1] * p->rw[1], din, det1_slice[k & 1], \
                                                                                        dout, det1_slice[(k + 1) & 1], Ho, Wo, as<T>(p->approx[1]), cnt1, p->f, tx, tx * ty, nslices, u, tn)
                     const int lt = p->f.len == 8 || p->f.len == 4 ? p->f.len : 0;
-                    if (lt == 8) P3D_W_FUSE1(8); else if (lt == 4) P3D_W_FUSE1(4); else P3D_W_FUSE1(0);
+                    const bool mb = u.mask_bits != nullptr;
+                    if (lt == 8) { if (mb) P3D_W_FUSE1(8, true); else P3D_W_FUSE1(8, false); }
+                    else if (lt == 4) { if (mb) P3D_W_FUSE1(4, true); else P3D_W_FUSE1(4, false); }
+                    else P3D_W_FUSE1(0, false);
 #undef P3D_W_FUSE1
                 }
             }
@@ -1837,6 +1907,15 @@ int p3d_wavelet_run(p3d_wplan* p, const void* x, int dtype, const float* mask, c
     // the mask may be a device pointer: a device-to-device hipMemcpy runs on the null stream, need not have finished when it returns, and the plan's
     // (non-blocking) stream does not wait for it -- every copy of this entry point goes onto the plan's stream
     W_TRY(hipMemcpyAsync(p->mask, mask, sizeof(float) * p->per(), hipMemcpyDefault, p->stream));
+    p->mask_binary = 0;
+    if ((p->l1fuse_c || p->l1fuse_r) && !getenv("P3D_WAVELET_NO_MASK_BITS")) {   // wfuse1_kernel reads a 0 / 1 mask as bits
+        int* flag = reinterpret_cast<int*>(p->mask_bits + (size_t)p->nil * p->mask_words);
+        const int one = 1, nw = p->nil * p->mask_words;
+        W_TRY(hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, p->stream));
+        wmask_pack_kernel<<<(nw + 255) / 256, 256, 0, p->stream>>>(p->mask, p->mask_bits, p->nil, p->nxl, p->mask_words, flag);
+        W_TRY(hipMemcpyAsync(&p->mask_binary, flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        W_TRY(hipStreamSynchronize(p->stream));
+    }
     W_TRY(hipMemcpyAsync(p->tau, tau_f.data(), sizeof(c32) * ntau, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     W_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));

@@ -429,3 +429,32 @@ def test_early_exit_rebuilds_a_finished_slice_from_its_coefficients(wo, monkeypa
             monkeypatch.delenv(sw)
         assert np.array_equal(got, other), switches
     P.release_plans()
+
+
+@pytest.mark.parametrize("shape,wavelet,real", [((200, 333), "db4", True), ((130, 97), "db2", False), ((96, 160), "coif2", True)])
+def test_mask_weights_as_bits_in_the_fused_level_one_kernel(wo, monkeypatch, shape, wavelet, real):
+    """wfuse1_kernel takes a 0 / 1 mask as one bit per sample (a tile's rows of mask words through LDS instead of ten float loads per thread); a mask
+    with any other weight -- the reference accepts every numeric mask with maximum <= 1, POCS.py:488, weights 1 - alpha * mask -- keeps the float
+    loads.  Bits and floats give the same bits of the result (odd widths: the last word of a row is partial; db2 / db4: the length-specialised
+    kernels, coif2: the general one, which has no bit form); a fractional mask agrees with the oracle."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    mask = po.synthetic_mask(*shape, 0.5)
+    cube = np.stack([po.synthetic_slice(*shape, 40 + s, real=real) for s in range(3)]) * mask
+    cube = cube.astype(np.float32 if real else np.complex64)
+    kw = dict(thresh_op="soft", thresh_model="exponential", niter=6, p_max=0.99, p_min=0.05, eps=0.0, alpha=0.9, version="adaptive")
+    got = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet=wavelet, **kw)
+    P.release_plans()
+    monkeypatch.setenv("P3D_WAVELET_NO_MASK_BITS", "1")
+    floats = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet=wavelet, **kw)
+    monkeypatch.delenv("P3D_WAVELET_NO_MASK_BITS")
+    P.release_plans()
+    assert np.array_equal(got, floats)
+    want = wo.pocs_cube_wavelet(cube.astype(np.float64 if real else np.complex128), mask, wavelet=wavelet, **kw)
+    assert max(rel_l2(got[s], want[s]) for s in range(3)) <= 2e-5
+    soft = mask.astype(np.float64)
+    soft[::3, 1::4] *= 0.5            # weights 0, 0.5 and 1
+    got_f = P.pocs_cube(cube, soft, transform_kind="WAVELET", wavelet=wavelet, **kw)
+    want_f = wo.pocs_cube_wavelet(cube.astype(np.float64 if real else np.complex128), soft, wavelet=wavelet, **kw)
+    assert max(rel_l2(got_f[s], want_f[s]) for s in range(3)) <= 2e-5
+    assert not np.array_equal(got_f, got)
