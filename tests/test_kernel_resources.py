@@ -75,8 +75,8 @@ def test_no_new_kernel_spills_registers():
 # kernels whose speed rests on a number of workgroups per CU that their LDS image allows and their registers must not take away again:
 # (pattern of the demangled name, threads per workgroup, workgroups per CU) -> at most 512 / (wavefronts per SIMD) registers, in steps of 8
 OCCUPANCY = [
-    (r"wfuse1_kernel<float, 32, (4|8)>", 512, 3),            # three 44-KiB tiles per CU: 24 wavefronts (profiles/r04_wavelet_workgroup_size.txt)
-    (r"wfuse1_kernel<p3d::c32, 32, (4|8)>", 1024, 1),
+    (r"wfuse1_kernel<float, 32, (4|8), (true|false)>", 512, 3),            # three 44-KiB tiles per CU: 24 wavefronts (profiles/r04_wavelet_workgroup_size.txt)
+    (r"wfuse1_kernel<p3d::c32, 32, (4|8), (true|false)>", 1024, 1),
     (r"dwt2_tile_kernel<float, 32, (4|8)>", 512, 4),
     (r"idwt2_tile_kernel<float, 32, (4|8)>", 512, 4),
     (r"row_pipe32_kernel<.*>", 512, 1),
