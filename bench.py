@@ -35,10 +35,12 @@ steady-state rate and a `roofline` object whose launch_ms and algorithmic_bytes_
 only when that file was measured on the kernel sources of this tree (`kernel_source_hash`); otherwise it is null and the stale
 measurement is named under `traffic_last_measured`.
 
-Inputs are generated without any torch random-number kernel (NumPy noise pool + plane waves / index writes + the library's
-own inverse FFT) and with ~1 500 torch dispatches per cube, so that `rocprofv3 --pmc ... -- python3 bench.py` completes: counter
-collection on this image does not survive some ten thousand dispatches of one process, whichever kernels they are
-(profiles/r02_pmc_on_bench.txt; the counter budget per pass is a separate matter, profiles/r03_pmc_counter_budget.txt).
+At N = 1 the process is torch-free: device memory comes from the library's own p3d_dev_* entry points, inputs are generated on the
+host with NumPy (plane waves as a rank-6 outer product per slice + pooled noise) and uploaded before the clock starts, and the library
+runs on the HIP runtime it was built against (`hip_runtime` in the line).  At N > 1 torch is imported FIRST (it must initialise its own
+copy of the HIP runtime before ours does, _ffi._preload_torch_hip) for torch.distributed over RCCL; the result blocks are torch tensors
+there so that the gather collective can take them.  No torch kernel runs in either case, so `rocprofv3 --pmc ... -- python3 bench.py`
+sees the library's dispatches only.
 """
 import argparse
 import glob
@@ -139,79 +141,105 @@ def measured_traffic(config, workload_key, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# synthetic inputs (no torch RNG)
+# synthetic inputs, generated on the host (NumPy) and uploaded; device memory without torch at N = 1
 # ---------------------------------------------------------------------------------------------------------------------------------
 NOISE_POOL = 16
+_GEN_THREADS = max(1, min(16, os.cpu_count() or 1))
+_gen_pool = None
 
 
-def noise_pool(torch, nil, nxl, device):
-    """NOISE_POOL complex Gaussian slices from NumPy, uploaded once; slice s uses pool[s % P] rolled by a slice-dependent shift."""
+def _threads():
+    global _gen_pool
+    if _gen_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _gen_pool = ThreadPoolExecutor(_GEN_THREADS)
+    return _gen_pool
+
+
+def noise_pool(nil, nxl):
+    """NOISE_POOL complex Gaussian slices; slice s uses pool[s % P] rolled by a slice-dependent shift."""
     rng = np.random.default_rng(20240917)
-    host = (rng.standard_normal((NOISE_POOL, nil, nxl), dtype=np.float32)
+    return (rng.standard_normal((NOISE_POOL, nil, nxl), dtype=np.float32)
             + 1j * rng.standard_normal((NOISE_POOL, nil, nxl), dtype=np.float32)).astype(np.complex64)
-    return torch.from_numpy(host).to(device)
 
 
-def _add_noise(torch, out, first, pool):
-    """out[i] += 0.01 * pool[s % P] rolled by a shift that depends on s // P (s = first + i), one roll per group of P slices."""
-    n = out.shape[0]
-    i = 0
-    while i < n:
+def _finish_slice(x, s, pool, mask):
+    """x += 0.01 * pool[s % P] rolled by a shift that depends on s // P; x *= mask (trace decimation)."""
+    r, j = s // NOISE_POOL, s % NOISE_POOL
+    x += np.float32(0.01) * np.roll(pool[j], shift=(3 * r + 1, 5 * r + 2), axis=(0, 1))
+    x *= mask
+    return x
+
+
+def plane_wave_slices(nil, nxl, first, count, pool, mask):
+    """The recipe of oracle.synthetic_slice: 6 complex plane waves + 1 % Gaussian noise per slice, times the trace mask.  A plane
+    wave is an outer product exp(2 pi i k1 il / nil) x exp(2 pi i k2 xl / nxl): one (nil x 6) @ (6 x nxl) product per slice."""
+    out = np.empty((count, nil, nxl), np.complex64)
+    il = np.arange(nil, dtype=np.float64) / nil
+    xl = np.arange(nxl, dtype=np.float64) / nxl
+    maskc = mask.astype(np.float32)
+
+    def one(i):
         s = first + i
-        r, j0 = s // NOISE_POOL, s % NOISE_POOL
-        cnt = min(NOISE_POOL - j0, n - i)
-        out[i:i + cnt] += 0.01 * torch.roll(pool[j0:j0 + cnt], shifts=(3 * r + 1, 5 * r + 2), dims=(1, 2))
-        i += cnt
+        rng = np.random.default_rng(1234 + s)
+        k1 = np.empty(6); k2 = np.empty(6); amp = np.empty(6, np.complex128)
+        for e in range(6):   # the draw order of oracle.synthetic_slice
+            k1[e] = int(rng.integers(-(nil // 8), max(nil // 8, 1)))
+            k2[e] = int(rng.integers(-(nxl // 8), max(nxl // 8, 1)))
+            amp[e] = complex(rng.standard_normal(), rng.standard_normal())
+        u = (np.exp(2j * np.pi * np.outer(il, k1)) * amp).astype(np.complex64)
+        v = np.exp(2j * np.pi * np.outer(k2, xl)).astype(np.complex64)
+        np.matmul(u, v, out=out[i])
+        _finish_slice(out[i], s, pool, maskc)
+    list(_threads().map(one, range(count)))
+    return out
 
 
-def fill_plane_waves(torch, out, nil, nxl, first, pool, batch=16):
-    """The recipe of oracle.synthetic_slice: 6 complex plane waves + 1 % Gaussian noise per slice, generated on the GPU
-    `batch` slices per kernel launch (a few hundred launches for the whole cube: rocprofv3's counter collection aborts inside
-    whichever torch kernel happens to be the N-thousandth dispatch of a process -- profiles/r02_pmc_on_bench.txt)."""
-    device = out.device
-    il = (torch.arange(nil, device=device, dtype=torch.float32) / nil)[None, :, None]
-    xl = (torch.arange(nxl, device=device, dtype=torch.float32) / nxl)[None, None, :]
-    n = out.shape[0]
-    for b0 in range(0, n, batch):
-        b1 = min(n, b0 + batch)
-        k1 = np.empty((b1 - b0, 6), np.float32); k2 = np.empty_like(k1); amp = np.empty((b1 - b0, 6), np.complex64)
-        for i in range(b0, b1):
-            rng = np.random.default_rng(1234 + first + i)
-            for e in range(6):   # the draw order of oracle.synthetic_slice
-                k1[i - b0, e] = int(rng.integers(-(nil // 8), max(nil // 8, 1)))
-                k2[i - b0, e] = int(rng.integers(-(nxl // 8), max(nxl // 8, 1)))
-                amp[i - b0, e] = complex(rng.standard_normal(), rng.standard_normal())
-        k1t, k2t, ampt = (torch.from_numpy(a).to(device) for a in (k1, k2, amp))
-        acc = out[b0:b1]
-        acc.zero_()
-        for e in range(6):
-            ph = (2.0 * np.pi) * (k1t[:, e, None, None] * il + k2t[:, e, None, None] * xl)
-            acc += ampt[:, e, None, None] * torch.polar(torch.ones_like(ph), ph)
-            del ph
-    _add_noise(torch, out, first, pool)
-
-
-def fill_random_spectrum(torch, out, nil, nxl, first, pool, m, plan):
-    """M random spectral coefficients per slice (positions uniform over the spectrum, complex normal amplitudes, seeded per
-    slice), brought to the space domain by the library's own inverse FFT, + 1 % noise."""
-    device = out.device
-    n = out.shape[0]
-    out.zero_()
-    flat = out.view(n, -1)
-    chunk = 64
+def random_spectrum_slices(dev, plan, nil, nxl, first, pool, mask, m, chunk=32):
+    """M random spectral coefficients per slice (positions uniform over the spectrum, complex normal amplitudes, seeded per slice), brought to the
+    space domain by the library's own inverse FFT, + 1 % noise, times the mask -- chunk by chunk through the device array `dev` (complex64)."""
+    n = dev.shape[0]
+    maskc = mask.astype(np.float32)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        rows, cols, vals = [], [], []
+        spec = np.zeros((hi - lo, nil * nxl), np.complex64)
         for i in range(lo, hi):
             rng = np.random.default_rng(4321 + first + i)
             pos = rng.choice(nil * nxl, size=m, replace=False)
-            amp = (rng.standard_normal(m) + 1j * rng.standard_normal(m)) * (nil * nxl / math.sqrt(m))
-            rows.append(np.full(m, i, np.int64)); cols.append(pos.astype(np.int64)); vals.append(amp.astype(np.complex64))
-        flat[torch.from_numpy(np.concatenate(rows)).to(device), torch.from_numpy(np.concatenate(cols)).to(device)] = \
-            torch.from_numpy(np.concatenate(vals)).to(device)
-    torch.cuda.synchronize()
-    plan.fft2_dev(out.data_ptr(), out.data_ptr(), n, inverse=True)
-    _add_noise(torch, out, first, pool)
+            spec[i - lo, pos] = ((rng.standard_normal(m) + 1j * rng.standard_normal(m)) * (nil * nxl / math.sqrt(m))).astype(np.complex64)
+        dev.upload(spec.reshape(hi - lo, nil, nxl), first=lo)
+        per = nil * nxl * 8
+        plan.fft2_dev(dev.ptr + lo * per, dev.ptr + lo * per, hi - lo, inverse=True)
+        x = dev.download(lo, hi - lo)
+        list(_threads().map(lambda i: _finish_slice(x[i - lo], first + i, pool, maskc), range(lo, hi)))
+        dev.upload(x, first=lo)
+
+
+class TorchArray:
+    """The interface of _ffi.DeviceArray over a torch tensor (N > 1: the gather collective takes the tensor)."""
+
+    def __init__(self, torch, shape, dtype, device):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.tensor = torch.empty(self.shape, dtype=getattr(torch, self.dtype.name), device=device)
+        self.ptr, self.nbytes, self._torch = self.tensor.data_ptr(), self.tensor.numel() * self.tensor.element_size(), torch
+
+    def upload(self, host, first=0):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        self.tensor[first:first + host.shape[0]].copy_(self._torch.from_numpy(host))
+        return self
+
+    def download(self, first=0, count=None, out=None):
+        count = self.shape[0] - first if count is None else count
+        res = self.tensor[first:first + count].cpu().numpy()
+        if out is not None:
+            out[...] = res
+            return out
+        return res
+
+    def free(self):
+        self.tensor = None
+        self.ptr = None
+        self._torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -304,14 +332,14 @@ def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None,
     }
 
 
-def cpu_baseline_shearlet(x, mask, psi, op, nslices_cube):
+def cpu_baseline_shearlet(x, mask, psi, op, nslices_cube, niter=2):
+    """(cpu_baseline record, the oracle's result on this slice after `niter` iterations)."""
     from oracle import shearlet_oracle as so
     cores = min(os.cpu_count() or 1, 16)   # the GPU box's CPU share for one GPU
-    niter = 2
     so.pocs_slice_shearlet_real(x[:64, :32].astype(np.float64), mask[:64, :32], np.ones((64, 32, 1)), niter=2, thresh_op=op, p_min=1e-3)  # imports, threads
     t0 = time.perf_counter()
-    so.pocs_slice_shearlet_real(x.astype(np.float64), mask, psi, niter=niter, thresh_op=op, thresh_model="exponential", p_max=0.99, p_min=1e-3,
-                                workers=cores)
+    res = so.pocs_slice_shearlet_real(x.astype(np.float64), mask, psi, niter=niter, thresh_op=op, thresh_model="exponential", p_max=0.99, p_min=1e-3,
+                                      workers=cores)
     wall = time.perf_counter() - t0
     sips = (niter + 1) / wall   # the schedule's transform + `niter` iterations: niter + 1 forward transforms, niter inverse ones ~ niter + 1/2 iterations
     return {
@@ -319,11 +347,11 @@ def cpu_baseline_shearlet(x, mask, psi, op, nslices_cube):
         "sample": f"1 slice x {niter} iterations (+ the schedule's transform) of the same cube, scipy.fft real transforms on {cores} threads, "
                   f"scaled by 1/{nslices_cube} slices",
         "slice_iterations_per_s": sips,
-    }
+    }, res
 
 
 class Ctx:
-    """What every leg shares: torch, the process group, this rank's device."""
+    """What every leg shares: this rank's device, device memory, fences -- and, for N > 1 only, torch and the process group."""
 
     def __init__(self, args):
         self.args = args
@@ -334,26 +362,40 @@ class Ctx:
             if self.world == 1 and args.gpus > 1:
                 raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
             raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {args.gpus}")
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        # P3D_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the multi-rank code path where no second GPU exists
-        # (the numbers mean nothing then).  The real thing: one rank per GPU over RCCL.
-        self.rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
-        self.dev_index = local_rank % max(torch.cuda.device_count(), 1) if self.rehearsal else local_rank
-        torch.cuda.set_device(self.dev_index)
-        self.device = torch.device("cuda", self.dev_index)
+        self.torch = self.dist = None
+        self.rehearsal = False
+        self.dev_index = local_rank
         if self.world > 1:
+            import torch   # BEFORE the library is loaded: torch's copy of the HIP runtime has to initialise first (_ffi._preload_torch_hip)
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            # P3D_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo -- exercises the multi-rank code path where no second GPU exists
+            # (the numbers mean nothing then).  The real thing: one rank per GPU over RCCL.
+            self.rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
+            self.dev_index = local_rank % max(torch.cuda.device_count(), 1) if self.rehearsal else local_rank
+            torch.cuda.set_device(self.dev_index)
+            self.device = torch.device("cuda", self.dev_index)
             if self.rehearsal:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.device)
+        from pseudo_3d_interpolation_amd import _ffi
+        self.ffi = _ffi
+
+    def empty(self, shape, dtype):
+        """Uninitialised device memory: the library's own allocation at N = 1, a torch tensor at N > 1."""
+        if self.torch is None:
+            return self.ffi.DeviceArray(shape, dtype, device=self.dev_index)
+        return TorchArray(self.torch, shape, dtype, self.device)
+
+    def sync(self):
+        self.ffi.device_synchronize(self.dev_index)
 
     def fence(self):
-        self.torch.cuda.synchronize()
+        self.sync()
         if self.world > 1:
             self.dist.barrier()
-            self.torch.cuda.synchronize()
+            self.sync()
 
     def max_over_ranks(self, sec):
         if self.world > 1:
@@ -366,8 +408,8 @@ class Ctx:
 def run_leg(ctx, config, K_override, main):
     """One BASELINE configuration: generate its cube in HBM (this rank's block), time R jobs of K iterations, profile, side runs.
     Returns the record of the leg (rank 0: complete; other ranks: the fields they computed)."""
-    args, torch, dist, rank, world = ctx.args, ctx.torch, ctx.dist, ctx.rank, ctx.world
-    from pseudo_3d_interpolation_amd import _ffi
+    args, rank, world = ctx.args, ctx.rank, ctx.world
+    _ffi = ctx.ffi
     from pseudo_3d_interpolation_amd.functions import POCS as P
     from pseudo_3d_interpolation_amd.sharding import slice_block
 
@@ -379,7 +421,7 @@ def run_leg(ctx, config, K_override, main):
     kind, nil, nxl, missing, op = cfg["kind"], cfg["nil"], cfg["nxl"], cfg["missing"], cfg["op"]
     K = K_override if K_override is not None else cfg["steps"]
     W = args.warmup
-    device, dev_index = ctx.device, ctx.dev_index
+    dev_index = ctx.dev_index
     p_min = args.p_min if args.p_min == "adaptive" else float(args.p_min)
     density = args.density if (main and kind == "FFT") else 0
 
@@ -402,33 +444,34 @@ def run_leg(ctx, config, K_override, main):
 
     # ---- inputs, resident in HBM before the clock starts -----------------------------------------
     mask = (np.random.default_rng(42).random((nil, nxl)) >= missing).astype(np.uint8)   # shared trace mask
-    mask_t = torch.from_numpy(mask.astype(np.float32)).to(device)
-    pool = noise_pool(torch, nil, nxl, device)
+    mask_t = ctx.empty((nil, nxl), np.float32).upload(mask.astype(np.float32))
+    pool = noise_pool(nil, nxl)
     fft_plan = _ffi.Plan(nil, nxl, n_local, device=dev_index) if kind == "FFT" else None
-    xc = torch.empty((n_local, nil, nxl), dtype=torch.complex64, device=device)
-
-    def generate(dens):
-        if dens > 0:
-            fill_random_spectrum(torch, xc, nil, nxl, lo, pool, dens, fft_plan)
-        else:
-            fill_plane_waves(torch, xc, nil, nxl, lo, pool)
-        xc.mul_(mask_t)
-
-    generate(density)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and density == 0 and (main or kind != "SHEARLET")
+    np_dtype = np.float32 if cfg["real"] else np.complex64
+    x_obs = ctx.empty((n_local, nil, nxl), np_dtype)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and density == 0
     cpu_slices = None
+    n_cpu = 0
     if want_cpu:   # the CPU baseline is a single-GPU-run extra (rank 0, N = 1)
         from oracle import pocs_oracle as orc  # the cpu_baseline leg (and the slices it is fed) -- nothing else touches the oracle
         n_cpu = max(1, min(os.cpu_count() or 1, 16, n_local)) if kind != "SHEARLET" else 1
         cpu_slices = np.stack([orc.synthetic_slice(nil, nxl, lo + s, real=cfg["real"]) for s in range(n_cpu)]) * mask
-        xc[:n_cpu] = torch.from_numpy(cpu_slices.astype(np.complex64)).to(device)   # the CPU sample sees exactly the slices the GPU processes
-    if cfg["real"]:
-        x_obs = xc.real.contiguous()
-        del xc
-    else:
-        x_obs = xc
-    out = torch.empty_like(x_obs)
-    torch.cuda.synchronize()
+
+    def generate(dens):
+        """This rank's observed block into x_obs, chunk by chunk from the host; returns nothing (the host copy is not kept)."""
+        if dens > 0:
+            random_spectrum_slices(x_obs, fft_plan, nil, nxl, lo, pool, mask, dens)
+        else:
+            chunk = max(1, (256 << 20) // (nil * nxl * 8))
+            for c0 in range(0, n_local, chunk):
+                xs = plane_wave_slices(nil, nxl, lo + c0, min(chunk, n_local - c0), pool, mask)
+                x_obs.upload(xs.real if cfg["real"] else xs, first=c0)
+        if n_cpu:   # the CPU sample sees exactly the slices the GPU processes
+            x_obs.upload(cpu_slices.astype(np_dtype), first=0)
+
+    generate(density)
+    out = ctx.empty((n_local, nil, nxl), np_dtype)
+    ctx.sync()
     DT = _ffi.P3D_F32 if cfg["real"] else _ffi.P3D_C64
     esz = 4 if cfg["real"] else 8
 
@@ -440,19 +483,19 @@ def run_leg(ctx, config, K_override, main):
 
         def job(niter, profile=False):
             # statistics of fft2(x_obs) with the mask at hand: the pass doubles as the first pass of the job (p3d_pocs_prime_dev)
-            stats = plan.prime_dev(x_obs.data_ptr(), DT, mask_t.data_ptr(), n_local)
+            stats = plan.prime_dev(x_obs.ptr, DT, mask_t.ptr, n_local)
             active = stats[:, 2] > 0
             stats[~active] = 1.0
             tau = P._schedule_from_stats(stats, nil * nxl, "exponential", niter, 0.99, p_min, "values")
-            return plan.run_dev(x_obs.data_ptr(), DT, mask_t.data_ptr(), tau, niter, out.data_ptr(), n_local,
+            return plan.run_dev(x_obs.ptr, DT, mask_t.ptr, tau, niter, out.ptr, n_local,
                                 thresh_op=op, eps=args.eps, alpha=args.alpha, active=active, profile=profile, want_sums=False, primed=True)
     elif kind == "WAVELET":
         plan = _ffi.WaveletPlan(nil, nxl, n_local, wavelet=cfg["wavelet"], device=dev_index)
 
         def job(niter, profile=False):
-            stats = plan.stats_dev(x_obs.data_ptr(), DT, n_local)
+            stats = plan.stats_dev(x_obs.ptr, DT, n_local)
             tau = P._wavelet_schedule_from_stats(stats, "exponential", niter, 0.99, p_min, "values")
-            return plan.run_dev(x_obs.data_ptr(), DT, mask_t.data_ptr(), tau, niter, out.data_ptr(), n_local, thresh_op=op, eps=args.eps,
+            return plan.run_dev(x_obs.ptr, DT, mask_t.ptr, tau, niter, out.ptr, n_local, thresh_op=op, eps=args.eps,
                                 alpha=args.alpha)
     else:
         from pseudo_3d_interpolation_amd.functions import shearlets
@@ -467,10 +510,10 @@ def run_leg(ctx, config, K_override, main):
             done_all, ms_all = [], 0.0
             for b0 in range(0, n_local, batch):
                 nb = min(batch, n_local - b0)
-                xp, op_ = x_obs.data_ptr() + b0 * per, out.data_ptr() + b0 * per
+                xp, op_ = x_obs.ptr + b0 * per, out.ptr + b0 * per
                 stats = plan.stats_dev(xp, DT, nb)
                 tau = P._shearlet_schedule_from_stats(stats, (nil, nxl), "exponential", niter, 0.99, p_min, "values")
-                done, _, ms = plan.run_dev(xp, DT, mask_t.data_ptr(), tau, niter, op_, nb, thresh_op=op, eps=args.eps, alpha=args.alpha)
+                done, _, ms = plan.run_dev(xp, DT, mask_t.ptr, tau, niter, op_, nb, thresh_op=op, eps=args.eps, alpha=args.alpha)
                 done_all.append(done)
                 ms_all += ms
             return np.concatenate(done_all), None, ms_all
@@ -498,7 +541,7 @@ def run_leg(ctx, config, K_override, main):
         dev_times.append(dms)
     seconds = float(np.median(times))
     # the timed job's result on the slices the CPU leg also computes (parity figure of the line; nothing below may overwrite it)
-    gpu_first = out[:len(cpu_slices)].cpu().numpy() if (cpu_slices is not None and kind != "SHEARLET" and args.eps == 0) else None
+    gpu_first = out.download(0, n_cpu) if (cpu_slices is not None and kind != "SHEARLET" and args.eps == 0) else None
 
     nz_fraction = plan.last_sparsity() if kind == "FFT" else -1.0
 
@@ -511,10 +554,10 @@ def run_leg(ctx, config, K_override, main):
             job(min(W, 3) or 1)
             bt = []
             for _ in range(5):
-                torch.cuda.synchronize()
+                ctx.sync()
                 b0 = time.perf_counter()
                 job(K)
-                torch.cuda.synchronize()
+                ctx.sync()
                 bt.append(time.perf_counter() - b0)
         finally:
             n_local = nl_full
@@ -608,44 +651,47 @@ def run_leg(ctx, config, K_override, main):
     if side and nz_fraction >= 0:
         os.environ["P3D_NO_SPARSE"] = "1"
         job(min(W, 3) or 1)
-        torch.cuda.synchronize()
+        ctx.sync()
         d0 = time.perf_counter()
         job(K)
-        torch.cuda.synchronize()
+        ctx.sync()
         dense_its = K / (time.perf_counter() - d0)   # the ranks run in parallel: rank 0's time for its block is the job's
         del os.environ["P3D_NO_SPARSE"]
 
     # ---- the real-valued (float32, time-domain) cube of the same shape, reported beside `value` (rank 0, N = 1 only) ----
     real_its = None
     if side and world == 1 and op == "hard" and config == 2:
-        xr = x_obs.real.contiguous()
-        outr = torch.empty_like(xr)
-        torch.cuda.synchronize()
+        xr = ctx.empty((n_local, nil, nxl), np.float32)
+        for c0 in range(0, n_local, 64):
+            xr.upload(x_obs.download(c0, min(64, n_local - c0)).real, first=c0)
+        outr = ctx.empty((n_local, nil, nxl), np.float32)
+        ctx.sync()
 
         def job_real(niter):
-            st = plan.prime_dev(xr.data_ptr(), _ffi.P3D_F32, mask_t.data_ptr(), n_local)   # (row pairs: the statistics pass is the job's first pass)
+            st = plan.prime_dev(xr.ptr, _ffi.P3D_F32, mask_t.ptr, n_local)   # (row pairs: the statistics pass is the job's first pass)
             act = st[:, 2] > 0
             st[~act] = 1.0
             tau_r = P._schedule_from_stats(st, nil * nxl, "exponential", niter, 0.99, p_min, "values")
-            return plan.run_dev(xr.data_ptr(), _ffi.P3D_F32, mask_t.data_ptr(), tau_r, niter, outr.data_ptr(), n_local,
+            return plan.run_dev(xr.ptr, _ffi.P3D_F32, mask_t.ptr, tau_r, niter, outr.ptr, n_local,
                                 thresh_op=op, eps=args.eps, alpha=args.alpha, active=act, want_sums=False, primed=True)
         job_real(min(W, 3) or 1)
-        torch.cuda.synchronize()
+        ctx.sync()
         rt = []
         for _ in range(3):
             r0 = time.perf_counter()
             job_real(K)
-            torch.cuda.synchronize()
+            ctx.sync()
             rt.append(time.perf_counter() - r0)
         real_its = K / float(np.median(rt))
-        del xr, outr
+        xr.free()
+        outr.free()
 
     # ---- the same loop in the reference's double precision (p3d_f64.hip), a sample of the cube (rank 0, N = 1, config 2 only) ----
     ref_prec = None
     if side and world == 1 and config == 2 and not cfg["real"]:
         n64 = min(32, n_local)
         plan64 = _ffi.Plan64(nil, nxl, n64, device=dev_index)
-        host64 = x_obs[:n64].cpu().numpy()
+        host64 = x_obs.download(0, n64)
         st64 = plan64.stats(host64)
         st64[st64[:, 2] == 0] = 1.0
         tau64 = P._schedule_from_stats(st64, nil * nxl, "exponential", K, 0.99, p_min, "values")
@@ -668,7 +714,7 @@ def run_leg(ctx, config, K_override, main):
     # ---- end to end: host NumPy cube in -> host NumPy cube out through the host-buffer entry point (every rank its block) ----
     e2e = None
     if not args.only_main and not args.no_end_to_end and kind != "SHEARLET" and density == 0:
-        host = x_obs.cpu().numpy()
+        host = x_obs.download()
         kw = dict(transform_kind=kind, thresh_op=op, thresh_model="exponential", eps=args.eps, alpha=args.alpha, p_max=0.99, p_min=p_min,
                   device=dev_index, wavelet=cfg.get("wavelet"))
         # plans, device buffers and streams of ALL chunk workers (four chunks of the size the timed call will use), not the cube's page-locking
@@ -703,7 +749,7 @@ def run_leg(ctx, config, K_override, main):
                       "summed_over_chunks_ms": {k: 1e3 * v for k, v in tot.items()},
                       "note": "h2d / d2h: copies on the worker's own stream between the caller's page-locked-in-place arrays and the device; prime: statistics pass = first pass; "
                               "loop: the K iterations; the workers run side by side, so the wall share of a phase is its sum / workers"}
-        same = bool(np.array_equal(res_host, out.cpu().numpy())) if args.eps == 0 else None
+        same = bool(np.array_equal(res_host, out.download())) if args.eps == 0 else None
         e2e = {"iterations_per_s": K / e_s, "interpolated_traces_per_s": float(np.count_nonzero(mask == 0)) / e_s, "seconds": e_s,
                "seconds_each": e_each, "host_bytes_in_plus_out": 2 * host.nbytes * world if world == 1 else 2 * host.nbytes,
                "equals_resident_result": same, "phases": phases,
@@ -718,14 +764,12 @@ def run_leg(ctx, config, K_override, main):
         by_density = [{"coefficients_per_slice": "survey recipe (6 plane waves)", "nonzero_block_fraction": nz_fraction,
                        "iterations_per_s": K / seconds, "steady_state_iterations_per_s": steady, "roofline_frac": roof["frac"]}]
         for m in (96, 1024):
-            xc_ = x_obs
-            fill_random_spectrum(torch, xc_, nil, nxl, lo, pool, m, fft_plan)
-            xc_.mul_(mask_t)
+            random_spectrum_slices(x_obs, fft_plan, nil, nxl, lo, pool, mask, m)
             job(min(W, 3) or 1)
-            torch.cuda.synchronize()
+            ctx.sync()
             d0 = time.perf_counter()
             _, _, d_ms = job(K)
-            torch.cuda.synchronize()
+            ctx.sync()
             d_s = time.perf_counter() - d0
             prof, kept = profile_fft()
             it_ms = prof["colpass_ms"] + prof["rowpass_ms"] if prof["colpass_launches"] else d_ms / K
@@ -736,7 +780,7 @@ def run_leg(ctx, config, K_override, main):
     gather = None
     if world > 1 and main:
         from pseudo_3d_interpolation_amd.sharding import gather_blocks, gather_blocks_to_root
-        src = out.cpu() if ctx.rehearsal else out
+        src = out.tensor.cpu() if ctx.rehearsal else out.tensor
         gather = {}
         for name, fn in (("all_gather", gather_blocks), ("gather_to_root", gather_blocks_to_root)):
             ctx.fence()
@@ -754,20 +798,34 @@ def run_leg(ctx, config, K_override, main):
     cpu = None
     parity = None
     if rank == 0 and cpu_slices is not None:
-        plan.close()
-        del x_obs, out
-        torch.cuda.empty_cache()
         budget = args.cpu_seconds if main else min(args.cpu_seconds, 5.0)
         if kind == "SHEARLET":
-            cpu = cpu_baseline_shearlet(cpu_slices[0], mask, psi, op, cube_slices)
+            # one slice, two iterations on all cores (a slice-iteration is 2 x 125 transforms of 2 Mi points): the timed job's 100 iterations are out of
+            # reach of the CPU leg, so the parity figure is that of a SECOND device job of the same two iterations on the same slice
+            n_par = 2
+            stats = plan.stats_dev(x_obs.ptr, DT, 1)
+            tau = P._shearlet_schedule_from_stats(stats, (nil, nxl), "exponential", n_par, 0.99, p_min, "values")
+            plan.run_dev(x_obs.ptr, DT, mask_t.ptr, tau, n_par, out.ptr, 1, thresh_op=op, eps=0.0, alpha=args.alpha)
+            gpu_two = out.download(0, 1)[0]
+            plan.close()
+            x_obs.free(); out.free()
+            cpu, ref_two = cpu_baseline_shearlet(cpu_slices[0], mask, psi, op, cube_slices, niter=n_par)
+            rel = float(np.linalg.norm(gpu_two - ref_two) / np.linalg.norm(ref_two))
+            parity = {"rel_l2_max": rel, "rel_l2_median": rel, "slices": 1, "niter": n_par, "tolerance": 1e-5,
+                      "against": "oracle/shearlet_oracle.py (NumPy / SciPy restatement; its FFST spectra are restated from the paper: transform parity UNPINNED, "
+                                 "the reference's SHEARLET branches of schedule and loop are pinned) fed the same observed slice in double precision",
+                      "what": f"slice 0 of the timed cube through a separate device job of {n_par} iterations (the schedule of a {n_par}-iteration run) vs the oracle's "
+                              f"{n_par} iterations -- the CPU leg cannot follow the timed job's {K} iterations of 125 shearlets on 2 Mi points"}
         else:
+            plan.close()
+            x_obs.free(); out.free()
             cs = cpu_slices if not cfg["real"] else cpu_slices.real.astype(np.float64)
             parity, cpu = cpu_baseline(kind, cs, mask, op, budget, cube_slices, extra=cfg.get("wavelet"), parity_of=gpu_first, parity_niter=K)
     else:
         plan.close()
-        del x_obs, out
-    del pool, mask_t
-    torch.cuda.empty_cache()
+        x_obs.free(); out.free()
+    mask_t.free()
+    del pool
 
     if rank != 0:
         return None
@@ -796,7 +854,7 @@ def run_leg(ctx, config, K_override, main):
         "dtype": f"{dtype_s} (f32 arithmetic)",
         "data": ("synthetic: 6 plane waves (SURVEY 8d's per-slice seeds) + 1% Gaussian noise per slice, random trace mask.  The noise of slice s is "
                  f"slice s % {NOISE_POOL} of a pool of {NOISE_POOL} NumPy-drawn slices rolled by a shift that depends on s // {NOISE_POOL} -- POOLED, not 8d's per-slice "
-                 f"generator (no torch RNG kernels: counter collection); the first slices (those the cpu_baseline / parity leg computes) ARE 8d's "
+                 f"generator (host-generated, uploaded before the clock starts); the first slices (those the cpu_baseline / parity leg computes) ARE 8d's "
                  f"oracle.synthetic_slice, noise included"
                  if density == 0 else
                  f"synthetic: {density} random spectral coefficients + 1% Gaussian noise per slice (seeded), random trace mask"),
@@ -854,11 +912,12 @@ def compact(rec):
 
 
 def release(ctx):
-    """Between legs: the tensors of the finished leg died with its frame -- hand their memory back to the device."""
+    """Between legs: the device arrays of the finished leg were freed explicitly; drop what Python still holds."""
     import gc
     gc.collect()
-    ctx.torch.cuda.synchronize()
-    ctx.torch.cuda.empty_cache()
+    ctx.sync()
+    if ctx.torch is not None:
+        ctx.torch.cuda.empty_cache()
 
 
 def main():

@@ -101,6 +101,15 @@ int p3d_malloc(p3d_plan* plan, void** dptr, size_t bytes);
 int p3d_free(p3d_plan* plan, void* dptr);   /* `plan` may be NULL (the buffer outlived its plan) */
 int p3d_memcpy_h2d(p3d_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
 int p3d_memcpy_d2h(p3d_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
+/* The same without a plan, for callers that keep whole cubes resident in HBM across several plans (bench.py, a pipeline that chains
+ * steps 12 -> 13 -> 14 on device buffers) and use no other GPU runtime: blocking calls on the device's null stream.
+ * kind: 0 host -> device, 1 device -> host, 2 device -> device. */
+int p3d_dev_malloc(int device, void** dptr, size_t bytes);
+int p3d_dev_free(void* dptr);
+int p3d_dev_memcpy(int device, void* dst, const void* src, size_t bytes, int kind);
+int p3d_dev_memset(int device, void* dptr, int value, size_t bytes);
+int p3d_dev_synchronize(int device);
+int p3d_dev_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* page-locked host memory: copies to / from it run at the PCIe rate (pageable NumPy memory is staged by the runtime at a
  * quarter of it); the chunk pipeline of pocs_cube keeps its staging buffers here */
 int p3d_host_alloc(void** hptr, size_t bytes);

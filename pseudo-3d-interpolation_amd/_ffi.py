@@ -64,6 +64,12 @@ PROTOTYPES = {
     "p3d_pocs64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_pocs64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams), C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "p3d_dev_malloc": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_size_t]),
+    "p3d_dev_free": (C.c_int, [C.c_void_p]),
+    "p3d_dev_memcpy": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "p3d_dev_memset": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_size_t]),
+    "p3d_dev_synchronize": (C.c_int, [C.c_int]),
+    "p3d_dev_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "p3d_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "p3d_host_unregister": (C.c_int, [C.c_void_p]),
     "p3d_pocs_prime_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -113,11 +119,13 @@ PROTOTYPES = {
 
 
 def _preload_torch_hip():
-    """PyTorch-ROCm wheels bring their own HIP runtime.  When THIS library's runtime (the system's, /opt/rocm) is the first to initialise
-    in a process, a later ``torch.cuda`` call finds no device ("No HIP GPUs are available", measured on the MI355X boxes); the other
-    order works.  Loading torch's runtime library ahead of ours -- a dlopen, torch itself is not imported -- makes both orders work.
-    Nothing happens without torch, when torch is already imported, or with P3D_NO_TORCH_HIP_PRELOAD=1."""
-    if os.environ.get("P3D_NO_TORCH_HIP_PRELOAD") or "torch" in sys.modules:
+    """PyTorch-ROCm wheels bring their own HIP runtime (same SONAME as /opt/rocm's).  The library is built against the SYSTEM runtime and, by
+    default, runs on it: nothing is preloaded.  A process that ALSO uses ``torch.cuda`` must let torch go first -- once this library's
+    runtime has initialised, a later ``torch.cuda`` call finds no device ("No HIP GPUs are available", measured on the MI355X boxes), the
+    other order works: ``import torch`` before the first call into this package (``sharding.py`` and ``bench.py --gpus N>1`` do), or set
+    ``P3D_TORCH_HIP_PRELOAD=1`` to have torch's runtime library dlopen'ed ahead of ours without importing torch.  In both cases the
+    library then runs on torch's runtime; `_check_runtime` records the pair of versions and warns when they differ."""
+    if not os.environ.get("P3D_TORCH_HIP_PRELOAD") or "torch" in sys.modules:
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -174,7 +182,8 @@ def _check_runtime(handle):
     if split(comp.value)[:2] != split(run.value)[:2]:
         import warnings
         warnings.warn(f"libp3d_hip.so was compiled against HIP {_runtime['compiled_hip_version']} but the process runs HIP "
-                      f"{_runtime['runtime_hip_version']} ({path}); set P3D_NO_TORCH_HIP_PRELOAD=1 to keep PyTorch's runtime out", RuntimeWarning, stacklevel=3)
+                      f"{_runtime['runtime_hip_version']} ({path}): another copy of the runtime was mapped first (PyTorch imported before this package, or "
+                      f"P3D_TORCH_HIP_PRELOAD=1); processes that do not need torch.cuda should load this package first", RuntimeWarning, stacklevel=3)
 
 
 def runtime_info():
@@ -237,6 +246,74 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class DeviceArray:
+    """A typed block of device memory that belongs to no plan (``p3d_dev_malloc``): cubes that stay resident in HBM across several plans
+    and jobs, without any other GPU runtime in the process.  ``ptr`` is what the ``*_dev`` entry points take."""
+
+    def __init__(self, shape, dtype, device=0):
+        self.shape, self.dtype, self.device = tuple(int(n) for n in shape), np.dtype(dtype), int(device)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().p3d_dev_malloc(self.device, C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+
+    def _span(self, first, count):
+        per = self.nbytes // self.shape[0] if self.shape[0] else 0
+        count = self.shape[0] - first if count is None else count
+        if first < 0 or count < 0 or first + count > self.shape[0]:
+            raise ValueError(f'rows {first}:{first + count} outside an array of {self.shape[0]}')
+        return self.ptr + first * per, count * per, count
+
+    def upload(self, host, first=0):
+        """rows ``first ...`` <- ``host`` (C-contiguous, this dtype, trailing shape of the array)."""
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.shape[1:] != self.shape[1:]:
+            raise ValueError(f'trailing shape {host.shape[1:]} does not match {self.shape[1:]}')
+        dst, nbytes, _ = self._span(first, host.shape[0])
+        check(lib().p3d_dev_memcpy(self.device, dst, _ptr(host), nbytes, 0))
+        return self
+
+    def download(self, first=0, count=None, out=None):
+        src, nbytes, count = self._span(first, count)
+        if out is None:
+            out = np.empty((count,) + self.shape[1:], self.dtype)
+        elif not out.flags.c_contiguous or out.nbytes != nbytes or out.dtype != self.dtype:
+            raise ValueError('out must be C-contiguous with the dtype and size of the rows asked for')
+        check(lib().p3d_dev_memcpy(self.device, _ptr(out), src, nbytes, 1))
+        return out
+
+    def copy_from(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError('size mismatch')
+        check(lib().p3d_dev_memcpy(self.device, self.ptr, other.ptr, self.nbytes, 2))
+        return self
+
+    def zero(self):
+        check(lib().p3d_dev_memset(self.device, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            check(lib().p3d_dev_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def device_synchronize(device=0):
+    check(lib().p3d_dev_synchronize(int(device)))
+
+
+def device_mem_info(device=0):
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    check(lib().p3d_dev_mem_info(int(device), C.byref(free), C.byref(total)))
+    return free.value, total.value
+
+
 def host_register(arr):
     """Page-lock a C-contiguous NumPy array in place (p3d_host_register).  True when it is registered now (and must be handed to
     :func:`host_unregister` later), False when the runtime refused -- the array is usable either way."""
@@ -247,6 +324,15 @@ def host_register(arr):
 
 def host_unregister(arr):
     check(lib().p3d_host_unregister(_ptr(arr)))
+
+
+def host_register_range(addr, nbytes):
+    """Page-lock ``nbytes`` of host memory from address ``addr`` (the caller keeps the memory alive); True when registered."""
+    return nbytes > 0 and lib().p3d_host_register(C.c_void_p(addr), nbytes) == P3D_OK
+
+
+def host_unregister_range(addr):
+    check(lib().p3d_host_unregister(C.c_void_p(addr)))
 
 
 class PinnedBuffer:

@@ -601,6 +601,56 @@ int p3d_free(p3d_plan* p, void* dptr)
     return P3D_OK;
 }
 
+int p3d_dev_malloc(int device, void** dptr, size_t bytes)
+{
+    if (!dptr) return fail(P3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(dptr, bytes));
+    return P3D_OK;
+}
+
+int p3d_dev_free(void* dptr)
+{
+    HIP_TRY(hipFree(dptr));
+    return P3D_OK;
+}
+
+int p3d_dev_memcpy(int device, void* dst, const void* src, size_t bytes, int kind)
+{
+    if (kind < 0 || kind > 2) return fail(P3D_ERR_INVALID, "kind must be 0 (h2d), 1 (d2h) or 2 (d2d)");
+    if (!bytes) return P3D_OK;
+    if (!dst || !src) return fail(P3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
+    if (kind == 2) HIP_TRY(hipDeviceSynchronize());   // (device-to-device copies return before they have run)
+    return P3D_OK;
+}
+
+int p3d_dev_memset(int device, void* dptr, int value, size_t bytes)
+{
+    if (!bytes) return P3D_OK;
+    if (!dptr) return fail(P3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemset(dptr, value, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return P3D_OK;
+}
+
+int p3d_dev_synchronize(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return P3D_OK;
+}
+
+int p3d_dev_mem_info(int device, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes) return fail(P3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return P3D_OK;
+}
+
 int p3d_host_alloc(void** hptr, size_t bytes)
 {
     if (!hptr) return fail(P3D_ERR_INVALID, "NULL argument");

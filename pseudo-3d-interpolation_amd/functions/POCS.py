@@ -369,6 +369,18 @@ def _holder(device):
 
 
 _batch_bufs = {}
+_device_locks = {}
+_device_locks_guard = __import__('threading').Lock()
+
+
+def _device_lock(device):
+    """One re-entrant lock per device: everything cached per device (plans, chunk workers, ``_batch_bufs``) is used under it."""
+    with _device_locks_guard:
+        lock = _device_locks.get(device)
+        if lock is None:
+            import threading
+            lock = _device_locks[device] = threading.RLock()
+        return lock
 
 
 def _batch_buffers(device, cube_bytes, mask_bytes):
@@ -429,7 +441,7 @@ class _HostPins:
 
     def __init__(self, cube, out, starts, step):
         import threading
-        self._regs = []
+        self._regs = []              # (address, bytes) of the registered ranges
         self._lock = threading.Lock()
         self._slabs = [(lo, lo + step) for lo in starts]
         self._in_done = [threading.Event() for _ in self._slabs]
@@ -445,11 +457,18 @@ class _HostPins:
         try:
             for f in after:
                 f.result()
-            for (lo, hi), ev in zip(self._slabs, done):
-                slab = arr[lo:hi]
-                if _ffi.host_register(slab):
+            # page-aligned, non-overlapping byte ranges: slab i is registered from the first page boundary at or after its start (the bytes
+            # before it lie in slab i-1's last page, registered one step earlier) up to the page boundary at or after its end
+            base, per = arr.ctypes.data, arr.strides[0]
+            page = 4096
+            last = len(self._slabs) - 1
+            for i, ((lo, hi), ev) in enumerate(zip(self._slabs, done)):
+                a, b = base + lo * per, base + min(hi, arr.shape[0]) * per
+                a = a // page * page if i == 0 else -(-a // page) * page
+                b = -(-b // page) * page
+                if b > a and _ffi.host_register_range(a, b - a):
                     with self._lock:
-                        self._regs.append(slab)
+                        self._regs.append((a, b - a))
                 ev.set()
         finally:
             for ev in done:
@@ -466,8 +485,12 @@ class _HostPins:
             t.join()
         with self._lock:
             regs, self._regs = self._regs, []
-        for a in regs:
-            _ffi.host_unregister(a)
+        for addr, nbytes in regs:   # best effort: this runs in a `finally` -- one refused release must neither hide the caller's exception
+            try:                    # nor keep the remaining slabs page-locked
+                _ffi.host_unregister_range(addr)
+            except _ffi.P3DError as exc:
+                import warnings
+                warnings.warn(f'could not release a page-locked slab of {nbytes} bytes: {exc}', RuntimeWarning, stacklevel=2)
 
 
 _CHUNK_WORKERS = int(os.environ.get('P3D_CHUNK_WORKERS', 4))   # chunks in flight (slots 0.. of the plan cache; slot 15 belongs to the unchunked path)
@@ -590,6 +613,7 @@ def _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alph
     plan's device sort (positions in the sorted spectrum; the values differ from a double sort's by float32 rounding)."""
     nslices, nil, nxl = cube.shape
     step = int(batch_slices) if batch_slices else max(1, min(nslices, (2 << 30) // (nil * nxl * 16)))   # work + staging: 48 B per point and slice
+    step = min(step, 65535)   # (plan64's limit: cubes of tiny slices)
     plan = _get_plan64(nil, nxl, min(step, nslices), device)
     mask64 = np.ascontiguousarray(mask, dtype=np.float64)
     # one upload per batch into device buffers, statistics and loop on the resident copy, the result downloaded straight into `out` (whose fresh
@@ -696,7 +720,8 @@ def pocs_cube(
     precision also for complex64 / float32 cubes, the result cast back (what the reference itself executes for the soft / garrote
     operators, FPOCS and APOCS, and for every run under NumPy < 2 -- SURVEY appendix A.16); ``'float32'``: the float32 kernels whatever the
     cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loop is a
-    precision path (about a tenth of the float32 rate), has the hard / soft / garrote operators and slice extents up to 5120.
+    precision path (about a tenth of the float32 rate, DESIGN.md section 5), has the hard / soft / garrote operators and slice extents up to 5120;
+    a call that asks for (or implies) double precision outside that coverage runs the float32 kernels and says so with a ``RuntimeWarning``.
 
     ``out`` (optional): an array of the shape and dtype of ``cube`` to write the result into (e.g. a slab of the merged cube of the
     step-13 driver) instead of a new one.
@@ -705,13 +730,24 @@ def pocs_cube(
     """
     cube, mask, kind, niter, eps, p_max, alpha, p_min = _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps,
                                                                          p_max, alpha, p_min)
-    nslices, nil, nxl = cube.shape
     if out is None:
         out = np.empty_like(cube)
     elif not isinstance(out, np.ndarray) or out.shape != cube.shape or out.dtype != cube.dtype:
         raise ValueError(f'out must be a NumPy array of shape {cube.shape} and dtype {cube.dtype}')
-    if nslices == 0:
+    if cube.shape[0] == 0:
         return out
+    # Plans, chunk workers and the batch buffers are cached per device and are not re-entrant (include/p3d.h: "a plan is bound to one
+    # device + stream"): calls on ONE device take turns -- a threaded caller (dask's threaded scheduler under xr.apply_ufunc) gets the same
+    # results as a serial one; calls on different devices run side by side.
+    with _device_lock(device):
+        return _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version,
+                                 results, device, batch_slices, wavelet, auxiliary_data, precision, out, ignored)
+
+
+def _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results, device,
+                      batch_slices, wavelet, auxiliary_data, precision, out, ignored):
+    """``pocs_cube`` behind its argument checks, with the device's lock held."""
+    nslices, nil, nxl = cube.shape
     step = int(batch_slices) if batch_slices else nslices
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
     if precision is None:
@@ -719,7 +755,13 @@ def pocs_cube(
     if precision not in (None, 'reference', 'float32'):
         raise ValueError(f"precision must be None, 'reference' or 'float32', got {precision!r}")
     wide = cube.dtype in (np.complex128, np.float64)
-    if kind == 'FFT' and thresh_op in _WAVELET_OPS and max(nil, nxl) <= 5120 and (precision == 'reference' or (wide and precision is None)):
+    want_double = precision == 'reference' or (wide and precision is None)
+    if want_double and not (kind == 'FFT' and thresh_op in _WAVELET_OPS and max(nil, nxl) <= 5120):
+        import warnings
+        why = (f'the {kind} transform' if kind != 'FFT' else f'thresh_op={thresh_op!r}' if thresh_op not in _WAVELET_OPS else f'slice extents above 5120 ({nil} x {nxl})')
+        warnings.warn(f'double-precision arithmetic was {"requested" if precision == "reference" else "implied by the " + str(cube.dtype) + " cube"}, but the double-precision '
+                      f'loop does not cover {why}: this call runs the float32 kernels (pass precision="float32" to say so explicitly)', RuntimeWarning, stacklevel=3)
+    if want_double and kind == 'FFT' and thresh_op in _WAVELET_OPS and max(nil, nxl) <= 5120:
         return _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results,
                                  device, batch_slices)
     if kind == 'SHEARLET':

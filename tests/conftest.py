@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """Which HIP runtime the library bound in THIS process (the test log records it: compiled vs. runtime version and the file; -q keeps the line)."""
+    try:
+        from pseudo_3d_interpolation_amd import _ffi
+        terminalreporter.write_line(f"hip_runtime: {_ffi.runtime_info()}")
+    except Exception as exc:  # noqa: BLE001 -- not built yet
+        terminalreporter.write_line(f"hip_runtime: unavailable ({type(exc).__name__})")
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
