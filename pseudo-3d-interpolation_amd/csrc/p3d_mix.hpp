@@ -1,0 +1,520 @@
+// p3d_mix.hpp -- the register-resident line-FFT engine for 7-smooth line lengths that are not powers of two, and the two fused POCS passes on it.
+//
+// numpy.fft.fft2 / ifft2 take every length (cube_POCS_interpolation_3D.py:255-257, called at functions/POCS.py:535, 592, 613) and survey grids
+// are rarely powers of two.  p3d_fft.hpp holds a line of 2^m points in registers, 16 per thread; p3d_flex.hip runs any other length as an
+// LDS image with one butterfly per thread and pass, radix and strides read at run time (0.27 - 0.40 of the tuned rate).  This file is the
+// engine of p3d_fft.hpp for N = R0 R1 ... with radices 2 ... 32 built from 2, 3, 5 and 7:
+//
+//   * a line is held by TPL = N / PPT threads, PPT points each, canonical layout  register q of thread tl <-> element tl + TPL q  before the
+//     first and after the last pass of a transform (global loads / stores coalesce over tl; forward -> threshold -> inverse chain through
+//     registers);
+//   * every radix divides PPT: butterfly s of thread tl in pass p is butterfly j = tl + s TPL of the Stockham recipe, its R inputs
+//     in[j + t N / R] are the registers s + (PPT / R) t -- no data moves before a pass; a pass of radix R (Ns = product of the radices
+//     before it) computes  v[t] = in[j + t N/R] w^(t (j mod Ns)),  out[(j div Ns) Ns R + (j mod Ns) + k Ns] = DFT_R(v)[k]  and hands its
+//     outputs round through LDS (scatter, barrier, canonical gather); the last pass leaves the canonical layout by itself;
+//   * everything about a plan is a compile-time constant (MixPlan<N, PPT, R...>): strides fold into instruction offsets, the division by
+//     Ns is a multiply, the small DFTs are straight-line code (Cooley-Tukey on 4 / 2 / 3 / 5 / 7, root constants as literals);
+//   * twiddles: per pass p >= 1 (R - 1) rows of Ns entries exp(-2 pi i t jm / (Ns R)) in the order neighbouring threads read them, one table
+//     per length in LDS, conjugated inside the multiply for the inverse transform;
+//   * LDS image of a line: one padding slot per R0 positions, so that the first scatter (stride R0) walks the banks with an odd stride.
+//
+// The plans are chosen by tools/gen_mix_plans.py (fewest passes, radices dividing PPT, PPT near 20) and listed in p3d_mix_plans.inc; the
+// kernels are instantiated per plan in p3d_mix_inst.hip (several translation units) and reached through the launchers of p3d_flex.hip,
+// i.e. behind the same LineOps / RowArgs / ColArgs interface and on the same column-blocked work buffer as every other length.
+#pragma once
+
+#include "p3d_kernels_common.hpp"
+
+namespace p3d {
+namespace mix {
+
+template <int R>
+struct Roots;
+#include "p3d_mix_roots.inc"
+
+// W^q, W = exp(DIR 2 pi i / R)
+template <int R, int DIR>
+__device__ __forceinline__ c32 root(int q)
+{
+    return c32{Roots<R>::c[q], DIR > 0 ? Roots<R>::s[q] : -Roots<R>::s[q]};
+}
+
+// ---- small DFTs on registers, natural order in and out: X[k] = sum_t x[t] W^(t k), W = exp(DIR 2 pi i / R) ------------------------------
+constexpr int first_factor(int r) { return r % 4 == 0 ? 4 : r % 2 == 0 ? 2 : r % 3 == 0 ? 3 : r % 5 == 0 ? 5 : r % 7 == 0 ? 7 : r; }
+
+template <int R, int DIR>
+struct SmallDft {
+    static __device__ __forceinline__ void run(c32 (&x)[R])
+    {
+        constexpr int R1 = first_factor(R);
+        if constexpr (R == 1) {
+        } else if constexpr (R == 2) {
+            const c32 a = x[0] + x[1], b = x[0] - x[1];
+            x[0] = a;
+            x[1] = b;
+        } else if constexpr (R == 4) {
+            const c32 a = x[0] + x[2], b = x[0] - x[2], s = x[1] + x[3], t = x[1] - x[3];
+            x[0] = a + s;
+            x[2] = a - s;
+            x[1] = DIR > 0 ? add_ib(b, t) : sub_ib(b, t);
+            x[3] = DIR > 0 ? sub_ib(b, t) : add_ib(b, t);
+        } else if constexpr (R1 == R) {
+            // odd prime: pair x[q] with x[R-q]:  X[k], X[R-k] = A_k +- i B_k,  A_k = x0 + sum_q cos(2 pi q k / R) (x[q] + x[R-q]),
+            // B_k = sum_q (DIR sin(2 pi q k / R)) (x[q] - x[R-q]) -- real coefficients only
+            constexpr int H = (R - 1) / 2;
+            c32 sp[H], dm[H];
+            c32 x0 = x[0];
+#pragma unroll
+            for (int q = 1; q <= H; ++q) {
+                sp[q - 1] = x[q] + x[R - q];
+                dm[q - 1] = x[q] - x[R - q];
+                x0 = x0 + sp[q - 1];
+            }
+            const c32 xin = x[0];
+            x[0] = x0;
+#pragma unroll
+            for (int k = 1; k <= H; ++k) {
+                c32 A = xin, B{0.f, 0.f};
+#pragma unroll
+                for (int q = 1; q <= H; ++q) {
+                    const c32 wq = root<R, DIR>((q * k) % R);
+                    A = A + sp[q - 1] * wq.x;
+                    B = B + dm[q - 1] * wq.y;
+                }
+                x[k] = add_ib(A, B);
+                x[R - k] = sub_ib(A, B);
+            }
+        } else {
+            // R = R1 R2, t = R2 t1 + t2, k = k1 + R1 k2:  X[k] = sum_t2 [ (sum_t1 x[t] W_R1^(t1 k1)) W_R^(t2 k1) ] W_R2^(t2 k2)
+            constexpr int R2 = R / R1;
+            c32 u[R];   // u[k1 R2 + t2]
+#pragma unroll
+            for (int t2 = 0; t2 < R2; ++t2) {
+                c32 a[R1];
+#pragma unroll
+                for (int t1 = 0; t1 < R1; ++t1) a[t1] = x[R2 * t1 + t2];
+                SmallDft<R1, DIR>::run(a);
+#pragma unroll
+                for (int k1 = 0; k1 < R1; ++k1) {
+                    const int e = (k1 * t2) % R;
+                    if (e == 0) u[k1 * R2 + t2] = a[k1];
+                    else if (4 * e == R) u[k1 * R2 + t2] = mul_i<DIR>(a[k1]);            // W^(R/4) = DIR i
+                    else if (2 * e == R) u[k1 * R2 + t2] = c32{-a[k1].x, -a[k1].y};        // W^(R/2) = -1
+                    else if (4 * e == 3 * R) u[k1 * R2 + t2] = mul_i<-DIR>(a[k1]);        // W^(3R/4) = -DIR i
+                    else u[k1 * R2 + t2] = a[k1] * root<R, DIR>(e);
+                }
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                c32 b[R2];
+#pragma unroll
+                for (int t2 = 0; t2 < R2; ++t2) b[t2] = u[k1 * R2 + t2];
+                SmallDft<R2, DIR>::run(b);
+#pragma unroll
+                for (int k2 = 0; k2 < R2; ++k2) x[k1 + R1 * k2] = b[k2];
+            }
+        }
+    }
+};
+
+// ---- compile-time plan ---------------------------------------------------------------------------------------------------------------
+template <int N_, int PPT_, int COLT_, int ROWLB_, int NPASS_, int R0, int R1, int R2, int R3, int R4>
+struct MixPlan {
+    static constexpr int N = N_, PPT = PPT_, TPL = N_ / PPT_, NPASS = NPASS_;
+    static constexpr int COLT = COLT_;     // columns per workgroup of the column pass
+    static constexpr int ROWLB = ROWLB_;   // rows per workgroup of the row pass
+    static constexpr int radix(int p) { return p == 0 ? R0 : p == 1 ? R1 : p == 2 ? R2 : p == 3 ? R3 : R4; }
+    static constexpr int ns(int p)
+    {
+        int r = 1;
+        for (int q = 0; q < p; ++q) r *= radix(q);
+        return r;
+    }
+    static_assert(ns(NPASS_) == N_, "the radices must multiply to N");
+    static_assert(PPT_ % R0 == 0 && PPT_ % R1 == 0 && PPT_ % R2 == 0 && PPT_ % R3 == 0 && PPT_ % R4 == 0, "every radix divides the points per thread");
+    static_assert(N_ % PPT_ == 0, "PPT divides N");
+    // padding of the LDS image: one slot per PADQ positions (0: none).  The compile-time offsets of gather and scatter need PADQ | TPL and
+    // PADQ | Ns of every later pass (Ns is a multiple of R0).
+    static constexpr int PADQ = (TPL % R0 == 0 && R0 > 2) ? R0 : 0;
+    static constexpr int pad(int pos) { return PADQ ? pos + pos / PADQ : pos; }
+    static constexpr int LINE = pad(N_);   // slots of one line's LDS image
+    // twiddle rows of pass p >= 1 start at tw_off(p): (R - 1) rows of Ns entries
+    static constexpr int tw_off(int p)
+    {
+        int o = 0;
+        for (int q = 1; q < p; ++q) o += (radix(q) - 1) * ns(q);
+        return o;
+    }
+    static constexpr int TW_SLOTS = tw_off(NPASS_);
+    static void build_tw(c32* out)
+    {
+        for (int p = 1; p < NPASS; ++p) {
+            const int R = radix(p), NS = ns(p), o = tw_off(p);
+            for (int t = 1; t < R; ++t)
+                for (int jm = 0; jm < NS; ++jm) {
+                    const double ang = -6.283185307179586476925286766559 * double(t) * double(jm) / (double(NS) * R);
+                    out[o + (t - 1) * NS + jm] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
+                }
+        }
+    }
+};
+
+// LDS view of one line: W lines interleaved element-major ([pos][W]); `base` points at this thread's line
+template <class PL, int W>
+struct Lds {
+    static constexpr int WIDTH = W;
+    c32* base;
+    __device__ __forceinline__ c32* ptr(int pos) const { return base + (PL::PADQ ? pos + pos / PL::PADQ : pos) * W; }
+    static constexpr int rel(int c) { return PL::pad(c) * W; }   // pad(p + c) == pad(p) + pad(c) when PADQ | c
+};
+
+template <class PL, int DIR, int P, int T>
+struct TwApply {   // a[t] = v[s + NB t] * w_t, t = T ... R-1 (compile-time t: the row offsets fold into the instruction)
+    template <int R, int NB>
+    static __device__ __forceinline__ void run(c32* a, const c32* v, int s, const c32* twp)
+    {
+        if constexpr (T < R) {
+            const c32 w = twp[(T - 1) * PL::ns(P)];
+            a[T] = DIR > 0 ? mul_conj(v[s + NB * T], w) : v[s + NB * T] * w;
+            TwApply<PL, DIR, P, T + 1>::template run<R, NB>(a, v, s, twp);
+        }
+    }
+};
+
+// one pass in registers: twiddles, NB radix-R DFTs; output k of butterfly s ends up in register s + NB k
+template <class PL, int DIR, int P>
+__device__ __forceinline__ void pass_compute(c32 (&v)[PL::PPT], const c32* tw, int tl)
+{
+    constexpr int R = PL::radix(P), NS = PL::ns(P), NB = PL::PPT / R;
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        c32 a[R];
+        a[0] = v[s];
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int t = 1; t < R; ++t) a[t] = v[s + NB * t];
+        } else {
+            const int jm = (tl + s * PL::TPL) % NS;
+            TwApply<PL, DIR, P, 1>::template run<R, NB>(a, v, s, tw + PL::tw_off(P) + jm);
+        }
+        SmallDft<R, DIR>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[s + NB * k] = a[k];
+    }
+}
+
+template <class PL, int P, class LDS>
+__device__ __forceinline__ void pass_scatter(const c32 (&v)[PL::PPT], LDS lds, int tl)
+{
+    constexpr int R = PL::radix(P), NS = PL::ns(P), NB = PL::PPT / R;
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        const int jb = tl + s * PL::TPL;
+        const int j0 = (jb / NS) * (NS * R) + jb % NS;
+        if constexpr (PL::PADQ == 0 || (NS % PL::PADQ == 0)) {
+            c32* p = lds.ptr(j0);
+#pragma unroll
+            for (int k = 0; k < R; ++k) p[LDS::rel(k * NS)] = v[s + NB * k];
+        } else if constexpr (P == 0 && R == PL::PADQ) {
+            c32* p = lds.ptr(j0);   // j0 = jb R0: a multiple of PADQ, and k < PADQ adds no padding slot
+#pragma unroll
+            for (int k = 0; k < R; ++k) p[k * LDS::WIDTH] = v[s + NB * k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) *lds.ptr(j0 + k * NS) = v[s + NB * k];
+        }
+    }
+}
+
+template <class PL, class LDS>
+__device__ __forceinline__ void canonical_gather(c32 (&v)[PL::PPT], LDS lds, int tl)
+{
+    const c32* p = lds.ptr(tl);
+#pragma unroll
+    for (int q = 0; q < PL::PPT; ++q) v[q] = p[LDS::rel(PL::TPL * q)];   // (PADQ | TPL)
+}
+
+template <class PL, int DIR, int P, class LDS>
+struct PassLoop {
+    static __device__ __forceinline__ void run(c32 (&v)[PL::PPT], LDS lds, const c32* tw, int tl)
+    {
+        if constexpr (P > 0) canonical_gather<PL>(v, lds, tl);
+        pass_compute<PL, DIR, P>(v, tw, tl);
+        if constexpr (P + 1 < PL::NPASS) {
+            __syncthreads();   // everybody is done reading the previous contents
+            pass_scatter<PL, P>(v, lds, tl);
+            __syncthreads();
+            PassLoop<PL, DIR, P + 1, LDS>::run(v, lds, tw, tl);
+        }
+    }
+};
+
+// Transform one line held in the canonical register layout; the result is canonical again.  Every thread of the workgroup must call this.
+template <class PL, int DIR, class LDS>
+__device__ __forceinline__ void line_fft(c32 (&v)[PL::PPT], LDS lds, const c32* tw, int tl)
+{
+    PassLoop<PL, DIR, 0, LDS>::run(v, lds, tw, tl);
+}
+
+__device__ __forceinline__ bool lex_gt(float ar, float ai, float br, float bi) { return (ar > br) || (ar == br && ai > bi); }
+
+// =========================================================================================================================================
+// spectrum (column) pass: forward transform, threshold, inverse transform of a tile of COLT columns (modes as col_kernel / flex_col_kernel)
+// =========================================================================================================================================
+template <class PL>
+__global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArgs a, const c32* __restrict__ tab, int mode)
+{
+    constexpr int N = PL::N, PPT = PL::PPT, TPL = PL::TPL, T = PL::COLT, THREADS = T * TPL;
+    using LDS = Lds<PL, T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ float red[((THREADS + 63) / 64) * 5];
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + PL::TW_SLOTS;
+
+    const int tid = threadIdx.x;
+    const int c_lo = tid % T, tl = tid / T;
+    const int slice = blockIdx.y, tile = blockIdx.x;
+    const int col = tile * T + c_lo;
+    const bool valid = col < a.n2;
+    if (a.done && a.done[slice] != 0) return;
+
+    for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
+    __syncthreads();
+
+    const LDS lds{data + c_lo};
+    const bool iter = mode == COL_ITER || mode == COL_ITER_SOFT || mode == COL_ITER_GARROTE;
+    const int vcol = valid ? col : 0;
+    const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
+    c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
+    const unsigned blk0 = ((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7);   // column-blocked: + row * 8
+    const bool in_std = a.in_std != 0, out_std = a.out_std != 0;
+    const unsigned in_org = in_std ? (unsigned)vcol : blk0, in_pitch = in_std ? (unsigned)a.n2 : 8u;
+    const unsigned out_org = out_std ? (unsigned)vcol : blk0, out_pitch = out_std ? (unsigned)a.n2 : 8u;
+
+    c32 v[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)   // (columns past the edge re-read column 0 and are never stored)
+        v[q] = *reinterpret_cast<const c32*>(reinterpret_cast<const char*>(inb) + (size_t)(in_org + (unsigned)(tl + TPL * q) * in_pitch) * 8u);
+
+    if (mode != COL_INV) line_fft<PL, FWD>(v, lds, twl, tl);
+
+    if (iter || (mode == COL_FWD && a.tau != nullptr)) {
+        const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
+        const int op = mode == COL_ITER_SOFT ? 1 : (mode == COL_ITER_GARROTE ? 2 : a.op);   // callers pass COL_ITER + a.op
+        const Shrink shr(tau, op);
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            v[q] = shr(v[q]);
+            bits |= (__float_as_uint(v[q].x) | __float_as_uint(v[q].y)) & 0x7fffffffu;
+        }
+        if (iter && a.nzflag != nullptr) {
+            // a tile the threshold emptied stays zeros after the inverse transform: say so instead of transforming and storing it
+            const int kept = __syncthreads_or((valid && bits != 0u) ? 1 : 0);
+            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
+            if (!kept) {
+                // the row pass skips whole 8-column BLOCKS: an empty tile narrower than a block must leave zeros behind for the case that a
+                // sibling tile of its block kept something (see col_kernel)
+                if constexpr (T < 8) {
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < PPT; ++q)
+                            *reinterpret_cast<c32*>(reinterpret_cast<char*>(outb) + (size_t)(out_org + (unsigned)(tl + TPL * q) * out_pitch) * 8u) = c32{0.f, 0.f};
+                    }
+                }
+                return;
+            }
+        }
+    }
+
+    if (mode == COL_STATS) {
+        // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
+        float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const float p = v[q].x * v[q].x + v[q].y * v[q].y;
+                if (lex_gt(v[q].x, v[q].y, lr, li)) { lr = v[q].x; li = v[q].y; }
+                mx = fmaxf(mx, p);
+                mn = fminf(mn, p);
+                sq += p;
+            }
+        }
+        const int lane = tid & 63;
+        const int nact = (THREADS - (tid & ~63)) < 64 ? (THREADS - (tid & ~63)) : 64;   // the last wavefront may be partial
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float orr = __shfl_down(lr, o, 64), oi = __shfl_down(li, o, 64);
+            const float omx = __shfl_down(mx, o, 64), omn = __shfl_down(mn, o, 64), osq = __shfl_down(sq, o, 64);
+            if (lane + o < nact) {
+                if (lex_gt(orr, oi, lr, li)) { lr = orr; li = oi; }
+                mx = fmaxf(mx, omx);
+                mn = fminf(mn, omn);
+                sq += osq;
+            }
+        }
+        const int wave = tid >> 6, nw = (THREADS + 63) >> 6;
+        if (lane == 0) {
+            red[wave * 5 + 0] = lr; red[wave * 5 + 1] = li; red[wave * 5 + 2] = mx; red[wave * 5 + 3] = mn; red[wave * 5 + 4] = sq;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < nw; ++w) {
+                if (lex_gt(red[w * 5], red[w * 5 + 1], lr, li)) { lr = red[w * 5]; li = red[w * 5 + 1]; }
+                mx = fmaxf(mx, red[w * 5 + 2]);
+                mn = fminf(mn, red[w * 5 + 3]);
+                sq += red[w * 5 + 4];
+            }
+            float* p = a.partials + ((size_t)slice * gridDim.x + tile) * STATS_PARTIAL;
+            p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
+        }
+        return;
+    }
+
+    if (iter || mode == COL_INV) line_fft<PL, INV>(v, lds, twl, tl);
+
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            *reinterpret_cast<c32*>(reinterpret_cast<char*>(outb) + (size_t)(out_org + (unsigned)(tl + TPL * q) * out_pitch) * 8u) = v[q];
+    }
+}
+
+// =========================================================================================================================================
+// row pass: inverse transform, re-insertion of the observed traces (POCS.py:616-619), cost sums, forward transform -- ROWLB rows per workgroup
+// (modes ROW_FIRST / ROW_MID / ROW_LAST as row_kernel / flex_row_kernel)
+// =========================================================================================================================================
+template <class PL>
+__global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowArgs a, const c32* __restrict__ tab, int mode)
+{
+    constexpr int N = PL::N, PPT = PL::PPT, TPL = PL::TPL, LB = PL::ROWLB, THREADS = LB * TPL;
+    using LDS = Lds<PL, 1>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c32* twl = reinterpret_cast<c32*>(smem_raw);
+    c32* data = twl + PL::TW_SLOTS;
+    const int tid = threadIdx.x, line = tid / TPL, tl = tid % TPL;
+    const int slice = blockIdx.y, row = blockIdx.x * LB + line;
+    const bool valid = row < a.n1;
+    const int vrow = valid ? row : 0;
+    for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
+    __syncthreads();
+    const LDS lds{data + line * PL::LINE};
+
+    const int dn = a.done ? a.done[slice] : 0;   // (uniform over the workgroup: every early return below is taken by all of its threads)
+    const size_t sbase = ((size_t)slice * a.n1 + vrow) * N;   // row-major cubes (x, out)
+    if (mode == ROW_LAST && a.only_done) {
+        if (dn <= a.only_done_lo || dn > a.only_done) return;
+    } else if (mode == ROW_LAST) {
+        if (dn > 0) return;   // converged earlier: `out` already holds that iterate
+        if (dn < 0) {         // an all-zero slice is handed back untouched (POCS.py:515-521)
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + tl + TPL * q] = c32{0.f, 0.f};
+                    else reinterpret_cast<float*>(a.out)[sbase + tl + TPL * q] = 0.f;
+                }
+            }
+            return;
+        }
+    } else if (dn != 0) {
+        return;
+    }
+    c32* const wrow = a.work + (size_t)slice * wk_slice_stride(a.n1, N) + (size_t)vrow * 8;   // + (i >> 3) n1 8 + (i & 7)
+    const unsigned wblk = (unsigned)a.n1 * 8;
+    auto woff = [&](int q) -> unsigned { const int i = tl + TPL * q; return (unsigned)(i >> 3) * wblk + (unsigned)(i & 7); };
+    auto obs_at = [&](int i) -> c32 {
+        if (a.dtype == 0) return reinterpret_cast<const c32*>(a.x)[sbase + i];
+        return c32{reinterpret_cast<const float*>(a.x)[sbase + i], 0.f};
+    };
+    const float* const mrow = a.mask ? a.mask + (size_t)vrow * N : nullptr;
+
+    float acc = 0.f;
+    c32 v[PPT];
+    if (mode == ROW_FIRST) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int i = tl + TPL * q;
+            const c32 x = valid ? obs_at(i) : c32{0.f, 0.f};
+            acc += abs_c32(x);
+            if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
+                const float m = mrow ? mrow[i] : 0.f;
+                const float w = 1.0f - a.alpha * m;
+                const c32 blend = x * a.alpha + x * w;
+                v[q] = blend + (x - x * m) * (1.0f - a.alpha);
+            } else {
+                v[q] = x;
+            }
+        }
+    } else {
+        // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros
+        const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
+        const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            bool kept = valid;
+            if (nzf) kept = kept && nzf[(tl + TPL * q) >> tsh] != 0;
+            v[q] = kept ? wrow[woff(q)] : c32{0.f, 0.f};
+        }
+        line_fft<PL, INV>(v, lds, twl, tl);
+        const bool need_obs = !a.plain && valid;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int i = tl + TPL * q;
+            const c32 xo = need_obs ? obs_at(i) : c32{0.f, 0.f};
+            const float mk = (mrow && !a.plain) ? mrow[i] : 0.f;
+            c32 xn = v[q] * a.scale;
+            float m = 0.f;
+            if (mode == ROW_LAST && a.only_done) {
+                // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
+                if (a.alpha == 1.0f && mrow && mk == 1.0f) xn = xo;
+            } else if (!a.plain) {
+                m = mk;
+                const float w = 1.0f - a.alpha * m;        // POCS.py:616
+                xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
+            }
+            acc += abs_c32(xn);
+            if ((mode == ROW_LAST || a.write_out) && valid) {
+                if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = xn;
+                else reinterpret_cast<float*>(a.out)[sbase + i] = xn.x;   // np.real(), POCS.py:656
+            }
+            if (mode == ROW_MID && a.adaptive) {   // x_input of the next iteration (POCS.py:574-575)
+                const float w = 1.0f - a.alpha * m;
+                const c32 blend = xo * a.alpha + xn * w;
+                v[q] = blend + (xo - xn * m) * (1.0f - a.alpha);
+            } else {
+                v[q] = xn;
+            }
+        }
+    }
+    if (a.sums != nullptr) {
+        // per-row sum of |x| in a fixed order: the threads' partial sums go through the row's LDS image, one thread adds them up in double
+        __syncthreads();   // (the image is free: the inverse transform's last gather is behind every thread)
+        float* part = reinterpret_cast<float*>(data + line * PL::LINE);
+        part[tl] = acc;
+        __syncthreads();
+        if (tl == 0 && valid) {
+            double t = 0.0;
+            for (int i = 0; i < TPL; ++i) t += (double)part[i];
+            a.sums[(size_t)slice * a.n1 + row] = t;
+        }
+    }
+    if (mode != ROW_LAST) {
+        line_fft<PL, FWD>(v, lds, twl, tl);
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) wrow[woff(q)] = v[q];
+        }
+    }
+}
+
+// what the launchers of p3d_flex.hip need to know about a plan
+struct Entry {
+    int n, col_tile, tw_slots;
+    void (*build_tw)(c32* out);
+    hipError_t (*row)(int mode, const RowArgs& a, const c32* tab, hipStream_t st);
+    hipError_t (*col)(int mode, const ColArgs& a, const c32* tab, hipStream_t st);
+};
+const Entry* find(int n);   // nullptr: no plan for this length (p3d_flex.hip runs it as an LDS image)
+
+}  // namespace mix
+}  // namespace p3d

@@ -457,15 +457,13 @@ class _HostPins:
         try:
             for f in after:
                 f.result()
-            # page-aligned, non-overlapping byte ranges: slab i is registered from the first page boundary at or after its start (the bytes
-            # before it lie in slab i-1's last page, registered one step earlier) up to the page boundary at or after its end
+            # Every slab is registered as exactly the bytes a worker's copy moves.  (Page-aligned, non-overlapping ranges were tried in round 5: a
+            # slab then starts in its predecessor's last page, and hipMemcpyAsync refuses a copy whose host range spans two registrations --
+            # "invalid argument".  Neighbouring slabs sharing a boundary page is what the runtime accepts: the driver pins pages per
+            # registration and counts them.)
             base, per = arr.ctypes.data, arr.strides[0]
-            page = 4096
-            last = len(self._slabs) - 1
-            for i, ((lo, hi), ev) in enumerate(zip(self._slabs, done)):
+            for (lo, hi), ev in zip(self._slabs, done):
                 a, b = base + lo * per, base + min(hi, arr.shape[0]) * per
-                a = a // page * page if i == 0 else -(-a // page) * page
-                b = -(-b // page) * page
                 if b > a and _ffi.host_register_range(a, b - a):
                     with self._lock:
                         self._regs.append((a, b - a))
