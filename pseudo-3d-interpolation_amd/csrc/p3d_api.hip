@@ -17,6 +17,7 @@
 #include "p3d_generic.hpp"
 #include "p3d_internal.hpp"
 #include "p3d_flex.hpp"
+#include "p3d_mix_entry.hpp"
 #include "p3d_resident.hpp"
 #include "p3d_select.hpp"
 #include "p3d_kernels.hpp"
@@ -352,6 +353,10 @@ struct p3d_plan {
     unsigned long long* bits64 = nullptr;       // tpl = 64, 128, 256: the same as lane masks (row_pipe64_kernel, pipe64_word)
     unsigned long long* nzl = nullptr;          // ... nzm as lane masks, per slice
     unsigned* cbase = nullptr;                  // ... observed traces before each word of bits64
+    unsigned long long* mbits = nullptr;        // mixed-radix row pass (p3d_mix.hpp): packed binary mask, one word per (row, thread of the row)
+    unsigned* mbase = nullptr;                  // ... and the compact-sample bases (RowArgs::mbase)
+    const p3d::mix::Entry* mix_row = nullptr;   // ... the plan of the row length (nullptr: none)
+    bool mix_binary = false;                    // ... the mask of the last pack_mask() was binary: mbits / mbase are valid
     // rows of 1024 samples: the one-exchange persistent row passes (row_pipe32_kernel).  use32 is fixed when the plan is created: the
     // first pass of EVERY job and of every statistics call is then that kernel's (its forward transform rounds differently from
     // line_fft<1024>; statistics and first iteration must see the same bits), whatever kernels the rest of a job takes
@@ -448,7 +453,7 @@ int p3d_plan_destroy(p3d_plan* p)
     if (p->pct_plan) p3d_plan_destroy(p->pct_plan);
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->cbase, p->bits64, p->bits32, p->tw32, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->sum0, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
+    void* bufs[] = {p->mbits, p->mbase, p->cbase, p->bits64, p->bits32, p->tw32, p->nzl, p->nzflag, p->nzm, p->nzcount, p->tw_col, p->tw_row, p->work, p->bits, p->flag, p->rowbase, p->xc, p->sums, p->rowsum, p->sum0, p->tau, p->pct_sel, p->pct_hist, p->pct_frac,
                     p->done,   p->partials, p->st_x, p->st_out, p->st_mask};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -550,6 +555,10 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
         if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
+        if (is_flex(orow) && (p->mix_row = p3d::mix::find(nxl)) != nullptr && !getenv("P3D_NO_MIX_BITS")) {
+            TRY_OR_BAIL(hipMalloc((void**)&p->mbits, sizeof(unsigned long long) * (size_t)nil * p->mix_row->tpl));
+            TRY_OR_BAIL(hipMalloc((void**)&p->mbase, sizeof(unsigned) * ((size_t)nil * p->mix_row->tpl + 1)));
+        }
         if (orow->tpl >= 8 && orow->tpl <= 256 && orow->ppt == 16 && nil % (orow->tpl >= 64 ? 1 : 64 / orow->tpl) == 0 &&
             !getenv("P3D_NO_PIPE64")) {   // the wave-uniform persistent row pass: rows of 128 ... 4096 samples
             const size_t wpl = orow->tpl >= 64 ? (size_t)orow->tpl / 64 : 1;
@@ -1092,6 +1101,19 @@ static int pack_mask(p3d_plan* p, const float* mask, int* nonbinary, unsigned* n
     HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
     *nonbinary = flex_rows ? 1 : 0;
     *nobs = 0;
+    p->mix_binary = false;
+    if (flex_rows && p->mbits) {
+        // rows on the mixed-radix register engine: their own packed words; the float weights stay with every other flexible row pass
+        // (`nonbinary` keeps saying so: the callers hand RowArgs::mask on), p->mix_binary says whether the words may be used beside them
+        int odd = 0;
+        HIP_TRY(p3d::mix::pack_mask(p->mix_row, mask, p->nil, p->mbits, p->mbase, p->flag, p->stream));
+        HIP_TRY(hipMemcpyAsync(&odd, p->flag, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(nobs, p->mbase + (size_t)p->nil * p->mix_row->tpl, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        p->mix_binary = odd == 0;
+        HIP_TRY(hipMemsetAsync(p->flag, 0, 2 * sizeof(int), p->stream));
+        return P3D_OK;
+    }
     if (flex_rows) return P3D_OK;
     const int words = p->nil * p->ops_row->tpl;
     pack_mask_kernel<<<(words + 255) / 256, 256, 0, p->stream>>>(mask, p->bits, p->flag, p->nil, p->nxl, p->ops_row->tpl, p->ops_row->ppt);
@@ -1474,6 +1496,19 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
         if (re == hipErrorNotSupported) real_path = false;
         else HIP_TRY(re);
     }
+    // Rows on the mixed-radix register engine (p3d_mix.hpp) with a binary mask: the packed words instead of the float weights, and in the
+    // steady state the compact observed samples its first pass writes (thread-major order, RowArgs::mbase) -- 1 bit + 8 (1 - missing) bytes
+    // per point and iteration instead of 12.
+    bool mix_compact = false;
+    if (flex_rows && p->mix_binary && !real_path && !sw.no_mask_bits) {
+        r.mbits = p->mbits;
+        r.mbase = p->mbase;
+        mix_compact = niter > 1 && !sw.no_compact && nobs > 0 && (double)nobs < 0.75 * (double)p->slice_elems();
+        if (mix_compact) {
+            if ((rc = ensure_xc(p, nslices, nobs, dtype))) return rc;
+            r.xc = p->xc;
+        }
+    }
     // The primed first pass is the one this run would make itself (row pairs for the real path, the complex one without the APOCS input
     // mix otherwise): work buffer, compact samples and sum |x_obs| are there.
     const bool primed = primed_in && !adaptive && (real_path ? primed_real : !primed_state.real);
@@ -1485,7 +1520,7 @@ int p3d_pocs_run_dev(p3d_plan* p, const void* x, int dtype, const float* mask, c
     } else if (!real_path) {
         HIP_TRY(first_row_pass(p, r));
     }
-    if (compact && !primed) {  // did every unobserved position hold a zero?
+    if ((compact || mix_compact) && !primed) {  // did every unobserved position hold a zero?
         int violation = 0;
         HIP_TRY(hipMemcpyAsync(&violation, p->flag + 1, sizeof(int), hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));

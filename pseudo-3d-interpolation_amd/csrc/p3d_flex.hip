@@ -30,6 +30,7 @@
 #include "p3d_chirp.hpp"
 #include "p3d_flex.hpp"
 #include "p3d_kernels.hpp"
+#include "p3d_mix_entry.hpp"
 
 namespace p3d {
 
@@ -115,6 +116,7 @@ int pick_col_tile(int n)
 {
     const FlexFactors pl = flex_factors(n);
     if (pl.blue) return chirp_col_tile(pl.m);   // chirp-z lengths: the kernels of p3d_chirp.hip
+    if (const mix::Entry* e = mix::find(n)) return e->col_tile;   // 7-smooth lengths: the register engine of p3d_mix.hpp
     if (col_lds(n, 8) <= FLEX_LDS_MAX) return 8;   // a whole 64-byte column block, even at one workgroup per CU (4-column tiles
                                                    // with two workgroups per CU measured 10-18 % slower)
     for (int T : {4, 2, 1}) if (col_lds(n, T) <= FLEX_LDS_MAX) return T;
@@ -958,6 +960,9 @@ ChirpTabs chirp_tabs(const c32* table, const FlexFactors& pl)
     return ChirpTabs{tuned, tuned + chirp_rowtab_slots(pl.m), table, table + pl.n, pl.n, pl.m};
 }
 
+// the tables of the register engine for a 7-smooth length inside its device table: [exp(-2 pi i k / n) | FlexFactors | per-pass twiddle rows]
+const c32* mix_tab(const c32* table, const FlexFactors& pl) { return table + flex_table_len(pl) + (sizeof(FlexFactors) + sizeof(c32) - 1) / sizeof(c32); }
+
 // row-pair passes for float32 cubes (mode = ROW_FIRST / ROW_MID / ROW_LAST)
 hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
 {
@@ -1007,6 +1012,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     if (LB == 0) return hipErrorNotSupported;
     const FlexFactors pl = flex_factors(n);
     if (pl.blue) return chirp_row(mode, a, chirp_tabs(a.tw, pl), st);
+    if (const mix::Entry* e = mix::find(n)) return e->row(mode, a, mix_tab(a.tw, pl), st);
     // two wavefronts per row where the narrowest pass still has ~48 butterflies for them (measured: 500, 768, 1000 gain 20-25 %,
     // 600 = 15*10*4 loses 8 %) and rows can be paired
     int widest = 2;
@@ -1055,6 +1061,7 @@ hipError_t flex_col(int mode, const ColArgs& a, hipStream_t st)
     while ((1 << tshift) < T) ++tshift;
     const FlexFactors pl = flex_factors(n);
     if (pl.blue) return chirp_col(mode, a, chirp_tabs(a.tw, pl), st);
+    if (const mix::Entry* e = mix::find(n)) return e->col(mode, a, mix_tab(a.tw, pl), st);
     const size_t lds = col_lds(n, T);
     if ((size_t)n * T > (size_t)FLEX_COL_PF * FLEX_COL_THREADS) return hipErrorNotSupported;   // (never: col_lds <= FLEX_LDS_MAX)
     int cus = a.cus;   // the plan's device (a.cus = 0: a caller without a plan -- ask the current device)
@@ -1106,6 +1113,11 @@ void flex_build_table(int n, std::vector<c32>& out)
         out.resize(n);
         gen_build_twiddles(n, out.data());
         append_factors();
+        if (const mix::Entry* e = mix::find(n)) {   // the per-pass twiddle rows of the register engine (p3d_mix.hpp), read through mix_tab()
+            const size_t at = out.size();
+            out.resize(at + (size_t)e->tw_slots + 1, c32{0.f, 0.f});
+            e->build_tw(out.data() + at);
+        }
         return;
     }
     const int M = pl.m;

@@ -185,6 +185,9 @@ struct RowArgs {
     const unsigned long long* bits32;  // row_pipe32_kernel (rows of 1024 samples, a row pair per wavefront): word (unit u, register k) bit l =
                                        // mask[2u + (l >> 5)][(l & 31) + 32 k]; [n1 / 2][32]
     const c32* tw32;                   // ... and its twiddles (P32::build_tw, device)
+    const unsigned long long* mbits;   // mixed-radix row pass (p3d_mix.hpp), binary masks: word (row, tl) bit q = mask[row][tl + TPL q]; [n1][TPL]
+    const unsigned* mbase;             // ... observed positions of the slice before thread (row, tl)'s own, in (row, tl) order: the compact samples
+                                       //     `xc` of that pass are stored thread by thread (thread-major), entry [n1 * TPL] = nobs
     float alpha;
     float scale;           // 1/(n1*N)
     int len;               // N, the row length (the tuned kernels know it at compile time; p3d_flex.hip reads it here)

@@ -24,6 +24,7 @@
 #pragma once
 
 #include "p3d_kernels_common.hpp"
+#include "p3d_mix_entry.hpp"
 
 namespace p3d {
 namespace mix {
@@ -135,7 +136,8 @@ struct MixPlan {
     static_assert(N_ % PPT_ == 0, "PPT divides N");
     // padding of the LDS image: one slot per PADQ positions (0: none).  The compile-time offsets of gather and scatter need PADQ | TPL and
     // PADQ | Ns of every later pass (Ns is a multiple of R0).
-    static constexpr int PADQ = (TPL % R0 == 0 && R0 > 2) ? R0 : 0;
+    // An ODD first radix already walks the banks with an odd stride (in positions): no padding then.
+    static constexpr int PADQ = (TPL % R0 == 0 && R0 > 2 && R0 % 2 == 0) ? R0 : 0;
     static constexpr int pad(int pos) { return PADQ ? pos + pos / PADQ : pos; }
     static constexpr int LINE = pad(N_);   // slots of one line's LDS image
     // twiddle rows of pass p >= 1 start at tw_off(p): (R - 1) rows of Ns entries
@@ -262,7 +264,7 @@ __device__ __forceinline__ bool lex_gt(float ar, float ai, float br, float bi) {
 // spectrum (column) pass: forward transform, threshold, inverse transform of a tile of COLT columns (modes as col_kernel / flex_col_kernel)
 // =========================================================================================================================================
 template <class PL>
-__global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArgs a, const c32* __restrict__ tab, int mode)
+__global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArgs a, const c32* __restrict__ tab, int mode, int ntiles)
 {
     constexpr int N = PL::N, PPT = PL::PPT, TPL = PL::TPL, T = PL::COLT, THREADS = T * TPL;
     using LDS = Lds<PL, T>;
@@ -273,7 +275,17 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
 
     const int tid = threadIdx.x;
     const int c_lo = tid % T, tl = tid / T;
-    const int slice = blockIdx.y, tile = blockIdx.x;
+    const int slice = blockIdx.y;
+    // Tiles narrower than a 64-byte column block (long columns): the 8 / T tiles of one block go to workgroups g, g + 8, ..., which the
+    // dispatcher places on the same XCD one after the other (workgroup g of a grid whose x extent is a multiple of 8 runs on XCD g % 8):
+    // the block's cache lines come from HBM once, the sibling tiles hit that XCD's L2.  The launcher rounds the grid up for this.
+    int tile = blockIdx.x;
+    if constexpr (T < 8) {
+        constexpr int G = 8 / T;
+        const int xcd = tile & 7, j = tile >> 3;
+        tile = ((j / G) * 8 + xcd) * G + (j % G);
+    }
+    if (tile >= ntiles) return;
     const int col = tile * T + c_lo;
     const bool valid = col < a.n2;
     if (a.done && a.done[slice] != 0) return;
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
         if (iter && a.nzflag != nullptr) {
             // a tile the threshold emptied stays zeros after the inverse transform: say so instead of transforming and storing it
             const int kept = __syncthreads_or((valid && bits != 0u) ? 1 : 0);
-            if (tid == 0) a.nzflag[(size_t)slice * gridDim.x + tile] = kept ? 1 : 0;
+            if (tid == 0) a.nzflag[(size_t)slice * ntiles + tile] = kept ? 1 : 0;
             if (!kept) {
                 // the row pass skips whole 8-column BLOCKS: an empty tile narrower than a block must leave zeros behind for the case that a
                 // sibling tile of its block kept something (see col_kernel)
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
                 mn = fminf(mn, red[w * 5 + 3]);
                 sq += red[w * 5 + 4];
             }
-            float* p = a.partials + ((size_t)slice * gridDim.x + tile) * STATS_PARTIAL;
+            float* p = a.partials + ((size_t)slice * ntiles + tile) * STATS_PARTIAL;
             p[0] = lr; p[1] = li; p[2] = sqrtf(mx); p[3] = sqrtf(mn); p[4] = sq;
         }
         return;
@@ -388,108 +400,182 @@ template <class PL>
 __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowArgs a, const c32* __restrict__ tab, int mode)
 {
     constexpr int N = PL::N, PPT = PL::PPT, TPL = PL::TPL, LB = PL::ROWLB, THREADS = LB * TPL;
-    using LDS = Lds<PL, 1>;
+    // Rows are taken in PAIRS (2 p, 2 p + 1) whose threads alternate lane by lane: the two rows' 64-byte pieces of a column block are
+    // neighbours in the column-blocked work buffer, so one load or store instruction of a wavefront then moves whole 128-byte lines (a row
+    // alone touches half of every line it reads or writes, the other half moved by another wavefront at another time); in LDS the pair is
+    // a two-line tile, element-major, like the column pass's.
+    static_assert(LB % 2 == 0, "rows are worked on in pairs");
+    using LDS = Lds<PL, 2>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ uint8_t nzl[N + 8];   // the slice's tile flags, one byte per column tile (a tile is 1 ... 8 columns wide: at most N of them)
     c32* twl = reinterpret_cast<c32*>(smem_raw);
     c32* data = twl + PL::TW_SLOTS;
-    const int tid = threadIdx.x, line = tid / TPL, tl = tid % TPL;
+    const int tid = threadIdx.x, par = tid & 1, tl = (tid >> 1) % TPL, pair = (tid >> 1) / TPL, line = 2 * pair + par;
     const int slice = blockIdx.y, row = blockIdx.x * LB + line;
     const bool valid = row < a.n1;
-    const int vrow = valid ? row : 0;
-    for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
-    __syncthreads();
-    const LDS lds{data + line * PL::LINE};
 
     const int dn = a.done ? a.done[slice] : 0;   // (uniform over the workgroup: every early return below is taken by all of its threads)
-    const size_t sbase = ((size_t)slice * a.n1 + vrow) * N;   // row-major cubes (x, out)
+    // Every access to the cubes and the work buffer is an UNCONDITIONAL buffer instruction; a lane that must not take part carries an offset
+    // beyond the descriptor's range (loads return zero, stores are dropped).  One branch per predicated access would end every wait of the
+    // unrolled loops at vmcnt(0): twenty exposed memory latencies in a row instead of one (measured: 1.5 -> 0.7 ms for this pass).
+    const unsigned esz = a.dtype == 0 ? 8u : 4u;
+    const unsigned cube_bytes = (unsigned)a.n1 * N * esz;            // one slice of x / out (< 2 GiB: extents <= 4096)
+    const __amdgpu_buffer_rsrc_t xsrd = buf_srd(reinterpret_cast<const char*>(a.x) + (size_t)slice * cube_bytes, cube_bytes);
+    const __amdgpu_buffer_rsrc_t osrd = buf_srd(reinterpret_cast<const char*>(a.out) + (size_t)slice * cube_bytes, a.out ? cube_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t msrd = buf_srd(a.mask, a.mask ? (unsigned)a.n1 * N * 4u : 0u);
+    const unsigned wbytes = (unsigned)(wk_slice_stride(a.n1, N) * sizeof(c32));
+    const __amdgpu_buffer_rsrc_t wsrd = buf_srd(a.work + (size_t)slice * wk_slice_stride(a.n1, N), wbytes);
+    const unsigned el0 = (unsigned)row * N + tl;                     // element (row, tl) of a row-major slice
+    const unsigned xoff = valid ? el0 * esz : BUF_OOB, moff = valid ? el0 * 4u : BUF_OOB;
+    const unsigned wblk = (unsigned)a.n1 * 8;
+    auto woff = [&](int q) -> unsigned {   // byte offset of element (row, tl + TPL q) in the column-blocked slice
+        const int i = tl + TPL * q;
+        return ((unsigned)(i >> 3) * wblk + (unsigned)row * 8 + (unsigned)(i & 7)) * 8u;
+    };
+
     if (mode == ROW_LAST && a.only_done) {
         if (dn <= a.only_done_lo || dn > a.only_done) return;
     } else if (mode == ROW_LAST) {
         if (dn > 0) return;   // converged earlier: `out` already holds that iterate
         if (dn < 0) {         // an all-zero slice is handed back untouched (POCS.py:515-521)
-            if (valid) {
 #pragma unroll
-                for (int q = 0; q < PPT; ++q) {
-                    if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + tl + TPL * q] = c32{0.f, 0.f};
-                    else reinterpret_cast<float*>(a.out)[sbase + tl + TPL * q] = 0.f;
-                }
+            for (int q = 0; q < PPT; ++q) {
+                if (a.dtype == 0) buf_store_c32(osrd, xoff, (unsigned)(TPL * q) * 8u, c32{0.f, 0.f});
+                else __builtin_amdgcn_raw_buffer_store_b32(0u, osrd, (int)xoff, (int)((unsigned)(TPL * q) * 4u), 0);
             }
             return;
         }
     } else if (dn != 0) {
         return;
     }
-    c32* const wrow = a.work + (size_t)slice * wk_slice_stride(a.n1, N) + (size_t)vrow * 8;   // + (i >> 3) n1 8 + (i & 7)
-    const unsigned wblk = (unsigned)a.n1 * 8;
-    auto woff = [&](int q) -> unsigned { const int i = tl + TPL * q; return (unsigned)(i >> 3) * wblk + (unsigned)(i & 7); };
-    auto obs_at = [&](int i) -> c32 {
-        if (a.dtype == 0) return reinterpret_cast<const c32*>(a.x)[sbase + i];
-        return c32{reinterpret_cast<const float*>(a.x)[sbase + i], 0.f};
+
+    // tables into LDS: the twiddle rows, and the slice's tile flags (column blocks the column pass found empty were not stored: they read as zeros)
+    const uint8_t* const nzf = (mode != ROW_FIRST && a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
+    for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
+    if (nzf)
+        for (int i = tid; i < a.nz_tiles; i += THREADS) nzl[i] = nzf[i];
+    __syncthreads();
+    const LDS lds{data + pair * (2 * PL::LINE) + par};
+
+    // binary masks travel as one 64-bit word per thread and row (bit q = mask[row][tl + TPL q]); the observed samples of the steady state
+    // then come from the COMPACT array the first pass wrote: thread by thread, a thread's samples in q order (RowArgs::mbits / mbase / xc)
+    unsigned long long mbits = 0;
+    unsigned cbase = 0;
+    if (a.mbits != nullptr && valid) {
+        mbits = a.mbits[(size_t)row * TPL + tl];
+        cbase = a.mbase[(size_t)row * TPL + tl];
+    }
+    const bool compact = a.xc != nullptr && a.mbits != nullptr;
+    const __amdgpu_buffer_rsrc_t csrd = buf_srd(reinterpret_cast<const char*>(a.xc) + (size_t)slice * a.nobs * esz, compact ? a.nobs * esz : 0u);
+    auto coff = [&](int q) -> unsigned {   // byte offset of this thread's sample q in the slice's compact array (switched off where the trace is missing)
+        const unsigned below = (unsigned)__popcll(mbits & ((1ull << q) - 1ull));
+        return ((mbits >> q) & 1ull) ? (cbase + below) * esz : BUF_OOB;
     };
-    const float* const mrow = a.mask ? a.mask + (size_t)vrow * N : nullptr;
+    auto load_obs = [&](c32 (&xo)[PPT]) {
+        if (compact && mode != ROW_FIRST) {
+            if (a.dtype == 0) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) xo[q] = buf_load_c32(csrd, coff(q), 0u);
+            } else {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) xo[q] = c32{buf_load_f32(csrd, coff(q), 0u), 0.f};
+            }
+        } else if (a.dtype == 0) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) xo[q] = buf_load_c32(xsrd, xoff, (unsigned)(TPL * q) * 8u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) xo[q] = c32{buf_load_f32(xsrd, xoff, (unsigned)(TPL * q) * 4u), 0.f};
+        }
+    };
+    auto load_mask = [&](float (&mk)[PPT]) {   // (no mask: the descriptor is empty, every lane reads zero)
+        if (a.mbits != nullptr) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) mk[q] = ((mbits >> q) & 1ull) ? 1.0f : 0.0f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) mk[q] = buf_load_f32(msrd, moff, (unsigned)(TPL * q) * 4u);
+        }
+    };
 
     float acc = 0.f;
     c32 v[PPT];
     if (mode == ROW_FIRST) {
+        load_obs(v);
+        if (compact) {
+            // the compact copy of the observed samples; a non-zero sample where the mask says "missing" makes it unusable (RowArgs::violation)
+            bool viol = false;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int i = tl + TPL * q;
-            const c32 x = valid ? obs_at(i) : c32{0.f, 0.f};
-            acc += abs_c32(x);
-            if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
-                const float m = mrow ? mrow[i] : 0.f;
-                const float w = 1.0f - a.alpha * m;
-                const c32 blend = x * a.alpha + x * w;
-                v[q] = blend + (x - x * m) * (1.0f - a.alpha);
-            } else {
-                v[q] = x;
+            for (int q = 0; q < PPT; ++q) {
+                if (a.dtype == 0) __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{__float_as_uint(v[q].x), __float_as_uint(v[q].y)}, csrd, (int)coff(q), 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), csrd, (int)coff(q), 0, 0);
+                viol = viol || (!((mbits >> q) & 1ull) && (v[q].x != 0.0f || v[q].y != 0.0f));
             }
+            if (viol && a.violation) *a.violation = 1;
+        }
+        if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
+            float mk[PPT];
+            load_mask(mk);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const c32 x = v[q];
+                acc += abs_c32(x);
+                const float w = 1.0f - a.alpha * mk[q];
+                const c32 blend = x * a.alpha + x * w;
+                v[q] = blend + (x - x * mk[q]) * (1.0f - a.alpha);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) acc += abs_c32(v[q]);
         }
     } else {
-        // column blocks the column pass found empty were not stored (RowArgs::nzflag): they read as zeros
-        const uint8_t* const nzf = (a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
         const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             bool kept = valid;
-            if (nzf) kept = kept && nzf[(tl + TPL * q) >> tsh] != 0;
-            v[q] = kept ? wrow[woff(q)] : c32{0.f, 0.f};
+            if (nzf) kept = kept && nzl[(tl + TPL * q) >> tsh] != 0;
+            v[q] = buf_load_c32(wsrd, kept ? woff(q) : BUF_OOB, 0u);
         }
         line_fft<PL, INV>(v, lds, twl, tl);
-        const bool need_obs = !a.plain && valid;
+        c32 xo[PPT];
+        float mk[PPT];
+        if (!a.plain) {
+            load_obs(xo);
+            load_mask(mk);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) { xo[q] = c32{0.f, 0.f}; mk[q] = 0.f; }
+        }
+        const bool handback = mode == ROW_LAST && a.only_done;
+        const bool store_out = mode == ROW_LAST || a.write_out;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int i = tl + TPL * q;
-            const c32 xo = need_obs ? obs_at(i) : c32{0.f, 0.f};
-            const float mk = (mrow && !a.plain) ? mrow[i] : 0.f;
             c32 xn = v[q] * a.scale;
             float m = 0.f;
-            if (mode == ROW_LAST && a.only_done) {
+            if (handback) {
                 // the converged iterate up to one row-transform round trip; an observed trace with alpha = 1 IS the observation
-                if (a.alpha == 1.0f && mrow && mk == 1.0f) xn = xo;
+                if (a.alpha == 1.0f && (a.mask || a.mbits) && mk[q] == 1.0f) xn = xo[q];
             } else if (!a.plain) {
-                m = mk;
+                m = mk[q];
                 const float w = 1.0f - a.alpha * m;        // POCS.py:616
-                xn = axpby(xn, w, xo, a.alpha);            // POCS.py:619
+                xn = axpby(xn, w, xo[q], a.alpha);         // POCS.py:619
             }
             acc += abs_c32(xn);
-            if ((mode == ROW_LAST || a.write_out) && valid) {
-                if (a.dtype == 0) reinterpret_cast<c32*>(a.out)[sbase + i] = xn;
-                else reinterpret_cast<float*>(a.out)[sbase + i] = xn.x;   // np.real(), POCS.py:656
-            }
+            if (a.dtype == 0) buf_store_c32(osrd, store_out ? xoff : BUF_OOB, (unsigned)(TPL * q) * 8u, xn);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn.x), osrd, (int)(store_out ? xoff : BUF_OOB), (int)((unsigned)(TPL * q) * 4u), 0);   // np.real(), POCS.py:656
             if (mode == ROW_MID && a.adaptive) {   // x_input of the next iteration (POCS.py:574-575)
                 const float w = 1.0f - a.alpha * m;
-                const c32 blend = xo * a.alpha + xn * w;
-                v[q] = blend + (xo - xn * m) * (1.0f - a.alpha);
+                const c32 blend = xo[q] * a.alpha + xn * w;
+                v[q] = blend + (xo[q] - xn * m) * (1.0f - a.alpha);
             } else {
                 v[q] = xn;
             }
         }
     }
     if (a.sums != nullptr) {
-        // per-row sum of |x| in a fixed order: the threads' partial sums go through the row's LDS image, one thread adds them up in double
+        // per-row sum of |x| in a fixed order: the threads' partial sums go through the pair's LDS image, one thread per row adds them up in double
         __syncthreads();   // (the image is free: the inverse transform's last gather is behind every thread)
-        float* part = reinterpret_cast<float*>(data + line * PL::LINE);
+        float* part = reinterpret_cast<float*>(data + pair * (2 * PL::LINE)) + par * TPL;
         part[tl] = acc;
         __syncthreads();
         if (tl == 0 && valid) {
@@ -500,21 +586,10 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
     }
     if (mode != ROW_LAST) {
         line_fft<PL, FWD>(v, lds, twl, tl);
-        if (valid) {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) wrow[woff(q)] = v[q];
-        }
+        for (int q = 0; q < PPT; ++q) buf_store_c32(wsrd, valid ? woff(q) : BUF_OOB, 0u, v[q]);
     }
 }
-
-// what the launchers of p3d_flex.hip need to know about a plan
-struct Entry {
-    int n, col_tile, tw_slots;
-    void (*build_tw)(c32* out);
-    hipError_t (*row)(int mode, const RowArgs& a, const c32* tab, hipStream_t st);
-    hipError_t (*col)(int mode, const ColArgs& a, const c32* tab, hipStream_t st);
-};
-const Entry* find(int n);   // nullptr: no plan for this length (p3d_flex.hip runs it as an LDS image)
 
 }  // namespace mix
 }  // namespace p3d

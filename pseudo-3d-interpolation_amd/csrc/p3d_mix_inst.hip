@@ -28,8 +28,14 @@ hipError_t launch_col(int mode, const ColArgs& a, const c32* tab, hipStream_t st
         if (e != hipSuccess) return e;
         attr = true;
     }
-    const dim3 grid((a.n2 + PL::COLT - 1) / PL::COLT, a.nslices);
-    mix_col_kernel<PL><<<grid, PL::COLT * PL::TPL, lds, st>>>(a, tab, mode);
+    // tiles narrower than a 64-byte column block: the grid is rounded up so that the kernel can deal the 8 / COLT tiles of one block to
+    // workgroups that share an XCD (see mix_col_kernel); the surplus workgroups leave at once
+    constexpr int G = 8 / PL::COLT;
+    int tiles = (a.n2 + PL::COLT - 1) / PL::COLT;
+    const int ntiles = tiles;
+    if (G > 1) tiles = (tiles + 8 * G - 1) / (8 * G) * (8 * G);
+    const dim3 grid(tiles, a.nslices);
+    mix_col_kernel<PL><<<grid, PL::COLT * PL::TPL, lds, st>>>(a, tab, mode, ntiles);
     return hipGetLastError();
 }
 
@@ -52,11 +58,11 @@ hipError_t launch_row(int mode, const RowArgs& a, const c32* tab, hipStream_t st
 }
 
 #define X(N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4)                                                                              \
-    {N, COLT, MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>::TW_SLOTS, &MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>::build_tw, \
+    {N, COLT, MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>::TW_SLOTS, N / PPT, PPT, &MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>::build_tw, \
      &launch_row<MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>>, &launch_col<MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>>},
 const Entry entries[] = {
 #include "p3d_mix_plans.inc"
-    {0, 0, 0, nullptr, nullptr, nullptr}};
+    {0, 0, 0, 0, 0, nullptr, nullptr, nullptr}};
 #undef X
 
 }  // namespace
