@@ -5,20 +5,20 @@
 // LDS image with one butterfly per thread and pass, radix and strides read at run time (0.27 - 0.40 of the tuned rate).  This file is the
 // engine of p3d_fft.hpp for N = R0 R1 ... with radices 2 ... 32 built from 2, 3, 5 and 7:
 //
-//   * a line is held by TPL = N / PPT threads, PPT points each, canonical layout  register q of thread tl <-> element tl + TPL q  before the
-//     first and after the last pass of a transform (global loads / stores coalesce over tl; forward -> threshold -> inverse chain through
-//     registers);
-//   * every radix divides PPT: butterfly s of thread tl in pass p is butterfly j = tl + s TPL of the Stockham recipe, its R inputs
-//     in[j + t N / R] are the registers s + (PPT / R) t -- no data moves before a pass; a pass of radix R (Ns = product of the radices
-//     before it) computes  v[t] = in[j + t N/R] w^(t (j mod Ns)),  out[(j div Ns) Ns R + (j mod Ns) + k Ns] = DFT_R(v)[k]  and hands its
-//     outputs round through LDS (scatter, barrier, canonical gather); the last pass leaves the canonical layout by itself;
+//   * in pass p a line is held by TPL_p = N / PPT_p threads, PPT_p = R_p B_p points each, layout  register q of thread tl <-> element
+//     tl + TPL_p q  (global loads / stores coalesce over tl); butterfly s of thread tl is butterfly j = tl + s TPL_p of the Stockham recipe,
+//     its R_p inputs in[j + t N / R_p] are the registers s + B_p t -- no data moves before a pass; a pass of radix R (Ns = product of the
+//     radices before it) computes  v[t] = in[j + t N/R] w^(t (j mod Ns)),  out[(j div Ns) Ns R + (j mod Ns) + k Ns] = DFT_R(v)[k]  and hands
+//     its outputs round through LDS (scatter, barrier, gather in the next pass's layout); the last pass leaves its own layout by itself.
+//     The split (B_p) is chosen per pass, and the inverse transform runs the passes in reversed order, so that transforms chain through
+//     registers (MixPlan below);
 //   * everything about a plan is a compile-time constant (MixPlan<N, PPT, R...>): strides fold into instruction offsets, the division by
 //     Ns is a multiply, the small DFTs are straight-line code (Cooley-Tukey on 4 / 2 / 3 / 5 / 7, root constants as literals);
-//   * twiddles: per pass p >= 1 (R - 1) rows of Ns entries exp(-2 pi i t jm / (Ns R)) in the order neighbouring threads read them, one table
-//     per length in LDS, conjugated inside the multiply for the inverse transform;
+//   * twiddles in LDS: one master table exp(-2 pi i k / N) for the last pass of either direction, ordered rows for the middle passes
+//     (MixPlan::build_tw), conjugated inside the multiply for the inverse transform;
 //   * LDS image of a line: one padding slot per R0 positions, so that the first scatter (stride R0) walks the banks with an odd stride.
 //
-// The plans are chosen by tools/gen_mix_plans.py (fewest passes, radices dividing PPT, PPT near 20) and listed in p3d_mix_plans.inc; the
+// The plans are chosen by tools/gen_mix_plans.py (fewest passes, ~16-24 points per thread in every pass) and listed in p3d_mix_plans.inc; the
 // kernels are instantiated per plan in p3d_mix_inst.hip (several translation units) and reached through the launchers of p3d_flex.hip,
 // i.e. behind the same LineOps / RowArgs / ColArgs interface and on the same column-blocked work buffer as every other length.
 #pragma once
@@ -119,75 +119,124 @@ struct SmallDft {
 };
 
 // ---- compile-time plan ---------------------------------------------------------------------------------------------------------------
-template <int N_, int PPT_, int COLT_, int ROWLB_, int NPASS_, int R0, int R1, int R2, int R3, int R4>
+// Forward passes p = 0 ... NPASS-1 have radix R_p and B_p butterflies per thread, i.e. PPT_p = R_p B_p points per thread and TPL_p = N / PPT_p
+// active threads per line IN THAT PASS: the data goes round through LDS between two passes anyway, so every pass picks the split that keeps
+// ~16-24 points in registers whatever its radix (960 = 15 x 8 x 8 runs as 64 x 15, 60 x 16, 60 x 16 points; one common PPT would have to be
+// 120).  The inverse transform runs the passes in REVERSED order: its first pass has the layout of the forward transform's last one, so
+// forward -> threshold -> inverse (column pass) and inverse -> re-insertion -> forward (row pass) chain through registers.  Two layouts
+// therefore meet global memory:  A = (PPT_0, TPL_0), the first forward pass -- cubes, masks, compact samples;  B = (PPT_last, TPL_last) --
+// the work buffer between the two passes of an iteration.
+template <int N_, int COLT_, int ROWLB_, int NPASS_, int R0, int B0, int R1, int B1, int R2, int B2, int R3, int B3>
 struct MixPlan {
-    static constexpr int N = N_, PPT = PPT_, TPL = N_ / PPT_, NPASS = NPASS_;
+    static constexpr int N = N_, NPASS = NPASS_;
     static constexpr int COLT = COLT_;     // columns per workgroup of the column pass
     static constexpr int ROWLB = ROWLB_;   // rows per workgroup of the row pass
-    static constexpr int radix(int p) { return p == 0 ? R0 : p == 1 ? R1 : p == 2 ? R2 : p == 3 ? R3 : R4; }
-    static constexpr int ns(int p)
+    static constexpr int fr(int p) { return p == 0 ? R0 : p == 1 ? R1 : p == 2 ? R2 : R3; }
+    static constexpr int fb(int p) { return p == 0 ? B0 : p == 1 ? B1 : p == 2 ? B2 : B3; }
+    static constexpr int fwd_index(int dir, int p) { return dir == FWD ? p : NPASS_ - 1 - p; }
+    static constexpr int radix(int dir, int p) { return fr(fwd_index(dir, p)); }
+    static constexpr int nb(int dir, int p) { return fb(fwd_index(dir, p)); }
+    static constexpr int ppt(int dir, int p) { return radix(dir, p) * nb(dir, p); }
+    static constexpr int tpl(int dir, int p) { return N_ / ppt(dir, p); }
+    static constexpr int ns(int dir, int p)
     {
         int r = 1;
-        for (int q = 0; q < p; ++q) r *= radix(q);
+        for (int q = 0; q < p; ++q) r *= radix(dir, q);
         return r;
     }
-    static_assert(ns(NPASS_) == N_, "the radices must multiply to N");
-    static_assert(PPT_ % R0 == 0 && PPT_ % R1 == 0 && PPT_ % R2 == 0 && PPT_ % R3 == 0 && PPT_ % R4 == 0, "every radix divides the points per thread");
-    static_assert(N_ % PPT_ == 0, "PPT divides N");
-    // padding of the LDS image: one slot per PADQ positions (0: none).  The compile-time offsets of gather and scatter need PADQ | TPL and
-    // PADQ | Ns of every later pass (Ns is a multiple of R0).
-    // An ODD first radix already walks the banks with an odd stride (in positions): no padding then.
-    static constexpr int PADQ = (TPL % R0 == 0 && R0 > 2 && R0 % 2 == 0) ? R0 : 0;
-    static constexpr int pad(int pos) { return PADQ ? pos + pos / PADQ : pos; }
-    static constexpr int LINE = pad(N_);   // slots of one line's LDS image
-    // twiddle rows of pass p >= 1 start at tw_off(p): (R - 1) rows of Ns entries
-    static constexpr int tw_off(int p)
+    static_assert(ns(FWD, NPASS_) == N_, "the radices must multiply to N");
+    static_assert(N_ % (R0 * B0) == 0 && N_ % (R1 * B1) == 0 && N_ % (R2 * B2) == 0 && N_ % (R3 * B3) == 0, "every pass splits the line evenly");
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int VMAX = cmax(cmax(R0 * B0, R1 * B1), cmax(NPASS_ > 2 ? R2 * B2 : 1, NPASS_ > 3 ? R3 * B3 : 1));   // registers (points) per thread
+    static constexpr int tmax()
+    {
+        int m = R0 * B0;
+        for (int p = 1; p < NPASS_; ++p) m = (fr(p) * fb(p) < m) ? fr(p) * fb(p) : m;
+        return N_ / m;
+    }
+    static constexpr int TMAX = tmax();   // threads per line
+    static constexpr int PPT_A = ppt(FWD, 0), TPL_A = tpl(FWD, 0), PPT_B = ppt(FWD, NPASS_ - 1), TPL_B = tpl(FWD, NPASS_ - 1);
+    // Padding of a line's LDS image, per direction: one slot per PADQ positions where the first radix of the direction is even (its scatter
+    // then walks the banks with the odd stride R + 1; an odd radix does so by itself).  Offsets fold into the instructions wherever PADQ
+    // divides the constant part of a position.
+    static constexpr int padq(int dir) { return (radix(dir, 0) % 2 == 0 && radix(dir, 0) > 2) ? radix(dir, 0) : 0; }
+    static constexpr int pad(int dir, int pos) { return padq(dir) ? pos + pos / padq(dir) : pos; }
+    static constexpr int LINE = cmax(pad(FWD, N_), pad(INV, N_));   // slots of one line's LDS image
+    // Twiddles.  The LAST pass of either direction (Ns = N / R) multiplies by exp(-+2 pi i t jm / N): both directions read ONE master table
+    // exp(-2 pi i k / N) at k = t jm (conjugated inside the multiply for the inverse transform), padded by one slot per 32 entries so that the
+    // strides t spread over the banks.  The MIDDLE passes (1 <= p < NPASS - 1) have (R - 1) rows of Ns entries exp(-2 pi i t jm / (Ns R)) each,
+    // in the order neighbouring threads read them, per direction.  (Ordered rows for the last passes too would take ~N entries per direction:
+    // with a 64-KiB column tile that is the difference between two workgroups per CU and one.)
+    static constexpr int master_idx(int k) { return k + (k >> 5); }
+    static constexpr int MASTER = NPASS_ > 1 ? master_idx(N_) + 1 : 0;
+    static constexpr int mid_len(int dir)
     {
         int o = 0;
-        for (int q = 1; q < p; ++q) o += (radix(q) - 1) * ns(q);
+        for (int q = 1; q + 1 < NPASS_; ++q) o += (radix(dir, q) - 1) * ns(dir, q);
         return o;
     }
-    static constexpr int TW_SLOTS = tw_off(NPASS_);
+    static constexpr int tw_off(int dir, int p)   // rows of middle pass p
+    {
+        int o = MASTER + (dir == FWD ? 0 : mid_len(FWD));
+        for (int q = 1; q < p; ++q) o += (radix(dir, q) - 1) * ns(dir, q);
+        return o;
+    }
+    static constexpr int TW_SLOTS = MASTER + mid_len(FWD) + mid_len(INV);
     static void build_tw(c32* out)
     {
-        for (int p = 1; p < NPASS; ++p) {
-            const int R = radix(p), NS = ns(p), o = tw_off(p);
-            for (int t = 1; t < R; ++t)
-                for (int jm = 0; jm < NS; ++jm) {
-                    const double ang = -6.283185307179586476925286766559 * double(t) * double(jm) / (double(NS) * R);
-                    out[o + (t - 1) * NS + jm] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
-                }
-        }
+        for (int i = 0; i < TW_SLOTS; ++i) out[i] = c32{0.f, 0.f};
+        if (NPASS > 1)
+            for (int k = 0; k < N; ++k) {
+                const double ang = -6.283185307179586476925286766559 * double(k) / double(N);
+                out[master_idx(k)] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
+            }
+        for (int dir = -1; dir <= 1; dir += 2)
+            for (int p = 1; p + 1 < NPASS; ++p) {
+                const int R = radix(dir, p), NS = ns(dir, p), o = tw_off(dir, p);
+                for (int t = 1; t < R; ++t)
+                    for (int jm = 0; jm < NS; ++jm) {
+                        const double ang = -6.283185307179586476925286766559 * double(t) * double(jm) / (double(NS) * R);
+                        out[o + (t - 1) * NS + jm] = c32{float(__builtin_cos(ang)), float(__builtin_sin(ang))};
+                    }
+            }
     }
 };
 
-// LDS view of one line: W lines interleaved element-major ([pos][W]); `base` points at this thread's line
-template <class PL, int W>
+// LDS view of one line for the transforms of one direction: W lines interleaved element-major ([pos][W]); `base` points at this thread's line
+template <class PL, int DIR, int W>
 struct Lds {
-    static constexpr int WIDTH = W;
+    static constexpr int WIDTH = W, PADQ = PL::padq(DIR);
     c32* base;
-    __device__ __forceinline__ c32* ptr(int pos) const { return base + (PL::PADQ ? pos + pos / PL::PADQ : pos) * W; }
-    static constexpr int rel(int c) { return PL::pad(c) * W; }   // pad(p + c) == pad(p) + pad(c) when PADQ | c
+    __device__ __forceinline__ c32* ptr(int pos) const { return base + (PADQ ? pos + pos / PADQ : pos) * W; }
+    static constexpr int rel(int c) { return PL::pad(DIR, c) * W; }   // pad(p + c) == pad(p) + pad(c) when PADQ | c
+    static constexpr bool folds(int c) { return PADQ == 0 || c % PADQ == 0; }
 };
 
 template <class PL, int DIR, int P, int T>
 struct TwApply {   // a[t] = v[s + NB t] * w_t, t = T ... R-1 (compile-time t: the row offsets fold into the instruction)
     template <int R, int NB>
-    static __device__ __forceinline__ void run(c32* a, const c32* v, int s, const c32* twp)
+    static __device__ __forceinline__ void run(c32* a, const c32* v, int s, const c32* tw, int jm)
     {
         if constexpr (T < R) {
-            const c32 w = twp[(T - 1) * PL::ns(P)];
+            c32 w;
+            if constexpr (P + 1 == PL::NPASS) {
+                const int k = T * jm;
+                w = tw[k + (k >> 5)];                                           // the master table (last pass)
+            } else {
+                w = (tw + (PL::tw_off(DIR, P) + (T - 1) * PL::ns(DIR, P)))[jm];   // ordered rows (middle pass)
+            }
             a[T] = DIR > 0 ? mul_conj(v[s + NB * T], w) : v[s + NB * T] * w;
-            TwApply<PL, DIR, P, T + 1>::template run<R, NB>(a, v, s, twp);
+            TwApply<PL, DIR, P, T + 1>::template run<R, NB>(a, v, s, tw, jm);
         }
     }
 };
 
-// one pass in registers: twiddles, NB radix-R DFTs; output k of butterfly s ends up in register s + NB k
+// one pass in registers: twiddles, NB radix-R DFTs; output k of butterfly s ends up in register s + NB k.  Threads tl >= TPL_p sit the pass out.
 template <class PL, int DIR, int P>
-__device__ __forceinline__ void pass_compute(c32 (&v)[PL::PPT], const c32* tw, int tl)
+__device__ __forceinline__ void pass_compute(c32 (&v)[PL::VMAX], const c32* tw, int tl)
 {
-    constexpr int R = PL::radix(P), NS = PL::ns(P), NB = PL::PPT / R;
+    constexpr int R = PL::radix(DIR, P), NS = PL::ns(DIR, P), NB = PL::nb(DIR, P), TPL = PL::tpl(DIR, P);
+    if (TPL < PL::TMAX && tl >= TPL) return;
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         c32 a[R];
@@ -196,8 +245,8 @@ __device__ __forceinline__ void pass_compute(c32 (&v)[PL::PPT], const c32* tw, i
 #pragma unroll
             for (int t = 1; t < R; ++t) a[t] = v[s + NB * t];
         } else {
-            const int jm = (tl + s * PL::TPL) % NS;
-            TwApply<PL, DIR, P, 1>::template run<R, NB>(a, v, s, tw + PL::tw_off(P) + jm);
+            const int jm = (tl + s * TPL) % NS;
+            TwApply<PL, DIR, P, 1>::template run<R, NB>(a, v, s, tw, jm);
         }
         SmallDft<R, DIR>::run(a);
 #pragma unroll
@@ -205,19 +254,20 @@ __device__ __forceinline__ void pass_compute(c32 (&v)[PL::PPT], const c32* tw, i
     }
 }
 
-template <class PL, int P, class LDS>
-__device__ __forceinline__ void pass_scatter(const c32 (&v)[PL::PPT], LDS lds, int tl)
+template <class PL, int DIR, int P, class LDS>
+__device__ __forceinline__ void pass_scatter(const c32 (&v)[PL::VMAX], LDS lds, int tl)
 {
-    constexpr int R = PL::radix(P), NS = PL::ns(P), NB = PL::PPT / R;
+    constexpr int R = PL::radix(DIR, P), NS = PL::ns(DIR, P), NB = PL::nb(DIR, P), TPL = PL::tpl(DIR, P);
+    if (TPL < PL::TMAX && tl >= TPL) return;
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
-        const int jb = tl + s * PL::TPL;
+        const int jb = tl + s * TPL;
         const int j0 = (jb / NS) * (NS * R) + jb % NS;
-        if constexpr (PL::PADQ == 0 || (NS % PL::PADQ == 0)) {
+        if constexpr (LDS::folds(NS)) {
             c32* p = lds.ptr(j0);
 #pragma unroll
             for (int k = 0; k < R; ++k) p[LDS::rel(k * NS)] = v[s + NB * k];
-        } else if constexpr (P == 0 && R == PL::PADQ) {
+        } else if constexpr (P == 0 && R == LDS::PADQ) {
             c32* p = lds.ptr(j0);   // j0 = jb R0: a multiple of PADQ, and k < PADQ adds no padding slot
 #pragma unroll
             for (int k = 0; k < R; ++k) p[k * LDS::WIDTH] = v[s + NB * k];
@@ -228,34 +278,43 @@ __device__ __forceinline__ void pass_scatter(const c32 (&v)[PL::PPT], LDS lds, i
     }
 }
 
-template <class PL, class LDS>
-__device__ __forceinline__ void canonical_gather(c32 (&v)[PL::PPT], LDS lds, int tl)
+// the inputs of pass P from the LDS image: register q <- element tl + TPL_P q
+template <class PL, int DIR, int P, class LDS>
+__device__ __forceinline__ void pass_gather(c32 (&v)[PL::VMAX], LDS lds, int tl)
 {
-    const c32* p = lds.ptr(tl);
+    constexpr int PPT = PL::ppt(DIR, P), TPL = PL::tpl(DIR, P);
+    if (TPL < PL::TMAX && tl >= TPL) return;
+    if constexpr (LDS::folds(TPL)) {
+        const c32* p = lds.ptr(tl);
 #pragma unroll
-    for (int q = 0; q < PL::PPT; ++q) v[q] = p[LDS::rel(PL::TPL * q)];   // (PADQ | TPL)
+        for (int q = 0; q < PPT; ++q) v[q] = p[LDS::rel(TPL * q)];
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = *lds.ptr(tl + TPL * q);
+    }
 }
 
 template <class PL, int DIR, int P, class LDS>
 struct PassLoop {
-    static __device__ __forceinline__ void run(c32 (&v)[PL::PPT], LDS lds, const c32* tw, int tl)
+    static __device__ __forceinline__ void run(c32 (&v)[PL::VMAX], LDS lds, const c32* tw, int tl)
     {
-        if constexpr (P > 0) canonical_gather<PL>(v, lds, tl);
+        if constexpr (P > 0) pass_gather<PL, DIR, P>(v, lds, tl);
         pass_compute<PL, DIR, P>(v, tw, tl);
         if constexpr (P + 1 < PL::NPASS) {
             __syncthreads();   // everybody is done reading the previous contents
-            pass_scatter<PL, P>(v, lds, tl);
+            pass_scatter<PL, DIR, P>(v, lds, tl);
             __syncthreads();
             PassLoop<PL, DIR, P + 1, LDS>::run(v, lds, tw, tl);
         }
     }
 };
 
-// Transform one line held in the canonical register layout; the result is canonical again.  Every thread of the workgroup must call this.
-template <class PL, int DIR, class LDS>
-__device__ __forceinline__ void line_fft(c32 (&v)[PL::PPT], LDS lds, const c32* tw, int tl)
+// Transform one line: in = layout of the direction's first pass (FWD: A, INV: B), out = layout of its last pass (FWD: B, INV: A).
+// Every thread of the workgroup must call this.  `image` points at this thread's line of the LDS tile (W lines interleaved).
+template <class PL, int DIR, int W>
+__device__ __forceinline__ void line_fft(c32 (&v)[PL::VMAX], c32* image, const c32* tw, int tl)
 {
-    PassLoop<PL, DIR, 0, LDS>::run(v, lds, tw, tl);
+    PassLoop<PL, DIR, 0, Lds<PL, DIR, W>>::run(v, Lds<PL, DIR, W>{image}, tw, tl);
 }
 
 __device__ __forceinline__ bool lex_gt(float ar, float ai, float br, float bi) { return (ar > br) || (ar == br && ai > bi); }
@@ -264,10 +323,10 @@ __device__ __forceinline__ bool lex_gt(float ar, float ai, float br, float bi) {
 // spectrum (column) pass: forward transform, threshold, inverse transform of a tile of COLT columns (modes as col_kernel / flex_col_kernel)
 // =========================================================================================================================================
 template <class PL>
-__global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArgs a, const c32* __restrict__ tab, int mode, int ntiles)
+__global__ __launch_bounds__(PL::COLT* PL::TMAX) void mix_col_kernel(const ColArgs a, const c32* __restrict__ tab, int mode, int ntiles)
 {
-    constexpr int N = PL::N, PPT = PL::PPT, TPL = PL::TPL, T = PL::COLT, THREADS = T * TPL;
-    using LDS = Lds<PL, T>;
+    constexpr int N = PL::N, VMAX = PL::VMAX, TMAX = PL::TMAX, T = PL::COLT, THREADS = T * TMAX;
+    constexpr int PPT_A = PL::PPT_A, TPL_A = PL::TPL_A, PPT_B = PL::PPT_B, TPL_B = PL::TPL_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ float red[((THREADS + 63) / 64) * 5];
     c32* twl = reinterpret_cast<c32*>(smem_raw);
@@ -293,22 +352,33 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
     for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
     __syncthreads();
 
-    const LDS lds{data + c_lo};
+    c32* const image = data + c_lo;
     const bool iter = mode == COL_ITER || mode == COL_ITER_SOFT || mode == COL_ITER_GARROTE;
-    const int vcol = valid ? col : 0;
-    const c32* const inb = a.in + (size_t)slice * (a.in_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
-    c32* const outb = a.out + (size_t)slice * (a.out_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2));
-    const unsigned blk0 = ((unsigned)(vcol >> 3) * N) * 8 + (vcol & 7);   // column-blocked: + row * 8
-    const bool in_std = a.in_std != 0, out_std = a.out_std != 0;
-    const unsigned in_org = in_std ? (unsigned)vcol : blk0, in_pitch = in_std ? (unsigned)a.n2 : 8u;
-    const unsigned out_org = out_std ? (unsigned)vcol : blk0, out_pitch = out_std ? (unsigned)a.n2 : 8u;
+    // unconditional buffer accesses; a lane that must not take part (column past the edge, thread outside the layout) carries an offset beyond
+    // the descriptor's range
+    const size_t in_slice = a.in_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2), out_slice = a.out_std ? (size_t)N * a.n2 : wk_slice_stride(N, a.n2);
+    const __amdgpu_buffer_rsrc_t isrd = buf_srd(a.in + (size_t)slice * in_slice, (unsigned)(in_slice * sizeof(c32)));
+    const __amdgpu_buffer_rsrc_t osrd = buf_srd(a.out + (size_t)slice * out_slice, (unsigned)(out_slice * sizeof(c32)));
+    const unsigned blk0 = ((unsigned)(col >> 3) * N) * 8 + (col & 7);   // column-blocked: + row * 8
+    const unsigned in_org = a.in_std ? (unsigned)col : blk0, in_pitch = a.in_std ? (unsigned)a.n2 : 8u;
+    const unsigned out_org = a.out_std ? (unsigned)col : blk0, out_pitch = a.out_std ? (unsigned)a.n2 : 8u;
 
-    c32 v[PPT];
+    c32 v[VMAX];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q)   // (columns past the edge re-read column 0 and are never stored)
-        v[q] = *reinterpret_cast<const c32*>(reinterpret_cast<const char*>(inb) + (size_t)(in_org + (unsigned)(tl + TPL * q) * in_pitch) * 8u);
-
-    if (mode != COL_INV) line_fft<PL, FWD>(v, lds, twl, tl);
+    for (int q = 0; q < VMAX; ++q) v[q] = c32{0.f, 0.f};
+    if (mode == COL_INV) {   // the inverse transform starts in layout B
+        const unsigned org = (valid && tl < TPL_B) ? (in_org + (unsigned)tl * in_pitch) * 8u : BUF_OOB;
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) v[q] = buf_load_c32(isrd, org + (unsigned)(TPL_B * q) * in_pitch * 8u, 0u);
+    } else {
+        const unsigned org = (valid && tl < TPL_A) ? (in_org + (unsigned)tl * in_pitch) * 8u : BUF_OOB;
+#pragma unroll
+        for (int q = 0; q < PPT_A; ++q) v[q] = buf_load_c32(isrd, org + (unsigned)(TPL_A * q) * in_pitch * 8u, 0u);
+        line_fft<PL, FWD, T>(v, image, twl, tl);
+    }
+    // (layout B from here to the inverse transform)
+    const bool live_b = valid && tl < TPL_B;
+    const unsigned out_b = live_b ? (out_org + (unsigned)tl * out_pitch) * 8u : BUF_OOB;
 
     if (iter || (mode == COL_FWD && a.tau != nullptr)) {
         const c32 tau = a.tau[(size_t)slice * a.niter + a.iter];
@@ -316,23 +386,20 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
         const Shrink shr(tau, op);
         unsigned bits = 0;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
+        for (int q = 0; q < PPT_B; ++q) {
             v[q] = shr(v[q]);
             bits |= (__float_as_uint(v[q].x) | __float_as_uint(v[q].y)) & 0x7fffffffu;
         }
         if (iter && a.nzflag != nullptr) {
             // a tile the threshold emptied stays zeros after the inverse transform: say so instead of transforming and storing it
-            const int kept = __syncthreads_or((valid && bits != 0u) ? 1 : 0);
+            const int kept = __syncthreads_or((live_b && bits != 0u) ? 1 : 0);
             if (tid == 0) a.nzflag[(size_t)slice * ntiles + tile] = kept ? 1 : 0;
             if (!kept) {
                 // the row pass skips whole 8-column BLOCKS: an empty tile narrower than a block must leave zeros behind for the case that a
                 // sibling tile of its block kept something (see col_kernel)
                 if constexpr (T < 8) {
-                    if (valid) {
 #pragma unroll
-                        for (int q = 0; q < PPT; ++q)
-                            *reinterpret_cast<c32*>(reinterpret_cast<char*>(outb) + (size_t)(out_org + (unsigned)(tl + TPL * q) * out_pitch) * 8u) = c32{0.f, 0.f};
-                    }
+                    for (int q = 0; q < PPT_B; ++q) buf_store_c32(osrd, out_b + (unsigned)(TPL_B * q) * out_pitch * 8u, 0u, c32{0.f, 0.f});
                 }
                 return;
             }
@@ -342,9 +409,9 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
     if (mode == COL_STATS) {
         // lexicographic complex max, max|X|, min|X|, sum|X|^2 of this tile (POCS.py:261-262, 288, 299)
         float lr = -INFINITY, li = -INFINITY, mx = 0.f, mn = INFINITY, sq = 0.f;
-        if (valid) {
+        if (live_b) {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
+            for (int q = 0; q < PPT_B; ++q) {
                 const float p = v[q].x * v[q].x + v[q].y * v[q].y;
                 if (lex_gt(v[q].x, v[q].y, lr, li)) { lr = v[q].x; li = v[q].y; }
                 mx = fmaxf(mx, p);
@@ -383,12 +450,14 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
         return;
     }
 
-    if (iter || mode == COL_INV) line_fft<PL, INV>(v, lds, twl, tl);
-
-    if (valid) {
+    if (iter || mode == COL_INV) {
+        line_fft<PL, INV, T>(v, image, twl, tl);   // -> layout A
+        const unsigned out_a = (valid && tl < TPL_A) ? (out_org + (unsigned)tl * out_pitch) * 8u : BUF_OOB;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q)
-            *reinterpret_cast<c32*>(reinterpret_cast<char*>(outb) + (size_t)(out_org + (unsigned)(tl + TPL * q) * out_pitch) * 8u) = v[q];
+        for (int q = 0; q < PPT_A; ++q) buf_store_c32(osrd, out_a + (unsigned)(TPL_A * q) * out_pitch * 8u, 0u, v[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) buf_store_c32(osrd, out_b + (unsigned)(TPL_B * q) * out_pitch * 8u, 0u, v[q]);
     }
 }
 
@@ -397,27 +466,30 @@ __global__ __launch_bounds__(PL::COLT* PL::TPL) void mix_col_kernel(const ColArg
 // (modes ROW_FIRST / ROW_MID / ROW_LAST as row_kernel / flex_row_kernel)
 // =========================================================================================================================================
 template <class PL>
-__global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowArgs a, const c32* __restrict__ tab, int mode)
+__global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void mix_row_kernel(const RowArgs a, const c32* __restrict__ tab, int mode)
 {
-    constexpr int N = PL::N, PPT = PL::PPT, TPL = PL::TPL, LB = PL::ROWLB, THREADS = LB * TPL;
+    constexpr int N = PL::N, VMAX = PL::VMAX, TMAX = PL::TMAX, LB = PL::ROWLB, THREADS = LB * TMAX;
+    constexpr int PPT_A = PL::PPT_A, TPL_A = PL::TPL_A, PPT_B = PL::PPT_B, TPL_B = PL::TPL_B;
     // Rows are taken in PAIRS (2 p, 2 p + 1) whose threads alternate lane by lane: the two rows' 64-byte pieces of a column block are
     // neighbours in the column-blocked work buffer, so one load or store instruction of a wavefront then moves whole 128-byte lines (a row
     // alone touches half of every line it reads or writes, the other half moved by another wavefront at another time); in LDS the pair is
     // a two-line tile, element-major, like the column pass's.
+    // (A persistent form -- runs of row groups per workgroup, tables copied once, the next group's input requested into registers ahead of the
+    // transforms -- was built in round 5: 256 VGPRs, or 800 bytes of scratch per lane at three waves per SIMD; 0.82 -> 1.5 ms.  Dropped.)
     static_assert(LB % 2 == 0, "rows are worked on in pairs");
-    using LDS = Lds<PL, 2>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ uint8_t nzl[N + 8];   // the slice's tile flags, one byte per column tile (a tile is 1 ... 8 columns wide: at most N of them)
     c32* twl = reinterpret_cast<c32*>(smem_raw);
     c32* data = twl + PL::TW_SLOTS;
-    const int tid = threadIdx.x, par = tid & 1, tl = (tid >> 1) % TPL, pair = (tid >> 1) / TPL, line = 2 * pair + par;
+    const int tid = threadIdx.x, par = tid & 1, tl = (tid >> 1) % TMAX, pair = (tid >> 1) / TMAX, line = 2 * pair + par;
     const int slice = blockIdx.y, row = blockIdx.x * LB + line;
     const bool valid = row < a.n1;
+    const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;   // this thread holds elements in layout A / B
 
     const int dn = a.done ? a.done[slice] : 0;   // (uniform over the workgroup: every early return below is taken by all of its threads)
     // Every access to the cubes and the work buffer is an UNCONDITIONAL buffer instruction; a lane that must not take part carries an offset
     // beyond the descriptor's range (loads return zero, stores are dropped).  One branch per predicated access would end every wait of the
-    // unrolled loops at vmcnt(0): twenty exposed memory latencies in a row instead of one (measured: 1.5 -> 0.7 ms for this pass).
+    // unrolled loops at vmcnt(0): twenty exposed memory latencies in a row instead of one (measured: 1.5 -> 0.9 ms for this pass).
     const unsigned esz = a.dtype == 0 ? 8u : 4u;
     const unsigned cube_bytes = (unsigned)a.n1 * N * esz;            // one slice of x / out (< 2 GiB: extents <= 4096)
     const __amdgpu_buffer_rsrc_t xsrd = buf_srd(reinterpret_cast<const char*>(a.x) + (size_t)slice * cube_bytes, cube_bytes);
@@ -426,10 +498,10 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
     const unsigned wbytes = (unsigned)(wk_slice_stride(a.n1, N) * sizeof(c32));
     const __amdgpu_buffer_rsrc_t wsrd = buf_srd(a.work + (size_t)slice * wk_slice_stride(a.n1, N), wbytes);
     const unsigned el0 = (unsigned)row * N + tl;                     // element (row, tl) of a row-major slice
-    const unsigned xoff = valid ? el0 * esz : BUF_OOB, moff = valid ? el0 * 4u : BUF_OOB;
+    const unsigned xoff = live_a ? el0 * esz : BUF_OOB, moff = live_a ? el0 * 4u : BUF_OOB;
     const unsigned wblk = (unsigned)a.n1 * 8;
-    auto woff = [&](int q) -> unsigned {   // byte offset of element (row, tl + TPL q) in the column-blocked slice
-        const int i = tl + TPL * q;
+    auto woff = [&](int q) -> unsigned {   // byte offset of element (row, tl + TPL_B q) in the column-blocked slice
+        const int i = tl + TPL_B * q;
         return ((unsigned)(i >> 3) * wblk + (unsigned)row * 8 + (unsigned)(i & 7)) * 8u;
     };
 
@@ -439,9 +511,9 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
         if (dn > 0) return;   // converged earlier: `out` already holds that iterate
         if (dn < 0) {         // an all-zero slice is handed back untouched (POCS.py:515-521)
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                if (a.dtype == 0) buf_store_c32(osrd, xoff, (unsigned)(TPL * q) * 8u, c32{0.f, 0.f});
-                else __builtin_amdgcn_raw_buffer_store_b32(0u, osrd, (int)xoff, (int)((unsigned)(TPL * q) * 4u), 0);
+            for (int q = 0; q < PPT_A; ++q) {
+                if (a.dtype == 0) buf_store_c32(osrd, xoff, (unsigned)(TPL_A * q) * 8u, c32{0.f, 0.f});
+                else __builtin_amdgcn_raw_buffer_store_b32(0u, osrd, (int)xoff, (int)((unsigned)(TPL_A * q) * 4u), 0);
             }
             return;
         }
@@ -449,21 +521,26 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
         return;
     }
 
-    // tables into LDS: the twiddle rows, and the slice's tile flags (column blocks the column pass found empty were not stored: they read as zeros)
+    // The slice's tile flags go to LDS first (column blocks the column pass found empty were not stored: they read as zeros); the twiddle
+    // tables follow BEHIND the requests for the rows (tables_to_lds() below), so that the two latencies run side by side.
     const uint8_t* const nzf = (mode != ROW_FIRST && a.nzflag && !a.only_done) ? a.nzflag + (size_t)slice * a.nz_tiles : nullptr;
-    for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
-    if (nzf)
+    if (nzf) {
         for (int i = tid; i < a.nz_tiles; i += THREADS) nzl[i] = nzf[i];
-    __syncthreads();
-    const LDS lds{data + pair * (2 * PL::LINE) + par};
+        __syncthreads();
+    }
+    auto tables_to_lds = [&]() {
+        for (int i = tid; i < PL::TW_SLOTS; i += THREADS) twl[i] = tab[i];
+        __syncthreads();
+    };
+    c32* const image = data + pair * (2 * PL::LINE) + par;
 
-    // binary masks travel as one 64-bit word per thread and row (bit q = mask[row][tl + TPL q]); the observed samples of the steady state
+    // binary masks travel as one 64-bit word per thread and row (bit q = mask[row][tl + TPL_A q]); the observed samples of the steady state
     // then come from the COMPACT array the first pass wrote: thread by thread, a thread's samples in q order (RowArgs::mbits / mbase / xc)
     unsigned long long mbits = 0;
     unsigned cbase = 0;
-    if (a.mbits != nullptr && valid) {
-        mbits = a.mbits[(size_t)row * TPL + tl];
-        cbase = a.mbase[(size_t)row * TPL + tl];
+    if (a.mbits != nullptr && live_a) {
+        mbits = a.mbits[(size_t)row * TPL_A + tl];
+        cbase = a.mbase[(size_t)row * TPL_A + tl];
     }
     const bool compact = a.xc != nullptr && a.mbits != nullptr;
     const __amdgpu_buffer_rsrc_t csrd = buf_srd(reinterpret_cast<const char*>(a.xc) + (size_t)slice * a.nobs * esz, compact ? a.nobs * esz : 0u);
@@ -471,42 +548,45 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
         const unsigned below = (unsigned)__popcll(mbits & ((1ull << q) - 1ull));
         return ((mbits >> q) & 1ull) ? (cbase + below) * esz : BUF_OOB;
     };
-    auto load_obs = [&](c32 (&xo)[PPT]) {
+    auto load_obs = [&](c32 (&xo)[VMAX]) {   // layout A
         if (compact && mode != ROW_FIRST) {
             if (a.dtype == 0) {
 #pragma unroll
-                for (int q = 0; q < PPT; ++q) xo[q] = buf_load_c32(csrd, coff(q), 0u);
+                for (int q = 0; q < PPT_A; ++q) xo[q] = buf_load_c32(csrd, coff(q), 0u);
             } else {
 #pragma unroll
-                for (int q = 0; q < PPT; ++q) xo[q] = c32{buf_load_f32(csrd, coff(q), 0u), 0.f};
+                for (int q = 0; q < PPT_A; ++q) xo[q] = c32{buf_load_f32(csrd, coff(q), 0u), 0.f};
             }
         } else if (a.dtype == 0) {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) xo[q] = buf_load_c32(xsrd, xoff, (unsigned)(TPL * q) * 8u);
+            for (int q = 0; q < PPT_A; ++q) xo[q] = buf_load_c32(xsrd, xoff, (unsigned)(TPL_A * q) * 8u);
         } else {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) xo[q] = c32{buf_load_f32(xsrd, xoff, (unsigned)(TPL * q) * 4u), 0.f};
+            for (int q = 0; q < PPT_A; ++q) xo[q] = c32{buf_load_f32(xsrd, xoff, (unsigned)(TPL_A * q) * 4u), 0.f};
         }
     };
-    auto load_mask = [&](float (&mk)[PPT]) {   // (no mask: the descriptor is empty, every lane reads zero)
+    auto load_mask = [&](float (&mk)[VMAX]) {   // (no mask: the descriptor is empty, every lane reads zero)
         if (a.mbits != nullptr) {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) mk[q] = ((mbits >> q) & 1ull) ? 1.0f : 0.0f;
+            for (int q = 0; q < PPT_A; ++q) mk[q] = ((mbits >> q) & 1ull) ? 1.0f : 0.0f;
         } else {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) mk[q] = buf_load_f32(msrd, moff, (unsigned)(TPL * q) * 4u);
+            for (int q = 0; q < PPT_A; ++q) mk[q] = buf_load_f32(msrd, moff, (unsigned)(TPL_A * q) * 4u);
         }
     };
 
     float acc = 0.f;
-    c32 v[PPT];
+    c32 v[VMAX];
+#pragma unroll
+    for (int q = 0; q < VMAX; ++q) v[q] = c32{0.f, 0.f};
     if (mode == ROW_FIRST) {
         load_obs(v);
+        tables_to_lds();
         if (compact) {
             // the compact copy of the observed samples; a non-zero sample where the mask says "missing" makes it unusable (RowArgs::violation)
             bool viol = false;
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
+            for (int q = 0; q < PPT_A; ++q) {
                 if (a.dtype == 0) __builtin_amdgcn_raw_buffer_store_b64(p3d_u2{__float_as_uint(v[q].x), __float_as_uint(v[q].y)}, csrd, (int)coff(q), 0, 0);
                 else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q].x), csrd, (int)coff(q), 0, 0);
                 viol = viol || (!((mbits >> q) & 1ull) && (v[q].x != 0.0f || v[q].y != 0.0f));
@@ -514,10 +594,10 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
             if (viol && a.violation) *a.violation = 1;
         }
         if (a.adaptive) {   // x_old = x at the first iteration (POCS.py:549, 574-575)
-            float mk[PPT];
+            float mk[VMAX];
             load_mask(mk);
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
+            for (int q = 0; q < PPT_A; ++q) {
                 const c32 x = v[q];
                 acc += abs_c32(x);
                 const float w = 1.0f - a.alpha * mk[q];
@@ -526,30 +606,31 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) acc += abs_c32(v[q]);
+            for (int q = 0; q < PPT_A; ++q) acc += abs_c32(v[q]);
         }
     } else {
         const int tsh = 31 - __builtin_clz((unsigned)a.nz_col_t);
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            bool kept = valid;
-            if (nzf) kept = kept && nzl[(tl + TPL * q) >> tsh] != 0;
+        for (int q = 0; q < PPT_B; ++q) {
+            bool kept = live_b;
+            if (nzf) kept = kept && nzl[(tl + TPL_B * q) >> tsh] != 0;
             v[q] = buf_load_c32(wsrd, kept ? woff(q) : BUF_OOB, 0u);
         }
-        line_fft<PL, INV>(v, lds, twl, tl);
-        c32 xo[PPT];
-        float mk[PPT];
+        tables_to_lds();
+        line_fft<PL, INV, 2>(v, image, twl, tl);   // layout B -> layout A
+        c32 xo[VMAX];
+        float mk[VMAX];
         if (!a.plain) {
             load_obs(xo);
             load_mask(mk);
         } else {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) { xo[q] = c32{0.f, 0.f}; mk[q] = 0.f; }
+            for (int q = 0; q < PPT_A; ++q) { xo[q] = c32{0.f, 0.f}; mk[q] = 0.f; }
         }
         const bool handback = mode == ROW_LAST && a.only_done;
         const bool store_out = mode == ROW_LAST || a.write_out;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
+        for (int q = 0; q < PPT_A; ++q) {
             c32 xn = v[q] * a.scale;
             float m = 0.f;
             if (handback) {
@@ -561,8 +642,8 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
                 xn = axpby(xn, w, xo[q], a.alpha);         // POCS.py:619
             }
             acc += abs_c32(xn);
-            if (a.dtype == 0) buf_store_c32(osrd, store_out ? xoff : BUF_OOB, (unsigned)(TPL * q) * 8u, xn);
-            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn.x), osrd, (int)(store_out ? xoff : BUF_OOB), (int)((unsigned)(TPL * q) * 4u), 0);   // np.real(), POCS.py:656
+            if (a.dtype == 0) buf_store_c32(osrd, store_out ? xoff : BUF_OOB, (unsigned)(TPL_A * q) * 8u, xn);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xn.x), osrd, (int)(store_out ? xoff : BUF_OOB), (int)((unsigned)(TPL_A * q) * 4u), 0);   // np.real(), POCS.py:656
             if (mode == ROW_MID && a.adaptive) {   // x_input of the next iteration (POCS.py:574-575)
                 const float w = 1.0f - a.alpha * m;
                 const c32 blend = xo[q] * a.alpha + xn * w;
@@ -575,19 +656,19 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TPL) void mix_row_kernel(const RowAr
     if (a.sums != nullptr) {
         // per-row sum of |x| in a fixed order: the threads' partial sums go through the pair's LDS image, one thread per row adds them up in double
         __syncthreads();   // (the image is free: the inverse transform's last gather is behind every thread)
-        float* part = reinterpret_cast<float*>(data + pair * (2 * PL::LINE)) + par * TPL;
-        part[tl] = acc;
+        float* part = reinterpret_cast<float*>(data + pair * (2 * PL::LINE)) + par * TMAX;
+        part[tl] = live_a ? acc : 0.f;
         __syncthreads();
         if (tl == 0 && valid) {
             double t = 0.0;
-            for (int i = 0; i < TPL; ++i) t += (double)part[i];
+            for (int i = 0; i < TPL_A; ++i) t += (double)part[i];
             a.sums[(size_t)slice * a.n1 + row] = t;
         }
     }
     if (mode != ROW_LAST) {
-        line_fft<PL, FWD>(v, lds, twl, tl);
+        line_fft<PL, FWD, 2>(v, image, twl, tl);   // layout A -> layout B
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) buf_store_c32(wsrd, valid ? woff(q) : BUF_OOB, 0u, v[q]);
+        for (int q = 0; q < PPT_B; ++q) buf_store_c32(wsrd, live_b ? woff(q) : BUF_OOB, 0u, v[q]);
     }
 }
 

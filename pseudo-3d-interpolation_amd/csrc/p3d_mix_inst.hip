@@ -20,7 +20,7 @@ hipError_t launch_col(int mode, const ColArgs& a, const c32* tab, hipStream_t st
 {
     constexpr size_t lds = sizeof(c32) * ((size_t)PL::TW_SLOTS + (size_t)PL::LINE * PL::COLT);
     static_assert(lds + 1024 <= LDS_LIMIT, "column tile does not fit LDS");
-    static_assert(PL::COLT * PL::TPL <= 1024, "column tile needs more than 1024 threads");
+    static_assert(PL::COLT * PL::TMAX <= 1024, "column tile needs more than 1024 threads");
     if (mode == COL_SHRINK) return hipErrorNotSupported;
     static bool attr = false;   // (idempotent: a race sets it twice)
     if (!attr) {
@@ -35,7 +35,7 @@ hipError_t launch_col(int mode, const ColArgs& a, const c32* tab, hipStream_t st
     const int ntiles = tiles;
     if (G > 1) tiles = (tiles + 8 * G - 1) / (8 * G) * (8 * G);
     const dim3 grid(tiles, a.nslices);
-    mix_col_kernel<PL><<<grid, PL::COLT * PL::TPL, lds, st>>>(a, tab, mode, ntiles);
+    mix_col_kernel<PL><<<grid, PL::COLT * PL::TMAX, lds, st>>>(a, tab, mode, ntiles);
     return hipGetLastError();
 }
 
@@ -44,7 +44,7 @@ hipError_t launch_row(int mode, const RowArgs& a, const c32* tab, hipStream_t st
 {
     constexpr size_t lds = sizeof(c32) * ((size_t)PL::TW_SLOTS + (size_t)PL::LINE * PL::ROWLB);
     static_assert(lds + 1024 <= LDS_LIMIT, "row group does not fit LDS");
-    static_assert(PL::ROWLB * PL::TPL <= 1024, "row group needs more than 1024 threads");
+    static_assert(PL::ROWLB * PL::TMAX <= 1024, "row group needs more than 1024 threads");
     if (mode != ROW_FIRST && mode != ROW_MID && mode != ROW_LAST) return hipErrorNotSupported;
     static bool attr = false;
     if (!attr) {
@@ -53,13 +53,15 @@ hipError_t launch_row(int mode, const RowArgs& a, const c32* tab, hipStream_t st
         attr = true;
     }
     const dim3 grid((a.n1 + PL::ROWLB - 1) / PL::ROWLB, a.nslices);
-    mix_row_kernel<PL><<<grid, PL::ROWLB * PL::TPL, lds, st>>>(a, tab, mode);
+    mix_row_kernel<PL><<<grid, PL::ROWLB * PL::TMAX, lds, st>>>(a, tab, mode);
     return hipGetLastError();
 }
 
-#define X(N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4)                                                                              \
-    {N, COLT, MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>::TW_SLOTS, N / PPT, PPT, &MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>::build_tw, \
-     &launch_row<MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>>, &launch_col<MixPlan<N, PPT, COLT, LB, NP, R0, R1, R2, R3, R4>>},
+#define P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3) MixPlan<N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3>
+#define X(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)                                                                              \
+    {N, COLT, P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TW_SLOTS, P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TPL_A, \
+     P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::PPT_A, &P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::build_tw,         \
+     &launch_row<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>, &launch_col<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>},
 const Entry entries[] = {
 #include "p3d_mix_plans.inc"
     {0, 0, 0, 0, 0, nullptr, nullptr, nullptr}};

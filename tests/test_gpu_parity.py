@@ -1,9 +1,11 @@
 """Parity of the HIP path (through the C ABI) with the oracle and with the reference's golden vectors.
 Needs a real MI355X:  python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import parse_params, rel_l2
+from conftest import ROOT, parse_params, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -1039,6 +1041,74 @@ def test_flexible_lengths_against_the_oracle(shape, kw):
     got = P.pocs_cube(real, mask, **kw)
     want = orc.pocs_cube(real.astype(np.float64), mask, **kw)
     assert got.dtype == np.float32 and rel_l2(got, want) <= 1e-5
+
+
+def _mix_lengths():
+    import re
+    inc = open(os.path.join(ROOT, "pseudo-3d-interpolation_amd", "csrc", "p3d_mix_plans.inc")).read()
+    return sorted(int(m) for m in re.findall(r"^X\((\d+),", inc, re.M))
+
+
+def test_every_planned_smooth_length_transforms_like_numpy():
+    """Every line length with a plan of the mixed-radix register engine (p3d_mix.hpp; the 7-smooth lengths of p3d_mix_plans.inc), as the row
+    and as the column axis: the fft2 / ifft2 hooks against NumPy (np.fft.fft2 at cube_POCS_interpolation_3D.py:255-257 takes any length)."""
+    from pseudo_3d_interpolation_amd import _ffi
+    rng = np.random.default_rng(3)
+    lengths = _mix_lengths()
+    assert len(lengths) > 100 and 1000 in lengths and 1500 in lengths
+    worst = 0.0
+    for n in lengths:
+        for shape in ((n, 24), (16, n)):
+            x = (rng.standard_normal((2,) + shape) + 1j * rng.standard_normal((2,) + shape)).astype(np.complex64)
+            plan = _ffi.Plan(shape[0], shape[1], 2)
+            f = plan.fft2(x)
+            b = plan.fft2(f, inverse=True)
+            plan.close()
+            e1, e2 = rel_l2(f, np.fft.fft2(x.astype(np.complex128))), rel_l2(b, x)
+            worst = max(worst, e1, e2)
+            assert e1 < 2e-6 and e2 < 2e-6, (shape, e1, e2)
+    print(f"{len(lengths)} lengths, worst rel-L2 {worst:.2e}")
+
+
+@pytest.mark.parametrize("shape", [(1000, 48), (40, 1500), (960, 768), (600, 500), (2000, 24), (16, 3000), (1200, 360), (126, 4000), (225, 2187)])
+@pytest.mark.parametrize("kw", [
+    dict(niter=8, thresh_op="soft", thresh_model="exponential", eps=0, p_max=0.99, p_min=1e-2),
+    dict(niter=8, thresh_op="soft", thresh_model="linear", eps=0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
+    dict(niter=30, thresh_op="soft", thresh_model="exponential", eps=1e-6, p_max=0.99, p_min=1e-2),
+])
+def test_smooth_lengths_on_the_register_engine_against_the_oracle(shape, kw, monkeypatch):
+    """7-smooth extents (one or both axes) run the two fused passes on the mixed-radix register engine: binary masks as packed words, compact
+    observed samples in the steady state, the sparse shortcut; a non-binary mask takes the float weights; a cube with energy at unobserved
+    positions falls back to the full observed cube.  Same parity bar as every other length (soft threshold: 1e-5 end to end), same iteration
+    counts under the early exit, and the same answer with the plans switched off (P3D_NO_MIX=1: the LDS-image passes of p3d_flex.hip)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as orc
+    nil, nxl = shape
+    mask = orc.synthetic_mask(nil, nxl, 0.5)
+    cube = (np.stack([orc.synthetic_slice(nil, nxl, 7 + s) for s in range(3)]) * mask).astype(np.complex64)
+    cube[1] = 0                                     # an all-zero slice passes through untouched
+    res, infos = [], []
+    got = P.pocs_cube(cube, mask, results=res, **kw)
+    want = orc.pocs_cube(cube.astype(np.complex128), mask, infos=infos, **kw)
+    for s in range(3):
+        assert res[s]["niterations"] == infos[s]["niterations"]
+        assert rel_l2(got[s], want[s]) <= 1e-5, (s, rel_l2(got[s], want[s]))
+    if kw["niter"] == 8 and "version" not in kw:
+        weights = mask.astype(np.float32) * np.float32(0.75)                        # not 0 / 1: the float weights
+        got = P.pocs_cube(cube, weights, **kw)
+        assert rel_l2(got, orc.pocs_cube(cube.astype(np.complex128), weights, **kw)) <= 1e-5
+        leaky = cube + np.complex64(1e-3) * (1 - mask)                              # energy where the mask says "missing"
+        got = P.pocs_cube(leaky, mask, **kw)
+        assert rel_l2(got, orc.pocs_cube(leaky.astype(np.complex128), mask, **kw)) <= 1e-5
+        real = np.ascontiguousarray(cube.real)                                     # float32 cube through the same shapes
+        got = P.pocs_cube(real, mask, **kw)
+        assert got.dtype == np.float32 and rel_l2(got, orc.pocs_cube(real.astype(np.float64), mask, **kw)) <= 1e-5
+        P.release_plans()
+        monkeypatch.setenv("P3D_NO_MIX_BITS", "1")                                  # the same passes on the float mask and the full observed cube
+        try:
+            assert rel_l2(P.pocs_cube(cube, mask, **kw), want) <= 1e-5
+        finally:
+            P.release_plans()
 
 
 @pytest.mark.parametrize("switch", ["P3D_FORCE_GENERIC", "P3D_NO_FLEX", "P3D_NO_PIPE", "P3D_NO_COMPACT", "P3D_NO_MASK_BITS"])
