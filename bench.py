@@ -405,7 +405,7 @@ class Ctx:
         return sec
 
 
-def run_leg(ctx, config, K_override, main):
+def run_leg(ctx, config, K_override, main, override=None):
     """One BASELINE configuration: generate its cube in HBM (this rank's block), time R jobs of K iterations, profile, side runs.
     Returns the record of the leg (rank 0: complete; other ranks: the fields they computed)."""
     args, rank, world = ctx.args, ctx.rank, ctx.world
@@ -418,6 +418,8 @@ def run_leg(ctx, config, K_override, main):
         for key, val in (("nil", args.nil), ("nxl", args.nxl), ("nslices", args.nslices), ("missing", args.missing), ("op", args.thresh_op)):
             if val is not None:
                 cfg[key] = val
+    if override:
+        cfg.update(override)   # a side leg on another grid (the 7-smooth extents of a survey grid): no CPU sample, no side runs
     kind, nil, nxl, missing, op = cfg["kind"], cfg["nil"], cfg["nxl"], cfg["missing"], cfg["op"]
     K = K_override if K_override is not None else cfg["steps"]
     W = args.warmup
@@ -449,7 +451,7 @@ def run_leg(ctx, config, K_override, main):
     fft_plan = _ffi.Plan(nil, nxl, n_local, device=dev_index) if kind == "FFT" else None
     np_dtype = np.float32 if cfg["real"] else np.complex64
     x_obs = ctx.empty((n_local, nil, nxl), np_dtype)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and density == 0
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and density == 0 and not override
     cpu_slices = None
     n_cpu = 0
     if want_cpu:   # the CPU baseline is a single-GPU-run extra (rank 0, N = 1)
@@ -602,6 +604,8 @@ def run_leg(ctx, config, K_override, main):
                 "kernel": (f"resident_kernel<{nil},{nxl}>: one workgroup per slice, all {K} iterations in registers / LDS -- the iterations "
                            f"move NO HBM bytes (16 B/point per job), so `achieved` (algorithmic bytes over time) may exceed the HBM peak"
                            if resident else
+                           f"mix_col_kernel<{nil}> + mix_row_kernel<{nxl}> (mixed-radix register engine, csrc/p3d_mix.hpp) = one POCS iteration of {n_local} slices"
+                           if (nil & (nil - 1)) and (nxl & (nxl - 1)) else
                            f"col_kernel<{nil},COL_ITER> + the persistent row pass (row_pipe32_kernel for rows of 1024 samples, row_pipe64_kernel<{nxl}> "
                            f"for other rows of whole wavefronts, row_pipe_kernel otherwise) = one POCS iteration of {n_local} slices"),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -723,12 +727,30 @@ def run_leg(ctx, config, K_override, main):
         ctx.fence()
         # three calls, each with a brand-new result array (what a pipeline that calls once per group of slices does); `seconds` is their
         # median, `seconds_each` all three -- the first one also pays for the first page-locking of the process
+        # N > 1: the sharded entry point without a collective (sharding.pocs_cube_sharded(gather='none', out=...)): the cube and the result are
+        # files in /dev/shm that every rank maps; each rank moves its own block through its own PCIe link, straight from one into the other
+        shared = None
+        if world > 1:
+            from pseudo_3d_interpolation_amd.sharding import pocs_cube_sharded
+            tag = f"{os.environ.get('MASTER_PORT', '0')}_{config}"
+            paths = [f"/dev/shm/p3d_bench_{name}_{tag}.npy" for name in ("cube", "out")]
+            if rank == 0:
+                for pth in paths:
+                    np.lib.format.open_memmap(pth, mode="w+", dtype=host.dtype, shape=(nslices, nil, nxl)).flush()
+            ctx.dist.barrier()
+            shared = [np.load(pth, mmap_mode="r+") for pth in paths]
+            shared[0][lo:lo + n_local] = host
+            ctx.dist.barrier()
         e_each = []
         for _ in range(3):
             res_host = None
             P._timeline = [] if kind == "FFT" else None      # phases of the chunk workers (rank 0's block), kept of the last call
+            ctx.fence()
             t0 = time.perf_counter()
-            res_host = P.pocs_cube(host, mask, niter=K, **kw)
+            if shared is None:
+                res_host = P.pocs_cube(host, mask, niter=K, **kw)
+            else:
+                res_host = pocs_cube_sharded(shared[0], mask, gather="none", out=shared[1], niter=K, **kw)[lo:lo + n_local]
             ctx.fence()
             t1 = time.perf_counter()
             e_each.append(ctx.max_over_ranks(t1 - t0))
@@ -755,6 +777,16 @@ def run_leg(ctx, config, K_override, main):
                "equals_resident_result": same, "phases": phases,
                "what": f"functions.POCS.pocs_cube(host cube, mask, niter={K}) per rank on its block: pageable NumPy array in, NumPy array "
                        f"out, statistics + schedule + iterations + PCIe both ways (FFT: chunks of ~128 MiB, four in flight); max over ranks; median of three calls (seconds_each), phases of the last"}
+        if shared is not None:
+            e2e["what"] = (f"sharding.pocs_cube_sharded(cube, mask, gather='none', out=result, niter={K}): cube and result are files in /dev/shm mapped by every "
+                           f"rank, each rank moves its own block of {n_local} slices host -> device -> host on its own PCIe link (page-locked in place, chunk "
+                           f"pipeline), no collective; wall time of the slowest rank, median of three calls")
+            del shared, res_host
+            ctx.dist.barrier()
+            if rank == 0:
+                for pth in paths:
+                    os.remove(pth)
+            res_host = None
         del host, res_host
         P.release_plans()
 
@@ -942,6 +974,19 @@ def main():
                     others[str(c)] = {"error": f"{type(exc).__name__}: {exc}"}
         if ctx.rank == 0:
             line["other_configs"] = others
+        if ctx.world == 1:
+            # survey grids are rarely powers of two: the same job (configs[2]'s parameters) on a 1000 x 1000 x 128 cube -- 7-smooth extents run the
+            # mixed-radix register engine (csrc/p3d_mix.hpp), not the tuned power-of-two kernels
+            try:
+                rec = run_leg(ctx, 2, args.steps, main=False, override=dict(nil=1000, nxl=1000, nslices=128))
+                release(ctx)
+                sg = compact(rec)
+                sg["points_per_s"] = rec["slice_iterations_per_s"] * 1000 * 1000
+                sg["note"] = ("BASELINE configs[2]'s job on a 1000 x 1000 x 128 cube (80 % missing, hard threshold, exponential decay): 1000 = 5 x 10 x 20 on the "
+                              "mixed-radix register engine; roofline on the same 28 B/point accounting; no CPU sample for this leg")
+                line["smooth_grid"] = sg
+            except Exception as exc:  # noqa: BLE001
+                line["smooth_grid"] = {"error": f"{type(exc).__name__}: {exc}"}
     if ctx.rank == 0:
         line["kernel_source_hash"] = kernel_source_hash()
         from pseudo_3d_interpolation_amd import _ffi as _f

@@ -279,6 +279,21 @@ int p3d_wavelet_run(p3d_wplan* plan, const void* x, int dtype, const float* mask
  * 589-590, 610-611) for spectra Psi supplied by the caller (the reference's `auxiliary_data`): ST_s = ifft2(Psi_s * fft2(x)),
  * x = ifft2(sum_s fft2(ST_s) * Psi_s); per-shearlet thresholds (POCS.py:598 with a (nsh,) tau).  psi: HOST float32
  * [nsh][nil][nxl], FFT order (what fftshift_spectra=True yields), real.  float32 cubes keep real coefficients. */
+/* The WAVELET loop in the REFERENCE's double precision (p3d_wavelet64.hip): pywt.wavedec2 / waverec2 keep float64 for float64 input and
+ * POCS_algorithm never narrows (functions/POCS.py:585-588, 596-597, 608-609; threshold_wavelet POCS.py:105-166); the driver casts to the input
+ * dtype only at the end (cube_POCS_interpolation_3D.py:324).  Same decomposition, thresholds, schedule layout (tau [nslices][niter][nlev][3][2],
+ * stats [nslices][nlev][3][4]) and error behaviour as p3d_wavelet_*; every sample, tap, weight and statistic in double.  dtype of x / out:
+ * P3D_C128, P3D_F64, or P3D_C64 / P3D_F32 (converted on load / store); x, out, mask may be host or device pointers; mask is DOUBLE [nil][nxl].
+ * A precision path (one thread per output sample and axis, no LDS tiles). */
+typedef struct p3d_wplan64 p3d_wplan64;
+int p3d_wavelet64_plan_create(p3d_wplan64** out, int device, int nil, int nxl, int max_slices, const double* dec_lo,
+                              const double* dec_hi, const double* rec_lo, const double* rec_hi, int filter_len, int level);
+int p3d_wavelet64_plan_destroy(p3d_wplan64* plan);
+int p3d_wavelet64_info(p3d_wplan64* plan, int* nlev, int64_t* ncoef);
+int p3d_wavelet64_stats(p3d_wplan64* plan, const void* x, int dtype, int nslices, double* stats);
+int p3d_wavelet64_run(p3d_wplan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
+                      const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);
+
 typedef struct p3d_splan p3d_splan;
 int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, int nxl, int nsh, const float* psi, int max_slices);
 int p3d_shearlet_plan_destroy(p3d_splan* plan);

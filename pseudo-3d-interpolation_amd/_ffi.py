@@ -107,6 +107,13 @@ PROTOTYPES = {
     "p3d_wavelet_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_wavelet_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "p3d_wavelet64_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "p3d_wavelet64_plan_destroy": (C.c_int, [C.c_void_p]),
+    "p3d_wavelet64_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "p3d_wavelet64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_wavelet64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_shearlet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "p3d_shearlet_plan_destroy": (C.c_int, [C.c_void_p]),
     "p3d_shearlet_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -244,6 +251,93 @@ class DeviceBuffer:
         if self.ptr:
             check(lib().p3d_free(self.plan.handle, self.ptr))
             self.ptr = None
+
+
+class WaveletPlan64:
+    """p3d_wplan64 wrapper: the WAVELET POCS loop in double precision (include/p3d.h) for complex128 / float64 cubes, and for complex64 /
+    float32 cubes on request (``precision='reference'``)."""
+    _DT = {np.dtype(np.complex128): P3D_C128, np.dtype(np.float64): P3D_F64, np.dtype(np.complex64): P3D_C64, np.dtype(np.float32): P3D_F32}
+
+    def __init__(self, nil, nxl, max_slices, wavelet="coif5", level=None, device=0):
+        self.nil, self.nxl, self.max_slices, self.device = int(nil), int(nxl), int(max_slices), int(device)
+        self.wavelet = wavelet
+        bank = wavelet if isinstance(wavelet, (tuple, list)) else wavelet_filters(wavelet)
+        bank = [np.ascontiguousarray(b, dtype=np.float64) for b in bank]
+        if len(bank) != 4 or len({b.size for b in bank}) != 1:
+            raise ValueError("a filter bank is (dec_lo, dec_hi, rec_lo, rec_hi) of equal length")
+        h = C.c_void_p()
+        check(lib().p3d_wavelet64_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.max_slices, *map(_ptr, bank),
+                                              bank[0].size, -1 if level is None else int(level)))
+        self.handle = h
+        nlev, ncoef = C.c_int(0), C.c_int64(0)
+        check(lib().p3d_wavelet64_info(self.handle, C.byref(nlev), C.byref(ncoef)))
+        self.nlev, self.ncoef = nlev.value, ncoef.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().p3d_wavelet64_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        if lib is not None:
+            self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _cube(self, x):
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[None]
+        if x.ndim != 3 or x.shape[1:] != (self.nil, self.nxl) or x.shape[0] > self.max_slices:
+            raise ValueError(f"expected (<= {self.max_slices}, {self.nil}, {self.nxl}), got {x.shape}")
+        if x.dtype not in self._DT:
+            x = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+        return np.ascontiguousarray(x), self._DT[x.dtype]
+
+    @staticmethod
+    def _tau(tau, n, niter, nlev):
+        tau = np.broadcast_to(np.asarray(tau), (n, niter, nlev, 3))
+        t = np.empty(tau.shape + (2,), np.float64)
+        t[..., 0] = tau.real
+        t[..., 1] = tau.imag if np.iscomplexobj(tau) else 0.0
+        return t
+
+    def stats(self, x):
+        """(nslices, nlev, 3, 4): Re / Im of the lexicographic max, max |d|, min |d| per detail array (coarsest level first), in double."""
+        xc, dt = self._cube(x)
+        return self.stats_dev(xc.ctypes.data, dt, xc.shape[0])
+
+    def stats_dev(self, x_ptr, dtype, n):
+        st = np.empty((n, self.nlev, 3, 4), np.float64)
+        check(lib().p3d_wavelet64_stats(self.handle, C.c_void_p(x_ptr), dtype, n, _ptr(st)))
+        return st
+
+    def run(self, x, mask, tau, niter, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """Host arrays in, host array out (dtype of ``x``).  tau: (nslices, niter, nlev, 3) real or complex.  Returns (out, niter_done, sums, ms)."""
+        xc, dt = self._cube(x)
+        m = np.ascontiguousarray(mask, dtype=np.float64)
+        if m.shape != (self.nil, self.nxl):
+            raise ValueError(f"mask shape {m.shape} != {(self.nil, self.nxl)}")
+        out = np.empty_like(xc)
+        done, sums, ms = self.run_dev(xc.ctypes.data, dt, m.ctypes.data, tau, niter, out.ctypes.data, xc.shape[0], thresh_op=thresh_op, version=version,
+                                      eps=eps, alpha=alpha, active=active)
+        return out, done, sums, ms
+
+    def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, n, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """`run` on raw pointers (host or device; the mask is DOUBLE [nil][nxl]).  Returns (niter_done, sums, device ms of the loop)."""
+        t = self._tau(tau, n, niter, self.nlev)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_wavelet64_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
+                                      C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return done, sums, ms.value
 
 
 class DeviceArray:

@@ -18,6 +18,8 @@
 //                workgroup per CU) run persistent workgroups that request the next tile into registers ahead of the transforms.
 //   row pass:    one, two or four wavefronts per row, LB rows per workgroup; in place (one LDS buffer per row, one butterfly per
 //                thread and pass) wherever every pass fits the row's threads, two buffers otherwise.
+// 7-smooth lengths with a compile-time plan (p3d_mix_plans.inc) leave this file at the launchers: flex_row / flex_col hand them to the mixed-radix
+// register engine of p3d_mix.hpp (round 5; 1.4 - 1.6 x the rate of the LDS-image passes below), whose tables sit behind this file's in the device table.
 // Arithmetic is float32 like the tuned path; results agree with it to rounding (different pass structure).
 // What the round-1 version of this file did wrong, and the measurements: profiles/r02_flex_shape_sweep.txt.
 #include <hip/hip_runtime.h>
@@ -972,6 +974,9 @@ hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
     if (LB == 0) return hipErrorNotSupported;
     const FlexFactors pl = flex_factors(n);
     if (pl.blue) return chirp_row_real(mode, a, chirp_tabs(a.tw, pl), st);
+    // 7-smooth rows: the complex passes of the register engine (p3d_mix.hpp) beat the row pairs of the LDS-image kernel below although they
+    // transform twice the columns; "not supported" sends the caller there (p3d_pocs_run_dev falls back to the complex path)
+    if (mix::find(n)) return hipErrorNotSupported;
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;

@@ -242,6 +242,17 @@ def _get_wavelet_plan(nil, nxl, nslices, wavelet, device):
     return plan
 
 
+def _get_wavelet_plan64(nil, nxl, nslices, wavelet, device):
+    key = ('wavelet64', nil, nxl, str(wavelet), device)
+    plan = _plans.get(key)
+    if plan is None or plan.max_slices < nslices:
+        if plan is not None:
+            plan.close()
+        plan = _ffi.WaveletPlan64(nil, nxl, max(nslices, 1), wavelet=wavelet, device=device)
+        _plans[key] = plan
+    return plan
+
+
 def _shearlet_adaptive_tau_min(sumsq, shape2d):
     """1/3 median_s(log10(j_s + 1) sqrt(||ST_s||^2 / ST.size)) with j_s the scale of shearlet s (POCS.py:302-320)."""
     nsh = sumsq.shape[-1]
@@ -657,6 +668,43 @@ def _pocs_cube_double(cube, mask, out, niter, thresh_op, thresh_model, eps, alph
     return out
 
 
+def _pocs_cube_wavelet_double(cube, mask, out, wavelet, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results, device,
+                              batch_slices):
+    """``pocs_cube`` for the WAVELET transform through the double-precision loop (``_ffi.WaveletPlan64``): statistics of the double-precision
+    decomposition -> the schedule (host, as always) -> the iterations, batch by batch; complex64 / float32 cubes are widened on load and the
+    result is cast back on store (the reference's final cast, cube_POCS_interpolation_3D.py:324)."""
+    nslices, nil, nxl = cube.shape
+    # coefficient vector, feed, row / column intermediates, approximations and reconstructions of every level, staging: ~7.5 slice-sized arrays of
+    # 16-byte elements
+    step = int(batch_slices) if batch_slices else max(1, min(nslices, (4 << 30) // (nil * nxl * 120)))
+    step = min(step, 65535, nslices)
+    plan = _get_wavelet_plan64(nil, nxl, step, wavelet, device)
+    mask64 = np.ascontiguousarray(mask, dtype=np.float64)
+    for lo in range(0, nslices, step):
+        chunk = cube[lo:lo + step]
+        n = chunk.shape[0]
+        t0 = time.perf_counter()
+        xc, dt = plan._cube(chunk)
+        active = _active_slices(chunk)   # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+        stats = plan.stats_dev(xc.ctypes.data, dt, n)
+        stats[~active] = 1.0       # keep NaNs of empty slices out of the (unused) schedule rows ...
+        stats[~active, ..., 1] = 0.0   # ... without making them complex
+        tau = _wavelet_schedule_from_stats(stats, thresh_model, niter, p_max, p_min, decay_kind)
+        if sqrt_decay:
+            tau = np.sqrt(tau)  # POCS.py:595
+        dst = out[lo:lo + n]
+        direct = dst.dtype == xc.dtype and dst.flags.c_contiguous
+        res = dst if direct else np.empty_like(xc)
+        done, sums, _ = plan.run_dev(xc.ctypes.data, dt, mask64.ctypes.data, tau, niter, res.ctypes.data, n, thresh_op=thresh_op, version=version, eps=eps,
+                                     alpha=alpha, active=active)
+        if not direct:
+            dst[...] = res
+        runtime = time.perf_counter() - t0
+        if results is not None:
+            results.extend(_result_rows(done, sums, runtime))
+    return out
+
+
 def _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps, p_max, alpha, p_min):
     """Argument checks of the batched entry points (``pocs_cube``, ``sharding.pocs_block_on_device``), made BEFORE anything is
     uploaded: the kernels read ``nil * nxl`` mask entries whatever the caller handed over.  Returns the normalised
@@ -712,13 +760,14 @@ def pocs_cube(
     callables in ``**ignored`` are accepted for signature compatibility and not called: the transform
     is selected by ``transform_kind``.
 
-    ``precision`` (FFT transform; default: the environment variable ``P3D_PRECISION``, else ``None``) -- the arithmetic of the loop:
+    ``precision`` (FFT and WAVELET transforms; default: the environment variable ``P3D_PRECISION``, else ``None``) -- the arithmetic of the loop:
     ``None``: that of the cube -- float32 kernels for complex64 / float32 cubes, the double-precision loop for complex128 / float64
     cubes (the reference computes such cubes in double precision; POCS.py:371-656 never narrows its input); ``'reference'``: double
     precision also for complex64 / float32 cubes, the result cast back (what the reference itself executes for the soft / garrote
     operators, FPOCS and APOCS, and for every run under NumPy < 2 -- SURVEY appendix A.16); ``'float32'``: the float32 kernels whatever the
-    cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loop is a
-    precision path (about a tenth of the float32 rate, DESIGN.md section 5), has the hard / soft / garrote operators and slice extents up to 5120;
+    cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loops are
+    precision paths (FFT: about a tenth of the float32 rate; WAVELET: per-axis kernels without LDS tiles), have the hard / soft /
+    garrote operators, the FFT one slice extents up to 5120;
     a call that asks for (or implies) double precision outside that coverage runs the float32 kernels and says so with a ``RuntimeWarning``.
 
     ``out`` (optional): an array of the shape and dtype of ``cube`` to write the result into (e.g. a slab of the merged cube of the
@@ -754,6 +803,12 @@ def _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alp
         raise ValueError(f"precision must be None, 'reference' or 'float32', got {precision!r}")
     wide = cube.dtype in (np.complex128, np.float64)
     want_double = precision == 'reference' or (wide and precision is None)
+    if want_double and kind == 'WAVELET' and thresh_op in _WAVELET_OPS:
+        if decay_kind == 'factors' and not all(s in thresh_model for s in ['inverse', 'proportional']):
+            raise IndexError('list index out of range (decay_kind="factors" yields one tau per iteration, the WAVELET '
+                             'thresholding needs one per level and detail)')   # (as the float32 path below: the reference fails here)
+        return _pocs_cube_wavelet_double(cube, mask, out, _wavelet_name(ignored.get('transform'), wavelet), niter, thresh_op, thresh_model, eps, alpha, p_max,
+                                         p_min, sqrt_decay, decay_kind, version, results, device, batch_slices)
     if want_double and not (kind == 'FFT' and thresh_op in _WAVELET_OPS and max(nil, nxl) <= 5120):
         import warnings
         why = (f'the {kind} transform' if kind != 'FFT' else f'thresh_op={thresh_op!r}' if thresh_op not in _WAVELET_OPS else f'slice extents above 5120 ({nil} x {nxl})')

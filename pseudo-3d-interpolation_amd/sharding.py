@@ -2,12 +2,23 @@
 farm, cube_POCS_interpolation_3D.py:291-340).
 
 Slices are independent (one ``POCS_algorithm`` call each in the reference), so the slice axis is cut
-into ``world`` contiguous blocks, every rank runs its block on its own GPU, and the blocks are put
-together again with ONE collective at the end: ``gather`` to rank 0 (the "trivial gather" -- only the
-rank that writes the result cube needs all of it) or ``all_gather`` (every rank ends up with the cube).
-On GPUs the collective moves DEVICE tensors over RCCL/xGMI -- the block never visits the host between
-the last kernel and the collective; the same code runs over gloo on CPU tensors, which is how the
-tests exercise it.
+into ``world`` contiguous blocks and every rank runs its block on its own GPU.  How the blocks come
+together again is the caller's choice (``pocs_cube_sharded(..., gather=...)``):
+
+``'none'``  every rank moves ITS OWN block host -> device -> host, straight from the caller's cube into
+            the caller's result array (``out=``: shared memory, a memory-mapped file -- what the step-13
+            driver merges its batch files into).  No collective at all, and the PCIe links of all GPUs
+            work side by side: a 4-GiB cube in and out is ~0.14 s through one link, ~0.02 s through
+            eight.  This is the end-to-end path.
+``'root'``  ONE collective on device tensors at the end, ``gather`` to rank 0 (the "trivial gather" of
+            north_star: only the rank that consumes the cube on its GPU needs all of it), or
+``'all'``   ``all_gather`` (every rank ends up with the cube).  On GPUs the collective moves DEVICE
+            tensors over RCCL / xGMI -- the block never visits the host between the last kernel and the
+            collective; the same code runs over gloo on CPU tensors, which is how the tests exercise it.
+
+``import torch`` comes BEFORE the first call into the HIP library in a process that uses both (torch's
+copy of the HIP runtime has to initialise first, _ffi._preload_torch_hip): import this module -- or
+torch -- before ``functions.POCS`` does any work.
 """
 import os
 
@@ -77,6 +88,47 @@ def gather_blocks_to_root(local, nslices, group=None, root=0):
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 
+def _upload(arr, dev):
+    """A C-contiguous NumPy array -> a tensor on ``dev``, page-locked IN PLACE for the copy (``_ffi.host_register``: a DMA transfer at the link's
+    rate instead of the runtime's staged copy of pageable memory, 26 GB/s on the MI355X boxes -- profiles/r04_pcie_probe.txt).  A refused
+    registration (read-only mapping, memory the caller locked itself) just means the pageable copy."""
+    import torch
+
+    from . import _ffi
+
+    t = torch.from_numpy(arr)
+    if dev.type != "cuda" or arr.nbytes < (8 << 20):
+        return t.to(dev)
+    pinned = _ffi.host_register(arr)
+    try:
+        return t.to(dev)
+    finally:
+        if pinned:
+            _ffi.host_unregister(arr)
+
+
+def _download(t):
+    """A device tensor -> a new NumPy array whose fresh pages are touched by a few threads and page-locked for the copy (a download into
+    untouched pageable pages runs at a third of the link's rate)."""
+    import torch
+
+    from . import _ffi
+    from .functions import POCS as P
+
+    if not t.is_cuda or t.numel() * t.element_size() < (8 << 20):
+        return t.cpu().numpy()
+    res = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+    for f in P._touch_pages(res):
+        f.result()
+    pinned = _ffi.host_register(res)
+    try:
+        torch.from_numpy(res).copy_(t)
+    finally:
+        if pinned:
+            _ffi.host_unregister(res)
+    return res
+
+
 def pocs_block_on_device(block, mask, device=0, **params):
     """``functions.POCS.pocs_cube`` for one rank's block with the RESULT LEFT ON THE GPU: the block is uploaded once into a torch
     tensor, statistics / schedule / iterations run on raw device pointers and the result comes back as a device tensor (complex64 or
@@ -109,8 +161,8 @@ def pocs_block_on_device(block, mask, device=0, **params):
             fast = False   # (pocs_cube raises the reference's IndexError there)
     if not fast:
         res = np.ascontiguousarray(P.pocs_cube(block, mask, device=int(device), **params))
-        return torch.from_numpy(res).to(dev)
-    x = torch.from_numpy(np.ascontiguousarray(block)).to(dev)
+        return _upload(res, dev)
+    x = _upload(np.ascontiguousarray(block), dev)
     out = torch.empty_like(x)
     m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32)).to(dev)
     dt = _ffi.P3D_C64 if np.iscomplexobj(block) else _ffi.P3D_F32
@@ -155,24 +207,45 @@ def pocs_block_on_device(block, mask, device=0, **params):
     return out
 
 
-def pocs_cube_sharded(cube, mask, group=None, compute=None, gather="root", **params):
+def pocs_cube_sharded(cube, mask, group=None, compute=None, gather="root", out=None, **params):
     """Run the POCS interpolation of ``cube`` (NumPy, the whole cube is visible to every rank, e.g. memory-mapped) sharded over the
-    ranks of ``group`` and return the gathered result as a NumPy array: on every rank with ``gather='all'``, on rank 0 only (``None``
-    elsewhere) with ``gather='root'``.
+    ranks of ``group``.
 
-    ``compute(block, mask, **params)`` defaults to the HIP path on device ``LOCAL_RANK`` with the result kept on the device
-    (:func:`pocs_block_on_device`), so that over RCCL the collective moves device tensors and only the gathered cube is downloaded;
-    a ``compute`` that returns NumPy (the gloo tests inject one) is gathered on CPU tensors.
+    ``gather='none'``: every rank interpolates its own block straight into ``out[lo:hi]`` -- ``out`` an array of the cube's shape and
+    dtype that all ranks see (shared memory, ``np.memmap`` / ``np.lib.format.open_memmap``) -- through the host-buffer entry point
+    (``functions.POCS.pocs_cube``: the rank's block page-locked in place, chunks up and down on its own PCIe link); no collective but the
+    barrier that tells every rank the result is complete.  Returns ``out`` (without ``out=``: the rank's own block, a new array).
+    ``gather='root'`` / ``'all'``: the gathered cube as a NumPy array on rank 0 only (``None`` elsewhere) / on every rank, through ONE
+    collective on device tensors.
+
+    ``compute(block, mask, **params)`` defaults to the HIP path on device ``LOCAL_RANK``: with a collective the result is kept on the
+    device (:func:`pocs_block_on_device`), so that over RCCL the collective moves device tensors and only the gathered cube is
+    downloaded; a ``compute`` that returns NumPy (the gloo tests inject one) is gathered on CPU tensors / written to ``out``.
     """
     import torch
     import torch.distributed as dist
 
-    if gather not in ("root", "all"):
-        raise ValueError("gather must be 'root' or 'all'")
+    if gather not in ("root", "all", "none"):
+        raise ValueError("gather must be 'root', 'all' or 'none'")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = slice_block(cube.shape[0], world, rank)
     on_gpu = dist.get_backend(group) == "nccl"
     local_dev = int(params.pop("device", os.environ.get("LOCAL_RANK", rank)))   # (a caller's device=... wins over LOCAL_RANK)
+    if out is not None and (gather != "none" or tuple(out.shape) != tuple(cube.shape) or out.dtype != cube.dtype):
+        raise ValueError("out= goes with gather='none' and has the shape and dtype of the cube")
+    if gather == "none":
+        block = np.asarray(cube[lo:hi])
+        if compute is None:
+            from .functions import POCS as P
+            res = P.pocs_cube(block, mask, device=local_dev, out=None if out is None else out[lo:hi], **params)
+        else:
+            res = np.asarray(compute(block, mask, **params))
+            if out is not None:
+                out[lo:hi] = res
+        if out is not None and hasattr(out, "flush") and hi > lo:
+            out.flush()   # a memory-mapped result: the block is in the page cache of the file every rank maps
+        dist.barrier(group)
+        return res if out is None else out
     if compute is None:
         block = pocs_block_on_device(np.asarray(cube[lo:hi]), mask, device=local_dev, **params)
         if not on_gpu:
@@ -192,5 +265,5 @@ def pocs_cube_sharded(cube, mask, group=None, compute=None, gather="root", **par
     full = gather_blocks(block, cube.shape[0], group) if gather == "all" else gather_blocks_to_root(block, cube.shape[0], group)
     if gather == "root" and rank != 0:
         return None
-    full = full.cpu().numpy()
+    full = _download(full)
     return full.view(complex_np) if complex_np is not None else full

@@ -39,6 +39,14 @@ for real, shape, prm in ((False, (64, 128), dict(niter=9, thresh_op="hard", thre
     assert everywhere.dtype == obs.dtype and np.array_equal(everywhere, want), (rank, shape)
     root = pocs_cube_sharded(obs, mask, **prm)
     assert (root is None) == (rank != 0) and (rank != 0 or np.array_equal(root, want))
+    # no collective at all: every rank moves its own block through its own PCIe link, straight into a result file all ranks map
+    path = os.path.join(os.environ["P3D_TMP"], f"out_{shape[0]}_{shape[1]}_{int(real)}_{prm.get('transform_kind', 'FFT')}.npy")
+    if rank == 0:
+        np.lib.format.open_memmap(path, mode="w+", dtype=obs.dtype, shape=obs.shape).flush()
+    dist.barrier()
+    shared = np.load(path, mmap_mode="r+")
+    assert pocs_cube_sharded(obs, mask, gather="none", out=shared, **prm) is shared
+    assert np.array_equal(np.load(path, mmap_mode="r"), want), (rank, shape, "gather='none'")
 dev = pocs_block_on_device(obs[:2], mask, device=0, **prm)      # (the SHEARLET case: the device-resident branch of configs[4])
 assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), want[:2])
 # the argument checks of pocs_cube come before any upload (a short mask would be read out of bounds by the kernels)
@@ -69,7 +77,7 @@ def test_sharded_hip_path_equals_the_single_process_result(tmp_path, world, nsli
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, P3D_ROOT=ROOT, P3D_NSLICES=str(nslices), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ, P3D_ROOT=ROOT, P3D_NSLICES=str(nslices), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), P3D_TMP=str(tmp_path))
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)

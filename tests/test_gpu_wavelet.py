@@ -458,3 +458,58 @@ def test_mask_weights_as_bits_in_the_fused_level_one_kernel(wo, monkeypatch, sha
     want_f = wo.pocs_cube_wavelet(cube.astype(np.float64 if real else np.complex128), soft, wavelet=wavelet, **kw)
     assert max(rel_l2(got_f[s], want_f[s]) for s in range(3)) <= 2e-5
     assert not np.array_equal(got_f, got)
+
+
+# ---- the WAVELET loop in the reference's double precision (p3d_wavelet64.hip) -----------------------------------------------------------
+@pytest.mark.parametrize("shape,wavelet,complex_", [((64, 64), "db4", False), ((96, 80), "coif5", True), ((61, 47), "sym5", False), ((50, 70), "bior2.2", True),
+                                                    ((128, 40), "haar", True), ((33, 70), "db2", False)])
+@pytest.mark.parametrize("kw", [
+    dict(niter=6, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2),
+    dict(niter=5, thresh_op="garrote", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
+    dict(niter=12, thresh_op="hard", thresh_model="inverse_proportional", eps=1e-4, p_max=0.99, p_min=1e-2),
+])
+def test_wavelet_loop_in_the_reference_precision(wo, shape, wavelet, complex_, kw):
+    """complex128 / float64 cubes run the WAVELET loop in double precision (pywt keeps float64 for float64 input and POCS_algorithm never
+    narrows: POCS.py:585-609), complex64 / float32 cubes on request: 1e-10 against the double-fed oracle where the float32 kernels hold 1e-5,
+    the same iteration counts under the early exit, an all-zero slice untouched."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    mask = po.synthetic_mask(shape[0], shape[1], 0.5)
+    cube = np.stack([_slice(shape, 10 + s, complex_) for s in range(3)]) * mask
+    cube[1] = 0
+    res, infos = [], []
+    got = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet=wavelet, results=res, **kw)
+    want = wo.pocs_cube_wavelet(cube, mask, wavelet=wavelet, infos=infos, **kw)
+    assert got.dtype == cube.dtype and not got[1].any()
+    for s in (0, 2):
+        assert res[s]["niterations"] == infos[s]["niterations"], (s, res[s]["niterations"], infos[s]["niterations"])
+        assert rel_l2(got[s], want[s]) <= 1e-10, (s, rel_l2(got[s], want[s]))
+    narrow = cube.astype(np.complex64 if complex_ else np.float32)
+    got32 = P.pocs_cube(narrow, mask, transform_kind="WAVELET", wavelet=wavelet, precision="reference", **kw)
+    want32 = wo.pocs_cube_wavelet(narrow.astype(cube.dtype), mask, wavelet=wavelet, **kw)
+    assert got32.dtype == narrow.dtype
+    if kw["thresh_op"] != "hard":     # (the result is cast back to float32: 6e-8 per sample; a hard threshold may flip a decision of the narrowed input)
+        assert rel_l2(got32, want32) <= 2e-7
+
+
+def test_wavelet_config3_at_its_own_size_in_the_reference_precision(wo):
+    """BASELINE configs[3] as stated (512 x 512 slices, 70 % missing, db4 / 'smooth', soft threshold, exponential decay to 1e-3 of the peak,
+    50 iterations) through the double-precision loop: <= 1e-8 against the double-fed oracle at the configuration's own size and length,
+    where the float32 kernels -- like the reference's own float32 run -- leave the float64 trajectory by 1e-3 ... 1e-2 (the iteration is
+    expansive on decimated data)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    n, K = 512, 50
+    mask = po.synthetic_mask(n, n, 0.7)
+    kw = dict(niter=K, thresh_op="soft", thresh_model="exponential", p_max=0.99, p_min=1e-3, eps=0.0)
+    x = np.stack([(po.synthetic_slice(n, n, seed, real=True) * mask).astype(np.float32) for seed in (0, 1)])
+    want = wo.pocs_cube_wavelet(x.astype(np.float64), mask, wavelet="db4", **kw)
+    got64 = P.pocs_cube(x.astype(np.float64), mask, transform_kind="WAVELET", wavelet="db4", **kw)             # float64 cube: double by default
+    got32 = P.pocs_cube(x, mask, transform_kind="WAVELET", wavelet="db4", precision="reference", **kw)         # float32 cube: on request
+    fast = P.pocs_cube(x, mask, transform_kind="WAVELET", wavelet="db4", **kw)                                 # the float32 kernels
+    for s in range(2):
+        e64, e32, ef = rel_l2(got64[s], want[s]), rel_l2(got32[s], want[s]), rel_l2(fast[s], want[s])
+        print(f"configs[3] slice {s}: double loop {e64:.3e} (float32 cube, cast back: {e32:.3e}), float32 kernels {ef:.3e}, max|x| {np.abs(want[s]).max():.3e}")
+        assert e64 <= 1e-8, (s, e64)
+        assert e32 <= 2e-7, (s, e32)
+    assert got64.dtype == np.float64 and got32.dtype == np.float32

@@ -67,6 +67,24 @@ got = gather_blocks_to_root(cplx, n)
 assert got.dtype == torch.complex64 and (rank != 0 or torch.equal(got, torch.from_numpy(cube)))
 as_tensor = pocs_cube_sharded(cube, mask, compute=lambda b, m, **kw: torch.from_numpy(np.ascontiguousarray(b * 3)), gather="all", niter=3)
 assert as_tensor.dtype == cube.dtype and np.array_equal(as_tensor, cube * 3)            # a compute that hands back a (complex) tensor
+# gather='none': every rank writes its own block into a result array all ranks map (here a .npy file; the step-13 driver's merged cube) -- no
+# collective, the result is complete on return (barrier inside)
+path = os.path.join(os.environ["P3D_TMP"], "out.npy")
+if rank == 0:
+    np.lib.format.open_memmap(path, mode="w+", dtype=cube.dtype, shape=cube.shape).flush()
+dist.barrier()
+shared = np.load(path, mmap_mode="r+")
+ret = pocs_cube_sharded(cube, mask, compute=fake_pocs, gather="none", out=shared, niter=3)
+assert ret is shared and np.array_equal(np.load(path, mmap_mode="r"), want), rank
+own = pocs_cube_sharded(cube, mask, compute=fake_pocs, gather="none", niter=3)          # without out=: the rank's own block
+assert own.shape[0] == hi - lo and np.array_equal(own, want[lo:hi])
+for bad in (dict(gather="root", out=shared), dict(gather="none", out=shared[:-1]), dict(gather="sideways")):
+    try:
+        pocs_cube_sharded(cube, mask, compute=fake_pocs, niter=3, **bad)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError(f"no ValueError for {list(bad)}")
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", seen)
@@ -80,7 +98,7 @@ def test_sharded_run_and_gather_gloo(tmp_path, world, nslices):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, P3D_ROOT=ROOT, P3D_NSLICES=str(nslices), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ, P3D_ROOT=ROOT, P3D_NSLICES=str(nslices), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), P3D_TMP=str(tmp_path))
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
