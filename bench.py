@@ -117,6 +117,26 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def measured_valu(config, kernel_substring):
+    """The VALU-issue figures of one kernel from profiles/traffic_config<i>.json (tools/traffic.py: SQ_INSTS_VALU per dispatch over the kernel's
+    average duration, as a fraction of the chip's vector issue rate) -- only while the file was measured on the kernel sources of this tree."""
+    path = os.path.join(ROOT, "profiles", f"traffic_config{config}.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    for name, k in rec.get("kernels", {}).items():
+        if kernel_substring in name and "valu_issue_frac" in k:
+            return {"kernel": name, "valu_wave_instructions_per_dispatch": k["valu_wave_instructions_per_dispatch"], "average_ns": k["average_ns"],
+                    "valu_frac": k["valu_issue_frac"], "peak_wave_instructions_per_s": rec.get("valu_issue_peak_wave_instructions_per_s"),
+                    "from": f"profiles/traffic_config{config}.json: rocprofv3 --pmc SQ_INSTS_VALU per dispatch / the kernel's average duration in the kernel trace of "
+                            f"the same command / (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wavefront instruction)"}
+    return None
+
+
 def measured_traffic(config, workload_key, scale=1.0):
     """(traffic, traffic_from, last_measured) from profiles/traffic_config<i>.json.  A measurement counts only for the kernel sources it
     was taken on; a stale one is named, not reported."""
@@ -277,7 +297,7 @@ def _cpu_worker(job):
     return (wall, res) if keep else wall
 
 
-def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None):
+def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None, also=None):
     """rel-L2 per slice between the GPU result of the TIMED job (the first slices of its output cube) and the oracle run on the
     same observed slices for the same number of iterations -- fed in double precision (BASELINE's yardstick), and once more in the
     cube's own precision: NumPy's float32-vs-float64 spread on these very slices, which is what the reference itself gives up."""
@@ -289,7 +309,12 @@ def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None):
     ref32 = [r for _, r in pool.map(_cpu_worker, [(kind32, s.astype(narrow), mask, niter, op, extra, True) for s in obs_slices])]
     rel = [float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(gpu_result, ref64)]
     spread = [float(np.linalg.norm(a.astype(wide) - r) / np.linalg.norm(r)) for a, r in zip(ref32, ref64)]
+    other = {}
+    for name, res in (also or {}).items():   # the same slices through another device path (the loop in double precision)
+        r2 = [float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(res, ref64)]
+        other[name] = {"rel_l2_max": max(r2), "rel_l2_median": float(np.median(r2)), "slices": len(r2), "niter": int(niter)}
     return {
+        "other_paths": other or None,
         "rel_l2_max": max(rel), "rel_l2_median": float(np.median(rel)), "slices": len(rel), "niter": int(niter),
         "against": "oracle (NumPy restatement of the reference, pinned on its golden vectors) fed the same observed slices in double precision",
         "what": "out[:slices] of the TIMED job (same cube, same K, same schedule) vs the oracle, ||gpu - ref|| / ||ref|| per slice",
@@ -303,7 +328,7 @@ def cpu_parity(pool, kind, obs_slices, mask, op, niter, gpu_result, extra=None):
     }
 
 
-def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None, parity_of=None, parity_niter=None):
+def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None, parity_of=None, parity_niter=None, also=None):
     """(cpu_baseline record, parity record or None).  parity_of: the GPU result on exactly these slices after parity_niter iterations."""
     import multiprocessing as mp
 
@@ -320,7 +345,7 @@ def cpu_baseline(kind, obs_slices, mask, op, budget_s, nslices_cube, extra=None,
         pool.map(_cpu_worker, [(kind, s, mask, niter, op, extra) for s in obs_slices])
         wall = time.perf_counter() - t0
         if parity_of is not None:
-            parity = cpu_parity(pool, kind, obs_slices, mask, op, parity_niter, parity_of, extra)
+            parity = cpu_parity(pool, kind, obs_slices, mask, op, parity_niter, parity_of, extra, also)
     slice_iters_per_s = workers * niter / wall
     return parity, {
         "value": slice_iters_per_s / nslices_cube,
@@ -638,6 +663,10 @@ def run_leg(ctx, config, K_override, main, override=None):
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": it_ms,
             }
             if shear_share is not None:
+                # the column pass of this leg is bound by vector-instruction issue, not by memory (profiles/r04_shearlet_column_ablation.txt): its roofline
+                vi = measured_valu(config, "col_shear_pair_kernel") if default_shape else None
+                roof["valu"] = vi
+                roof["valu_frac"] = None if vi is None else vi["valu_frac"]
                 roof["shearlet_rows"] = dict(shear_share, note=(
                     "algorithmic bytes = 40 B x points x shearlets x rows_moved_fraction: rows on which a shearlet's spectrum vanishes carry only zeros "
                     "through the iteration (row_group_fraction = share of the (shearlet, 8-row group) pairs that do not), and a float32 cube on symmetric "
@@ -712,6 +741,27 @@ def run_leg(ctx, config, K_override, main, override=None):
                          "note": "28 B/point of the float32 accounting, doubled; the two fused passes move ~80 B/point (16 + 16 per pass, observed sample and weight "
                                  "in the row pass) and are bound by their double-precision butterflies in LDS, not by memory (round 4 first cut, six unfused "
                                  "passes: ~210 B/point, half this rate)"},
+        }
+        del host64
+
+    # ---- the WAVELET loop in the reference's double precision (p3d_wavelet64.hip): the slices the CPU leg computes, the full schedule ----
+    also64 = None
+    if kind == "WAVELET" and rank == 0 and world == 1 and n_cpu > 0 and args.eps == 0:
+        host64 = x_obs.download(0, n_cpu)
+        with _ffi.WaveletPlan64(nil, nxl, n_cpu, wavelet=cfg["wavelet"], device=dev_index) as plan64:
+            tau64 = P._wavelet_schedule_from_stats(plan64.stats(host64), "exponential", K, 0.99, p_min, "values")
+            runs = [plan64.run(host64, mask, tau64, K, thresh_op=op, eps=args.eps, alpha=args.alpha) for _ in range(2)]
+        it64 = min(r[3] for r in runs) / K            # ms per iteration of the n_cpu-slice sample (device time of the loop)
+        also64 = {"reference_precision": runs[-1][0]}
+        b64 = 2.0 * ALG_BYTES["WAVELET"](0) * nil * nxl * n_cpu
+        ref_prec = {
+            "what": f"the same job with precision='reference': the WAVELET loop in double precision (pywt keeps float64 for float64 input, POCS.py:585-609 never "
+                    f"narrows) on per-axis kernels without LDS tiles -- the first {n_cpu} slices of the cube (those of the parity figure), float32 in and out, device "
+                    f"time of the {K}-iteration loop; parity under parity.other_paths.reference_precision",
+            "slice_iterations_per_s": n_cpu / (it64 * 1e-3), "iterations_per_s_of_the_cube": n_cpu / (it64 * 1e-3) / cube_slices,
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": 2.0 * ALG_BYTES["WAVELET"](0), "achieved": b64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": b64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "note": "the float32 accounting (29.33 B/point), doubled; three launches per level and direction move several times that"},
         }
         del host64
 
@@ -852,7 +902,7 @@ def run_leg(ctx, config, K_override, main, override=None):
             plan.close()
             x_obs.free(); out.free()
             cs = cpu_slices if not cfg["real"] else cpu_slices.real.astype(np.float64)
-            parity, cpu = cpu_baseline(kind, cs, mask, op, budget, cube_slices, extra=cfg.get("wavelet"), parity_of=gpu_first, parity_niter=K)
+            parity, cpu = cpu_baseline(kind, cs, mask, op, budget, cube_slices, extra=cfg.get("wavelet"), parity_of=gpu_first, parity_niter=K, also=also64)
     else:
         plan.close()
         x_obs.free(); out.free()
@@ -934,7 +984,7 @@ def run_leg(ctx, config, K_override, main, override=None):
 def compact(rec):
     """What an `other_configs` entry keeps of a leg's record: enough to recompute its rate and roofline fraction."""
     keep = ("value", "unit", "steps", "ms_per_step", "dtype", "steady_state_iterations_per_s", "fixed_ms_per_job", "slice_iterations_per_s",
-            "interpolated_traces_per_s", "end_to_end", "roofline", "cpu_baseline", "parity")
+            "interpolated_traces_per_s", "end_to_end", "roofline", "cpu_baseline", "parity", "reference_precision")
     out = {"workload": rec["config"]["workload"], "slices_per_gpu": rec["config"]["slices_per_gpu"]}
     out.update({k: rec[k] for k in keep})
     out["repeats"] = {k: rec["repeats"][k] for k in ("n", "job_s_median", "job_s_min", "job_s_max")}

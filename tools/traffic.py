@@ -44,7 +44,15 @@ def counters(name):
     return out
 
 
-fetch, write = counters("FETCH_SIZE"), counters("WRITE_SIZE")
+fetch, write, valu = counters("FETCH_SIZE"), counters("WRITE_SIZE"), counters("SQ_INSTS_VALU")
+# average duration of every kernel in the run WITHOUT counters (the kernel trace of the same command)
+dur_ns = {}
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur_ns[r["Name"]] = float(r["AverageNs"])
+# one wavefront instruction per SIMD every two cycles (64 lanes on a SIMD-32): 256 CUs x 4 SIMDs x 2.4 GHz / 2 -- the rate behind the
+# 157.3 TFLOP/s FP32 vector peak of /opt/skills/guides/MI355X_MICROARCH.md (x 64 lanes x 2 flop per FMA)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
 line = json.loads([l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1])
 loop_re, once_re = re.compile(LOOP[0]), re.compile(LOOP[1])
 kernels, read_b, written_b, iters = {}, 0.0, 0.0, 0
@@ -57,6 +65,10 @@ for k in sorted(set(fetch) | set(write)):
     if short in kernels:
         short = short + f" #{len(kernels)}"
     kernels[short] = {"dispatches": n, "read_bytes_per_dispatch": rb / max(fetch[k][1], 1), "written_bytes_per_dispatch": wb / max(write[k][1], 1)}
+    if k in valu and valu[k][1] and k in dur_ns:
+        per = valu[k][0] / valu[k][1]
+        kernels[short].update({"valu_wave_instructions_per_dispatch": per, "average_ns": dur_ns[k],
+                               "valu_issue_frac": per / (dur_ns[k] * 1e-9) / VALU_ISSUE_PEAK})
     read_b += rb
     written_b += wb
     if once_re.search(k):
@@ -77,6 +89,7 @@ rec = {
     "method": "tools/traffic.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_slots.py) over bench.py --config "
               f"{config} --only-main --no-cpu-baseline --no-dense --repeats 1 --warmup 0 --steps {steps}; (FETCH_SIZE x 2 [gfx950 wide-read correction] + "
               "WRITE_SIZE) x 1024 B summed over the loop's kernels / iterations in the trace",
+    "valu_issue_peak_wave_instructions_per_s": VALU_ISSUE_PEAK,
     "kernel_source_hash": bench.kernel_source_hash(), "round": rnd,
 }
 print(json.dumps(rec, indent=1))
