@@ -53,14 +53,14 @@ def factorizations(n, allowed, maxlen):
 def splits(n, r):
     """(B, PPT) choices of a pass of radix r: PPT = r B divides n, 12 <= PPT <= 32 where possible (else the nearest)."""
     cands = [(b, r * b) for b in range(1, 33) if n % (r * b) == 0 and r * b <= 64]
-    good = [c for c in cands if 12 <= c[1] <= 32]
+    good = [c for c in cands if 12 <= c[1] <= 32 and (r <= 20 or c[0] == 1)]
     return good or sorted(cands, key=lambda c: abs(c[1] - 20))[:2]
 
 
-def best_plan(n):
+def best_plan(n, max_radix=None):
     """(score, colt, ((R0, B0), (R1, B1), ...)) -- forward order."""
     best = None
-    allowed = sorted([d for d in range(2, MAX_RADIX + 1) if smooth(d) and n % d == 0], reverse=True)
+    allowed = sorted([d for d in range(2, (max_radix or MAX_RADIX) + 1) if smooth(d) and n % d == 0], reverse=True)
     for fac in factorizations(n, allowed, 4):
         if len(fac) == 1 and n > 32:
             continue
@@ -92,7 +92,8 @@ def best_plan(n):
 
 def row_lines(n, tmax):
     """rows per workgroup of the row pass: an even number (rows are worked on in pairs), ~256 threads, at most ~44 KiB of line images (three
-    workgroups per CU), the candidate that fills its wavefronts best"""
+    workgroups per CU beside the twiddle tables), the candidate that fills its wavefronts best.  (Larger workgroups would amortise the copy of
+    the twiddle tables -- ~1.25 N entries per workgroup -- but leave one or two workgroups per CU, whose phases then no longer cover each other.)"""
     best = None
     for lb in range(2, 65, 2):
         thr = lb * tmax
@@ -112,12 +113,15 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--only", type=int, nargs="*")
     ap.add_argument("--parts", type=int, default=8, help="translation units the instantiations are spread over (#if P3D_MIX_PART == k)")
+    ap.add_argument("--two-pass-below", type=int, default=1024,
+                    help="lengths up to this one may use radices up to 32: two-pass plans, one exchange per transform (measured: 960-point columns 0.41 -> 0.24 ms, "
+                         "900 x 900 1.05 -> 0.91 ms per iteration of 128 slices; 768-point rows lose 8 %%)")
     ap.add_argument("--roots", action="store_true", help="write the root tables Roots<R> (csrc/p3d_mix_roots.inc) instead of the plan list")
     args = ap.parse_args()
     if args.roots:
         import math
         print("// generated by tools/gen_mix_plans.py --roots -- do not edit.  cos / sin of 2 pi q / R, evaluated in double precision, rounded once")
-        for r in range(2, MAX_RADIX + 1):
+        for r in range(2, 33):
             if not smooth(r):
                 continue
             def fmt(x):
@@ -129,7 +133,7 @@ def main():
     lengths = args.only or [n for n in range(args.min, args.max + 1) if smooth(n) and n & (n - 1)]
     rows = []
     for n in lengths:
-        b = best_plan(n)
+        b = best_plan(n, 32 if n <= args.two_pass_below else None)
         if b is None:
             continue
         _, colt, order = b
