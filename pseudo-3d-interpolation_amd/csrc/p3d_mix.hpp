@@ -207,9 +207,9 @@ template <class PL, int DIR, int W>
 struct Lds {
     static constexpr int WIDTH = W, PADQ = PL::padq(DIR);
     c32* base;
-    __device__ __forceinline__ c32* ptr(int pos) const { return base + (PADQ ? pos + pos / PADQ : pos) * W; }
+    __device__ __forceinline__ c32* ptr(int pos) const { return base + (PADQ ? pos + pos / (PADQ ? PADQ : 1) : pos) * W; }
     static constexpr int rel(int c) { return PL::pad(DIR, c) * W; }   // pad(p + c) == pad(p) + pad(c) when PADQ | c
-    static constexpr bool folds(int c) { return PADQ == 0 || c % PADQ == 0; }
+    static constexpr bool folds(int c) { return PADQ == 0 || c % (PADQ ? PADQ : 1) == 0; }
 };
 
 template <class PL, int DIR, int P, int T>

@@ -72,7 +72,16 @@ def best_plan(n, max_radix=None):
             if tmax < 4:
                 continue
             line = n * 1.1
-            colt = next((t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * line * 8 <= 72 * 1024), 0)
+            # Column tile: 8 columns (a whole 64-byte column block per row) where two workgroups' tiles share a CU's LDS (<= 72 KiB each).  LONG
+            # columns: the widest tile that fits ONE workgroup per CU (image + tables <= 154 KiB) if that workgroup has >= 600 threads to cover its
+            # own latencies -- narrower tiles move 32- or 16-byte pieces of every row (measured: 2000-point columns 2.09 -> 1.27 ms per 128 x 1500
+            # columns with 8 instead of 4 per tile, 1600 points 1.00 -> 0.79, 1500 points 1.62 -> 1.32; 1200 points, 480 threads: 0.78 -> 0.87) --,
+            # else the widest one of which two fit.
+            worst = 1 + max([1 / r for r in fac if r % 2 == 0 and r > 2] or [0])   # padding of the LDS image: one slot per (even) first radix
+            tables = 1.3 * n * 8
+            small = next((t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * line * 8 <= 72 * 1024), 0)
+            big = next((t for t in (8, 4, 2) if t * tmax <= 1024 and t * tmax >= (600 if small >= 4 else 450) and t * n * 8 * worst + tables <= 154 * 1024), 0)
+            colt = big if big > small else small
             if not colt:
                 continue
             regs = 2 * max(ppts) + 2 * max(fac) + 24
