@@ -141,7 +141,17 @@ def main():
         return
     lengths = args.only or [n for n in range(args.min, args.max + 1) if smooth(n) and n & (n - 1)]
     rows = []
+    forced = {}   # experiments: P3D_GEN_FORCE="1000:10x2,10x2,10x2;768:8x3,8x3,12x2" (forward order, radix x butterflies per thread)
+    for item in filter(None, __import__("os").environ.get("P3D_GEN_FORCE", "").split(";")):
+        nn, plan = item.split(":")
+        forced[int(nn)] = tuple(tuple(int(v) for v in ps.split("x")) for ps in plan.split(","))
     for n in lengths:
+        if n in forced:
+            order = forced[n]
+            tmax = max(n // (r * nb) for r, nb in order)
+            colt = next(t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * n * 1.1 * 8 <= 72 * 1024)
+            rows.append((n, colt, row_lines(n, tmax), order))
+            continue
         b = best_plan(n, 32 if n <= args.two_pass_below else None)
         if b is None:
             continue
