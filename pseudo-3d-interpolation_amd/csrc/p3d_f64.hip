@@ -26,6 +26,7 @@
 #include "p3d.h"
 #include "p3d_generic.hpp"
 #include "p3d_internal.hpp"
+#include "p3d_mix64.hpp"
 
 namespace {
 
@@ -704,6 +705,14 @@ struct p3d_plan64 {
     Fft64 fcol{}, frow{};
     int ln_col = 0, ln_row = 0, tw_col_lds = 0, tw_row_lds = 0, thr_col = F64_THREADS, thr_row = F64_THREADS;
     size_t lds_col = 0, lds_row = 0;
+    // passes on the mixed-radix register engine (p3d_mix64.hip) where the axis' length has a plan: chosen per axis, same work buffer
+    const p3d::mix64::Entry *mcol = nullptr, *mrow = nullptr;
+    c64 *tw_mcol = nullptr, *tw_mrow = nullptr;
+    unsigned char* nzflag = nullptr;   // both passes on the register engine: [max_slices][tiles_col] tile flags of the sparse shortcut
+    bool sparse = false;               // ... in use for the job in progress
+    // the observed cube and the result of the job in progress: the caller's own device buffers where it passed such, else the staging buffers
+    const void* cur_x = nullptr;
+    void* cur_out = nullptr;
     int tiles_col() const { return (nxl + ln_col - 1) / ln_col; }
     int tiles_row() const { return (nil + ln_row - 1) / ln_row; }
 };
@@ -758,6 +767,15 @@ int pick_tile64(int n, size_t budget, int want, int* tw_lds, size_t* lds)
 template <int MODE>
 int col_pass64(p3d_plan64* p, int nslices, int niter, int iter, int op, const int* done)
 {
+    if (p->mcol) {
+        p3d::mix64::ColArgs64 a{};
+        a.work = reinterpret_cast<p3d::mix::c64d*>(p->work); a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mcol);
+        a.n2 = p->nxl; a.nslices = nslices; a.tau = reinterpret_cast<const p3d::mix::c64d*>(p->tau); a.niter = niter; a.iter = iter; a.op = op;
+        a.partial = p->partial; a.done = done;
+        a.nzflag = (MODE == C64_ITER && p->sparse) ? p->nzflag : nullptr;
+        F_TRY(p->mcol->col(MODE, a, p->stream));
+        return P3D_OK;
+    }
     auto kern = p->tw_col_lds ? col64_kernel<MODE, true> : col64_kernel<MODE, false>;
     if (p->lds_col > 64 * 1024) F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_col));
     kern<<<dim3(p->tiles_col(), nslices), p->thr_col, p->lds_col, p->stream>>>(p->work, p->tw_col, p->fcol, p->nxl, p->ln_col, p->tw_col_lds, p->tau, niter, iter, op, p->partial, done);
@@ -768,10 +786,21 @@ int col_pass64(p3d_plan64* p, int nslices, int niter, int iter, int op, const in
 template <int MODE>
 int row_pass64(p3d_plan64* p, int dtype, double* sums_row, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill)
 {
+    if (p->mrow) {
+        p3d::mix64::RowArgs64 a{};
+        a.work = reinterpret_cast<p3d::mix::c64d*>(p->work); a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mrow);
+        a.n1 = p->nil; a.nslices = nslices; a.x = p->cur_x; a.dtype = dtype; a.mask = (MODE == R64_FIRST && !adaptive) ? nullptr : p->mask; a.out = p->cur_out;
+        a.partial = p->spart; a.adaptive = adaptive; a.write_out = write_out; a.alpha = alpha; a.done = done; a.zero_fill = zero_fill;
+        a.nzflag = (MODE != R64_FIRST && p->sparse) ? p->nzflag : nullptr; a.nz_tiles = p->tiles_col(); a.nz_col_t = p->ln_col;
+        F_TRY(p->mrow->row(MODE, a, p->stream));
+        fold64_kernel<<<nslices, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p->tiles_row());
+        F_TRY(hipGetLastError());
+        return P3D_OK;
+    }
     auto kern = p->tw_row_lds ? row64_kernel<MODE, true> : row64_kernel<MODE, false>;
     if (p->lds_row > 64 * 1024) F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_row));
-    kern<<<dim3(p->tiles_row(), nslices), p->thr_row, p->lds_row, p->stream>>>(p->work, p->tw_row, p->frow, p->nil, p->ln_row, p->tw_row_lds, p->st_x, dtype,
-                                                                              (MODE == R64_FIRST && !adaptive) ? nullptr : p->mask, p->st_out, p->spart, adaptive, write_out, alpha,
+    kern<<<dim3(p->tiles_row(), nslices), p->thr_row, p->lds_row, p->stream>>>(p->work, p->tw_row, p->frow, p->nil, p->ln_row, p->tw_row_lds, p->cur_x, dtype,
+                                                                              (MODE == R64_FIRST && !adaptive) ? nullptr : p->mask, p->cur_out, p->spart, adaptive, write_out, alpha,
                                                                               done, zero_fill);
     fold64_kernel<<<nslices, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p->tiles_row());
     F_TRY(hipGetLastError());
@@ -779,6 +808,17 @@ int row_pass64(p3d_plan64* p, int dtype, double* sums_row, int adaptive, int wri
 }
 
 size_t esize(int dtype) { return dtype == P3D_C128 ? 16 : (dtype == P3D_F64 || dtype == P3D_C64 ? 8 : 4); }
+
+// a pointer into the memory of the plan's own device (the entry points take host or device pointers)
+bool on_plan_device(const p3d_plan64* p, const void* ptr)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+        (void)hipGetLastError();   // ordinary host memory
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice && at.device == p->device;
+}
 
 int check64(p3d_plan64* p, int nslices, int dtype)
 {
@@ -791,7 +831,7 @@ int check64(p3d_plan64* p, int nslices, int dtype)
 
 int update(p3d_plan64* p, int dtype, double* sums_row, int mode, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill)
 {
-    update64_kernel<<<dim3(p3d_plan64::BLOCKS, nslices), 256, 0, p->stream>>>(p->work, p->st_x, dtype, mode == 0 && !adaptive ? nullptr : p->mask, p->st_out, p->spart, mode,
+    update64_kernel<<<dim3(p3d_plan64::BLOCKS, nslices), 256, 0, p->stream>>>(p->work, p->cur_x, dtype, mode == 0 && !adaptive ? nullptr : p->mask, p->cur_out, p->spart, mode,
                                                                               adaptive, write_out, alpha, p->per(), done, zero_fill);
     fold64_kernel<<<nslices, 64, 0, p->stream>>>(p->spart, sums_row, nslices, p3d_plan64::BLOCKS);
     F_TRY(hipGetLastError());
@@ -807,7 +847,7 @@ int p3d_plan64_destroy(p3d_plan64* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->tw_col, p->tw_row, p->work, p->tau, p->st_x, p->st_out, p->mask, p->partial, p->sums, p->spart, p->done};
+    void* bufs[] = {p->nzflag, p->tw_mcol, p->tw_mrow, p->tw_col, p->tw_row, p->work, p->tau, p->st_x, p->st_out, p->mask, p->partial, p->sums, p->spart, p->done};
     for (void* b : bufs)
         if (b) hipFree(b);
     if (p->ev0) hipEventDestroy(p->ev0);
@@ -870,6 +910,21 @@ int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_sl
         p->fused = p->ln_col > 0 && p->ln_row > 0 && p->fcol.nf > 0 && p->frow.nf > 0 && !getenv("P3D_F64_UNFUSED");
         if (!p->fused) p->ln_col = p->ln_row = 1;
     }
+    if (p->fused) {
+        // the register-engine passes where the axis has a plan (p3d_mix64.hip): their tiles define the partial-sum layouts
+        p->mcol = p3d::mix64::find(nil);
+        p->mrow = p3d::mix64::find(nxl);
+        for (int which = 0; which < 2; ++which) {
+            const p3d::mix64::Entry* en = which ? p->mrow : p->mcol;
+            if (!en) continue;
+            std::vector<c64> host((size_t)en->tw_slots + 1);
+            en->build_tw(reinterpret_cast<p3d::mix::c64d*>(host.data()));
+            c64** dst = which ? &p->tw_mrow : &p->tw_mcol;
+            if ((e = hipMalloc((void**)dst, sizeof(c64) * host.size())) != hipSuccess) return bail("twiddles", e);
+            if ((e = hipMemcpy(*dst, host.data(), sizeof(c64) * host.size(), hipMemcpyHostToDevice)) != hipSuccess) return bail("twiddles", e);
+            if (which) p->ln_row = en->row_lines; else p->ln_col = en->col_tile;
+        }
+    }
     const size_t S = (size_t)max_slices, per = p->per();
     const size_t nparts = (size_t)std::max(std::max(p3d_plan64::BLOCKS, p->tiles_col()), p->tiles_row());
 #define ALLOC64(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(#ptr, e)
@@ -880,6 +935,7 @@ int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_sl
     ALLOC64(p->partial, sizeof(double) * 8 * nparts * S);
     ALLOC64(p->spart, sizeof(double) * nparts * S);
     ALLOC64(p->done, sizeof(int) * S);
+    if (p->mcol && p->mrow && !getenv("P3D_F64_NO_SPARSE")) ALLOC64(p->nzflag, (size_t)p->tiles_col() * S);
 #undef ALLOC64
     *out = p;
     return P3D_OK;
@@ -891,7 +947,14 @@ int p3d_pocs64_stats(p3d_plan64* p, const void* x, int dtype, int nslices, doubl
     int rc = check64(p, nslices, dtype);
     if (rc) return rc;
     if (!x || !stats) return f64fail(P3D_ERR_INVALID, "NULL buffer");
-    F_TRY(hipMemcpyAsync(p->st_x, x, esize(dtype) * p->per() * nslices, hipMemcpyDefault, p->stream));
+    if (on_plan_device(p, x)) {
+        p->cur_x = x;
+    } else {
+        F_TRY(hipMemcpyAsync(p->st_x, x, esize(dtype) * p->per() * nslices, hipMemcpyDefault, p->stream));
+        p->cur_x = p->st_x;
+    }
+    p->cur_out = p->st_out;
+    p->sparse = false;
     const int nblocks = p->fused ? p->tiles_col() : p3d_plan64::BLOCKS;
     if (p->fused) {
         if ((rc = row_pass64<R64_FIRST>(p, dtype, p->partial, 0, 0, 1.0, nslices, nullptr, 0))) return rc;   // rows of x (its sums go to a scratch row)
@@ -950,12 +1013,25 @@ int p3d_pocs64_run(p3d_plan64* p, const void* x, int dtype, const double* mask, 
     bool any_off = early;
     if (active) for (int s = 0; s < nslices; ++s) { done_h[s] = active[s] ? 0 : -1; any_off = any_off || !active[s]; }
     const int* done_d = any_off ? p->done : nullptr;
-    F_TRY(hipMemcpyAsync(p->st_x, x, esize(dtype) * per * nslices, hipMemcpyDefault, p->stream));
+    // the caller's own device buffers where it passed such (no staging copies: 80 bytes per point and two passes less for a resident batch);
+    // a result buffer that overlaps the observed cube -- read in every iteration -- goes through the staging buffer
+    const size_t cube_bytes = esize(dtype) * per * nslices;
+    if (on_plan_device(p, x)) {
+        p->cur_x = x;
+    } else {
+        F_TRY(hipMemcpyAsync(p->st_x, x, cube_bytes, hipMemcpyDefault, p->stream));
+        p->cur_x = p->st_x;
+    }
+    const char* const xb = static_cast<const char*>(x);
+    char* const ob = static_cast<char*>(out);
+    const bool direct_out = on_plan_device(p, out) && (ob + cube_bytes <= xb || xb + cube_bytes <= ob);
+    p->cur_out = direct_out ? out : p->st_out;
     F_TRY(hipMemcpyAsync(p->mask, mask, sizeof(double) * per, hipMemcpyDefault, p->stream));
     F_TRY(hipMemcpyAsync(p->tau, tau, sizeof(c64) * ntau, hipMemcpyHostToDevice, p->stream));   // (Re, Im) pairs of doubles: c64's layout
     F_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     F_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
     F_TRY(hipEventRecord(p->ev0, p->stream));
+    p->sparse = p->nzflag != nullptr;   // (tiles of the spectrum that the threshold empties are neither transformed back, stored nor read again: exact)
     if (p->fused) {
         // two kernels per iteration: rows (inverse transform, re-insertion, forward transform), columns (forward, threshold, inverse)
         if ((rc = row_pass64<R64_FIRST>(p, dtype, p->sums, adaptive ? 1 : 0, 0, prm->alpha, nslices, done_d, 0))) return rc;
@@ -985,7 +1061,7 @@ int p3d_pocs64_run(p3d_plan64* p, const void* x, int dtype, const double* mask, 
     F_TRY(hipEventRecord(p->ev1, p->stream));
     F_TRY(hipMemcpyAsync(done_h.data(), p->done, sizeof(int) * nslices, hipMemcpyDeviceToHost, p->stream));
     if (sums) F_TRY(hipMemcpyAsync(sums, p->sums, sizeof(double) * nsum, hipMemcpyDeviceToHost, p->stream));
-    F_TRY(hipMemcpyAsync(out, p->st_out, esize(dtype) * per * nslices, hipMemcpyDefault, p->stream));
+    if (!direct_out) F_TRY(hipMemcpyAsync(out, p->st_out, cube_bytes, hipMemcpyDefault, p->stream));
     F_TRY(hipStreamSynchronize(p->stream));
     if (niter_done) for (int s = 0; s < nslices; ++s) niter_done[s] = done_h[s] < 0 ? 0 : (done_h[s] > 0 ? done_h[s] : niter);
     if (elapsed_ms) {

@@ -1,0 +1,52 @@
+// p3d_mix64.hpp -- the double-precision passes on the mixed-radix register engine (p3d_mix64.hip), seen from p3d_f64.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace p3d {
+namespace mix {
+struct c64d;
+}
+namespace mix64 {
+
+// column pass of a batch: work [nslices][N][n2] complex128, row-major; modes COL_ITER / COL_STATS / COL_FWD (p3d_kernels_common.hpp)
+struct ColArgs64 {
+    mix::c64d* work;
+    const mix::c64d* tab;      // MixPlan::build_tw<c64d> (device)
+    int n2, nslices;
+    const mix::c64d* tau;      // [nslices][niter]
+    int niter, iter, op;
+    double* partial;           // COL_STATS: [nslices][tiles][8]
+    const int* done;
+    unsigned char* nzflag;     // COL_ITER: [nslices][tiles] 1 = the tile kept a coefficient; tiles the threshold emptied are neither transformed back nor stored (NULL: always)
+};
+// row pass: modes ROW_FIRST / ROW_MID / ROW_LAST; partial [nslices][row groups] sums of |x|
+struct RowArgs64 {
+    mix::c64d* work;
+    const mix::c64d* tab;
+    int n1, nslices;
+    const void* x;
+    int dtype;                 // P3D_C128 / P3D_F64 / P3D_C64 / P3D_F32 (of x and out)
+    const double* mask;
+    void* out;
+    double* partial;
+    int adaptive, write_out;
+    double alpha;
+    const int* done;
+    int zero_fill;
+    const unsigned char* nzflag;   // ROW_MID / ROW_LAST: the column pass's tile flags [nslices][nz_tiles], a tile = nz_col_t columns: emptied tiles read as zeros (NULL: dense)
+    int nz_tiles, nz_col_t;
+};
+// mode numbers (= ColMode / RowMode of p3d_kernels_common.hpp, = the C64_* / R64_* of p3d_f64.hip)
+enum { M64_COL_ITER = 0, M64_COL_STATS = 1, M64_COL_FWD = 2, M64_ROW_FIRST = 0, M64_ROW_MID = 1, M64_ROW_LAST = 2 };
+
+struct Entry {
+    int n, col_tile, row_lines, tw_slots;
+    void (*build_tw)(mix::c64d* out);
+    hipError_t (*col)(int mode, const ColArgs64& a, hipStream_t st);
+    hipError_t (*row)(int mode, const RowArgs64& a, hipStream_t st);
+};
+const Entry* find(int n);   // nullptr: no plan (p3d_f64.hip's LDS-image passes)
+const Entry* part_0();
+
+}  // namespace mix64
+}  // namespace p3d

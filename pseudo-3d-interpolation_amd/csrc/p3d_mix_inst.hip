@@ -60,7 +60,7 @@ hipError_t launch_row(int mode, const RowArgs& a, const c32* tab, hipStream_t st
 #define P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3) MixPlan<N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3>
 #define X(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)                                                                              \
     {N, COLT, P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TW_SLOTS, P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TPL_A, \
-     P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::PPT_A, &P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::build_tw,         \
+     P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::PPT_A, &P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::template build_tw<c32>,         \
      &launch_row<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>, &launch_col<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>},
 const Entry entries[] = {
 #include "p3d_mix_plans.inc"

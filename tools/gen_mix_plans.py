@@ -50,11 +50,14 @@ def factorizations(n, allowed, maxlen):
     return out
 
 
+PPT_LO, PPT_HI, PPT_TARGET, ELEM = 12, 32, 20, 8   # float32 engine; --f64: 6, 16, 8 and 16-byte elements
+
+
 def splits(n, r):
-    """(B, PPT) choices of a pass of radix r: PPT = r B divides n, 12 <= PPT <= 32 where possible (else the nearest)."""
+    """(B, PPT) choices of a pass of radix r: PPT = r B divides n, PPT_LO <= PPT <= PPT_HI where possible (else the nearest)."""
     cands = [(b, r * b) for b in range(1, 33) if n % (r * b) == 0 and r * b <= 64]
-    good = [c for c in cands if 12 <= c[1] <= 32 and (r <= 20 or c[0] == 1)]
-    return good or sorted(cands, key=lambda c: abs(c[1] - 20))[:2]
+    good = [c for c in cands if PPT_LO <= c[1] <= PPT_HI and (r <= 20 or c[0] == 1)]
+    return good or sorted(cands, key=lambda c: abs(c[1] - PPT_TARGET))[:2]
 
 
 def best_plan(n, max_radix=None):
@@ -78,16 +81,16 @@ def best_plan(n, max_radix=None):
             # columns with 8 instead of 4 per tile, 1600 points 1.00 -> 0.79, 1500 points 1.62 -> 1.32; 1200 points, 480 threads: 0.78 -> 0.87) --,
             # else the widest one of which two fit.
             worst = 1 + max([1 / r for r in fac if r % 2 == 0 and r > 2] or [0])   # padding of the LDS image: one slot per (even) first radix
-            tables = 1.3 * n * 8
-            small = next((t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * line * 8 <= 72 * 1024), 0)
-            big = next((t for t in (8, 4, 2) if t * tmax <= 1024 and t * tmax >= (600 if small >= 4 else 450) and t * n * 8 * worst + tables <= 154 * 1024), 0)
+            tables = 1.3 * n * ELEM if ELEM == 8 else 0   # (the double-precision passes read their tables from memory)
+            small = next((t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * line * ELEM <= (72 if ELEM == 8 else 78) * 1024), 0)
+            big = next((t for t in (8, 4, 2) if t * tmax <= 1024 and t * tmax >= (600 if small >= 4 else 450) and t * n * ELEM * worst + tables <= 154 * 1024), 0)
             colt = big if big > small else small
             if not colt:
                 continue
-            regs = 2 * max(ppts) + 2 * max(fac) + 24
+            regs = (2 * max(ppts) + 2 * max(fac) + 24) * ELEM // 8
             idle = sum(1 - t / tmax for t in tpls)
-            score = (len(fac) * 1000 + sum(dft_cost(r) / r for r in fac) * 4 + sum(abs(p - 20) for p in ppts) * 3 + idle * 60
-                     + (200 if regs > 128 else 0) + (150 if colt < 8 and n <= 1100 else 0) + (0 if (colt * tmax) % 64 == 0 else 10))
+            score = (len(fac) * 1000 + sum(dft_cost(r) / r for r in fac) * 4 + sum(abs(p - PPT_TARGET) for p in ppts) * 3 + idle * 60
+                     + (200 if regs > (128 if ELEM == 8 else 256) else 0) + (150 if colt < 8 and n <= 1100 else 0) + (0 if (colt * tmax) % 64 == 0 else 10))
             pairs = list(zip(fac, [c[0] for c in combo]))
             # forward order: an odd radix first where there is one (its scatter has an odd stride without padding), the largest radix last
             # (the last pass scatters nothing; it is the inverse transform's first)
@@ -102,11 +105,15 @@ def best_plan(n, max_radix=None):
 def row_lines(n, tmax):
     """rows per workgroup of the row pass: an even number (rows are worked on in pairs), ~256 threads, at most ~44 KiB of line images (three
     workgroups per CU beside the twiddle tables), the candidate that fills its wavefronts best.  (Larger workgroups would amortise the copy of
-    the twiddle tables -- ~1.25 N entries per workgroup -- but leave one or two workgroups per CU, whose phases then no longer cover each other.)"""
+    the twiddle tables -- ~1.25 N entries per workgroup -- but leave one or two workgroups per CU, whose phases then no longer cover each other.)
+    --f64: any number of rows (they are not paired there), 16-byte elements."""
+    if ELEM == 16:   # double precision: small workgroups, many of them per CU (1024-point rows: one row per workgroup 0.67 ms, two 0.70, four 0.70)
+        return max(1, -(-128 // tmax))
     best = None
-    for lb in range(2, 65, 2):
+    step = 2 if ELEM == 8 else 1
+    for lb in range(step, 65, step):
         thr = lb * tmax
-        if thr > 1024 or (lb > 2 and (lb * n * 8 * 1.1 > 44 * 1024 or thr > 320)):
+        if thr > 1024 or (lb > step and (lb * n * ELEM * 1.1 > (44 if ELEM == 8 else 78) * 1024 or thr > 320)):
             break
         fill = thr / (64 * -(-thr // 64))
         cand = (-(fill > 0.9), -thr if fill > 0.9 else -round(fill, 2), -lb)
@@ -125,6 +132,8 @@ def main():
     ap.add_argument("--two-pass-below", type=int, default=1024,
                     help="lengths up to this one may use radices up to 32: two-pass plans, one exchange per transform (measured: 960-point columns 0.41 -> 0.24 ms, "
                          "900 x 900 1.05 -> 0.91 ms per iteration of 128 slices; 768-point rows lose 8 %%)")
+    ap.add_argument("--f64", action="store_true", help="plans of the double-precision passes (csrc/p3d_mix64_plans.inc): 16-byte elements, 8 ... 20 points per "
+                    "thread, powers of two included; --only / the default list of lengths")
     ap.add_argument("--roots", action="store_true", help="write the root tables Roots<R> (csrc/p3d_mix_roots.inc) instead of the plan list")
     args = ap.parse_args()
     if args.roots:
@@ -138,8 +147,18 @@ def main():
             cs = ", ".join(fmt(math.cos(2 * math.pi * q / r)) for q in range(r))
             sn = ", ".join(fmt(math.sin(2 * math.pi * q / r)) for q in range(r))
             print(f"template <> struct Roots<{r}> {{\n    static constexpr float c[{r}] = {{{cs}}};\n    static constexpr float s[{r}] = {{{sn}}};\n}};")
+            def fmtd(x):
+                return "%.17e" % (0.0 if abs(x) < 1e-17 else x)
+            csd = ", ".join(fmtd(math.cos(2 * math.pi * q / r)) for q in range(r))
+            snd = ", ".join(fmtd(math.sin(2 * math.pi * q / r)) for q in range(r))
+            print(f"template <> struct RootsD<{r}> {{\n    static constexpr double c[{r}] = {{{csd}}};\n    static constexpr double s[{r}] = {{{snd}}};\n}};")
         return
-    lengths = args.only or [n for n in range(args.min, args.max + 1) if smooth(n) and n & (n - 1)]
+    if args.f64:
+        global PPT_LO, PPT_HI, PPT_TARGET, ELEM
+        PPT_LO, PPT_HI, PPT_TARGET, ELEM = 6, 16, 8, 16   # (measured on 1024-point lines: 8 points per thread 0.70 ms per iteration, 16 points 1.0-1.2 ms)
+        args.two_pass_below = 0
+    F64_LENGTHS = [64, 128, 256, 512, 1024, 2048, 4096, 500, 600, 720, 768, 800, 900, 960, 1000, 1200, 1280, 1440, 1500, 1536, 1600, 1800, 1920, 2000, 2400, 3000, 3072]
+    lengths = args.only or (sorted(F64_LENGTHS) if args.f64 else [n for n in range(args.min, args.max + 1) if smooth(n) and n & (n - 1)])
     rows = []
     forced = {}   # experiments: P3D_GEN_FORCE="1000:10x2,10x2,10x2;768:8x3,8x3,12x2" (forward order, radix x butterflies per thread)
     for item in filter(None, __import__("os").environ.get("P3D_GEN_FORCE", "").split(";")):
@@ -149,8 +168,8 @@ def main():
         if n in forced:
             order = forced[n]
             tmax = max(n // (r * nb) for r, nb in order)
-            colt = next(t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * n * 1.1 * 8 <= 72 * 1024)
-            rows.append((n, colt, row_lines(n, tmax), order))
+            colt = int(__import__("os").environ.get("P3D_GEN_FORCE_COLT", "0")) or next(t for t in (8, 4, 2, 1) if t * tmax <= 1024 and t * n * 1.1 * ELEM <= 76 * 1024)
+            rows.append((n, colt, int(__import__("os").environ.get("P3D_GEN_FORCE_LB", "0")) or row_lines(n, tmax), order))
             continue
         b = best_plan(n, 32 if n <= args.two_pass_below else None)
         if b is None:
