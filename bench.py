@@ -733,14 +733,14 @@ def run_leg(ctx, config, K_override, main, override=None):
         it64 = float(np.median(ms64)) / K            # ms per iteration of the n64-slice sample (device time of the loop)
         ref_prec = {
             "what": f"the same job with precision='reference': the loop in double precision (the reference's arithmetic for soft / garrote / FPOCS / APOCS and "
-                    f"for every run under NumPy < 2), two fused kernels per iteration on LDS-resident tiles (col64_kernel / row64_kernel) -- a sample of {n64} slices of the cube, "
-                    f"complex64 in and out, device time of the {K}-iteration loop",
+                    f"for every run under NumPy < 2), two fused kernels per iteration on the mixed-radix register engine with complex128 elements (p3d_mix64.hip: "
+                    f"8 points per thread, twiddles from memory, sparse shortcut; round 4: LDS-resident tiles, col64_kernel / row64_kernel) -- a sample of {n64} slices "
+                    f"of the cube, complex64 in and out, device time of the {K}-iteration loop",
             "slice_iterations_per_s": n64 / (it64 * 1e-3), "iterations_per_s_of_the_cube": n64 / (it64 * 1e-3) / cube_slices,
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": 56.0, "achieved": 56.0 * nil * nxl * n64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": 56.0 * nil * nxl * n64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "note": "28 B/point of the float32 accounting, doubled; the two fused passes move ~80 B/point (16 + 16 per pass, observed sample and weight "
-                                 "in the row pass) and are bound by their double-precision butterflies in LDS, not by memory (round 4 first cut, six unfused "
-                                 "passes: ~210 B/point, half this rate)"},
+                         "note": "28 B/point of the float32 accounting, doubled; the two fused passes move 16 B/point per read or write of the work buffer (emptied "
+                                 "column tiles excepted), the observed sample and an 8-byte weight in the row pass"},
         }
         del host64
 

@@ -882,6 +882,41 @@ def test_fused_double_precision_passes_equal_the_unfused_ones(ffi, orc, monkeypa
     assert np.allclose(sums_f, sums_u, rtol=1e-12)
 
 
+@pytest.mark.parametrize("shape", [(1024, 512), (1000, 96), (64, 1500), (256, 45), (300, 2048)])
+@pytest.mark.parametrize("switch", ["P3D_NO_MIX64", "P3D_F64_NO_SPARSE"])
+def test_double_precision_passes_on_the_register_engine_equal_the_lds_image_ones(ffi, orc, monkeypatch, shape, switch):
+    """Axes whose length has a plan in p3d_mix64_plans.inc (powers of two, round 7-smooth lengths) run the double-precision passes on the
+    mixed-radix register engine (p3d_mix64.hip), per axis -- the other axis may stay on the LDS-image kernels of p3d_f64.hip (45, 300 here) --,
+    with the sparse shortcut when both do.  P3D_NO_MIX64=1 keeps the LDS-image passes for every length, P3D_F64_NO_SPARSE=1 transforms and
+    stores every tile: iterates to double rounding, statistics and cost sums to 1e-12, iteration counts exactly; hard threshold, early exit, an
+    empty slice, float32 in and out."""
+    from pseudo_3d_interpolation_amd.functions.POCS import _schedule_from_stats
+    nil, nxl = shape
+    _, mask, obs = orc.synthetic_cube(nil, nxl, 3, 0.7)
+    obs = obs.astype(np.complex128)
+    obs[1] = 0
+    K = 10
+    act = np.array([1, 0, 1], np.uint8)
+
+    def run(cube, op, **kw):
+        with ffi.Plan64(nil, nxl, 3) as plan:
+            st = plan.stats(cube)
+            st[1] = 1.0
+            tau = _schedule_from_stats(st, nil * nxl, "exponential", K, 0.99, 1e-3, "values")
+            return (st,) + plan.run(cube, mask, tau, K, thresh_op=op, active=act, **kw)[:3]
+
+    cases = [(obs, "hard", dict(eps=0.0)), (obs, "soft", dict(version="adaptive", alpha=0.9, eps=1e-6)), (np.ascontiguousarray(obs.real).astype(np.float32), "garrote", dict(eps=0.0))]
+    fast = [run(*c[:2], **c[2]) for c in cases]
+    monkeypatch.setenv(switch, "1")
+    slow = [run(*c[:2], **c[2]) for c in cases]
+    for (st_f, out_f, done_f, sums_f), (st_u, out_u, done_u, sums_u), case in zip(fast, slow, cases):
+        assert np.allclose(st_f[[0, 2]], st_u[[0, 2]], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(done_f, done_u) and done_f[1] == 0 and not out_f[1].any()
+        tol = 1e-6 if out_f.dtype == np.float32 else (1e-9 if case[1] == "hard" else 1e-12)   # (a hard threshold may turn a last-bit difference into a kept / zeroed coefficient)
+        assert out_f.dtype == case[0].dtype and max(rel_l2(out_f[s], out_u[s]) for s in (0, 2)) <= tol
+        assert np.allclose(sums_f, sums_u, rtol=1e-9)
+
+
 @pytest.mark.parametrize("family", ["one-exchange (row_pipe32_kernel)", "row_pipe64_kernel"])
 def test_compact_observed_samples_path_is_exact(ffi, orc, monkeypatch, family):
     """The steady-state row pass reads the observed samples from a compact copy when x is zero at every
