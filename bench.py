@@ -36,7 +36,7 @@ only when that file was measured on the kernel sources of this tree (`kernel_sou
 measurement is named under `traffic_last_measured`.
 
 At N = 1 the process is torch-free: device memory comes from the library's own p3d_dev_* entry points, inputs are generated on the
-host with NumPy (plane waves as a rank-6 outer product per slice + pooled noise) and uploaded before the clock starts, and the library
+host with NumPy (SURVEY 8d's generator for every slice: plane waves as a rank-6 outer product + its own noise) and uploaded before the clock starts, and the library
 runs on the HIP runtime it was built against (`hip_runtime` in the line).  At N > 1 torch is imported FIRST (it must initialise its own
 copy of the HIP runtime before ours does, _ffi._preload_torch_hip) for torch.distributed over RCCL; the result blocks are torch tensors
 there so that the gather collective can take them.  No torch kernel runs in either case, so `rocprofv3 --pmc ... -- python3 bench.py`
@@ -177,7 +177,8 @@ def _threads():
 
 
 def noise_pool(nil, nxl):
-    """NOISE_POOL complex Gaussian slices; slice s uses pool[s % P] rolled by a slice-dependent shift."""
+    """NOISE_POOL complex Gaussian slices for the random-spectrum cubes of the density curve (not SURVEY 8d's recipe anyway): slice s uses
+    pool[s % P] rolled by a slice-dependent shift."""
     rng = np.random.default_rng(20240917)
     return (rng.standard_normal((NOISE_POOL, nil, nxl), dtype=np.float32)
             + 1j * rng.standard_normal((NOISE_POOL, nil, nxl), dtype=np.float32)).astype(np.complex64)
@@ -192,25 +193,28 @@ def _finish_slice(x, s, pool, mask):
 
 
 def plane_wave_slices(nil, nxl, first, count, pool, mask):
-    """The recipe of oracle.synthetic_slice: 6 complex plane waves + 1 % Gaussian noise per slice, times the trace mask.  A plane
-    wave is an outer product exp(2 pi i k1 il / nil) x exp(2 pi i k2 xl / nxl): one (nil x 6) @ (6 x nxl) product per slice."""
+    """SURVEY 8d's generator, slice by slice (the recipe and the random stream of oracle.synthetic_slice: rng = default_rng(1234 + s); six plane
+    waves with integer wavenumbers and complex normal amplitudes; 1 % complex Gaussian noise drawn from the same stream), times the trace mask.
+    Re-stated here (the oracle is not imported for data generation): a plane wave is an outer product exp(2 pi i k1 il / nil) x
+    exp(2 pi i k2 xl / nxl), so a slice is one (nil x 6) @ (6 x nxl) product in double precision + its noise, cast to complex64 -- the oracle's
+    values up to the order of a six-term sum.  A few threads share the slices (NumPy's generators and BLAS release the GIL)."""
     out = np.empty((count, nil, nxl), np.complex64)
     il = np.arange(nil, dtype=np.float64) / nil
     xl = np.arange(nxl, dtype=np.float64) / nxl
     maskc = mask.astype(np.float32)
 
     def one(i):
-        s = first + i
-        rng = np.random.default_rng(1234 + s)
+        rng = np.random.default_rng(1234 + first + i)
         k1 = np.empty(6); k2 = np.empty(6); amp = np.empty(6, np.complex128)
         for e in range(6):   # the draw order of oracle.synthetic_slice
             k1[e] = int(rng.integers(-(nil // 8), max(nil // 8, 1)))
             k2[e] = int(rng.integers(-(nxl // 8), max(nxl // 8, 1)))
             amp[e] = complex(rng.standard_normal(), rng.standard_normal())
-        u = (np.exp(2j * np.pi * np.outer(il, k1)) * amp).astype(np.complex64)
-        v = np.exp(2j * np.pi * np.outer(k2, xl)).astype(np.complex64)
-        np.matmul(u, v, out=out[i])
-        _finish_slice(out[i], s, pool, maskc)
+        acc = (np.exp(2j * np.pi * np.outer(il, k1)) * amp) @ np.exp(2j * np.pi * np.outer(k2, xl))
+        nre = rng.standard_normal((nil, nxl))
+        acc += 0.01 * (nre + 1j * rng.standard_normal((nil, nxl)))
+        out[i] = acc
+        out[i] *= maskc
     list(_threads().map(one, range(count)))
     return out
 
@@ -934,10 +938,9 @@ def run_leg(ctx, config, K_override, main, override=None):
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": f"{dtype_s} (f32 arithmetic)",
-        "data": ("synthetic: 6 plane waves (SURVEY 8d's per-slice seeds) + 1% Gaussian noise per slice, random trace mask.  The noise of slice s is "
-                 f"slice s % {NOISE_POOL} of a pool of {NOISE_POOL} NumPy-drawn slices rolled by a shift that depends on s // {NOISE_POOL} -- POOLED, not 8d's per-slice "
-                 f"generator (host-generated, uploaded before the clock starts); the first slices (those the cpu_baseline / parity leg computes) ARE 8d's "
-                 f"oracle.synthetic_slice, noise included"
+        "data": ("synthetic: SURVEY 8d's generator for every slice (6 complex plane waves + 1% complex Gaussian noise from default_rng(1234 + s), random trace "
+                 "mask from default_rng(42)), generated on the host and uploaded before the clock starts; the first slices (those the cpu_baseline / parity leg "
+                 "computes) are the oracle's own arrays, the others its recipe and random stream re-stated in bench.py"
                  if density == 0 else
                  f"synthetic: {density} random spectral coefficients + 1% Gaussian noise per slice (seeded), random trace mask"),
         "config": {

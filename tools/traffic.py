@@ -90,6 +90,7 @@ rec = {
               f"{config} --only-main --no-cpu-baseline --no-dense --repeats 1 --warmup 0 --steps {steps}; (FETCH_SIZE x 2 [gfx950 wide-read correction] + "
               "WRITE_SIZE) x 1024 B summed over the loop's kernels / iterations in the trace",
     "valu_issue_peak_wave_instructions_per_s": VALU_ISSUE_PEAK,
+    "valu_note": "SQ_INSTS_VALU counts wavefront instructions; a packed-f32 instruction (v_pk_*: two results per lane) counts once",
     "kernel_source_hash": bench.kernel_source_hash(), "round": rnd,
 }
 print(json.dumps(rec, indent=1))
