@@ -555,7 +555,8 @@ static int create_plan(p3d_plan** out, int device, int nil, int nxl, int max_sli
             TRY_OR_BAIL(hipMalloc((void**)&p->nzcount, sizeof(unsigned long long)));
         }
         if (orow->tpl > 0) TRY_OR_BAIL(hipMalloc((void**)&p->bits, sizeof(uint16_t) * (size_t)nil * orow->tpl));
-        if (is_flex(orow) && (p->mix_row = p3d::mix::find(nxl)) != nullptr && !getenv("P3D_NO_MIX_BITS")) {
+        if (is_flex(orow) && (p->mix_row = p3d::mix::find(nxl)) != nullptr && p->mix_row->row == nullptr) p->mix_row = nullptr;   // (a columns-only plan)
+        if (is_flex(orow) && p->mix_row != nullptr && !getenv("P3D_NO_MIX_BITS")) {
             TRY_OR_BAIL(hipMalloc((void**)&p->mbits, sizeof(unsigned long long) * (size_t)nil * p->mix_row->tpl));
             TRY_OR_BAIL(hipMalloc((void**)&p->mbase, sizeof(unsigned) * ((size_t)nil * p->mix_row->tpl + 1)));
         }

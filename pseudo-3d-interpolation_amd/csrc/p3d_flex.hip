@@ -976,7 +976,7 @@ hipError_t flex_row_real(int mode, const RowArgs& a, int, hipStream_t st)
     if (pl.blue) return chirp_row_real(mode, a, chirp_tabs(a.tw, pl), st);
     // 7-smooth rows: the complex passes of the register engine (p3d_mix.hpp) beat the row pairs of the LDS-image kernel below although they
     // transform twice the columns; "not supported" sends the caller there (p3d_pocs_run_dev falls back to the complex path)
-    if (mix::find(n)) return hipErrorNotSupported;
+    if (const mix::Entry* e = mix::find(n); e && e->row) return hipErrorNotSupported;
     int widest = 2;
     for (int p = 0; p < pl.nf; ++p) widest = pl.f[p] > widest ? pl.f[p] : widest;
     const bool two = LB >= 2 && pl.m / widest >= 48;
@@ -1017,7 +1017,7 @@ hipError_t flex_row(int mode, const RowArgs& a, hipStream_t st)
     if (LB == 0) return hipErrorNotSupported;
     const FlexFactors pl = flex_factors(n);
     if (pl.blue) return chirp_row(mode, a, chirp_tabs(a.tw, pl), st);
-    if (const mix::Entry* e = mix::find(n)) return e->row(mode, a, mix_tab(a.tw, pl), st);
+    if (const mix::Entry* e = mix::find(n); e && e->row) return e->row(mode, a, mix_tab(a.tw, pl), st);
     // two wavefronts per row where the narrowest pass still has ~48 butterflies for them (measured: 500, 768, 1000 gain 20-25 %,
     // 600 = 15*10*4 loses 8 %) and rows can be paired
     int widest = 2;

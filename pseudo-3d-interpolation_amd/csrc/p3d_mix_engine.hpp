@@ -37,7 +37,7 @@ __device__ __forceinline__ C root(int q)
 }
 
 // ---- small DFTs on registers, natural order in and out: X[k] = sum_t x[t] W^(t k), W = exp(DIR 2 pi i / R) ------------------------------
-constexpr int first_factor(int r) { return r % 4 == 0 ? 4 : r % 2 == 0 ? 2 : r % 3 == 0 ? 3 : r % 5 == 0 ? 5 : r % 7 == 0 ? 7 : r; }
+constexpr int first_factor(int r) { return r % 4 == 0 ? 4 : r % 2 == 0 ? 2 : r % 3 == 0 ? 3 : r % 5 == 0 ? 5 : r % 7 == 0 ? 7 : r % 11 == 0 ? 11 : r % 13 == 0 ? 13 : r; }
 
 template <class C, int R, int DIR>
 struct SmallDft {
@@ -151,6 +151,16 @@ struct MixPlan {
         return N_ / m;
     }
     static constexpr int TMAX = tmax();   // threads per line
+    // a radix with a factor 11 or 13 (paired-form butterflies: register hungry).  Such plans are used for COLUMNS only: their row passes measured
+    // slower than the in-place LDS-image rows of p3d_flex.hip (1430-point rows 2.83 vs 1.76 ms, 2002: 3.20 vs 2.86, 990: 1.62 vs 1.38 per 128 x 1024
+    // rows; 770 and 1573 would gain 10-20 %), their column passes 7-40 % faster (1573 points: 0.89 vs 1.44 ms)
+    static constexpr bool big_prime()
+    {
+        for (int p = 0; p < NPASS_; ++p)
+            if (fr(p) % 11 == 0 || fr(p) % 13 == 0) return true;
+        return false;
+    }
+    static constexpr bool BIG_PRIME = big_prime();
     static constexpr int PPT_A = ppt(FWD, 0), TPL_A = tpl(FWD, 0), PPT_B = ppt(FWD, NPASS_ - 1), TPL_B = tpl(FWD, NPASS_ - 1);
     // Padding of a line's LDS image, per direction: one slot per PADQ positions where the first radix of the direction is even (its scatter
     // then walks the banks with the odd stride R + 1; an odd radix does so by itself).  Offsets fold into the instructions wherever PADQ

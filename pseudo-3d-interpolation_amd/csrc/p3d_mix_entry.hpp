@@ -13,7 +13,7 @@ namespace mix {
 struct Entry {
     int n, col_tile, tw_slots, tpl, ppt;
     void (*build_tw)(c32* out);
-    hipError_t (*row)(int mode, const RowArgs& a, const c32* tab, hipStream_t st);
+    hipError_t (*row)(int mode, const RowArgs& a, const c32* tab, hipStream_t st);   // nullptr: the plan serves columns only (radix-11 / 13 passes)
     hipError_t (*col)(int mode, const ColArgs& a, const c32* tab, hipStream_t st);
 };
 const Entry* find(int n);   // nullptr: no plan for this length (p3d_flex.hip runs it as an LDS image)

@@ -57,11 +57,19 @@ hipError_t launch_row(int mode, const RowArgs& a, const c32* tab, hipStream_t st
     return hipGetLastError();
 }
 
+// plans with a radix-11 / 13 pass serve columns only (MixPlan::BIG_PRIME): no row kernel is instantiated for them
+template <class PL>
+constexpr auto row_launcher() -> hipError_t (*)(int, const RowArgs&, const c32*, hipStream_t)
+{
+    if constexpr (PL::BIG_PRIME) return nullptr;
+    else return &launch_row<PL>;
+}
+
 #define P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3) MixPlan<N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3>
 #define X(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)                                                                              \
     {N, COLT, P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TW_SLOTS, P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TPL_A, \
      P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::PPT_A, &P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::template build_tw<c32>,         \
-     &launch_row<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>, &launch_col<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>},
+     row_launcher<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>(), &launch_col<P3D_MIX_PLAN(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>},
 const Entry entries[] = {
 #include "p3d_mix_plans.inc"
     {0, 0, 0, 0, 0, nullptr, nullptr, nullptr}};

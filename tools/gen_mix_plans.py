@@ -10,6 +10,9 @@ import itertools
 import sys
 
 
+PRIMES13 = (2, 3, 5, 7, 11, 13)   # radices may contain 11 and 13 (in-register butterflies of the paired form); lengths with such factors from --min13 on
+
+
 def smooth(n, ps=(2, 3, 5, 7)):
     for p in ps:
         while n % p == 0:
@@ -19,10 +22,10 @@ def smooth(n, ps=(2, 3, 5, 7)):
 
 def dft_cost(r):
     """rough real-operation count of the in-register DFT of size r (recursive Cooley-Tukey on 2/3/4/5/7 bases)."""
-    base = {1: 0, 2: 4, 3: 16, 4: 16, 5: 40, 7: 84}
+    base = {1: 0, 2: 4, 3: 16, 4: 16, 5: 40, 7: 84, 11: 230, 13: 330}
     if r in base:
         return base[r]
-    for a in (4, 2, 3, 5, 7):
+    for a in (4, 2, 3, 5, 7, 11, 13):
         if r % a == 0:
             b = r // a
             return b * dft_cost(a) + a * dft_cost(b) + 6 * (a - 1) * (b - 1)
@@ -50,7 +53,7 @@ def factorizations(n, allowed, maxlen):
     return out
 
 
-PPT_LO, PPT_HI, PPT_TARGET, ELEM = 12, 32, 20, 8   # float32 engine; --f64: 6, 16, 8 and 16-byte elements
+PPT_LO, PPT_HI, PPT_TARGET, ELEM = 11, 32, 20, 8   # float32 engine; --f64: 6, 16, 8 and 16-byte elements
 
 
 def splits(n, r):
@@ -63,7 +66,7 @@ def splits(n, r):
 def best_plan(n, max_radix=None):
     """(score, colt, ((R0, B0), (R1, B1), ...)) -- forward order."""
     best = None
-    allowed = sorted([d for d in range(2, (max_radix or MAX_RADIX) + 1) if smooth(d) and n % d == 0], reverse=True)
+    allowed = sorted([d for d in range(2, (max_radix or MAX_RADIX) + 1) if smooth(d, PRIMES13) and n % d == 0], reverse=True)
     for fac in factorizations(n, allowed, 4):
         if len(fac) == 1 and n > 32:
             continue
@@ -72,7 +75,7 @@ def best_plan(n, max_radix=None):
             ppts = [c[1] for c in combo]
             tpls = [n // p for p in ppts]
             tmax = max(tpls)
-            if tmax < 4:
+            if tmax < 4 or 2 * tmax > 1024:   # (a row pair is the smallest workgroup of the row pass)
                 continue
             line = n * 1.1
             # Column tile: 8 columns (a whole 64-byte column block per row) where two workgroups' tiles share a CU's LDS (<= 72 KiB each).  LONG
@@ -129,6 +132,7 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--only", type=int, nargs="*")
     ap.add_argument("--parts", type=int, default=8, help="translation units the instantiations are spread over (#if P3D_MIX_PART == k)")
+    ap.add_argument("--min13", type=int, default=480, help="lengths with prime factors 11 and 13 from this one on (below: 7-smooth lengths only)")
     ap.add_argument("--two-pass-below", type=int, default=1024,
                     help="lengths up to this one may use radices up to 32: two-pass plans, one exchange per transform (measured: 960-point columns 0.41 -> 0.24 ms, "
                          "900 x 900 1.05 -> 0.91 ms per iteration of 128 slices; 768-point rows lose 8 %%)")
@@ -140,7 +144,7 @@ def main():
         import math
         print("// generated by tools/gen_mix_plans.py --roots -- do not edit.  cos / sin of 2 pi q / R, evaluated in double precision, rounded once")
         for r in range(2, 33):
-            if not smooth(r):
+            if not smooth(r, PRIMES13):
                 continue
             def fmt(x):
                 return "%.9ef" % (0.0 if abs(x) < 1e-15 else x)
@@ -158,7 +162,8 @@ def main():
         PPT_LO, PPT_HI, PPT_TARGET, ELEM = 6, 16, 8, 16   # (measured on 1024-point lines: 8 points per thread 0.70 ms per iteration, 16 points 1.0-1.2 ms)
         args.two_pass_below = 0
     F64_LENGTHS = [64, 128, 256, 512, 1024, 2048, 4096, 500, 600, 720, 768, 800, 900, 960, 1000, 1200, 1280, 1440, 1500, 1536, 1600, 1800, 1920, 2000, 2400, 3000, 3072]
-    lengths = args.only or (sorted(F64_LENGTHS) if args.f64 else [n for n in range(args.min, args.max + 1) if smooth(n) and n & (n - 1)])
+    lengths = args.only or (sorted(F64_LENGTHS) if args.f64 else
+                            [n for n in range(args.min, args.max + 1) if n & (n - 1) and (smooth(n) or (n >= args.min13 and smooth(n, PRIMES13)))])
     rows = []
     forced = {}   # experiments: P3D_GEN_FORCE="1000:10x2,10x2,10x2;768:8x3,8x3,12x2" (forward order, radix x butterflies per thread)
     for item in filter(None, __import__("os").environ.get("P3D_GEN_FORCE", "").split(";")):
