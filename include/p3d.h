@@ -274,11 +274,6 @@ int p3d_wavelet_run(p3d_wplan* plan, const void* x, int dtype, const float* mask
                     const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
                     double* elapsed_ms);
 
-/* ---- SHEARLET variant (transform_kind = 'SHEARLET') --------------------------------------------------------------------------
- * Replaces FFST.shearletTransformSpect / inverseShearletTransformSpect (cube_POCS_interpolation_3D.py:269-274; POCS.py:526-527,
- * 589-590, 610-611) for spectra Psi supplied by the caller (the reference's `auxiliary_data`): ST_s = ifft2(Psi_s * fft2(x)),
- * x = ifft2(sum_s fft2(ST_s) * Psi_s); per-shearlet thresholds (POCS.py:598 with a (nsh,) tau).  psi: HOST float32
- * [nsh][nil][nxl], FFT order (what fftshift_spectra=True yields), real.  float32 cubes keep real coefficients. */
 /* The WAVELET loop in the REFERENCE's double precision (p3d_wavelet64.hip): pywt.wavedec2 / waverec2 keep float64 for float64 input and
  * POCS_algorithm never narrows (functions/POCS.py:585-588, 596-597, 608-609; threshold_wavelet POCS.py:105-166); the driver casts to the input
  * dtype only at the end (cube_POCS_interpolation_3D.py:324).  Same decomposition, thresholds, schedule layout (tau [nslices][niter][nlev][3][2],
@@ -294,6 +289,11 @@ int p3d_wavelet64_stats(p3d_wplan64* plan, const void* x, int dtype, int nslices
 int p3d_wavelet64_run(p3d_wplan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
                       const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);
 
+/* ---- SHEARLET variant (transform_kind = 'SHEARLET') --------------------------------------------------------------------------
+ * Replaces FFST.shearletTransformSpect / inverseShearletTransformSpect (cube_POCS_interpolation_3D.py:269-274; POCS.py:526-527,
+ * 589-590, 610-611) for spectra Psi supplied by the caller (the reference's `auxiliary_data`): ST_s = ifft2(Psi_s * fft2(x)),
+ * x = ifft2(sum_s fft2(ST_s) * Psi_s); per-shearlet thresholds (POCS.py:598 with a (nsh,) tau).  psi: HOST float32
+ * [nsh][nil][nxl], FFT order (what fftshift_spectra=True yields), real.  float32 cubes keep real coefficients. */
 typedef struct p3d_splan p3d_splan;
 int p3d_shearlet_plan_create(p3d_splan** out, int device, int nil, int nxl, int nsh, const float* psi, int max_slices);
 int p3d_shearlet_plan_destroy(p3d_splan* plan);
@@ -315,6 +315,18 @@ int p3d_shearlet_stats(p3d_splan* plan, const void* x, int dtype, int nslices, d
 int p3d_shearlet_run(p3d_splan* plan, const void* x, int dtype, const float* mask, const double* tau, const uint8_t* active,
                      const p3d_pocs_params* prm, void* out, int nslices, int32_t* niter_done, double* sums,
                      double* elapsed_ms);
+/* The SHEARLET loop in the REFERENCE's double precision (p3d_shearlet64.hip): np.fft.fft2 / ifft2 inside FFST compute in double and hand back
+ * complex128 / float64 coefficients, so POCS_algorithm's loop runs in double whatever the cube's dtype; the driver narrows at the end
+ * (cube_POCS_interpolation_3D.py:324).  Same frame, thresholds, schedule layout (tau [nslices][niter][nsh][2], stats [nslices][nsh][5]) and error
+ * behaviour as p3d_shearlet_*; every sample, spectrum, weight and statistic in double.  psi: HOST DOUBLE [nsh][nil][nxl].  dtype of x / out:
+ * P3D_C128, P3D_F64, or P3D_C64 / P3D_F32 (converted on load / store); x, out, mask may be host or device pointers; mask is DOUBLE [nil][nxl].
+ * A precision path: unfused passes on the double-precision FFT of p3d_plan64. */
+typedef struct p3d_splan64 p3d_splan64;
+int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, int nsh, const double* psi, int max_slices);
+int p3d_shearlet64_plan_destroy(p3d_splan64* plan);
+int p3d_shearlet64_stats(p3d_splan64* plan, const void* x, int dtype, int nslices, double* stats);
+int p3d_shearlet64_run(p3d_splan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
+                       const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);
 
 /* ---- step-15 slice smoothing (cube_postprocessing_3D.py:88-124 wraps scipy.ndimage.gaussian_filter / median_filter) ----------
  * x/out HOST float32 [nslices][ny][nx]; boundary mode 'reflect'.  gaussian: separable, radius int(truncate * sigma + 0.5);

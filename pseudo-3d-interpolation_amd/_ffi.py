@@ -115,6 +115,11 @@ PROTOTYPES = {
     "p3d_wavelet64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_shearlet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "p3d_shearlet64_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "p3d_shearlet64_plan_destroy": (C.c_int, [C.c_void_p]),
+    "p3d_shearlet64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_shearlet64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_shearlet_plan_destroy": (C.c_int, [C.c_void_p]),
     "p3d_shearlet_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "p3d_shearlet_transform_c64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -966,6 +971,78 @@ class ShearletPlan:
         ms = C.c_double(0.0)
         check(lib().p3d_shearlet_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
                                      C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
+        return done, sums, ms.value
+
+
+class ShearletPlan64:
+    """p3d_splan64 wrapper: the SHEARLET POCS loop in double precision (include/p3d.h) for complex128 / float64 cubes, and for complex64 /
+    float32 cubes on request (``precision='reference'``); ``psi`` (nil, nxl, nsh) as for :class:`ShearletPlan`, kept in double."""
+    _DT = WaveletPlan64._DT
+
+    def __init__(self, psi, max_slices=1, device=0):
+        psi = np.asarray(psi)
+        if psi.ndim != 3:
+            raise ValueError(f"Psi must be (nil, nxl, nshearlets), got shape {psi.shape}")
+        if np.iscomplexobj(psi):
+            raise NotImplementedError("complex shearlet spectra (realCoefficients=False) are not implemented")
+        self.nil, self.nxl, self.nsh = (int(v) for v in psi.shape)
+        self.max_slices, self.device = int(max_slices), int(device)
+        dev_psi = np.ascontiguousarray(np.moveaxis(psi, -1, 0), dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().p3d_shearlet64_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.nsh, _ptr(dev_psi), self.max_slices))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().p3d_shearlet64_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        if lib is not None:
+            self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    _cube = WaveletPlan64._cube
+
+    def stats(self, x):
+        """(nslices, nsh, 5): Re / Im of the lexicographic (real cubes: signed) max, max |c|, min |c|, sum |c|^2 per shearlet, in double."""
+        xc, dt = self._cube(x)
+        return self.stats_dev(xc.ctypes.data, dt, xc.shape[0])
+
+    def stats_dev(self, x_ptr, dtype, n):
+        st = np.empty((n, self.nsh, 5), np.float64)
+        check(lib().p3d_shearlet64_stats(self.handle, C.c_void_p(x_ptr), dtype, n, _ptr(st)))
+        return st
+
+    def run(self, x, mask, tau, niter, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """Host arrays in, host array out (dtype of ``x``).  tau: (nslices, niter, nsh) real or complex.  Returns (out, niter_done, sums, ms)."""
+        xc, dt = self._cube(x)
+        m = np.ascontiguousarray(mask, dtype=np.float64)
+        if m.shape != (self.nil, self.nxl):
+            raise ValueError(f"mask shape {m.shape} != {(self.nil, self.nxl)}")
+        out = np.empty_like(xc)
+        done, sums, ms = self.run_dev(xc.ctypes.data, dt, m.ctypes.data, tau, niter, out.ctypes.data, xc.shape[0], thresh_op=thresh_op, version=version,
+                                      eps=eps, alpha=alpha, active=active)
+        return out, done, sums, ms
+
+    def run_dev(self, x_ptr, dtype, mask_ptr, tau, niter, out_ptr, n, thresh_op="hard", version="regular", eps=0.0, alpha=1.0, active=None):
+        """`run` on raw pointers (host or device; the mask is DOUBLE [nil][nxl]).  Returns (niter_done, sums, device ms of the loop)."""
+        tau = np.broadcast_to(np.asarray(tau), (n, niter, self.nsh))
+        t = np.empty(tau.shape + (2,), np.float64)
+        t[..., 0] = tau.real
+        t[..., 1] = tau.imag if np.iscomplexobj(tau) else 0.0
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        prm = Plan._params(niter, thresh_op, version, eps, alpha, False)
+        done = np.zeros(n, np.int32)
+        sums = np.zeros((niter + 1, n), np.float64)
+        ms = C.c_double(0.0)
+        check(lib().p3d_shearlet64_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
+                                       C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return done, sums, ms.value
 
 

@@ -719,7 +719,7 @@ struct p3d_plan64 {
 
 namespace {
 
-int fft_pass(p3d_plan64* p, const c64* in, c64* out, int nslices, bool rows, int dir, double scale, const int* done)
+int fft_pass(p3d_plan64* p, const c64* in, c64* out, int nslices, bool rows, int dir, double scale, const int* done, int group = 1)
 {
     const GenPlan& pl = rows ? p->grow : p->gcol;
     const int n = pl.n;
@@ -728,8 +728,8 @@ int fft_pass(p3d_plan64* p, const c64* in, c64* out, int nslices, bool rows, int
     if (lds > 64 * 1024) F_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(line_fft64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int threads = 64;
     while (threads < 256 && threads * 4 < n) threads *= 2;
-    if (rows) line_fft64<<<dim3((unsigned)lines), threads, lds, p->stream>>>(in, out, p->tw_row, pl, dir, scale, 1, p->nil, p->per(), (size_t)p->nxl, done, p->nil);
-    else line_fft64<<<dim3((unsigned)lines), threads, lds, p->stream>>>(in, out, p->tw_col, pl, dir, scale, p->nxl, p->nxl, p->per(), (size_t)1, done, p->nxl);
+    if (rows) line_fft64<<<dim3((unsigned)lines), threads, lds, p->stream>>>(in, out, p->tw_row, pl, dir, scale, 1, p->nil, p->per(), (size_t)p->nxl, done, p->nil * group);
+    else line_fft64<<<dim3((unsigned)lines), threads, lds, p->stream>>>(in, out, p->tw_col, pl, dir, scale, p->nxl, p->nxl, p->per(), (size_t)1, done, p->nxl * group);
     F_TRY(hipGetLastError());
     return P3D_OK;
 }
@@ -857,7 +857,8 @@ int p3d_plan64_destroy(p3d_plan64* p)
     return P3D_OK;
 }
 
-int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_slices)
+// bare: twiddles and the work buffer only (a plan whose transforms another loop borrows, p3d_shearlet64.hip)
+static int create64(p3d_plan64** out, int device, int nil, int nxl, int max_slices, bool bare)
 {
     if (!out) return f64fail(P3D_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -929,8 +930,10 @@ int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_sl
     const size_t nparts = (size_t)std::max(std::max(p3d_plan64::BLOCKS, p->tiles_col()), p->tiles_row());
 #define ALLOC64(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return bail(#ptr, e)
     ALLOC64(p->work, sizeof(c64) * per * S);
-    ALLOC64(p->st_x, sizeof(c64) * per * S);
-    ALLOC64(p->st_out, sizeof(c64) * per * S);
+    if (!bare) {
+        ALLOC64(p->st_x, sizeof(c64) * per * S);
+        ALLOC64(p->st_out, sizeof(c64) * per * S);
+    }
     ALLOC64(p->mask, sizeof(double) * per);
     ALLOC64(p->partial, sizeof(double) * 8 * nparts * S);
     ALLOC64(p->spart, sizeof(double) * nparts * S);
@@ -940,6 +943,8 @@ int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_sl
     *out = p;
     return P3D_OK;
 }
+
+int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_slices) { return create64(out, device, nil, nxl, max_slices, false); }
 
 // statistics of fft2(x) for the schedule: stats[nslices][P3D_STATS_PER_SLICE] as p3d_pocs_stats (x: host or device pointer)
 int p3d_pocs64_stats(p3d_plan64* p, const void* x, int dtype, int nslices, double* stats)
@@ -1073,3 +1078,24 @@ int p3d_pocs64_run(p3d_plan64* p, const void* x, int dtype, const double* mask, 
 }
 
 }  // extern "C"
+
+// ---- what p3d_shearlet64.hip borrows (p3d_internal.hpp) ------------------------------------------------------------------------------------------------
+namespace p3d {
+
+int plan64_create_bare(p3d_plan64** out, int device, int nil, int nxl, int max_slices) { return create64(out, device, nil, nxl, max_slices, true); }
+hipStream_t plan64_stream(p3d_plan64* p) { return p->stream; }
+void* plan64_work(p3d_plan64* p) { return p->work; }
+
+int plan64_fft2(p3d_plan64* p, void* buf, int nslices, bool inverse, const int* done, int done_group)
+{
+    c64* w = reinterpret_cast<c64*>(buf);
+    int rc;
+    if (!inverse) {
+        if ((rc = fft_pass(p, w, w, nslices, true, -1, 1.0, done, done_group))) return rc;
+        return fft_pass(p, w, w, nslices, false, -1, 1.0, done, done_group);
+    }
+    if ((rc = fft_pass(p, w, w, nslices, false, +1, 1.0 / p->nil, done, done_group))) return rc;
+    return fft_pass(p, w, w, nslices, true, +1, 1.0 / p->nxl, done, done_group);
+}
+
+}  // namespace p3d

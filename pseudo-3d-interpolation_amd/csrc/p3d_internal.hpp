@@ -56,4 +56,13 @@ int shearlet_col_stats_pair(p3d_plan* plan, int nb, int nsh, const unsigned* sup
 // sup: device bitmap [nsh][sup_words] of the 8-row groups on which a shearlet's spectrum does not vanish (ShearArgs::sup); the three
 // passes of one iteration must be given the SAME table (a group one pass skips is never stored for the next to read)
 
+// ---- the double-precision 2-D FFT of p3d_f64.hip, borrowed by the double-precision SHEARLET loop (p3d_shearlet64.hip) --------------------
+// a plan without the loop's staging buffers: twiddles and the complex128 work buffer [max_slices][nil][nxl]
+int plan64_create_bare(p3d_plan64** out, int device, int nil, int nxl, int max_slices);
+hipStream_t plan64_stream(p3d_plan64* plan);
+void* plan64_work(p3d_plan64* plan);
+// in-place batched fft2 / ifft2 (numpy.fft conventions) of complex128 slices [nslices][nil][nxl] at `buf` (device), enqueued on the plan's
+// stream; slice i is skipped where done[i / done_group] != 0 (done: device, may be NULL)
+int plan64_fft2(p3d_plan64* plan, void* buf, int nslices, bool inverse, const int* done, int done_group);
+
 }  // namespace p3d

@@ -294,6 +294,19 @@ def _get_shearlet_plan(psi, nslices, device):
     return plan
 
 
+def _get_shearlet_plan64(psi, nslices, device):
+    psi = np.asarray(psi)
+    probe = psi[::max(psi.shape[0] // 7, 1), ::max(psi.shape[1] // 5, 1), ::max(psi.shape[2] // 3, 1)]
+    key = ('double', psi.shape, str(psi.dtype), float(np.sum(probe)), float(np.sum(np.abs(probe) ** 2)), device)
+    plan = _shearlet_plans.get(key)
+    if plan is None or plan.max_slices < nslices:
+        if plan is not None:
+            plan.close()
+        plan = _ffi.ShearletPlan64(psi, max_slices=max(nslices, 1), device=device)
+        _shearlet_plans[key] = plan
+    return plan
+
+
 def release_plans():
     """Free the cached GPU plans (work buffers) of this process."""
     for w in _workers.values():
@@ -705,6 +718,43 @@ def _pocs_cube_wavelet_double(cube, mask, out, wavelet, niter, thresh_op, thresh
     return out
 
 
+def _pocs_cube_shearlet_double(cube, mask, out, psi, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results, device,
+                               batch_slices):
+    """``pocs_cube`` for the SHEARLET transform through the double-precision loop (``_ffi.ShearletPlan64``), batch by batch as
+    ``_pocs_cube_wavelet_double``: statistics of the double-precision coefficients -> the schedule (host) -> the iterations; complex64 / float32
+    cubes are widened on load and the result is cast back on store (the reference's final cast, cube_POCS_interpolation_3D.py:324)."""
+    nslices, nil, nxl = cube.shape
+    nsh = psi.shape[2]
+    # coefficients of one slice are nsh full-size complex128 arrays on the device: bound the batch by memory (<= 16 GiB of coefficients)
+    fit = max(1, min(int((16 << 30) // (nsh * nil * nxl * 16)), 65535 // nsh))
+    step = min(int(batch_slices) if batch_slices else nslices, fit, nslices)
+    plan = _get_shearlet_plan64(psi, step, device)
+    mask64 = np.ascontiguousarray(mask, dtype=np.float64)
+    for lo in range(0, nslices, step):
+        chunk = cube[lo:lo + step]
+        n = chunk.shape[0]
+        t0 = time.perf_counter()
+        xc, dt = plan._cube(chunk)
+        active = _active_slices(chunk)   # np.count_nonzero(x) == 0 -> untouched (POCS.py:515-521)
+        stats = plan.stats_dev(xc.ctypes.data, dt, n)
+        stats[~active] = 1.0
+        stats[~active, ..., 1] = 0.0
+        tau = _shearlet_schedule_from_stats(stats, (nil, nxl), thresh_model, niter, p_max, p_min, decay_kind)
+        if sqrt_decay:
+            tau = np.sqrt(tau)  # POCS.py:595
+        dst = out[lo:lo + n]
+        direct = dst.dtype == xc.dtype and dst.flags.c_contiguous
+        res = dst if direct else np.empty_like(xc)
+        done, sums, _ = plan.run_dev(xc.ctypes.data, dt, mask64.ctypes.data, tau, niter, res.ctypes.data, n, thresh_op=thresh_op, version=version, eps=eps,
+                                     alpha=alpha, active=active)
+        if not direct:
+            dst[...] = res
+        runtime = time.perf_counter() - t0
+        if results is not None:
+            results.extend(_result_rows(done, sums, runtime))
+    return out
+
+
 def _check_cube_args(cube, mask, transform_kind, thresh_op, version, niter, eps, p_max, alpha, p_min):
     """Argument checks of the batched entry points (``pocs_cube``, ``sharding.pocs_block_on_device``), made BEFORE anything is
     uploaded: the kernels read ``nil * nxl`` mask entries whatever the caller handed over.  Returns the normalised
@@ -809,6 +859,12 @@ def _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alp
                              'thresholding needs one per level and detail)')   # (as the float32 path below: the reference fails here)
         return _pocs_cube_wavelet_double(cube, mask, out, _wavelet_name(ignored.get('transform'), wavelet), niter, thresh_op, thresh_model, eps, alpha, p_max,
                                          p_min, sqrt_decay, decay_kind, version, results, device, batch_slices)
+    if want_double and kind == 'SHEARLET' and thresh_op in _WAVELET_OPS and auxiliary_data is not None and max(nil, nxl) <= 5120:
+        psi = np.asarray(auxiliary_data)
+        if psi.ndim != 3 or psi.shape[:2] != (nil, nxl):
+            raise ValueError(f'Psi must be ({nil}, {nxl}, nshearlets), got shape {psi.shape}')
+        return _pocs_cube_shearlet_double(cube, mask, out, psi, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version,
+                                          results, device, batch_slices)
     if want_double and not (kind == 'FFT' and thresh_op in _WAVELET_OPS and max(nil, nxl) <= 5120):
         import warnings
         why = (f'the {kind} transform' if kind != 'FFT' else f'thresh_op={thresh_op!r}' if thresh_op not in _WAVELET_OPS else f'slice extents above 5120 ({nil} x {nxl})')

@@ -355,3 +355,109 @@ def test_two_columns_per_transform_against_the_general_column_pass(so, shape, op
     monkeypatch.delenv("P3D_SHEARLET_NO_PAIR")
     P.release_plans()
     assert np.array_equal(a, b)
+
+
+# ---- the SHEARLET loop in the reference's double precision (p3d_shearlet64.hip) ----------------------------------------------------------
+@pytest.mark.parametrize("shape,complex_", [((48, 64), False), ((48, 64), True), ((33, 31), False), ((40, 24), True), ((128, 96), False), ((150, 240), False)])
+@pytest.mark.parametrize("kw", [
+    dict(niter=6, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2),
+    dict(niter=5, thresh_op="garrote", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
+    dict(niter=30, thresh_op="hard", thresh_model="exponential", eps=1e-4, p_max=0.99, p_min=1e-2),
+    dict(niter=5, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min="adaptive"),
+    dict(niter=5, thresh_op="soft", thresh_model="inverse_proportional-2", eps=0.0, sqrt_decay=True),
+])
+def test_shearlet_loop_in_the_reference_precision(so, shape, complex_, kw):
+    """complex128 / float64 cubes run the SHEARLET loop in double precision (np.fft inside FFST computes in double and POCS_algorithm never
+    narrows: POCS.py:589-619), complex64 / float32 cubes on request: 1e-10 against the double-fed oracle where the float32 kernels hold
+    1e-5 ... 2e-4, the same iteration counts under the early exit, the same costs, an all-zero slice untouched."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    if complex_ and (kw["thresh_op"] == "garrote" or kw.get("p_min") == "adaptive"):
+        pytest.skip("complex tau with garrote amplifies rounding noise (see test_gpu_wavelet); 'adaptive' p_min is real-only in practice")
+    psi = shearlets.scalesShearsAndSpectra(shape)
+    mask = po.synthetic_mask(shape[0], shape[1], 0.5)
+    cube = np.stack([po.synthetic_slice(shape[0], shape[1], 20 + s, real=not complex_) for s in range(3)])
+    if kw.get("p_min") == "adaptive":
+        cube = cube + 2.0   # (a positive mean: the signed maximum of the low-pass coefficients, which scales the schedule, is then positive)
+    cube = (cube * mask).astype(np.complex128 if complex_ else np.float64)
+    cube[1] = 0
+    res, infos = [], []
+    got = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, results=res, **kw)
+    want = so.pocs_cube_shearlet(cube, mask, psi, infos=infos, **kw)
+    assert got.dtype == cube.dtype and not got[1].any()
+    compared = 0
+    for s in (0, 2):
+        if not np.isfinite(want[s]).all():
+            # a slice whose low-pass coefficients are all negative has a negative signed maximum there: the exponential schedule takes the
+            # logarithm of a negative ratio and the reference's whole slice turns NaN (POCS.py:340-341) -- nothing to compare with
+            continue
+        compared += 1
+        assert res[s]["niterations"] == infos[s]["niterations"], (s, res[s]["niterations"], infos[s]["niterations"])
+        assert rel_l2(got[s], want[s]) <= 1e-10, (s, rel_l2(got[s], want[s]))
+        np.testing.assert_allclose(res[s]["costs"], infos[s]["costs"], rtol=1e-6, atol=1e-24)
+    assert compared >= 1
+    narrow = cube.astype(np.complex64 if complex_ else np.float32)
+    got32 = P.pocs_cube(narrow, mask, transform_kind="SHEARLET", auxiliary_data=psi, precision="reference", **kw)
+    want32 = so.pocs_cube_shearlet(narrow.astype(cube.dtype), mask, psi, **kw)
+    assert got32.dtype == narrow.dtype
+    if kw["thresh_op"] != "hard":     # (the result is cast back to float32: 6e-8 per sample; a hard threshold may flip a decision of the narrowed input)
+        for s in (0, 2):
+            if np.isfinite(want32[s]).all():
+                assert rel_l2(got32[s], want32[s]) <= 2e-7
+    # batching is transparent, and the float32 kernels are still what a float32 cube gets by default
+    alone = P.pocs_cube(cube[2:3], mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+    assert np.array_equal(alone[0], got[2])
+    split = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, batch_slices=2, **kw)
+    assert np.array_equal(split, got)
+
+
+def test_shearlet_plan64_statistics_and_errors(ffi, so):
+    """The double-precision plan by itself: statistics of the coefficients against the oracle's transform, argument checks."""
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    shape = (40, 56)
+    psi = shearlets.scalesShearsAndSpectra(shape)
+    nsh = psi.shape[2]
+    with ffi.ShearletPlan64(psi, max_slices=2) as plan:
+        for real in (True, False):
+            x = np.stack([po.synthetic_slice(*shape, 3 + s, real=real) for s in range(2)]).astype(np.float64 if real else np.complex128)
+            st = plan.stats(x)
+            assert st.shape == (2, nsh, 5)
+            for s in range(2):
+                c = so.shearlet_transform(x[s], psi)
+                peak = np.max(c, axis=(0, 1))
+                np.testing.assert_allclose(st[s, :, 0] + 1j * st[s, :, 1], peak, rtol=1e-12, atol=1e-15)
+                np.testing.assert_allclose(st[s, :, 2], np.abs(c).max(axis=(0, 1)), rtol=1e-12)
+                np.testing.assert_allclose(st[s, :, 3], np.abs(c).min(axis=(0, 1)), rtol=1e-9, atol=1e-15)
+                np.testing.assert_allclose(st[s, :, 4], (np.abs(c) ** 2).sum(axis=(0, 1)), rtol=1e-12)
+        with pytest.raises(ValueError):
+            plan.stats(np.zeros((3,) + shape))                      # more slices than the plan holds
+        with pytest.raises(ffi.P3DError):
+            plan.run(np.zeros((1,) + shape), np.ones(shape), np.full((1, 2, nsh), 1j), 2)      # complex thresholds on a real cube
+    with pytest.raises(NotImplementedError):
+        ffi.ShearletPlan64(psi.astype(np.complex128))
+
+
+def test_shearlet_config4_slice_in_the_reference_precision(so):
+    """BASELINE configs[4]'s slice as stated (2048 x 1024, 125 shearlets, 80 % missing, hard threshold, exponential decay), first iterations
+    through the double-precision loop against the oracle's real-transform form: 1e-10 where the float32 kernels hold 2e-4."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    kw = dict(thresh_op="hard", thresh_model="exponential", niter=3, p_max=0.99, p_min=0.05)
+    shape = (2048, 1024)
+    psi = shearlets.scalesShearsAndSpectra(shape)
+    mask = po.synthetic_mask(*shape, 0.8)
+    x = (po.synthetic_slice(*shape, 40, real=True) * mask).astype(np.float32)
+    info, res = {}, []
+    want = so.pocs_slice_shearlet_real(x.astype(np.float64), mask, psi, info=info, **kw)
+    got = P.pocs_cube(x[None], mask, transform_kind="SHEARLET", auxiliary_data=psi, precision="reference", results=res, eps=0.0, **kw)
+    assert got.dtype == np.float32
+    err = rel_l2(got[0], want)
+    print(f"configs[4] slice in double: device-vs-oracle rel-L2 {err:.3e} (float32 result)")
+    assert err <= 2e-7, err
+    np.testing.assert_allclose(res[0]["costs"], info["costs"], rtol=1e-6, atol=1e-24)
+    got64 = P.pocs_cube(x[None].astype(np.float64), mask, transform_kind="SHEARLET", auxiliary_data=psi, eps=0.0, **kw)
+    assert got64.dtype == np.float64 and rel_l2(got64[0], want) <= 1e-10, rel_l2(got64[0], want)
+    P.release_plans()
