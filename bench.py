@@ -902,6 +902,29 @@ def run_leg(ctx, config, K_override, main, override=None):
                                  "the reference's SHEARLET branches of schedule and loop are pinned) fed the same observed slice in double precision",
                       "what": f"slice 0 of the timed cube through a separate device job of {n_par} iterations (the schedule of a {n_par}-iteration run) vs the oracle's "
                               f"{n_par} iterations -- the CPU leg cannot follow the timed job's {K} iterations of 125 shearlets on 2 Mi points"}
+            if world == 1 and not args.only_main:
+                # the same two iterations in the reference's double precision (p3d_shearlet64.hip), and the device time of a short loop of it
+                with _ffi.ShearletPlan64(psi, max_slices=1, device=dev_index) as plan64:
+                    x1 = np.ascontiguousarray(cpu_slices[0], dtype=np.float32 if cfg["real"] else np.complex64)
+                    tau64 = P._shearlet_schedule_from_stats(plan64.stats(x1), (nil, nxl), "exponential", n_par, 0.99, p_min, "values")
+                    got64 = plan64.run(x1, mask, tau64, n_par, thresh_op=op, eps=0.0, alpha=args.alpha)[0][0]
+                    k64 = 6
+                    tau64 = P._shearlet_schedule_from_stats(plan64.stats(x1), (nil, nxl), "exponential", k64, 0.99, p_min, "values")
+                    ms64 = min(plan64.run(x1, mask, tau64, k64, thresh_op=op, eps=0.0, alpha=args.alpha)[3] for _ in range(2))
+                rel64 = float(np.linalg.norm(got64 - ref_two) / np.linalg.norm(ref_two))
+                parity["other_paths"] = {"reference_precision": {"rel_l2_max": rel64, "rel_l2_median": rel64, "slices": 1, "niter": n_par}}
+                it64 = ms64 / k64
+                b64 = 2.0 * ALG_BYTES["SHEARLET"](nsh) * nil * nxl
+                ref_prec = {
+                    "what": f"the same job with precision='reference': the SHEARLET loop in double precision (np.fft inside FFST computes in double, POCS.py:589-619 "
+                            f"never narrows), unfused passes on the double-precision FFT -- slice 0 of the cube, float32 in and out, device time of a {k64}-iteration "
+                            f"loop; parity under parity.other_paths.reference_precision",
+                    "slice_iterations_per_s": 1.0 / (it64 * 1e-3), "iterations_per_s_of_the_cube": 1.0 / (it64 * 1e-3) / cube_slices,
+                    "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": b64 / (nil * nxl), "achieved": b64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                                 "unit": "GB/s", "frac": b64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 "note": "the float32 accounting (40 B per point and shearlet), doubled; the unfused passes (four transforms of the coefficient "
+                                         "buffer, each two passes, between spread, threshold and gather) move about five times that"},
+                }
         else:
             plan.close()
             x_obs.free(); out.free()
