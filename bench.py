@@ -917,13 +917,13 @@ def run_leg(ctx, config, K_override, main, override=None):
                 b64 = 2.0 * ALG_BYTES["SHEARLET"](nsh) * nil * nxl
                 ref_prec = {
                     "what": f"the same job with precision='reference': the SHEARLET loop in double precision (np.fft inside FFST computes in double, POCS.py:589-619 "
-                            f"never narrows), unfused passes on the double-precision FFT -- slice 0 of the cube, float32 in and out, device time of a {k64}-iteration "
+                            f"never narrows), three fused passes over the coefficients on the double-precision register engine (p3d_mix64.hip) -- slice 0 of the cube, float32 in and out, device time of a {k64}-iteration "
                             f"loop; parity under parity.other_paths.reference_precision",
                     "slice_iterations_per_s": 1.0 / (it64 * 1e-3), "iterations_per_s_of_the_cube": 1.0 / (it64 * 1e-3) / cube_slices,
                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": b64 / (nil * nxl), "achieved": b64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": b64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 "note": "the float32 accounting (40 B per point and shearlet), doubled; the unfused passes (four transforms of the coefficient "
-                                         "buffer, each two passes, between spread, threshold and gather) move about five times that"},
+                                 "note": "the float32 accounting (40 B per point and shearlet), doubled: spectrum x Psi -> coefficients (16 + 8), threshold in "
+                                         "place between two column transforms (32), coefficients x Psi -> sum (16 + 8); no support skipping, no Hermitian halves"},
                 }
         else:
             plan.close()

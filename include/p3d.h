@@ -320,10 +320,14 @@ int p3d_shearlet_run(p3d_splan* plan, const void* x, int dtype, const float* mas
  * (cube_POCS_interpolation_3D.py:324).  Same frame, thresholds, schedule layout (tau [nslices][niter][nsh][2], stats [nslices][nsh][5]) and error
  * behaviour as p3d_shearlet_*; every sample, spectrum, weight and statistic in double.  psi: HOST DOUBLE [nsh][nil][nxl].  dtype of x / out:
  * P3D_C128, P3D_F64, or P3D_C64 / P3D_F32 (converted on load / store); x, out, mask may be host or device pointers; mask is DOUBLE [nil][nxl].
- * A precision path: unfused passes on the double-precision FFT of p3d_plan64. */
+ * Three fused passes per iteration over the coefficients where both extents have a plan on the double-precision register engine (p3d_mix64.hip), unfused
+ * passes on the line transforms of p3d_plan64 otherwise. */
 typedef struct p3d_splan64 p3d_splan64;
 int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, int nsh, const double* psi, int max_slices);
 int p3d_shearlet64_plan_destroy(p3d_splan64* plan);
+/* fused: 1 when the loop runs its three fused passes on the double-precision register engine (both extents have a plan there; P3D_SHEARLET64_UNFUSED=1 at
+ * plan creation switches them off), 0 for the unfused passes */
+int p3d_shearlet64_info(p3d_splan64* plan, int* fused);
 int p3d_shearlet64_stats(p3d_splan64* plan, const void* x, int dtype, int nslices, double* stats);
 int p3d_shearlet64_run(p3d_splan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
                        const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);

@@ -1086,6 +1086,61 @@ int plan64_create_bare(p3d_plan64** out, int device, int nil, int nxl, int max_s
 hipStream_t plan64_stream(p3d_plan64* p) { return p->stream; }
 void* plan64_work(p3d_plan64* p) { return p->work; }
 
+bool plan64_shear_supported(p3d_plan64* p) { return p->fused && p->mcol && p->mrow && p->st_x != nullptr; }
+double* plan64_mask(p3d_plan64* p) { return p->mask; }
+void* plan64_stage_x(p3d_plan64* p) { return p->st_x; }
+void* plan64_stage_out(p3d_plan64* p) { return p->st_out; }
+void plan64_bind(p3d_plan64* p, const void* x, void* out)
+{
+    p->cur_x = x;
+    p->cur_out = out;
+    p->sparse = false;
+}
+
+int plan64_shear_first(p3d_plan64* p, int dtype, double* sums_row, int adaptive, double alpha, int nslices, const int* done)
+{
+    int rc = row_pass64<R64_FIRST>(p, dtype, sums_row, adaptive, 0, alpha, nslices, done, 0);
+    if (rc) return rc;
+    return col_pass64<C64_FWD>(p, nslices, 0, 0, 0, done);
+}
+
+int plan64_shear_spread(p3d_plan64* p, const double* psi, void* U, int nb, int nsh, const int* done)
+{
+    p3d::mix64::SpreadRow64 a{};
+    a.F = reinterpret_cast<const p3d::mix::c64d*>(p->work); a.psi = psi; a.U = reinterpret_cast<p3d::mix::c64d*>(U);
+    a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mrow); a.n1 = p->nil; a.nb = nb; a.nsh = nsh; a.done = done;
+    F_TRY(p->mrow->spread_row(a, p->stream));
+    return P3D_OK;
+}
+
+int plan64_shear_cols(p3d_plan64* p, void* U, const void* tau, int nb, int nsh, int niter, int iter, int op, int real_only, int mode, double scale, const int* done)
+{
+    p3d::mix64::ShearCol64 a{};
+    a.U = reinterpret_cast<p3d::mix::c64d*>(U ? U : p->work); a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mcol);
+    a.n2 = p->nxl; a.nslices = nb * nsh; a.nsh = nsh; a.tau = reinterpret_cast<const p3d::mix::c64d*>(tau); a.niter = niter; a.iter = iter; a.op = op;
+    a.real_only = real_only; a.mode = mode; a.scale = scale; a.done = done;
+    F_TRY(p->mcol->shear_col(a, p->stream));
+    return P3D_OK;
+}
+
+int plan64_shear_gather(p3d_plan64* p, const void* U, const double* psi, int nb, int nsh, const int* done)
+{
+    p3d::mix64::GatherRow64 a{};
+    a.U = reinterpret_cast<const p3d::mix::c64d*>(U); a.psi = psi; a.F = reinterpret_cast<p3d::mix::c64d*>(p->work);
+    a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mrow); a.n1 = p->nil; a.nb = nb; a.nsh = nsh; a.done = done;
+    F_TRY(p->mrow->gather_row(a, p->stream));
+    return P3D_OK;
+}
+
+int plan64_shear_back(p3d_plan64* p, int dtype, double* sums_row, bool last, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill)
+{
+    int rc = plan64_shear_cols(p, nullptr, nullptr, nslices, 1, 0, 0, 0, 0, 1, 1.0 / p->nil, done);   // (the row pass divides by nxl)
+    if (rc) return rc;
+    if (last) return row_pass64<R64_LAST>(p, dtype, sums_row, 0, 1, alpha, nslices, done, zero_fill);
+    if ((rc = row_pass64<R64_MID>(p, dtype, sums_row, adaptive, write_out, alpha, nslices, done, zero_fill))) return rc;
+    return col_pass64<C64_FWD>(p, nslices, 0, 0, 0, done);
+}
+
 int plan64_fft2(p3d_plan64* p, void* buf, int nslices, bool inverse, const int* done, int done_group)
 {
     c64* w = reinterpret_cast<c64*>(buf);

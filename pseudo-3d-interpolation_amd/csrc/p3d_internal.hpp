@@ -64,5 +64,23 @@ void* plan64_work(p3d_plan64* plan);
 // in-place batched fft2 / ifft2 (numpy.fft conventions) of complex128 slices [nslices][nil][nxl] at `buf` (device), enqueued on the plan's
 // stream; slice i is skipped where done[i / done_group] != 0 (done: device, may be NULL)
 int plan64_fft2(p3d_plan64* plan, void* buf, int nslices, bool inverse, const int* done, int done_group);
+// ---- ... and the fused passes of that loop on the register engine (p3d_mix64.hip), for a FULL plan64 of nb slices whose two extents have a plan:
+// the plan's work buffer holds the slices' spectra F, U is the caller's coefficient buffer [nb * nsh][nil][nxl] complex128, psi [nsh][nil][nxl] doubles
+bool plan64_shear_supported(p3d_plan64* plan);
+double* plan64_mask(p3d_plan64* plan);      // device [nil][nxl]: the caller fills it
+void* plan64_stage_x(p3d_plan64* plan);     // staging buffers for host cubes (max_slices slices of complex128)
+void* plan64_stage_out(p3d_plan64* plan);
+void plan64_bind(p3d_plan64* plan, const void* x, void* out);   // device pointers of the observed cube and the result the row passes read / write
+// work = fft2 of the first input (x, or its APOCS mix); sums_row[slice] = sum |x|
+int plan64_shear_first(p3d_plan64* plan, int dtype, double* sums_row, int adaptive, double alpha, int nslices, const int* done);
+// U[b * nsh + s] = inverse row transform of psi_s x work[b]
+int plan64_shear_spread(p3d_plan64* plan, const double* psi, void* U, int nb, int nsh, const int* done);
+// columns of U (NULL: of the work buffer, nsh = 1): inverse transform, x scale, real part if real_only; mode 0: threshold with tau[b][iter][s] and forward
+// transform; mode 1: nothing more (samples)
+int plan64_shear_cols(p3d_plan64* plan, void* U, const void* tau, int nb, int nsh, int niter, int iter, int op, int real_only, int mode, double scale, const int* done);
+// work[b] = sum_s psi_s x forward row transform of U[b * nsh + s]
+int plan64_shear_gather(p3d_plan64* plan, const void* U, const double* psi, int nb, int nsh, const int* done);
+// work (spectra) -> ifft2, re-insertion (POCS.py:616-619), sums_row[slice] = sum |x_new|, result to `out` if write_out; unless last: work = fft2 of the next input
+int plan64_shear_back(p3d_plan64* plan, int dtype, double* sums_row, bool last, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill);
 
 }  // namespace p3d

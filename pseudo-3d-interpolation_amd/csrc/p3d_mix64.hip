@@ -265,7 +265,183 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void row_kernel(const RowArgs6
     }
 }
 
+// ---- the SHEARLET loop's passes (p3d_mix64.hpp) ----------------------------------------------------------------------------------------------------------
+template <class PL>
+__global__ __launch_bounds__(PL::COLT* PL::TMAX) void shear_col_kernel(const ShearCol64 a)
+{
+    constexpr int N = PL::N, VMAX = PL::VMAX, T = PL::COLT;
+    constexpr int PPT_A = PL::PPT_A, TPL_A = PL::TPL_A, PPT_B = PL::PPT_B, TPL_B = PL::TPL_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c64d* data = reinterpret_cast<c64d*>(smem_raw);
+    const c64d* const twl = a.tab;
+    const int tid = threadIdx.x, c_lo = tid % T, tl = tid / T, u = blockIdx.y, tile = blockIdx.x;
+    const int b = u / a.nsh, s = u - b * a.nsh;
+    const int col = tile * T + c_lo;
+    const bool valid = col < a.n2;
+    if (a.done && a.done[b] != 0) return;
+    c64d* const base = a.U + (size_t)u * N * a.n2 + (valid ? col : 0);
+    const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
+    c64d v[VMAX];
+#pragma unroll
+    for (int q = 0; q < VMAX; ++q) v[q] = c64d{0.0, 0.0};
+    {
+        const int r0 = tl < TPL_B ? tl : 0;
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) v[q] = base[(size_t)(r0 + TPL_B * q) * a.n2];
+        if (!live_b) {
+#pragma unroll
+            for (int q = 0; q < PPT_B; ++q) v[q] = c64d{0.0, 0.0};
+        }
+    }
+    mix::line_fft<PL, INV, T>(v, data + c_lo, twl, tl);   // layout B -> layout A
+#pragma unroll
+    for (int q = 0; q < PPT_A; ++q) {
+        v[q] = v[q] * a.scale;
+        if (a.real_only) v[q].y = 0.0;   // FFST hands back ST.real for real data
+    }
+    if (a.mode == 1) {
+        if (live_a) {
+#pragma unroll
+            for (int q = 0; q < PPT_A; ++q) base[(size_t)(tl + TPL_A * q) * a.n2] = v[q];
+        }
+        return;
+    }
+    const c64d t = a.tau[((size_t)b * a.niter + a.iter) * a.nsh + s];
+#pragma unroll
+    for (int q = 0; q < PPT_A; ++q) v[q] = live_a ? shrink(v[q], t, a.op) : c64d{0.0, 0.0};
+    mix::line_fft<PL, FWD, T>(v, data + c_lo, twl, tl);   // layout A -> layout B
+    if (live_b) {
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) base[(size_t)(tl + TPL_B * q) * a.n2] = v[q];
+    }
+}
+
+template <class PL>
+__global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void spread_row_kernel(const SpreadRow64 a)
+{
+    constexpr int N = PL::N, VMAX = PL::VMAX, TMAX = PL::TMAX, LB = PL::ROWLB;
+    constexpr int PPT_A = PL::PPT_A, TPL_A = PL::TPL_A, PPT_B = PL::PPT_B, TPL_B = PL::TPL_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c64d* data = reinterpret_cast<c64d*>(smem_raw);
+    const c64d* const twl = a.tab;
+    const int tid = threadIdx.x, line = tid / TMAX, tl = tid % TMAX, u = blockIdx.y, row = blockIdx.x * LB + line;
+    const int b = u / a.nsh, s = u - b * a.nsh;
+    if (a.done && a.done[b] != 0) return;
+    const bool valid = row < a.n1;
+    const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
+    const size_t per = (size_t)a.n1 * N, rbase = (size_t)(valid ? row : 0) * N;
+    const c64d* const frow = a.F + (size_t)b * per + rbase;
+    const double* const prow = a.psi + (size_t)s * per + rbase;
+    c64d* const image = data + (size_t)line * PL::LINE;
+    c64d v[VMAX];
+#pragma unroll
+    for (int q = 0; q < VMAX; ++q) v[q] = c64d{0.0, 0.0};
+    {
+        const int i0 = tl < TPL_B ? tl : 0;
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) v[q] = frow[i0 + TPL_B * q] * prow[i0 + TPL_B * q];
+        if (!live_b) {
+#pragma unroll
+            for (int q = 0; q < PPT_B; ++q) v[q] = c64d{0.0, 0.0};
+        }
+    }
+    mix::line_fft<PL, INV, 1>(v, image, twl, tl);   // layout B -> layout A
+    if (live_a) {
+        c64d* const urow = a.U + (size_t)u * per + rbase;
+#pragma unroll
+        for (int q = 0; q < PPT_A; ++q) urow[tl + TPL_A * q] = v[q];
+    }
+}
+
+template <class PL>
+__global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void gather_row_kernel(const GatherRow64 a)
+{
+    constexpr int N = PL::N, VMAX = PL::VMAX, TMAX = PL::TMAX, LB = PL::ROWLB;
+    constexpr int PPT_A = PL::PPT_A, TPL_A = PL::TPL_A, PPT_B = PL::PPT_B, TPL_B = PL::TPL_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c64d* data = reinterpret_cast<c64d*>(smem_raw);
+    const c64d* const twl = a.tab;
+    const int tid = threadIdx.x, line = tid / TMAX, tl = tid % TMAX, b = blockIdx.y, row = blockIdx.x * LB + line;
+    if (a.done && a.done[b] != 0) return;
+    const bool valid = row < a.n1;
+    const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
+    const size_t per = (size_t)a.n1 * N, rbase = (size_t)(valid ? row : 0) * N;
+    c64d* const image = data + (size_t)line * PL::LINE;
+    const int ia = tl < TPL_A ? tl : 0, ib = tl < TPL_B ? tl : 0;
+    c64d acc[PPT_B];
+#pragma unroll
+    for (int q = 0; q < PPT_B; ++q) acc[q] = c64d{0.0, 0.0};
+    for (int s = 0; s < a.nsh; ++s) {
+        const c64d* const urow = a.U + ((size_t)b * a.nsh + s) * per + rbase;
+        const double* const prow = a.psi + (size_t)s * per + rbase;
+        c64d v[VMAX];
+#pragma unroll
+        for (int q = 0; q < VMAX; ++q) v[q] = c64d{0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < PPT_A; ++q) v[q] = urow[ia + TPL_A * q];
+        if (!live_a) {
+#pragma unroll
+            for (int q = 0; q < PPT_A; ++q) v[q] = c64d{0.0, 0.0};
+        }
+        mix::line_fft<PL, FWD, 1>(v, image, twl, tl);   // layout A -> layout B
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) {
+            const double w = prow[ib + TPL_B * q];
+            acc[q].x += v[q].x * w;
+            acc[q].y += v[q].y * w;
+        }
+    }
+    if (live_b) {
+        c64d* const frow = a.F + (size_t)b * per + rbase;
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) frow[tl + TPL_B * q] = acc[q];
+    }
+}
+
 constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <class PL, class KERN>
+hipError_t raise_lds(KERN kern, size_t lds, bool* done)
+{
+    if (*done) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) *done = true;
+    return e;
+}
+
+template <class PL>
+hipError_t launch_shear_col(const ShearCol64& a, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(c64d) * ((size_t)PL::LINE * PL::COLT);
+    static bool attr = false;
+    const hipError_t e = raise_lds<PL>(shear_col_kernel<PL>, lds, &attr);
+    if (e != hipSuccess) return e;
+    shear_col_kernel<PL><<<dim3((a.n2 + PL::COLT - 1) / PL::COLT, a.nslices), PL::COLT * PL::TMAX, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <class PL>
+hipError_t launch_spread_row(const SpreadRow64& a, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(c64d) * ((size_t)PL::LINE * PL::ROWLB);
+    static bool attr = false;
+    const hipError_t e = raise_lds<PL>(spread_row_kernel<PL>, lds, &attr);
+    if (e != hipSuccess) return e;
+    spread_row_kernel<PL><<<dim3((a.n1 + PL::ROWLB - 1) / PL::ROWLB, a.nb * a.nsh), PL::ROWLB * PL::TMAX, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+template <class PL>
+hipError_t launch_gather_row(const GatherRow64& a, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(c64d) * ((size_t)PL::LINE * PL::ROWLB);
+    static bool attr = false;
+    const hipError_t e = raise_lds<PL>(gather_row_kernel<PL>, lds, &attr);
+    if (e != hipSuccess) return e;
+    gather_row_kernel<PL><<<dim3((a.n1 + PL::ROWLB - 1) / PL::ROWLB, a.nb), PL::ROWLB * PL::TMAX, lds, st>>>(a);
+    return hipGetLastError();
+}
+
 
 template <class PL>
 hipError_t launch_col(int mode, const ColArgs64& a, hipStream_t st)
@@ -304,10 +480,12 @@ hipError_t launch_row(int mode, const RowArgs64& a, hipStream_t st)
 #define X(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)                                                                             \
     {N, COLT, LB, P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::TW_SLOTS,                                                  \
      &P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)::template build_tw<c64d>,                                               \
-     &launch_col<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>, &launch_row<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>},
+     &launch_col<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>, &launch_row<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>,                     \
+     &launch_shear_col<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>, &launch_spread_row<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>,       \
+     &launch_gather_row<P3D_PLAN64(N, COLT, LB, NP, R0, B0, R1, B1, R2, B2, R3, B3)>},
 const Entry entries[] = {
 #include "p3d_mix64_plans.inc"
-    {0, 0, 0, 0, nullptr, nullptr, nullptr}};
+    {0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
 #undef X
 
 }  // namespace

@@ -39,11 +39,46 @@ struct RowArgs64 {
 // mode numbers (= ColMode / RowMode of p3d_kernels_common.hpp, = the C64_* / R64_* of p3d_f64.hip)
 enum { M64_COL_ITER = 0, M64_COL_STATS = 1, M64_COL_FWD = 2, M64_ROW_FIRST = 0, M64_ROW_MID = 1, M64_ROW_LAST = 2 };
 
+// ---- the fused passes of the double-precision SHEARLET loop (p3d_shearlet64.hip): coefficient buffer U [nb * nsh][N][n2] complex128, entry
+// b * nsh + s = shearlet s of slice b; F [nb][n1][n2] spectra; psi [nsh][n1][n2] doubles (real spectra, FFT order) -------------------------------
+// column pass of U (or of F with nsh = 1): inverse transform, x scale, real part if real_only, then
+//   mode 0: threshold with tau[b][iter][s], forward transform, stored as a spectrum along the columns again;   mode 1: stored as it is (samples)
+struct ShearCol64 {
+    mix::c64d* U;
+    const mix::c64d* tab;
+    int n2, nslices, nsh;      // nslices = nb * nsh entries
+    const mix::c64d* tau;      // [nb][niter][nsh]
+    int niter, iter, op, real_only, mode;
+    double scale;
+    const int* done;           // [nb]
+};
+// rows of U[b * nsh + s] = inverse row transform (unscaled) of psi_s x F[b]
+struct SpreadRow64 {
+    const mix::c64d* F;
+    const double* psi;
+    mix::c64d* U;
+    const mix::c64d* tab;
+    int n1, nb, nsh;
+    const int* done;
+};
+// rows of F[b] = sum_s psi_s x forward row transform of U[b * nsh + s]
+struct GatherRow64 {
+    const mix::c64d* U;
+    const double* psi;
+    mix::c64d* F;
+    const mix::c64d* tab;
+    int n1, nb, nsh;
+    const int* done;
+};
+
 struct Entry {
     int n, col_tile, row_lines, tw_slots;
     void (*build_tw)(mix::c64d* out);
     hipError_t (*col)(int mode, const ColArgs64& a, hipStream_t st);
     hipError_t (*row)(int mode, const RowArgs64& a, hipStream_t st);
+    hipError_t (*shear_col)(const ShearCol64& a, hipStream_t st);
+    hipError_t (*spread_row)(const SpreadRow64& a, hipStream_t st);
+    hipError_t (*gather_row)(const GatherRow64& a, hipStream_t st);
 };
 const Entry* find(int n);   // nullptr: no plan (p3d_f64.hip's LDS-image passes)
 const Entry* part_0();

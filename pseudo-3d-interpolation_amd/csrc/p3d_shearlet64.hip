@@ -8,9 +8,13 @@
 // instead of 1e-4.
 //
 // One iteration of a batch of nb slices:  fft2(feed) -> x Psi_s into the coefficient buffer (nb * nsh slices) -> batched ifft2 -> threshold
-// (real cubes: of the real part, FFST returns ST.real) -> batched fft2 -> sum over s of x Psi_s -> ifft2 -> re-insertion, cost.  The transforms are
-// p3d_f64.hip's (p3d_internal.hpp: plan64_fft2); the coefficient buffer is that plan's work buffer.  Costs are sums of row sums added in a
-// fixed order (reproducible).
+// (real cubes: of the real part, FFST returns ST.real) -> batched fft2 -> sum over s of x Psi_s -> ifft2 -> re-insertion, cost.
+//   fused form (both extents have a plan on the double-precision register engine, p3d_mix64.hip): three passes over the coefficients --
+//     x Psi_s folded into the inverse row pass, the threshold into the column pass between its two transforms, x Psi_s and the sum over s into
+//     the forward row pass (80 B per coefficient instead of ~210) -- and the slice-sized passes of p3d_f64.hip's own loop around them;
+//   unfused form (any other shape; P3D_SHEARLET64_UNFUSED=1): separate kernels around p3d_f64.hip's line transforms (plan64_fft2), the
+//     coefficient buffer being that plan's work buffer.
+// Costs are sums of partial sums added in a fixed order (reproducible).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -258,7 +262,8 @@ __global__ void sconv64_kernel(const double* sums, int* done, int nslices, int i
 
 struct p3d_splan64 {
     int device = 0, nil = 0, nxl = 0, nsh = 0, max_slices = 0;
-    p3d_plan64* fft = nullptr;   // transforms + the coefficient buffer: max_slices * nsh complex128 slices
+    p3d_plan64* fft = nullptr;   // unfused form: transforms + the coefficient buffer: max_slices * nsh complex128 slices
+    p3d_plan64* pf = nullptr;    // fused form: the slice-sized passes (work buffer = the slices' spectra, staging buffers, mask); U is then the plan's own
     hipStream_t stream = nullptr;
     double* psi = nullptr;       // [nsh][nil][nxl]
     c64 *U = nullptr, *F = nullptr, *tau = nullptr;
@@ -350,11 +355,19 @@ int p3d_shearlet64_plan_destroy(p3d_splan64* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->psi, p->F, p->tau, p->sums, p->rowsum, p->stats, p->mask, p->done, p->st_x, p->st_out};
+    void* bufs[] = {p->psi, p->F, p->tau, p->sums, p->rowsum, p->stats, p->done};
     for (void* b : bufs) if (b) hipFree(b);
+    if (p->pf) {
+        if (p->U) hipFree(p->U);
+    } else {
+        if (p->mask) hipFree(p->mask);
+        if (p->st_x) hipFree(p->st_x);
+        if (p->st_out) hipFree(p->st_out);
+    }
     if (p->ev0) hipEventDestroy(p->ev0);
     if (p->ev1) hipEventDestroy(p->ev1);
-    if (p->fft) p3d_plan64_destroy(p->fft);   // (owns the stream and U)
+    if (p->fft) p3d_plan64_destroy(p->fft);   // (owns the stream and U of the unfused form)
+    if (p->pf) p3d_plan64_destroy(p->pf);     // (owns the stream, the mask and the staging buffers of the fused form)
     delete p;
     return P3D_OK;
 }
@@ -368,10 +381,19 @@ int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, 
     if ((long long)max_slices * nsh > 65535) return s64fail(P3D_ERR_INVALID, "max_slices * nsh = %lld exceeds 65535", (long long)max_slices * nsh);
     p3d_splan64* p = new p3d_splan64;
     p->device = device; p->nil = nil; p->nxl = nxl; p->nsh = nsh; p->max_slices = max_slices;
-    int rc = p3d::plan64_create_bare(&p->fft, device, nil, nxl, max_slices * nsh);
+    int rc = p3d_plan64_create(&p->pf, device, nil, nxl, max_slices);
     if (rc) { delete p; return rc; }   // message already set
-    p->stream = p3d::plan64_stream(p->fft);
-    p->U = reinterpret_cast<c64*>(p3d::plan64_work(p->fft));
+    const char* env = getenv("P3D_SHEARLET64_UNFUSED");
+    if (!p3d::plan64_shear_supported(p->pf) || (env && env[0] == '1')) {
+        p3d_plan64_destroy(p->pf);
+        p->pf = nullptr;
+        rc = p3d::plan64_create_bare(&p->fft, device, nil, nxl, max_slices * nsh);
+        if (rc) { delete p; return rc; }
+        p->stream = p3d::plan64_stream(p->fft);
+        p->U = reinterpret_cast<c64*>(p3d::plan64_work(p->fft));
+    } else {
+        p->stream = p3d::plan64_stream(p->pf);
+    }
     auto bail = [&](const char* what, hipError_t e) {
         p3d_shearlet64_plan_destroy(p);
         return s64fail(P3D_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
@@ -383,16 +405,30 @@ int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, 
     if ((e = hipEventCreate(&p->ev1)) != hipSuccess) return bail("event", e);
     const size_t S = (size_t)max_slices, per = p->per();
     ALLOC(p->psi, sizeof(double) * per * nsh);
-    ALLOC(p->F, sizeof(c64) * per * S);
     ALLOC(p->done, sizeof(int) * S);
     ALLOC(p->stats, sizeof(double) * 5 * nsh * S);
-    ALLOC(p->rowsum, sizeof(double) * nil * S);
-    ALLOC(p->mask, sizeof(double) * per);
-    ALLOC(p->st_x, sizeof(c64) * per * S);
-    ALLOC(p->st_out, sizeof(c64) * per * S);
+    if (p->pf) {
+        ALLOC(p->U, sizeof(c64) * per * nsh * S);
+        p->mask = p3d::plan64_mask(p->pf);
+        p->st_x = p3d::plan64_stage_x(p->pf);
+        p->st_out = p3d::plan64_stage_out(p->pf);
+    } else {
+        ALLOC(p->F, sizeof(c64) * per * S);
+        ALLOC(p->rowsum, sizeof(double) * nil * S);
+        ALLOC(p->mask, sizeof(double) * per);
+        ALLOC(p->st_x, sizeof(c64) * per * S);
+        ALLOC(p->st_out, sizeof(c64) * per * S);
+    }
 #undef ALLOC
     if ((e = hipMemcpy(p->psi, psi, sizeof(double) * per * nsh, hipMemcpyHostToDevice)) != hipSuccess) return bail("upload of Psi", e);
     *out = p;
+    return P3D_OK;
+}
+
+int p3d_shearlet64_info(p3d_splan64* p, int* fused)
+{
+    if (!p || !fused) return s64fail(P3D_ERR_INVALID, "NULL argument");
+    *fused = p->pf ? 1 : 0;
     return P3D_OK;
 }
 
@@ -404,8 +440,16 @@ int p3d_shearlet64_stats(p3d_splan64* p, const void* x, int dtype, int nslices, 
     S_RC(s_check(p, nslices, dtype));
     if (!x || !stats) return s64fail(P3D_ERR_INVALID, "NULL buffer");
     S_RC(take_x(p, x, dtype, nslices));
-    supdate64_kernel<<<dim3(p->nil, nslices), 256, 0, p->stream>>>(p->F, p->cur_x, dtype, nullptr, nullptr, p->rowsum, 0, 0, 0, 1.0, p->nil, p->nxl, nullptr, 0, 0);
-    S_RC(s_forward(p, nslices, nullptr));
+    if (p->pf) {
+        S_RC(ensure_sums(p, (size_t)nslices));
+        p3d::plan64_bind(p->pf, p->cur_x, nullptr);
+        S_RC(p3d::plan64_shear_first(p->pf, dtype, p->sums, 0, 1.0, nslices, nullptr));
+        S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, p->nsh, nullptr));
+        S_RC(p3d::plan64_shear_cols(p->pf, p->U, nullptr, nslices, p->nsh, 0, 0, 0, 0, 1, 1.0 / ((double)p->nil * p->nxl), nullptr));
+    } else {
+        supdate64_kernel<<<dim3(p->nil, nslices), 256, 0, p->stream>>>(p->F, p->cur_x, dtype, nullptr, nullptr, p->rowsum, 0, 0, 0, 1.0, p->nil, p->nxl, nullptr, 0, 0);
+        S_RC(s_forward(p, nslices, nullptr));
+    }
     sstats64_kernel<<<nslices * p->nsh, 256, 0, p->stream>>>(p->U, p->per(), real_dtype(dtype) ? 1 : 0, p->stats);
     S_TRY(hipGetLastError());
     S_TRY(hipMemcpyAsync(stats, p->stats, sizeof(double) * 5 * (size_t)nslices * p->nsh, hipMemcpyDeviceToHost, p->stream));
@@ -447,20 +491,35 @@ int p3d_shearlet64_run(p3d_splan64* p, const void* x, int dtype, const double* m
     S_TRY(hipMemcpyAsync(p->done, done_h.data(), sizeof(int) * nslices, hipMemcpyHostToDevice, p->stream));
     S_TRY(hipMemsetAsync(p->sums, 0, sizeof(double) * nsum, p->stream));
     S_TRY(hipEventRecord(p->ev0, p->stream));
-    const dim3 ugrid(p->nil, nslices);
-    supdate64_kernel<<<ugrid, 256, 0, p->stream>>>(p->F, p->cur_x, dtype, p->mask, p->cur_out, p->rowsum, 0, adaptive ? 1 : 0, 0, prm->alpha, p->nil, p->nxl, p->done, 0,
-                                                  real_only ? 1 : 0);
-    srowsum64_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil, p->done);
-    for (int k = 0; k < niter; ++k) {
-        const bool last = k + 1 == niter;
-        S_RC(s_forward(p, nslices, p->done));
-        sthreshold64_kernel<<<dim3(blocks_for(per, 64), nslices * nsh), 256, 0, p->stream>>>(p->U, per, nsh, p->tau, niter, k, prm->thresh_op, real_only ? 1 : 0, p->done);
-        S_RC(s_inverse(p, nslices, p->done));
-        // (early exit: every iterate is stored, so that a slice that converges keeps its last one -- sconv64_kernel switches it off afterwards)
-        supdate64_kernel<<<ugrid, 256, 0, p->stream>>>(p->F, p->cur_x, dtype, p->mask, p->cur_out, p->rowsum, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
-                                                      prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0, real_only ? 1 : 0);
-        srowsum64_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums + (size_t)(k + 1) * nslices, p->nil, p->done);
-        if (early) sconv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+    if (p->pf) {
+        const double scale = 1.0 / ((double)p->nil * p->nxl);
+        p3d::plan64_bind(p->pf, p->cur_x, p->cur_out);
+        S_RC(p3d::plan64_shear_first(p->pf, dtype, p->sums, adaptive ? 1 : 0, prm->alpha, nslices, p->done));
+        for (int k = 0; k < niter; ++k) {
+            const bool last = k + 1 == niter;
+            S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, nsh, p->done));
+            S_RC(p3d::plan64_shear_cols(p->pf, p->U, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, 0, scale, p->done));
+            S_RC(p3d::plan64_shear_gather(p->pf, p->U, p->psi, nslices, nsh, p->done));
+            S_RC(p3d::plan64_shear_back(p->pf, dtype, p->sums + (size_t)(k + 1) * nslices, last, adaptive ? 1 : 0, early ? 1 : 0, prm->alpha, nslices, p->done,
+                                        last ? 1 : 0));
+            if (early) sconv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+        }
+    } else {
+        const dim3 ugrid(p->nil, nslices);
+        supdate64_kernel<<<ugrid, 256, 0, p->stream>>>(p->F, p->cur_x, dtype, p->mask, p->cur_out, p->rowsum, 0, adaptive ? 1 : 0, 0, prm->alpha, p->nil, p->nxl, p->done, 0,
+                                                      real_only ? 1 : 0);
+        srowsum64_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums, p->nil, p->done);
+        for (int k = 0; k < niter; ++k) {
+            const bool last = k + 1 == niter;
+            S_RC(s_forward(p, nslices, p->done));
+            sthreshold64_kernel<<<dim3(blocks_for(per, 64), nslices * nsh), 256, 0, p->stream>>>(p->U, per, nsh, p->tau, niter, k, prm->thresh_op, real_only ? 1 : 0, p->done);
+            S_RC(s_inverse(p, nslices, p->done));
+            // (early exit: every iterate is stored, so that a slice that converges keeps its last one -- sconv64_kernel switches it off afterwards)
+            supdate64_kernel<<<ugrid, 256, 0, p->stream>>>(p->F, p->cur_x, dtype, p->mask, p->cur_out, p->rowsum, 1, (adaptive && !last) ? 1 : 0, (early || last) ? 1 : 0,
+                                                          prm->alpha, p->nil, p->nxl, p->done, last ? 1 : 0, real_only ? 1 : 0);
+            srowsum64_kernel<<<nslices, 256, 0, p->stream>>>(p->rowsum, p->sums + (size_t)(k + 1) * nslices, p->nil, p->done);
+            if (early) sconv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);
+        }
     }
     S_TRY(hipGetLastError());
     S_TRY(hipEventRecord(p->ev1, p->stream));

@@ -358,7 +358,8 @@ def test_two_columns_per_transform_against_the_general_column_pass(so, shape, op
 
 
 # ---- the SHEARLET loop in the reference's double precision (p3d_shearlet64.hip) ----------------------------------------------------------
-@pytest.mark.parametrize("shape,complex_", [((48, 64), False), ((48, 64), True), ((33, 31), False), ((40, 24), True), ((128, 96), False), ((150, 240), False)])
+@pytest.mark.parametrize("shape,complex_", [((48, 64), False), ((48, 64), True), ((33, 31), False), ((40, 24), True), ((128, 96), False), ((150, 240), False),
+                                            ((64, 128), False), ((128, 64), True), ((256, 128), False)])   # (the last three: both extents on the register engine)
 @pytest.mark.parametrize("kw", [
     dict(niter=6, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2),
     dict(niter=5, thresh_op="garrote", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive"),
@@ -412,14 +413,15 @@ def test_shearlet_loop_in_the_reference_precision(so, shape, complex_, kw):
     assert np.array_equal(split, got)
 
 
-def test_shearlet_plan64_statistics_and_errors(ffi, so):
+@pytest.mark.parametrize("shape,fused", [((40, 56), False), ((64, 128), True)])
+def test_shearlet_plan64_statistics_and_errors(ffi, so, shape, fused):
     """The double-precision plan by itself: statistics of the coefficients against the oracle's transform, argument checks."""
     from oracle import pocs_oracle as po
     from pseudo_3d_interpolation_amd.functions import shearlets
-    shape = (40, 56)
     psi = shearlets.scalesShearsAndSpectra(shape)
     nsh = psi.shape[2]
     with ffi.ShearletPlan64(psi, max_slices=2) as plan:
+        assert plan.fused == fused
         for real in (True, False):
             x = np.stack([po.synthetic_slice(*shape, 3 + s, real=real) for s in range(2)]).astype(np.float64 if real else np.complex128)
             st = plan.stats(x)
@@ -461,3 +463,45 @@ def test_shearlet_config4_slice_in_the_reference_precision(so):
     got64 = P.pocs_cube(x[None].astype(np.float64), mask, transform_kind="SHEARLET", auxiliary_data=psi, eps=0.0, **kw)
     assert got64.dtype == np.float64 and rel_l2(got64[0], want) <= 1e-10, rel_l2(got64[0], want)
     P.release_plans()
+
+
+@pytest.mark.parametrize("shape,complex_,kw", [
+    ((64, 128), False, dict(niter=6, thresh_op="hard", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)),
+    ((128, 64), True, dict(niter=5, thresh_op="soft", thresh_model="linear", eps=0.0, p_max=0.9, p_min=0.05, alpha=0.8, version="adaptive")),
+    ((512, 256), False, dict(niter=25, thresh_op="garrote", thresh_model="exponential", eps=1e-4, p_max=0.99, p_min=1e-2)),
+    ((600, 500), False, dict(niter=4, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)),
+])
+def test_fused_double_precision_shearlet_passes_equal_the_unfused_ones(ffi, shape, complex_, kw, monkeypatch):
+    """The three fused passes on the register engine (p3d_mix64.hip: x Psi_s + inverse rows; inverse columns, threshold, forward columns; forward
+    rows, x Psi_s, sum over s) against the separate kernels around the line transforms: the same loop to rounding (1e-12), the same iteration
+    counts, statistics alike."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    psi = shearlets.scalesShearsAndSpectra(shape)
+    mask = po.synthetic_mask(shape[0], shape[1], 0.6)
+    cube = np.stack([po.synthetic_slice(shape[0], shape[1], 50 + s, real=not complex_) for s in range(3)]) * mask
+    cube = cube.astype(np.complex128 if complex_ else np.float64)
+    cube[1] = 0
+    P.release_plans()
+    with ffi.ShearletPlan64(psi, max_slices=3) as plan:
+        assert plan.fused
+        st_f = plan.stats(cube)
+    res_f = []
+    fused = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, results=res_f, batch_slices=2, **kw)
+    P.release_plans()
+    monkeypatch.setenv("P3D_SHEARLET64_UNFUSED", "1")
+    with ffi.ShearletPlan64(psi, max_slices=3) as plan:
+        assert not plan.fused
+        st_u = plan.stats(cube)
+    res_u = []
+    plain = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, results=res_u, batch_slices=2, **kw)
+    P.release_plans()
+    monkeypatch.delenv("P3D_SHEARLET64_UNFUSED")
+    np.testing.assert_allclose(st_f[[0, 2]][..., [0, 2, 4]], st_u[[0, 2]][..., [0, 2, 4]], rtol=1e-11)
+    np.testing.assert_allclose(st_f[[0, 2]][..., 3], st_u[[0, 2]][..., 3], rtol=1e-6, atol=1e-14)   # min |c|: next to a zero crossing
+    assert not fused[1].any() and not plain[1].any()
+    for s in (0, 2):
+        assert res_f[s]["niterations"] == res_u[s]["niterations"]
+        assert rel_l2(fused[s], plain[s]) <= 1e-12, (s, rel_l2(fused[s], plain[s]))
+        np.testing.assert_allclose(res_f[s]["costs"], res_u[s]["costs"], rtol=1e-7, atol=1e-26)
