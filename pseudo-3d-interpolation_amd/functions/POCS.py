@@ -810,14 +810,15 @@ def pocs_cube(
     callables in ``**ignored`` are accepted for signature compatibility and not called: the transform
     is selected by ``transform_kind``.
 
-    ``precision`` (FFT and WAVELET transforms; default: the environment variable ``P3D_PRECISION``, else ``None``) -- the arithmetic of the loop:
+    ``precision`` (every transform; default: the environment variable ``P3D_PRECISION``, else ``None``) -- the arithmetic of the loop:
     ``None``: that of the cube -- float32 kernels for complex64 / float32 cubes, the double-precision loop for complex128 / float64
     cubes (the reference computes such cubes in double precision; POCS.py:371-656 never narrows its input); ``'reference'``: double
     precision also for complex64 / float32 cubes, the result cast back (what the reference itself executes for the soft / garrote
     operators, FPOCS and APOCS, and for every run under NumPy < 2 -- SURVEY appendix A.16); ``'float32'``: the float32 kernels whatever the
     cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loops are
-    precision paths (FFT: about a tenth of the float32 rate; WAVELET: per-axis kernels without LDS tiles), have the hard / soft /
-    garrote operators, the FFT one slice extents up to 5120;
+    precision paths (FFT: about a quarter of the float32 rate; WAVELET: per-axis kernels without LDS tiles; SHEARLET: three fused
+    passes per iteration where both extents have a plan on the double-precision register engine, a tenth of the float32 rate), have the hard / soft /
+    garrote operators, the FFT and SHEARLET ones slice extents up to 5120;
     a call that asks for (or implies) double precision outside that coverage runs the float32 kernels and says so with a ``RuntimeWarning``.
 
     ``out`` (optional): an array of the shape and dtype of ``cube`` to write the result into (e.g. a slab of the merged cube of the
