@@ -199,6 +199,8 @@ typedef struct p3d_plan64 p3d_plan64;
 int p3d_plan64_create(p3d_plan64** out, int device, int nil, int nxl, int max_slices);
 int p3d_plan64_destroy(p3d_plan64* plan);
 int p3d_pocs64_stats(p3d_plan64* plan, const void* x, int dtype, int nslices, double* stats_host);
+/* test hook: batched fft2 / ifft2 (numpy.fft conventions) of HOST complex128 slices [nslices][nil][nxl] through the loop's own passes (p3d_f64.hip) */
+int p3d_fft2_c128(p3d_plan64* plan, const void* in_host, void* out_host, int nslices, int inverse);
 int p3d_pocs64_run(p3d_plan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
                    const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);
 

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "p3d_plan64_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "p3d_plan64_destroy": (C.c_int, [C.c_void_p]),
     "p3d_pocs64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "p3d_fft2_c128": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "p3d_pocs64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams), C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "p3d_dev_malloc": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_size_t]),
@@ -817,6 +818,18 @@ class Plan64:
         if x.dtype not in self._DT:
             x = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
         return np.ascontiguousarray(x), self._DT[x.dtype]
+
+    def fft2(self, x, inverse=False):
+        """Test hook: fft2 / ifft2 of complex128 slices through the loop's own passes (``p3d_fft2_c128``)."""
+        xc = np.ascontiguousarray(np.asarray(x, dtype=np.complex128))
+        squeeze = xc.ndim == 2
+        if squeeze:
+            xc = xc[None]
+        if xc.shape[1:] != (self.nil, self.nxl) or xc.shape[0] > self.max_slices:
+            raise ValueError(f"expected (<= {self.max_slices}, {self.nil}, {self.nxl}), got {xc.shape}")
+        out = np.empty_like(xc)
+        check(lib().p3d_fft2_c128(self.handle, _ptr(xc), _ptr(out), xc.shape[0], 1 if inverse else 0))
+        return out[0] if squeeze else out
 
     def stats(self, x):
         """(nslices, 6) float64, the layout of ``Plan.stats``: statistics of the double-precision ``fft2(x)``."""

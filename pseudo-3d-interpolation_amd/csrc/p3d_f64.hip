@@ -1077,6 +1077,49 @@ int p3d_pocs64_run(p3d_plan64* p, const void* x, int dtype, const double* mask, 
     return P3D_OK;
 }
 
+// test hook: batched fft2 / ifft2 (numpy.fft conventions) of HOST complex128 slices THROUGH THE LOOP'S OWN PASSES -- forward = the first row pass
+// (rows of x) + the forward column pass; inverse = the inverse column pass + the last row pass on an all-zero observed cube with an all-zero
+// mask (its re-insertion then adds nothing) -- so that every axis length is checked element by element on the engine the loop uses for it
+int p3d_fft2_c128(p3d_plan64* p, const void* in_host, void* out_host, int nslices, int inverse)
+{
+    int rc = check64(p, nslices, P3D_C128);
+    if (rc) return rc;
+    if (!in_host || !out_host) return f64fail(P3D_ERR_INVALID, "NULL buffer");
+    const size_t bytes = sizeof(c64) * p->per() * nslices;
+    p->sparse = false;
+    if (!inverse) {
+        F_TRY(hipMemcpyAsync(p->st_x, in_host, bytes, hipMemcpyHostToDevice, p->stream));
+        p->cur_x = p->st_x;
+        p->cur_out = p->st_out;
+        if (p->fused) {
+            if ((rc = row_pass64<R64_FIRST>(p, P3D_C128, p->partial, 0, 0, 1.0, nslices, nullptr, 0))) return rc;
+            if ((rc = col_pass64<C64_FWD>(p, nslices, 0, 0, 0, nullptr))) return rc;
+        } else {
+            if ((rc = update(p, P3D_C128, p->partial, 0, 0, 0, 1.0, nslices, nullptr, 0))) return rc;
+            if ((rc = fft2_64(p, nslices, false, nullptr))) return rc;
+        }
+        F_TRY(hipMemcpyAsync(out_host, p->work, bytes, hipMemcpyDeviceToHost, p->stream));
+    } else {
+        F_TRY(hipMemcpyAsync(p->work, in_host, bytes, hipMemcpyHostToDevice, p->stream));
+        if (p->fused) {
+            F_TRY(hipMemsetAsync(p->st_x, 0, bytes, p->stream));
+            F_TRY(hipMemsetAsync(p->mask, 0, sizeof(double) * p->per(), p->stream));
+            p->cur_x = p->st_x;
+            p->cur_out = p->st_out;
+            if (p->mcol) rc = p3d::plan64_shear_cols(p, nullptr, nullptr, nslices, 1, 0, 0, 0, 0, 1, 1.0 / p->nil, nullptr);
+            else rc = fft_pass(p, p->work, p->work, nslices, false, +1, 1.0 / p->nil, nullptr);
+            if (rc) return rc;
+            if ((rc = row_pass64<R64_LAST>(p, P3D_C128, p->partial, 0, 1, 1.0, nslices, nullptr, 0))) return rc;
+            F_TRY(hipMemcpyAsync(out_host, p->st_out, bytes, hipMemcpyDeviceToHost, p->stream));
+        } else {
+            if ((rc = fft2_64(p, nslices, true, nullptr))) return rc;
+            F_TRY(hipMemcpyAsync(out_host, p->work, bytes, hipMemcpyDeviceToHost, p->stream));
+        }
+    }
+    F_TRY(hipStreamSynchronize(p->stream));
+    return P3D_OK;
+}
+
 }  // extern "C"
 
 // ---- what p3d_shearlet64.hip borrows (p3d_internal.hpp) ------------------------------------------------------------------------------------------------

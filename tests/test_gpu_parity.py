@@ -882,11 +882,11 @@ def test_fused_double_precision_passes_equal_the_unfused_ones(ffi, orc, monkeypa
     assert np.allclose(sums_f, sums_u, rtol=1e-12)
 
 
-@pytest.mark.parametrize("shape", [(1024, 512), (1000, 96), (64, 1500), (256, 45), (300, 2048)])
+@pytest.mark.parametrize("shape", [(1024, 512), (1000, 96), (64, 1500), (256, 45), (330, 2048)])
 @pytest.mark.parametrize("switch", ["P3D_NO_MIX64", "P3D_F64_NO_SPARSE"])
 def test_double_precision_passes_on_the_register_engine_equal_the_lds_image_ones(ffi, orc, monkeypatch, shape, switch):
-    """Axes whose length has a plan in p3d_mix64_plans.inc (powers of two, round 7-smooth lengths) run the double-precision passes on the
-    mixed-radix register engine (p3d_mix64.hip), per axis -- the other axis may stay on the LDS-image kernels of p3d_f64.hip (45, 300 here) --,
+    """Axes whose length has a plan in p3d_mix64_plans.inc (powers of two, 7-smooth lengths from 96 on) run the double-precision passes on the
+    mixed-radix register engine (p3d_mix64.hip), per axis -- the other axis may stay on the LDS-image kernels of p3d_f64.hip (45, 330 here) --,
     with the sparse shortcut when both do.  P3D_NO_MIX64=1 keeps the LDS-image passes for every length, P3D_F64_NO_SPARSE=1 transforms and
     stores every tile: iterates to double rounding, statistics and cost sums to 1e-12, iteration counts exactly; hard threshold, early exit, an
     empty slice, float32 in and out."""
@@ -1102,6 +1102,30 @@ def test_every_planned_smooth_length_transforms_like_numpy():
             e1, e2 = rel_l2(f, np.fft.fft2(x.astype(np.complex128))), rel_l2(b, x)
             worst = max(worst, e1, e2)
             assert e1 < 2e-6 and e2 < 2e-6, (shape, e1, e2)
+    print(f"{len(lengths)} lengths, worst rel-L2 {worst:.2e}")
+
+
+def test_every_planned_length_of_the_double_precision_engine_transforms_like_numpy():
+    """Every line length with a plan of the double-precision register engine (p3d_mix64_plans.inc: powers of two and the 7-smooth lengths), as the
+    column and as the row axis, element by element through the loop's own passes (p3d_fft2_c128: first row pass + forward column pass; inverse
+    column pass + last row pass) against NumPy."""
+    import os
+    import re
+    from pseudo_3d_interpolation_amd import _ffi
+    inc = open(os.path.join(os.path.dirname(_ffi.__file__), "csrc", "p3d_mix64_plans.inc")).read()
+    lengths = sorted(int(m) for m in re.findall(r"^X\((\d+),", inc, re.M))
+    assert len(lengths) > 150 and {64, 1000, 1024, 1350, 2000, 4096} <= set(lengths)
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for n in lengths:
+        for shape in ((n, 64), (64, n)):
+            x = rng.standard_normal((2,) + shape) + 1j * rng.standard_normal((2,) + shape)
+            with _ffi.Plan64(shape[0], shape[1], 2) as plan:
+                f = plan.fft2(x)
+                b = plan.fft2(f, inverse=True)
+            e1, e2 = rel_l2(f, np.fft.fft2(x)), rel_l2(b, x)
+            worst = max(worst, e1, e2)
+            assert e1 < 1e-14 and e2 < 1e-14, (shape, e1, e2)
     print(f"{len(lengths)} lengths, worst rel-L2 {worst:.2e}")
 
 

@@ -138,6 +138,7 @@ def main():
                          "900 x 900 1.05 -> 0.91 ms per iteration of 128 slices; 768-point rows lose 8 %%)")
     ap.add_argument("--f64", action="store_true", help="plans of the double-precision passes (csrc/p3d_mix64_plans.inc): 16-byte elements, 8 ... 20 points per "
                     "thread, powers of two included; --only / the default list of lengths")
+    ap.add_argument("--all-smooth", action="store_true", help="with --f64: plans for every 7-smooth length min ... max, not only the default list")
     ap.add_argument("--roots", action="store_true", help="write the root tables Roots<R> (csrc/p3d_mix_roots.inc) instead of the plan list")
     args = ap.parse_args()
     if args.roots:
@@ -162,6 +163,8 @@ def main():
         PPT_LO, PPT_HI, PPT_TARGET, ELEM = 6, 16, 8, 16   # (measured on 1024-point lines: 8 points per thread 0.70 ms per iteration, 16 points 1.0-1.2 ms)
         args.two_pass_below = 0
     F64_LENGTHS = [64, 128, 256, 512, 1024, 2048, 4096, 500, 600, 720, 768, 800, 900, 960, 1000, 1200, 1280, 1440, 1500, 1536, 1600, 1800, 1920, 2000, 2400, 3000, 3072]
+    if args.f64 and args.all_smooth:   # every 7-smooth length of the float32 engine's range, and the powers of two
+        F64_LENGTHS = sorted(set(F64_LENGTHS) | {n for n in range(args.min, args.max + 1) if smooth(n)})
     lengths = args.only or (sorted(F64_LENGTHS) if args.f64 else
                             [n for n in range(args.min, args.max + 1) if n & (n - 1) and (smooth(n) or (n >= args.min13 and smooth(n, PRIMES13)))])
     rows = []
