@@ -505,3 +505,27 @@ def test_fused_double_precision_shearlet_passes_equal_the_unfused_ones(ffi, shap
         assert res_f[s]["niterations"] == res_u[s]["niterations"]
         assert rel_l2(fused[s], plain[s]) <= 1e-12, (s, rel_l2(fused[s], plain[s]))
         np.testing.assert_allclose(res_f[s]["costs"], res_u[s]["costs"], rtol=1e-7, atol=1e-26)
+
+
+@pytest.mark.parametrize("n", [96, 100, 125, 147, 189, 225, 243, 343, 375, 500, 625, 720, 875, 1029, 1125, 1250, 1715, 2058, 2401, 2500, 3000, 3645, 4096])
+def test_fused_double_precision_shearlet_passes_on_every_kind_of_plan(ffi, n, monkeypatch):
+    """The fused passes read and write the two register layouts of a plan (first / last forward pass); lengths with two-, three- and four-pass
+    plans, odd lengths, lengths whose passes use different thread counts -- as the row and as the column extent, against the unfused passes."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    kw = dict(niter=2, thresh_op="soft", thresh_model="linear", eps=0.0, p_max=0.8, p_min=0.2)
+    for shape in ((n, 64), (64, n)):
+        psi = shearlets.scalesShearsAndSpectra(shape)
+        mask = po.synthetic_mask(shape[0], shape[1], 0.5)
+        cube = (po.synthetic_slice(shape[0], shape[1], 77, real=True) * mask).astype(np.float64)[None]
+        P.release_plans()
+        with ffi.ShearletPlan64(psi, max_slices=1) as plan:
+            assert plan.fused
+        fused = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+        P.release_plans()
+        monkeypatch.setenv("P3D_SHEARLET64_UNFUSED", "1")
+        plain = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+        P.release_plans()
+        monkeypatch.delenv("P3D_SHEARLET64_UNFUSED")
+        assert np.isfinite(plain).all() and rel_l2(fused[0], plain[0]) <= 1e-12, (shape, rel_l2(fused[0], plain[0]))
