@@ -678,6 +678,15 @@ def run_leg(ctx, config, K_override, main, override=None):
                 roof["dense_accounting"] = {"algorithmic_bytes_per_launch": dense_bytes, "achieved": dense_bytes / (it_ms * 1e-3) / 1e9,
                                             "note": "40 B x points x shearlets, every row of every shearlet counted (the round-2 figure): not a bound any more -- `achieved` here "
                                                     "may exceed the HBM peak"}
+        if kind == "FFT" and default_shape:
+            # the second resource the two passes spend: vector-instruction issue (the transforms), from the SQ_INSTS_VALU pass of tools/traffic.sh
+            vc, vr = measured_valu(config, "col_kernel<"), measured_valu(config, "row_pipe")
+            if vc and vr:
+                roof["valu"] = {"colpass": vc, "rowpass": vr,
+                                "note": "valu_frac = wave instructions per second over the guide's FP32 vector rate (one wavefront instruction per 2 cycles and SIMD); "
+                                        "packed-math and single-wave issue cost 4 cycles, and SQ_ACTIVE_INST_VALU has the vector ALU busy about half of either pass "
+                                        "(profiles/r05_sq_counters_1024x1024.txt): the passes are bound by neither resource alone but by how little two wavefronts per "
+                                        "SIMD overlap them"}
         if roof["traffic"]:
             roof["moved_GBps"] = roof["traffic"] / (roof["launch_ms"] * 1e-3) / 1e9
             roof["moved_frac"] = roof["moved_GBps"] / HBM_PEAK_GBPS
