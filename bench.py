@@ -760,18 +760,19 @@ def run_leg(ctx, config, K_override, main, override=None):
     # ---- the WAVELET loop in the reference's double precision (p3d_wavelet64.hip): the slices the CPU leg computes, the full schedule ----
     also64 = None
     if kind == "WAVELET" and rank == 0 and world == 1 and n_cpu > 0 and args.eps == 0:
-        host64 = x_obs.download(0, n_cpu)
-        with _ffi.WaveletPlan64(nil, nxl, n_cpu, wavelet=cfg["wavelet"], device=dev_index) as plan64:
+        n64 = n_local   # (a batch of 16 slices is bound by its ~40 launches per iteration: 186 against 303 cube-iterations/s for the whole block)
+        host64 = x_obs.download(0, n64)
+        with _ffi.WaveletPlan64(nil, nxl, n64, wavelet=cfg["wavelet"], device=dev_index) as plan64:
             tau64 = P._wavelet_schedule_from_stats(plan64.stats(host64), "exponential", K, 0.99, p_min, "values")
             runs = [plan64.run(host64, mask, tau64, K, thresh_op=op, eps=args.eps, alpha=args.alpha) for _ in range(2)]
-        it64 = min(r[3] for r in runs) / K            # ms per iteration of the n_cpu-slice sample (device time of the loop)
-        also64 = {"reference_precision": runs[-1][0]}
-        b64 = 2.0 * ALG_BYTES["WAVELET"](0) * nil * nxl * n_cpu
+        it64 = min(r[3] for r in runs) / K            # ms per iteration of this rank's block (device time of the loop)
+        also64 = {"reference_precision": runs[-1][0][:n_cpu]}
+        b64 = 2.0 * ALG_BYTES["WAVELET"](0) * nil * nxl * n64
         ref_prec = {
             "what": f"the same job with precision='reference': the WAVELET loop in double precision (pywt keeps float64 for float64 input, POCS.py:585-609 never "
-                    f"narrows) on per-axis kernels without LDS tiles -- the first {n_cpu} slices of the cube (those of the parity figure), float32 in and out, device "
-                    f"time of the {K}-iteration loop; parity under parity.other_paths.reference_precision",
-            "slice_iterations_per_s": n_cpu / (it64 * 1e-3), "iterations_per_s_of_the_cube": n_cpu / (it64 * 1e-3) / cube_slices,
+                    f"narrows) on per-axis kernels without LDS tiles -- the {n64} slices of the block, float32 in and out, device time of the {K}-iteration loop; "
+                    f"parity (first {n_cpu} slices) under parity.other_paths.reference_precision",
+            "slice_iterations_per_s": n64 / (it64 * 1e-3), "iterations_per_s_of_the_cube": n64 / (it64 * 1e-3) / cube_slices,
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": 2.0 * ALG_BYTES["WAVELET"](0), "achieved": b64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": b64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "note": "the float32 accounting (29.33 B/point), doubled; three launches per level and direction move several times that"},
