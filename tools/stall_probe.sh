@@ -23,7 +23,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:70]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:70]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     if not any(s in k for s in ("row", "col")):
