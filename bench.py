@@ -933,7 +933,9 @@ def run_leg(ctx, config, K_override, main, override=None):
                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_point": b64 / (nil * nxl), "achieved": b64 / (it64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": b64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "note": "the float32 accounting (40 B per point and shearlet), doubled: spectrum x Psi -> coefficients (16 + 8), threshold in "
-                                         "place between two column transforms (32), coefficients x Psi -> sum (16 + 8); no support skipping, no Hermitian halves"},
+                                         "place between two column transforms (32), coefficients x Psi -> sum (16 + 8), every row of every shearlet counted -- the passes skip the "
+                                         "rows on which a shearlet's spectrum vanishes (p3d_shearlet64_info: row_group_fraction), so `achieved` is above what moves; no "
+                                         "Hermitian halves"},
                 }
         else:
             plan.close()

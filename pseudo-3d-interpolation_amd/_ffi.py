@@ -118,7 +118,7 @@ PROTOTYPES = {
     "p3d_shearlet_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "p3d_shearlet64_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "p3d_shearlet64_plan_destroy": (C.c_int, [C.c_void_p]),
-    "p3d_shearlet64_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "p3d_shearlet64_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "p3d_shearlet64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_shearlet64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -1005,9 +1005,10 @@ class ShearletPlan64:
         h = C.c_void_p()
         check(lib().p3d_shearlet64_plan_create(C.byref(h), self.device, self.nil, self.nxl, self.nsh, _ptr(dev_psi), self.max_slices))
         self.handle = h
-        fused = C.c_int(0)
-        check(lib().p3d_shearlet64_info(self.handle, C.byref(fused)))
+        fused, frac = C.c_int(0), C.c_double(1.0)
+        check(lib().p3d_shearlet64_info(self.handle, C.byref(fused), C.byref(frac)))
         self.fused = bool(fused.value)   # three fused passes per iteration on the double-precision register engine (both extents have a plan there)
+        self.row_group_fraction = frac.value   # share of the (shearlet, row group) pairs those passes touch (rows off a spectrum's support are skipped)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -281,13 +281,22 @@ __global__ __launch_bounds__(PL::COLT* PL::TMAX) void shear_col_kernel(const She
     if (a.done && a.done[b] != 0) return;
     c64d* const base = a.U + (size_t)u * N * a.n2 + (valid ? col : 0);
     const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
+    __shared__ unsigned char supl[N];   // per row of this shearlet's slice: 1 = the row exists (its spectrum does not vanish there)
+    if (a.sup != nullptr) {
+        const unsigned char* const sg = a.sup + (size_t)s * a.sup_groups;
+        for (int r = tid; r < N; r += T * PL::TMAX) supl[r] = sg[r / a.sup_rows];
+        __syncthreads();
+    }
     c64d v[VMAX];
 #pragma unroll
     for (int q = 0; q < VMAX; ++q) v[q] = c64d{0.0, 0.0};
     {
         const int r0 = tl < TPL_B ? tl : 0;
 #pragma unroll
-        for (int q = 0; q < PPT_B; ++q) v[q] = base[(size_t)(r0 + TPL_B * q) * a.n2];
+        for (int q = 0; q < PPT_B; ++q) {
+            const int r = r0 + TPL_B * q;
+            if (a.sup == nullptr || supl[r] != 0) v[q] = base[(size_t)r * a.n2];
+        }
         if (!live_b) {
 #pragma unroll
             for (int q = 0; q < PPT_B; ++q) v[q] = c64d{0.0, 0.0};
@@ -312,7 +321,10 @@ __global__ __launch_bounds__(PL::COLT* PL::TMAX) void shear_col_kernel(const She
     mix::line_fft<PL, FWD, T>(v, data + c_lo, twl, tl);   // layout A -> layout B
     if (live_b) {
 #pragma unroll
-        for (int q = 0; q < PPT_B; ++q) base[(size_t)(tl + TPL_B * q) * a.n2] = v[q];
+        for (int q = 0; q < PPT_B; ++q) {
+            const int r = tl + TPL_B * q;
+            if (a.sup == nullptr || supl[r] != 0) base[(size_t)r * a.n2] = v[q];   // (rows off the support: the gather pass multiplies them by zero -- it skips them)
+        }
     }
 }
 
@@ -327,6 +339,7 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void spread_row_kernel(const S
     const int tid = threadIdx.x, line = tid / TMAX, tl = tid % TMAX, u = blockIdx.y, row = blockIdx.x * LB + line;
     const int b = u / a.nsh, s = u - b * a.nsh;
     if (a.done && a.done[b] != 0) return;
+    if (a.sup != nullptr && a.sup[(size_t)s * gridDim.x + blockIdx.x] == 0) return;   // the spectrum vanishes on this workgroup's rows: they are never read
     const bool valid = row < a.n1;
     const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
     const size_t per = (size_t)a.n1 * N, rbase = (size_t)(valid ? row : 0) * N;
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void gather_row_kernel(const G
 #pragma unroll
     for (int q = 0; q < PPT_B; ++q) acc[q] = c64d{0.0, 0.0};
     for (int s = 0; s < a.nsh; ++s) {
+        if (a.sup != nullptr && a.sup[(size_t)s * gridDim.x + blockIdx.x] == 0) continue;   // (uniform over the workgroup)
         const c64d* const urow = a.U + ((size_t)b * a.nsh + s) * per + rbase;
         const double* const prow = a.psi + (size_t)s * per + rbase;
         c64d v[VMAX];

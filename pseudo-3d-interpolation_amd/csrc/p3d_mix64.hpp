@@ -51,6 +51,8 @@ struct ShearCol64 {
     int niter, iter, op, real_only, mode;
     double scale;
     const int* done;           // [nb]
+    const unsigned char* sup;  // [nsh][sup_groups] or NULL: 0 = the spectrum of shearlet s vanishes on rows g * sup_rows ... (+ sup_rows - 1): those rows of U are
+    int sup_groups, sup_rows;  //   never written by the spread pass, read as zeros here and not stored (the gather pass skips them)
 };
 // rows of U[b * nsh + s] = inverse row transform (unscaled) of psi_s x F[b]
 struct SpreadRow64 {
@@ -60,6 +62,7 @@ struct SpreadRow64 {
     const mix::c64d* tab;
     int n1, nb, nsh;
     const int* done;
+    const unsigned char* sup;  // [nsh][row groups of the launch] or NULL (a group = the rows of one workgroup, Entry::row_lines)
 };
 // rows of F[b] = sum_s psi_s x forward row transform of U[b * nsh + s]
 struct GatherRow64 {
@@ -69,6 +72,7 @@ struct GatherRow64 {
     const mix::c64d* tab;
     int n1, nb, nsh;
     const int* done;
+    const unsigned char* sup;
 };
 
 struct Entry {

@@ -11,7 +11,8 @@
 // (real cubes: of the real part, FFST returns ST.real) -> batched fft2 -> sum over s of x Psi_s -> ifft2 -> re-insertion, cost.
 //   fused form (both extents have a plan on the double-precision register engine, p3d_mix64.hip): three passes over the coefficients --
 //     x Psi_s folded into the inverse row pass, the threshold into the column pass between its two transforms, x Psi_s and the sum over s into
-//     the forward row pass (80 B per coefficient instead of ~210) -- and the slice-sized passes of p3d_f64.hip's own loop around them;
+//     the forward row pass (80 B per coefficient instead of ~210), row groups on which a shearlet's spectrum vanishes skipped by all three
+//     (p3d_splan64::sup; P3D_SHEARLET64_NO_SUPPORT=1 moves every row) -- and the slice-sized passes of p3d_f64.hip's own loop around them;
 //   unfused form (any other shape; P3D_SHEARLET64_UNFUSED=1): separate kernels around p3d_f64.hip's line transforms (plan64_fft2), the
 //     coefficient buffer being that plan's work buffer.
 // Costs are sums of partial sums added in a fixed order (reproducible).
@@ -258,6 +259,18 @@ __global__ void sconv64_kernel(const double* sums, int* done, int nslices, int i
     if (iter > 2 && (d * d) / (cur * cur) < eps) done[s] = iter + 1;   // POCS.py:622, 631
 }
 
+// sup[s][g] = 1 where rows g * G ... of Psi_s hold a non-zero sample (one wavefront per (g, s); sup zeroed before)
+__global__ void rowsup64_kernel(const double* psi, unsigned char* sup, int nil, int nxl, int G, int ng)
+{
+    const int s = blockIdx.y, g = blockIdx.x;
+    const int r0 = g * G, r1 = min(r0 + G, nil);
+    const double* p = psi + ((size_t)s * nil + r0) * nxl;
+    const size_t n = (size_t)(r1 - r0) * nxl;
+    bool any = false;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) any = any || (p[i] != 0.0);
+    if (__ballot(any) != 0ull && threadIdx.x == 0) sup[(size_t)s * ng + g] = 1;
+}
+
 }  // namespace
 
 struct p3d_splan64 {
@@ -266,6 +279,9 @@ struct p3d_splan64 {
     p3d_plan64* pf = nullptr;    // fused form: the slice-sized passes (work buffer = the slices' spectra, staging buffers, mask); U is then the plan's own
     hipStream_t stream = nullptr;
     double* psi = nullptr;       // [nsh][nil][nxl]
+    unsigned char* sup = nullptr;   // fused form: [nsh][sup_groups] row groups (of sup_rows rows: one workgroup of the row passes) on which Psi_s does not vanish
+    int sup_groups = 0, sup_rows = 0;
+    double sup_fraction = 1.0;
     c64 *U = nullptr, *F = nullptr, *tau = nullptr;
     size_t tau_cap = 0, sums_cap = 0;
     double *sums = nullptr, *rowsum = nullptr, *stats = nullptr, *mask = nullptr;
@@ -355,7 +371,7 @@ int p3d_shearlet64_plan_destroy(p3d_splan64* p)
     if (!p) return P3D_OK;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
-    void* bufs[] = {p->psi, p->F, p->tau, p->sums, p->rowsum, p->stats, p->done};
+    void* bufs[] = {p->psi, p->sup, p->F, p->tau, p->sums, p->rowsum, p->stats, p->done};
     for (void* b : bufs) if (b) hipFree(b);
     if (p->pf) {
         if (p->U) hipFree(p->U);
@@ -421,14 +437,31 @@ int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, 
     }
 #undef ALLOC
     if ((e = hipMemcpy(p->psi, psi, sizeof(double) * per * nsh, hipMemcpyHostToDevice)) != hipSuccess) return bail("upload of Psi", e);
+    if (p->pf && !getenv("P3D_SHEARLET64_NO_SUPPORT")) {
+        // which row groups of every spectrum hold anything at all: the fused passes skip the others (a Parseval frame covers every frequency about
+        // twice, a shearlet's spectrum vanishes on most rows) -- exact, those rows carry only zeros through the iteration
+        p->sup_rows = p3d::plan64_shear_row_group(p->pf);
+        p->sup_groups = (nil + p->sup_rows - 1) / p->sup_rows;
+        const size_t nflag = (size_t)nsh * p->sup_groups;
+        if ((e = hipMalloc((void**)&p->sup, nflag)) != hipSuccess) return bail("sup", e);
+        if ((e = hipMemsetAsync(p->sup, 0, nflag, p->stream)) != hipSuccess) return bail("sup", e);
+        rowsup64_kernel<<<dim3(p->sup_groups, nsh), 64, 0, p->stream>>>(p->psi, p->sup, nil, nxl, p->sup_rows, p->sup_groups);
+        std::vector<unsigned char> host(nflag);
+        if ((e = hipMemcpyAsync(host.data(), p->sup, nflag, hipMemcpyDeviceToHost, p->stream)) != hipSuccess) return bail("sup", e);
+        if ((e = hipStreamSynchronize(p->stream)) != hipSuccess) return bail("sup", e);
+        size_t on = 0;
+        for (unsigned char f : host) on += f;
+        p->sup_fraction = (double)on / (double)nflag;
+    }
     *out = p;
     return P3D_OK;
 }
 
-int p3d_shearlet64_info(p3d_splan64* p, int* fused)
+int p3d_shearlet64_info(p3d_splan64* p, int* fused, double* row_group_fraction)
 {
     if (!p || !fused) return s64fail(P3D_ERR_INVALID, "NULL argument");
     *fused = p->pf ? 1 : 0;
+    if (row_group_fraction) *row_group_fraction = p->sup ? p->sup_fraction : 1.0;
     return P3D_OK;
 }
 
@@ -444,8 +477,8 @@ int p3d_shearlet64_stats(p3d_splan64* p, const void* x, int dtype, int nslices, 
         S_RC(ensure_sums(p, (size_t)nslices));
         p3d::plan64_bind(p->pf, p->cur_x, nullptr);
         S_RC(p3d::plan64_shear_first(p->pf, dtype, p->sums, 0, 1.0, nslices, nullptr));
-        S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, p->nsh, nullptr));
-        S_RC(p3d::plan64_shear_cols(p->pf, p->U, nullptr, nslices, p->nsh, 0, 0, 0, 0, 1, 1.0 / ((double)p->nil * p->nxl), nullptr));
+        S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, p->nsh, nullptr, p->sup));
+        S_RC(p3d::plan64_shear_cols(p->pf, p->U, nullptr, nslices, p->nsh, 0, 0, 0, 0, 1, 1.0 / ((double)p->nil * p->nxl), nullptr, p->sup));
     } else {
         supdate64_kernel<<<dim3(p->nil, nslices), 256, 0, p->stream>>>(p->F, p->cur_x, dtype, nullptr, nullptr, p->rowsum, 0, 0, 0, 1.0, p->nil, p->nxl, nullptr, 0, 0);
         S_RC(s_forward(p, nslices, nullptr));
@@ -497,9 +530,9 @@ int p3d_shearlet64_run(p3d_splan64* p, const void* x, int dtype, const double* m
         S_RC(p3d::plan64_shear_first(p->pf, dtype, p->sums, adaptive ? 1 : 0, prm->alpha, nslices, p->done));
         for (int k = 0; k < niter; ++k) {
             const bool last = k + 1 == niter;
-            S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, nsh, p->done));
-            S_RC(p3d::plan64_shear_cols(p->pf, p->U, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, 0, scale, p->done));
-            S_RC(p3d::plan64_shear_gather(p->pf, p->U, p->psi, nslices, nsh, p->done));
+            S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, nsh, p->done, p->sup));
+            S_RC(p3d::plan64_shear_cols(p->pf, p->U, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, 0, scale, p->done, p->sup));
+            S_RC(p3d::plan64_shear_gather(p->pf, p->U, p->psi, nslices, nsh, p->done, p->sup));
             S_RC(p3d::plan64_shear_back(p->pf, dtype, p->sums + (size_t)(k + 1) * nslices, last, adaptive ? 1 : 0, early ? 1 : 0, prm->alpha, nslices, p->done,
                                         last ? 1 : 0));
             if (early) sconv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);

@@ -485,7 +485,7 @@ def test_fused_double_precision_shearlet_passes_equal_the_unfused_ones(ffi, shap
     cube[1] = 0
     P.release_plans()
     with ffi.ShearletPlan64(psi, max_slices=3) as plan:
-        assert plan.fused
+        assert plan.fused and 0.0 < plan.row_group_fraction <= 1.0
         st_f = plan.stats(cube)
     res_f = []
     fused = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, results=res_f, batch_slices=2, **kw)
@@ -529,3 +529,32 @@ def test_fused_double_precision_shearlet_passes_on_every_kind_of_plan(ffi, n, mo
         P.release_plans()
         monkeypatch.delenv("P3D_SHEARLET64_UNFUSED")
         assert np.isfinite(plain).all() and rel_l2(fused[0], plain[0]) <= 1e-12, (shape, rel_l2(fused[0], plain[0]))
+
+
+def test_skipping_rows_off_a_shearlets_support_changes_nothing_in_double_precision(ffi, monkeypatch):
+    """The fused double-precision passes skip the row groups on which a shearlet's spectrum vanishes (p3d_shearlet64_info: row_group_fraction);
+    P3D_SHEARLET64_NO_SUPPORT=1 moves every row: the same result to rounding (the skipped rows carry exact zeros), half of the (shearlet, row
+    group) pairs or fewer at this size."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    shape = (512, 256)
+    kw = dict(niter=5, thresh_op="hard", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)
+    psi = shearlets.scalesShearsAndSpectra(shape)
+    mask = po.synthetic_mask(shape[0], shape[1], 0.6)
+    cube = np.stack([po.synthetic_slice(shape[0], shape[1], 60 + s, real=True) for s in range(2)]) * mask
+    P.release_plans()
+    with ffi.ShearletPlan64(psi, max_slices=1) as plan:
+        assert plan.fused and plan.row_group_fraction < 0.6, plan.row_group_fraction
+        st_s = plan.stats(cube[:1])
+    fast = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+    P.release_plans()
+    monkeypatch.setenv("P3D_SHEARLET64_NO_SUPPORT", "1")
+    with ffi.ShearletPlan64(psi, max_slices=1) as plan:
+        assert plan.fused and plan.row_group_fraction == 1.0
+        st_d = plan.stats(cube[:1])
+    dense = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+    P.release_plans()
+    monkeypatch.delenv("P3D_SHEARLET64_NO_SUPPORT")
+    np.testing.assert_allclose(st_s[..., [0, 2, 4]], st_d[..., [0, 2, 4]], rtol=1e-12)
+    assert rel_l2(fast, dense) <= 1e-13, rel_l2(fast, dense)

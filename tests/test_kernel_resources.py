@@ -31,7 +31,7 @@ KNOWN_SCRATCH = {
     "loop's column pass, same tile): whole 64-byte-per-row tiles (or the widest that fits) need 600-1024 threads, i.e. 128 VGPRs, and the last pass of complex128 "
     "butterflies spills 4-86 of them; the narrower tile that does not spill measured SLOWER (1024-point columns: 0.74 vs 0.71 ms per iteration of 32 slices, "
     "tools/mix64_try_plans.sh), and every length is 1.8-4 x faster than on the LDS-image passes (tools/f64_sweep.sh), so the spill is the accepted price",
-    r"mix64::gather_row_kernel<mix::MixPlan<(3200|3920|4000|4032), .*> >": "the SHEARLET loop's gather pass at the longest rows: 16-20 points and as many accumulators "
+    r"mix64::gather_row_kernel<mix::MixPlan<(2800|3200|3920|4000|4032), .*> >": "the SHEARLET loop's gather pass at the longest rows: 16-20 points and as many accumulators "
     "of complex128 per thread, 2-12 registers over 256",
 }
 
