@@ -331,6 +331,8 @@ int p3d_shearlet64_plan_destroy(p3d_splan64* plan);
  * plan creation switches them off), 0 for the unfused passes; row_group_fraction (may be NULL): share of the (shearlet, row group) pairs the fused passes
  * touch -- rows on which a shearlet's spectrum vanishes are skipped, exactly (1.0: none skipped; P3D_SHEARLET64_NO_SUPPORT=1) */
 int p3d_shearlet64_info(p3d_splan64* plan, int* fused, double* row_group_fraction);
+/* 1 when a plan for (nil, nxl) slices would run the fused passes */
+int p3d_shearlet64_fused_shape(int nil, int nxl);
 int p3d_shearlet64_stats(p3d_splan64* plan, const void* x, int dtype, int nslices, double* stats);
 int p3d_shearlet64_run(p3d_splan64* plan, const void* x, int dtype, const double* mask, const double* tau, const uint8_t* active,
                        const p3d_pocs_params* params, void* out, int nslices, int32_t* niter_done, double* sums, double* elapsed_ms);

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "p3d_shearlet64_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "p3d_shearlet64_plan_destroy": (C.c_int, [C.c_void_p]),
     "p3d_shearlet64_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "p3d_shearlet64_fused_shape": (C.c_int, [C.c_int, C.c_int]),
     "p3d_shearlet64_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "p3d_shearlet64_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PocsParams),
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -986,6 +987,11 @@ class ShearletPlan:
         check(lib().p3d_shearlet_run(self.handle, C.c_void_p(x_ptr), dtype, C.c_void_p(mask_ptr), _ptr(t), None if act is None else _ptr(act),
                                      C.byref(prm), C.c_void_p(out_ptr), n, _ptr(done), _ptr(sums), C.byref(ms)))
         return done, sums, ms.value
+
+
+def shearlet64_fused_shape(nil, nxl):
+    """True when the double-precision SHEARLET loop runs its fused passes for (nil, nxl) slices (both extents on the register engine)."""
+    return bool(lib().p3d_shearlet64_fused_shape(int(nil), int(nxl)))
 
 
 class ShearletPlan64:

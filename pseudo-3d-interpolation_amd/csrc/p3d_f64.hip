@@ -1130,6 +1130,10 @@ hipStream_t plan64_stream(p3d_plan64* p) { return p->stream; }
 void* plan64_work(p3d_plan64* p) { return p->work; }
 
 bool plan64_shear_supported(p3d_plan64* p) { return p->fused && p->mcol && p->mrow && p->st_x != nullptr; }
+bool plan64_engine_shape(int nil, int nxl)
+{
+    return nil >= 1 && nxl >= 1 && nil <= F64_MAX_N && nxl <= F64_MAX_N && !getenv("P3D_F64_UNFUSED") && p3d::mix64::find(nil) != nullptr && p3d::mix64::find(nxl) != nullptr;
+}
 double* plan64_mask(p3d_plan64* p) { return p->mask; }
 void* plan64_stage_x(p3d_plan64* p) { return p->st_x; }
 void* plan64_stage_out(p3d_plan64* p) { return p->st_out; }

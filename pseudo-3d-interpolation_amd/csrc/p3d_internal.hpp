@@ -67,6 +67,7 @@ int plan64_fft2(p3d_plan64* plan, void* buf, int nslices, bool inverse, const in
 // ---- ... and the fused passes of that loop on the register engine (p3d_mix64.hip), for a FULL plan64 of nb slices whose two extents have a plan:
 // the plan's work buffer holds the slices' spectra F, U is the caller's coefficient buffer [nb * nsh][nil][nxl] complex128, psi [nsh][nil][nxl] doubles
 bool plan64_shear_supported(p3d_plan64* plan);
+bool plan64_engine_shape(int nil, int nxl);   // both extents have a plan on the register engine (what plan64_shear_supported will find for such a plan)
 double* plan64_mask(p3d_plan64* plan);      // device [nil][nxl]: the caller fills it
 void* plan64_stage_x(p3d_plan64* plan);     // staging buffers for host cubes (max_slices slices of complex128)
 void* plan64_stage_out(p3d_plan64* plan);

@@ -457,6 +457,15 @@ int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, 
     return P3D_OK;
 }
 
+// 1 when a plan for (nil, nxl) slices would run the fused passes (both extents on the double-precision register engine): what the host asks before it
+// prefers this loop to the float32 one for a single-precision cube (functions/POCS.py)
+int p3d_shearlet64_fused_shape(int nil, int nxl)
+{
+    const char* env = getenv("P3D_SHEARLET64_UNFUSED");
+    if (env && env[0] == '1') return 0;
+    return p3d::plan64_engine_shape(nil, nxl) ? 1 : 0;
+}
+
 int p3d_shearlet64_info(p3d_splan64* p, int* fused, double* row_group_fraction)
 {
     if (!p || !fused) return s64fail(P3D_ERR_INVALID, "NULL argument");

@@ -815,7 +815,9 @@ def pocs_cube(
     cubes (the reference computes such cubes in double precision; POCS.py:371-656 never narrows its input); ``'reference'``: double
     precision also for complex64 / float32 cubes, the result cast back (what the reference itself executes for the soft / garrote
     operators, FPOCS and APOCS, and for every run under NumPy < 2 -- SURVEY appendix A.16); ``'float32'``: the float32 kernels whatever the
-    cube (double cubes are converted on the way in, the result widened on the way out).  The double-precision loops are
+    cube (double cubes are converted on the way in, the result widened on the way out).  One exception to ``None``: SHEARLET on slice extents that are not
+    powers of two but have plans on the double-precision register engine (7-smooth extents 96 ... 4096) runs the double-precision loop for single-precision
+    cubes too -- it is the faster loop there (fused passes) as well as the reference's arithmetic.  The double-precision loops are
     precision paths (FFT: about a quarter of the float32 rate; WAVELET: per-axis kernels without LDS tiles; SHEARLET: three fused
     passes per iteration where both extents have a plan on the double-precision register engine, a tenth of the float32 rate), have the hard / soft /
     garrote operators, the FFT and SHEARLET ones slice extents up to 5120;
@@ -860,6 +862,12 @@ def _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alp
                              'thresholding needs one per level and detail)')   # (as the float32 path below: the reference fails here)
         return _pocs_cube_wavelet_double(cube, mask, out, _wavelet_name(ignored.get('transform'), wavelet), niter, thresh_op, thresh_model, eps, alpha, p_max,
                                          p_min, sqrt_decay, decay_kind, version, results, device, batch_slices)
+    if (kind == 'SHEARLET' and precision is None and not wide and thresh_op in _WAVELET_OPS and auxiliary_data is not None
+            and (nil & (nil - 1) or nxl & (nxl - 1)) and _ffi.shearlet64_fused_shape(nil, nxl)):
+        # Extents that are not powers of two: the float32 loop runs unfused passes there, the double-precision loop its three fused ones -- faster
+        # (1000 x 1000: 1.0 against 1.6 ms per slice-iteration, tools/shearlet_probe.py) AND the reference's own arithmetic (np.fft inside FFST computes in
+        # double whatever the cube's dtype): single-precision cubes take it by default on such grids; precision='float32' keeps the float32 kernels
+        want_double = True
     if want_double and kind == 'SHEARLET' and thresh_op in _WAVELET_OPS and auxiliary_data is not None and max(nil, nxl) <= 5120:
         psi = np.asarray(auxiliary_data)
         if psi.ndim != 3 or psi.shape[:2] != (nil, nxl):

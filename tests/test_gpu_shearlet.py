@@ -558,3 +558,28 @@ def test_skipping_rows_off_a_shearlets_support_changes_nothing_in_double_precisi
     monkeypatch.delenv("P3D_SHEARLET64_NO_SUPPORT")
     np.testing.assert_allclose(st_s[..., [0, 2, 4]], st_d[..., [0, 2, 4]], rtol=1e-12)
     assert rel_l2(fast, dense) <= 1e-13, rel_l2(fast, dense)
+
+
+def test_single_precision_cubes_take_the_double_loop_where_it_is_the_fused_one(so, monkeypatch):
+    """Extents that are not powers of two but have plans on the double-precision register engine: the float32 loop is unfused there, the double one fused
+    -- faster and the reference's arithmetic -- so `pocs_cube` routes float32 / complex64 cubes to it by default (1e-7 of the oracle: the cast back);
+    precision='float32' keeps the float32 kernels, powers of two keep them anyway."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    kw = dict(niter=6, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)
+    calls = []
+    real_double = P._pocs_cube_shearlet_double
+    monkeypatch.setattr(P, "_pocs_cube_shearlet_double", lambda *a, **k: (calls.append(a[0].shape), real_double(*a, **k))[1])
+    for shape, expect in (((150, 240), True), ((128, 64), False), ((48, 40), False)):
+        psi = shearlets.scalesShearsAndSpectra(shape)
+        mask = po.synthetic_mask(shape[0], shape[1], 0.5)
+        cube = (np.stack([po.synthetic_slice(shape[0], shape[1], 30 + s, real=True) for s in range(2)]) * mask).astype(np.float32)
+        want = so.pocs_cube_shearlet(cube.astype(np.float64), mask, psi, **kw)
+        calls.clear()
+        got = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+        assert got.dtype == np.float32 and bool(calls) == expect, (shape, calls)
+        assert rel_l2(got, want) <= (2e-7 if expect else 1e-5), (shape, rel_l2(got, want))
+        calls.clear()
+        fast = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, precision="float32", **kw)
+        assert not calls and rel_l2(fast, want) <= 1e-5
