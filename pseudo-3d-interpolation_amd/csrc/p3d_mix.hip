@@ -74,9 +74,11 @@ hipError_t pack_mask(const Entry* e, const float* mask, int n1, unsigned long lo
 
 const Entry* find(int n)
 {
+    // experiment switch: every non-power-of-two length on the LDS-image passes of p3d_flex.hip.  Read at every call (a static table that looked at the
+    // environment once per process made the switch a no-op for every plan after the first); callers release their plans before they flip it
+    if (getenv("P3D_NO_MIX")) return nullptr;
     static const std::map<int, const Entry*> table = [] {
         std::map<int, const Entry*> t;
-        if (getenv("P3D_NO_MIX")) return t;   // experiment switch: every non-power-of-two length on the LDS-image passes of p3d_flex.hip
         for (const Entry* (*part)() : {&part_0, &part_1, &part_2, &part_3, &part_4, &part_5, &part_6, &part_7})
             for (const Entry* e = part(); e->n != 0; ++e) t[e->n] = e;
         return t;

@@ -519,9 +519,9 @@ const Entry* part_7();
 
 const Entry* find(int n)
 {
+    if (getenv("P3D_NO_MIX64")) return nullptr;   // experiment switch: the LDS-image passes of p3d_f64.hip for every length (read per call = per plan)
     static const std::map<int, const Entry*> table = [] {
         std::map<int, const Entry*> t;
-        if (getenv("P3D_NO_MIX64")) return t;   // experiment switch: the LDS-image passes of p3d_f64.hip for every length
         for (const Entry* (*part)() : {&part_0, &part_1, &part_2, &part_3, &part_4, &part_5, &part_6, &part_7})
             for (const Entry* e = part(); e->n != 0; ++e) t[e->n] = e;
         return t;

@@ -909,7 +909,15 @@ def test_double_precision_passes_on_the_register_engine_equal_the_lds_image_ones
     fast = [run(*c[:2], **c[2]) for c in cases]
     monkeypatch.setenv(switch, "1")
     slow = [run(*c[:2], **c[2]) for c in cases]
+    if switch == "P3D_NO_MIX64":   # (the switch is read when a plan is created: the other engine rounds differently somewhere)
+        assert any(not np.array_equal(f[1], s_[1]) for f, s_ in zip(fast, slow))
     for (st_f, out_f, done_f, sums_f), (st_u, out_u, done_u, sums_u), case in zip(fast, slow, cases):
+        if case[0].dtype.kind == "f":
+            # a real slice has a Hermitian spectrum: X[-k] = conj X[k] share their real part up to rounding, so WHICH of the two the lexicographic complex
+            # maximum (POCS.py:288) picks -- the sign of Im tau -- is decided by the last bit, differently by every engine (and by NumPy).  Harmless: with
+            # conj(tau) every iterate is the complex conjugate, and a real cube gets np.real() of it (POCS.py:656)
+            st_f, st_u = st_f.copy(), st_u.copy()
+            st_f[:, 1], st_u[:, 1] = np.abs(st_f[:, 1]), np.abs(st_u[:, 1])
         assert np.allclose(st_f[[0, 2]], st_u[[0, 2]], rtol=1e-12, atol=1e-12)
         assert np.array_equal(done_f, done_u) and done_f[1] == 0 and not out_f[1].any()
         tol = 1e-6 if out_f.dtype == np.float32 else (1e-9 if case[1] == "hard" else 1e-12)   # (a hard threshold may turn a last-bit difference into a kept / zeroed coefficient)
@@ -1148,6 +1156,7 @@ def test_smooth_lengths_on_the_register_engine_against_the_oracle(shape, kw, mon
     cube[1] = 0                                     # an all-zero slice passes through untouched
     res, infos = [], []
     got = P.pocs_cube(cube, mask, results=res, **kw)
+    got0 = got
     want = orc.pocs_cube(cube.astype(np.complex128), mask, infos=infos, **kw)
     for s in range(3):
         assert res[s]["niterations"] == infos[s]["niterations"]
@@ -1166,6 +1175,13 @@ def test_smooth_lengths_on_the_register_engine_against_the_oracle(shape, kw, mon
         monkeypatch.setenv("P3D_NO_MIX_BITS", "1")                                  # the same passes on the float mask and the full observed cube
         try:
             assert rel_l2(P.pocs_cube(cube, mask, **kw), want) <= 1e-5
+        finally:
+            P.release_plans()
+        monkeypatch.delenv("P3D_NO_MIX_BITS")
+        monkeypatch.setenv("P3D_NO_MIX", "1")                                       # the LDS-image passes of p3d_flex.hip: another sequence of roundings
+        try:
+            other = P.pocs_cube(cube, mask, **kw)
+            assert rel_l2(other, want) <= 1e-5 and not np.array_equal(other, got0)
         finally:
             P.release_plans()
 
