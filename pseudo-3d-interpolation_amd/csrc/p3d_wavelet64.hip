@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int MAXL = 64;
+constexpr int MAXL = 128;   // longest filter (PyWavelets: coif17 has 102 taps)
 
 struct c64 {
     double x, y;

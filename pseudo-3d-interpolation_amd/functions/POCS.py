@@ -856,6 +856,11 @@ def _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alp
         raise ValueError(f"precision must be None, 'reference' or 'float32', got {precision!r}")
     wide = cube.dtype in (np.complex128, np.float64)
     want_double = precision == 'reference' or (wide and precision is None)
+    if kind == 'WAVELET' and precision is None and not wide and thresh_op in _WAVELET_OPS:
+        bank = _wavelet_name(ignored.get('transform'), wavelet)
+        taps = len(bank[0]) if isinstance(bank, (tuple, list)) else len(_ffi.wavelet_filters(bank)[0])
+        if taps > 64:   # the float32 tile kernels hold filters of up to 64 taps (db32); the longer banks (db33-38, coif11-17 ...) run the double-precision loop
+            want_double = True
     if want_double and kind == 'WAVELET' and thresh_op in _WAVELET_OPS:
         if decay_kind == 'factors' and not all(s in thresh_model for s in ['inverse', 'proportional']):
             raise IndexError('list index out of range (decay_kind="factors" yields one tau per iteration, the WAVELET '

@@ -519,3 +519,21 @@ def test_wavelet_config3_at_its_own_size_in_the_reference_precision(wo):
         assert e64 <= 1e-8, (s, e64)
         assert e32 <= 2e-7, (s, e32)
     assert got64.dtype == np.float64 and got32.dtype == np.float32
+
+
+@pytest.mark.parametrize("wavelet", ["db38", "coif17", "sym20"])
+def test_banks_longer_than_the_float32_tiles_hold_run_the_double_precision_loop(wo, wavelet):
+    """Filters of more than 64 taps (db33-38, coif11-17) do not fit the float32 tile kernels: single-precision cubes take the double-precision loop for
+    them (1e-7 of the oracle: the cast back), double-precision cubes anyway; sym20 (40 taps) stays on the float32 kernels."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    shape = (230, 260)
+    kw = dict(niter=4, thresh_op="soft", thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)
+    mask = po.synthetic_mask(shape[0], shape[1], 0.5)
+    cube = (np.stack([_slice(shape, 3 + s, False) for s in range(2)]) * mask).astype(np.float32)
+    want = wo.pocs_cube_wavelet(cube.astype(np.float64), mask, wavelet=wavelet, **kw)
+    got = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet=wavelet, **kw)
+    assert got.dtype == np.float32
+    assert rel_l2(got, want) <= (1e-5 if wavelet == "sym20" else 2e-7), rel_l2(got, want)
+    got64 = P.pocs_cube(cube.astype(np.float64), mask, transform_kind="WAVELET", wavelet=wavelet, **kw)
+    assert got64.dtype == np.float64 and rel_l2(got64, want) <= 1e-10

@@ -8,7 +8,7 @@ Prints one line per failure and a summary; exit status 1 if anything failed."""
 import os, re, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import pocs_oracle as orc, shearlet_oracle as so
+from oracle import pocs_oracle as orc, shearlet_oracle as so, wavelet_oracle as wo
 from pseudo_3d_interpolation_amd import _ffi
 from pseudo_3d_interpolation_amd.functions import POCS as P, shearlets
 
@@ -18,7 +18,9 @@ csrc = os.path.join(os.path.dirname(_ffi.__file__), "csrc")
 L64 = sorted(int(m) for m in re.findall(r"^X\((\d+),", open(os.path.join(csrc, "p3d_mix64_plans.inc")).read(), re.M))
 L32 = sorted(int(m) for m in re.findall(r"^X\((\d+),", open(os.path.join(csrc, "p3d_mix_plans.inc")).read(), re.M))
 rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-t_end, fails, runs = time.time() + budget, 0, {"fft64": 0, "fft32": 0, "shear64": 0}
+t_end, fails, runs = time.time() + budget, 0, {"fft64": 0, "fft32": 0, "shear64": 0, "wav64": 0}
+import json
+WAVELETS = sorted(json.load(open(os.path.join(os.path.dirname(_ffi.__file__), "wavelets.json")))["wavelets"])
 
 
 def pick(lengths, hi):
@@ -27,7 +29,7 @@ def pick(lengths, hi):
 
 
 while time.time() < t_end:
-    kind = rng.choice(["fft64", "fft32", "shear64"], p=[float(v) for v in os.environ.get("FUZZ_MIX", "0.4,0.3,0.3").split(",")])
+    kind = rng.choice(["fft64", "fft32", "shear64", "wav64"], p=[float(v) for v in os.environ.get("FUZZ_MIX", "0.3,0.2,0.25,0.25").split(",")])
     real = bool(rng.integers(2))
     op = str(rng.choice(["hard", "soft", "garrote"])) if real else str(rng.choice(["hard", "soft"]))
     kw = dict(niter=int(rng.integers(2, 12)), thresh_op=op, thresh_model=str(rng.choice(["exponential", "linear", "exponential-2"])),
@@ -35,7 +37,28 @@ while time.time() < t_end:
               version=str(rng.choice(["regular", "regular", "adaptive"])))
     missing = float(rng.uniform(0.3, 0.8))
     try:
-        if kind == "shear64":
+        if kind == "wav64":
+            nil, nxl = int(rng.integers(24, 260)), int(rng.integers(24, 260))
+            wavelet = str(rng.choice(WAVELETS))
+            flen = len(_ffi.wavelet_filters(wavelet)[0])
+            if min(nil, nxl) < 2 * (flen - 1):
+                continue   # (no decomposition level)
+            if not real and op == "garrote":
+                op = kw["thresh_op"] = "soft"
+            if op == "hard" and "linear" not in kw["thresh_model"] and kw["thresh_model"] != "exponential":
+                kw["thresh_model"] = "exponential"
+            kw["niter"] = min(kw["niter"], 6)   # (the 'smooth' iteration is expansive: long runs amplify the last bit)
+            mask = orc.synthetic_mask(nil, nxl, missing)
+            cube = np.stack([orc.synthetic_slice(nil, nxl, int(rng.integers(1000)) + s, real=real) for s in range(2)]) * mask
+            cube = cube.astype(np.float64 if real else np.complex128)
+            infos, res = [], []
+            want = wo.pocs_cube_wavelet(cube, mask, wavelet=wavelet, infos=infos, **kw)
+            if not np.isfinite(want).all():
+                continue
+            got = P.pocs_cube(cube, mask, transform_kind="WAVELET", wavelet=wavelet, results=res, **kw)
+            kw["wavelet"] = wavelet
+            tol = 1e-7 if op == "hard" else 1e-9
+        elif kind == "shear64":
             nil, nxl = pick(L64, 300), pick(L64, 300)
             psi = shearlets.scalesShearsAndSpectra((nil, nxl))
             if not np.all(np.abs(psi).reshape(-1, psi.shape[2]).max(axis=0) > 0):
