@@ -60,6 +60,8 @@ while time.time() < t_end:
             tol = 1e-7 if op == "hard" else 1e-9
         elif kind == "shear64":
             nil, nxl = pick(L64, 300), pick(L64, 300)
+            if rng.integers(2):   # any extent: the unfused passes around the line transforms
+                nil = int(rng.integers(24, 200))
             psi = shearlets.scalesShearsAndSpectra((nil, nxl))
             if not np.all(np.abs(psi).reshape(-1, psi.shape[2]).max(axis=0) > 0):
                 continue   # (a degenerate frame: a shearlet without any sample, the reference's schedule divides by zero)
@@ -75,6 +77,10 @@ while time.time() < t_end:
         else:
             lengths = L64 if kind == "fft64" else L32
             nil, nxl = pick(lengths, 1300), pick(lengths, 1300)
+            if kind == "fft64" and rng.integers(2):   # any length (primes included): the LDS-image passes of p3d_f64.hip, alone or beside the register engine
+                nil = int(rng.integers(17, 700))
+                if rng.integers(2):
+                    nxl = int(rng.integers(17, 700))
             mask = orc.synthetic_mask(nil, nxl, missing)
             cube = np.stack([orc.synthetic_slice(nil, nxl, int(rng.integers(1000)) + s, real=real) for s in range(2)]) * mask
             if kind == "fft64":
