@@ -844,35 +844,45 @@ def pocs_cube(
                                  results, device, batch_slices, wavelet, auxiliary_data, precision, out, ignored)
 
 
+def _double_loop_wanted(dtype, nil, nxl, kind, thresh_op, precision, wavelet=None, transform=None, auxiliary_data=None):
+    """``(precision, want_double)``: the normalised ``precision`` argument (``P3D_PRECISION`` when it is None) and whether the call asks for one of
+    the double-precision loops -- explicitly (``'reference'``), by the cube's dtype (complex128 / float64), or because the double-precision loop is the
+    only / the faster one for the job: WAVELET banks of more than 64 taps (the float32 tile kernels hold db1 ... db32), SHEARLET on extents that are
+    not powers of two but have plans on the double-precision register engine (fused passes there against the float32 loop's unfused ones).  One rule
+    for ``pocs_cube`` and for ``sharding.pocs_block_on_device``."""
+    if precision is None:
+        precision = os.environ.get('P3D_PRECISION') or None
+    if precision not in (None, 'reference', 'float32'):
+        raise ValueError(f"precision must be None, 'reference' or 'float32', got {precision!r}")
+    wide = np.dtype(dtype) in (np.dtype(np.complex128), np.dtype(np.float64))
+    want_double = precision == 'reference' or (wide and precision is None)
+    if precision is None and not wide and thresh_op in _WAVELET_OPS:
+        if kind == 'WAVELET':
+            bank = _wavelet_name(transform, wavelet)
+            taps = len(bank[0]) if isinstance(bank, (tuple, list)) else len(_ffi.wavelet_filters(bank)[0])
+            if taps > 64:   # the longer banks (db33-38, coif11-17 ...) run the double-precision loop
+                want_double = True
+        elif kind == 'SHEARLET' and auxiliary_data is not None and (nil & (nil - 1) or nxl & (nxl - 1)) and _ffi.shearlet64_fused_shape(nil, nxl):
+            # Extents that are not powers of two: the float32 loop runs unfused passes there, the double-precision loop its three fused ones -- faster
+            # (1000 x 1000: 1.0 against 1.6 ms per slice-iteration, tools/shearlet_probe.py) AND the reference's own arithmetic (np.fft inside FFST computes
+            # in double whatever the cube's dtype): single-precision cubes take it by default on such grids; precision='float32' keeps the float32 kernels
+            want_double = True
+    return precision, want_double
+
+
 def _pocs_cube_locked(cube, mask, kind, niter, thresh_op, thresh_model, eps, alpha, p_max, p_min, sqrt_decay, decay_kind, version, results, device,
                       batch_slices, wavelet, auxiliary_data, precision, out, ignored):
     """``pocs_cube`` behind its argument checks, with the device's lock held."""
     nslices, nil, nxl = cube.shape
     step = int(batch_slices) if batch_slices else nslices
     maskf = np.ascontiguousarray(mask, dtype=np.float32)
-    if precision is None:
-        precision = os.environ.get('P3D_PRECISION') or None
-    if precision not in (None, 'reference', 'float32'):
-        raise ValueError(f"precision must be None, 'reference' or 'float32', got {precision!r}")
-    wide = cube.dtype in (np.complex128, np.float64)
-    want_double = precision == 'reference' or (wide and precision is None)
-    if kind == 'WAVELET' and precision is None and not wide and thresh_op in _WAVELET_OPS:
-        bank = _wavelet_name(ignored.get('transform'), wavelet)
-        taps = len(bank[0]) if isinstance(bank, (tuple, list)) else len(_ffi.wavelet_filters(bank)[0])
-        if taps > 64:   # the float32 tile kernels hold filters of up to 64 taps (db32); the longer banks (db33-38, coif11-17 ...) run the double-precision loop
-            want_double = True
+    precision, want_double = _double_loop_wanted(cube.dtype, nil, nxl, kind, thresh_op, precision, wavelet, ignored.get('transform'), auxiliary_data)
     if want_double and kind == 'WAVELET' and thresh_op in _WAVELET_OPS:
         if decay_kind == 'factors' and not all(s in thresh_model for s in ['inverse', 'proportional']):
             raise IndexError('list index out of range (decay_kind="factors" yields one tau per iteration, the WAVELET '
                              'thresholding needs one per level and detail)')   # (as the float32 path below: the reference fails here)
         return _pocs_cube_wavelet_double(cube, mask, out, _wavelet_name(ignored.get('transform'), wavelet), niter, thresh_op, thresh_model, eps, alpha, p_max,
                                          p_min, sqrt_decay, decay_kind, version, results, device, batch_slices)
-    if (kind == 'SHEARLET' and precision is None and not wide and thresh_op in _WAVELET_OPS and auxiliary_data is not None
-            and (nil & (nil - 1) or nxl & (nxl - 1)) and _ffi.shearlet64_fused_shape(nil, nxl)):
-        # Extents that are not powers of two: the float32 loop runs unfused passes there, the double-precision loop its three fused ones -- faster
-        # (1000 x 1000: 1.0 against 1.6 ms per slice-iteration, tools/shearlet_probe.py) AND the reference's own arithmetic (np.fft inside FFST computes in
-        # double whatever the cube's dtype): single-precision cubes take it by default on such grids; precision='float32' keeps the float32 kernels
-        want_double = True
     if want_double and kind == 'SHEARLET' and thresh_op in _WAVELET_OPS and auxiliary_data is not None and max(nil, nxl) <= 5120:
         psi = np.asarray(auxiliary_data)
         if psi.ndim != 3 or psi.shape[:2] != (nil, nxl):

@@ -153,6 +153,8 @@ def pocs_block_on_device(block, mask, device=0, **params):
     n, nil, nxl = block.shape
     psi = params.get("auxiliary_data")
     fast = (n > 0 and block.dtype in (np.complex64, np.float32) and params.get("results") is None and not params.get("batch_slices"))
+    # a job that asks for (or is routed to) one of the double-precision loops goes through pocs_cube: the resident path below is the float32 kernels'
+    fast = fast and not P._double_loop_wanted(block.dtype, nil, nxl, kind, thresh_op, params.get("precision"), params.get("wavelet"), params.get("transform"), psi)[1]
     if kind == "FFT":
         fast = fast and model != "data-driven" and thresh_op in _ffi.P3D_OP
     else:
