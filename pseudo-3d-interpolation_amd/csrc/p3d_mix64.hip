@@ -4,11 +4,13 @@
 // p3d_f64.hip's own passes (col64_kernel / row64_kernel) keep a tile of lines in LDS and run one butterfly per thread and pass with run-time
 // factors: 16 barriers per tile, 0.165 of the pass's 56 B/point roofline (profiles/r04_f64_fused.txt).  Here a line of N = R0 R1 R2 points is
 // held by N / PPT threads, 16-20 points each in registers, compile-time radices, ONE exchange through LDS between two passes -- the
-// float32 engine of p3d_mix.hpp, instantiated for complex128 and for powers of two as well (p3d_mix64_plans.inc: tools/gen_mix_plans.py --f64).
+// float32 engine of p3d_mix.hpp, instantiated for complex128 and for powers of two as well (p3d_mix64_plans.inc: tools/gen_mix_plans.py --f64
+// --all-smooth: the powers of two 64 ... 4096 and every 7-smooth length 96 ... 4096, 8 points per thread).
 // Same semantics as col64_kernel / row64_kernel, same row-major complex128 work buffer [slice][n1][n2], same partial-sum layouts; p3d_f64.hip
-// picks these passes per axis where a plan exists (P3D_NO_MIX64=1: never).
+// picks these passes per axis where a plan exists (P3D_NO_MIX64=1: never).  The three fused passes of the double-precision SHEARLET loop
+// (p3d_shearlet64.hip) live here too: shear_col_kernel / spread_row_kernel / gather_row_kernel, same engine, same two register layouts.
 //
-// Compiled P3D_MIX64_PARTS times (-DP3D_MIX64_PART=k); part 0 holds the registry.
+// Compiled once per part of the plan list (-DP3D_MIX64_PART=k, eight translation units); part 0 holds the registry.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
