@@ -934,8 +934,8 @@ def run_leg(ctx, config, K_override, main, override=None):
                                  "unit": "GB/s", "frac": b64 / (it64 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  "note": "the float32 accounting (40 B per point and shearlet), doubled: spectrum x Psi -> coefficients (16 + 8), threshold in "
                                          "place between two column transforms (32), coefficients x Psi -> sum (16 + 8), every row of every shearlet counted -- the passes skip the "
-                                         "rows on which a shearlet's spectrum vanishes (p3d_shearlet64_info: row_group_fraction), so `achieved` is above what moves; no "
-                                         "Hermitian halves"},
+                                         "rows on which a shearlet's spectrum vanishes (p3d_shearlet64_info: row_group_fraction), and a real cube works on Hermitian coefficient slices (rows 0 ... nil/2, "
+                                         "two columns per transform), so `achieved` is above what moves and may exceed the peak"},
                 }
         else:
             plan.close()

@@ -328,7 +328,8 @@ typedef struct p3d_splan64 p3d_splan64;
 int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, int nsh, const double* psi, int max_slices);
 int p3d_shearlet64_plan_destroy(p3d_splan64* plan);
 /* fused: 1 when the loop runs its three fused passes on the double-precision register engine (both extents have a plan there; P3D_SHEARLET64_UNFUSED=1 at
- * plan creation switches them off), 0 for the unfused passes; row_group_fraction (may be NULL): share of the (shearlet, row group) pairs the fused passes
+ * plan creation switches them off; bit 1 set as well -- 3 -- when REAL cubes take the Hermitian form of those passes: symmetric spectra, even extents, rows
+ * 0 ... nil/2 only and two columns per transform, P3D_SHEARLET64_NO_PAIR=1 switches it off), 0 for the unfused passes; row_group_fraction (may be NULL): share of the (shearlet, row group) pairs the fused passes
  * touch -- rows on which a shearlet's spectrum vanishes are skipped, exactly (1.0: none skipped; P3D_SHEARLET64_NO_SUPPORT=1) */
 int p3d_shearlet64_info(p3d_splan64* plan, int* fused, double* row_group_fraction);
 /* 1 when a plan for (nil, nxl) slices would run the fused passes */

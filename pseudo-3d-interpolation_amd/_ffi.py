@@ -1013,7 +1013,8 @@ class ShearletPlan64:
         self.handle = h
         fused, frac = C.c_int(0), C.c_double(1.0)
         check(lib().p3d_shearlet64_info(self.handle, C.byref(fused), C.byref(frac)))
-        self.fused = bool(fused.value)   # three fused passes per iteration on the double-precision register engine (both extents have a plan there)
+        self.fused = bool(fused.value & 1)   # three fused passes per iteration on the double-precision register engine (both extents have a plan there)
+        self.paired = bool(fused.value & 2)  # ... and real cubes on Hermitian coefficient slices, two columns per transform (symmetric spectra, even extents)
         self.row_group_fraction = frac.value   # share of the (shearlet, row group) pairs those passes touch (rows off a spectrum's support are skipped)
 
     def close(self):

@@ -1106,7 +1106,7 @@ int p3d_fft2_c128(p3d_plan64* p, const void* in_host, void* out_host, int nslice
             F_TRY(hipMemsetAsync(p->mask, 0, sizeof(double) * p->per(), p->stream));
             p->cur_x = p->st_x;
             p->cur_out = p->st_out;
-            if (p->mcol) rc = p3d::plan64_shear_cols(p, nullptr, nullptr, nslices, 1, 0, 0, 0, 0, 1, 1.0 / p->nil, nullptr, nullptr);
+            if (p->mcol) rc = p3d::plan64_shear_cols(p, nullptr, nullptr, nslices, 1, 0, 0, 0, 0, 1, 1.0 / p->nil, nullptr, nullptr, 0);
             else rc = fft_pass(p, p->work, p->work, nslices, false, +1, 1.0 / p->nil, nullptr);
             if (rc) return rc;
             if ((rc = row_pass64<R64_LAST>(p, P3D_C128, p->partial, 0, 1, 1.0, nslices, nullptr, 0))) return rc;
@@ -1153,39 +1153,41 @@ int plan64_shear_first(p3d_plan64* p, int dtype, double* sums_row, int adaptive,
 
 int plan64_shear_row_group(p3d_plan64* p) { return p->mrow ? p->mrow->row_lines : 0; }
 
-int plan64_shear_spread(p3d_plan64* p, const double* psi, void* U, int nb, int nsh, const int* done, const unsigned char* sup)
+int plan64_shear_spread(p3d_plan64* p, const double* psi, void* U, int nb, int nsh, const int* done, const unsigned char* sup, int rows)
 {
     p3d::mix64::SpreadRow64 a{};
     a.F = reinterpret_cast<const p3d::mix::c64d*>(p->work); a.psi = psi; a.U = reinterpret_cast<p3d::mix::c64d*>(U);
     a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mrow); a.n1 = p->nil; a.nb = nb; a.nsh = nsh; a.done = done; a.sup = sup;
+    a.sup_groups = (p->nil + p->mrow->row_lines - 1) / p->mrow->row_lines; a.rows = rows > 0 ? rows : p->nil;
     F_TRY(p->mrow->spread_row(a, p->stream));
     return P3D_OK;
 }
 
 int plan64_shear_cols(p3d_plan64* p, void* U, const void* tau, int nb, int nsh, int niter, int iter, int op, int real_only, int mode, double scale, const int* done,
-                      const unsigned char* sup)
+                      const unsigned char* sup, int pair)
 {
     p3d::mix64::ShearCol64 a{};
     a.U = reinterpret_cast<p3d::mix::c64d*>(U ? U : p->work); a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mcol);
     a.n2 = p->nxl; a.nslices = nb * nsh; a.nsh = nsh; a.tau = reinterpret_cast<const p3d::mix::c64d*>(tau); a.niter = niter; a.iter = iter; a.op = op;
     a.real_only = real_only; a.mode = mode; a.scale = scale; a.done = done;
-    a.sup = sup; a.sup_rows = p->mrow->row_lines; a.sup_groups = (p->nil + a.sup_rows - 1) / a.sup_rows;
+    a.sup = sup; a.sup_rows = p->mrow->row_lines; a.sup_groups = (p->nil + a.sup_rows - 1) / a.sup_rows; a.pair = pair;
     F_TRY(p->mcol->shear_col(a, p->stream));
     return P3D_OK;
 }
 
-int plan64_shear_gather(p3d_plan64* p, const void* U, const double* psi, int nb, int nsh, const int* done, const unsigned char* sup)
+int plan64_shear_gather(p3d_plan64* p, const void* U, const double* psi, int nb, int nsh, const int* done, const unsigned char* sup, int rows)
 {
     p3d::mix64::GatherRow64 a{};
     a.U = reinterpret_cast<const p3d::mix::c64d*>(U); a.psi = psi; a.F = reinterpret_cast<p3d::mix::c64d*>(p->work);
     a.tab = reinterpret_cast<const p3d::mix::c64d*>(p->tw_mrow); a.n1 = p->nil; a.nb = nb; a.nsh = nsh; a.done = done; a.sup = sup;
+    a.sup_groups = (p->nil + p->mrow->row_lines - 1) / p->mrow->row_lines; a.rows = rows > 0 ? rows : p->nil;
     F_TRY(p->mrow->gather_row(a, p->stream));
     return P3D_OK;
 }
 
 int plan64_shear_back(p3d_plan64* p, int dtype, double* sums_row, bool last, int adaptive, int write_out, double alpha, int nslices, const int* done, int zero_fill)
 {
-    int rc = plan64_shear_cols(p, nullptr, nullptr, nslices, 1, 0, 0, 0, 0, 1, 1.0 / p->nil, done, nullptr);   // (the row pass divides by nxl)
+    int rc = plan64_shear_cols(p, nullptr, nullptr, nslices, 1, 0, 0, 0, 0, 1, 1.0 / p->nil, done, nullptr, 0);   // (the row pass divides by nxl)
     if (rc) return rc;
     if (last) return row_pass64<R64_LAST>(p, dtype, sums_row, 0, 1, alpha, nslices, done, zero_fill);
     if ((rc = row_pass64<R64_MID>(p, dtype, sums_row, adaptive, write_out, alpha, nslices, done, zero_fill))) return rc;

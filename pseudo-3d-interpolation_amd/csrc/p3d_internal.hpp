@@ -75,13 +75,16 @@ void plan64_bind(p3d_plan64* plan, const void* x, void* out);   // device pointe
 // work = fft2 of the first input (x, or its APOCS mix); sums_row[slice] = sum |x|
 int plan64_shear_first(p3d_plan64* plan, int dtype, double* sums_row, int adaptive, double alpha, int nslices, const int* done);
 // U[b * nsh + s] = inverse row transform of psi_s x work[b]
-int plan64_shear_spread(p3d_plan64* plan, const double* psi, void* U, int nb, int nsh, const int* done, const unsigned char* sup);
+int plan64_shear_spread(p3d_plan64* plan, const double* psi, void* U, int nb, int nsh, const int* done, const unsigned char* sup, int rows);
 // columns of U (NULL: of the work buffer, nsh = 1): inverse transform, x scale, real part if real_only; mode 0: threshold with tau[b][iter][s] and forward
 // transform; mode 1: nothing more (samples)
 int plan64_shear_cols(p3d_plan64* plan, void* U, const void* tau, int nb, int nsh, int niter, int iter, int op, int real_only, int mode, double scale, const int* done,
-                      const unsigned char* sup);
+                      const unsigned char* sup, int pair);
 // work[b] = sum_s psi_s x forward row transform of U[b * nsh + s]
-int plan64_shear_gather(p3d_plan64* plan, const void* U, const double* psi, int nb, int nsh, const int* done, const unsigned char* sup);
+int plan64_shear_gather(p3d_plan64* plan, const void* U, const double* psi, int nb, int nsh, const int* done, const unsigned char* sup, int rows);
+// rows (spread / gather): 0 = all nil rows; nil / 2 + 1 with pair = 1 in the column pass -- REAL cubes on symmetric spectra have real coefficients, U is Hermitian along
+// its columns, only rows 0 ... nil / 2 exist and two adjacent columns share one transform (mix64::ShearCol64::pair); the gather pass then leaves rows nil / 2 + 1 ... of
+// the work buffer unwritten (the caller mirrors them: the spectrum of a real slice)
 // sup (the three passes alike, device [nsh][groups] bytes or NULL): 0 = the spectrum of shearlet s vanishes on the rows of row group g (plan64_shear_row_group rows
 // each: the rows of one workgroup of the row passes); such rows of U are never written, read as zeros by the column pass and skipped by the gather pass (exact)
 int plan64_shear_row_group(p3d_plan64* plan);

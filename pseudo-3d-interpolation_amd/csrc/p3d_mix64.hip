@@ -330,6 +330,90 @@ __global__ __launch_bounds__(PL::COLT* PL::TMAX) void shear_col_kernel(const She
     }
 }
 
+// The same pass for REAL cubes on symmetric spectra (ShearCol64::pair): the coefficients c_s are real, so the slice U[b * nsh + s] -- the row-transformed
+// spectrum, i.e. the column transform of c_s -- is Hermitian along its columns: U[N - k][x] = conj U[k][x].  Only rows 0 ... N / 2 exist (the row passes work on
+// those alone), and two adjacent columns a, b go through ONE complex transform: Z[k] = Ua[k] + i Ub[k] (the rows beyond N / 2 from their mirror images) ->
+// inverse transform -> Re = c_a, Im = c_b -> real threshold -> forward transform -> Ua'[k] = (Z'[k] + conj Z'[N - k]) / 2, Ub'[k] = (Z'[k] - conj Z'[N - k]) / 2i
+// (the partner row comes through LDS).  A tile = COLT column pairs.  mode 1: c_a, c_b stored as samples (all N rows), for the statistics.
+template <class PL>
+__global__ __launch_bounds__(PL::COLT* PL::TMAX) void shear_col_pair_kernel(const ShearCol64 a)
+{
+    constexpr int N = PL::N, VMAX = PL::VMAX, T = PL::COLT, H = N / 2;
+    constexpr int PPT_A = PL::PPT_A, TPL_A = PL::TPL_A, PPT_B = PL::PPT_B, TPL_B = PL::TPL_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    c64d* data = reinterpret_cast<c64d*>(smem_raw);
+    const c64d* const twl = a.tab;
+    const int tid = threadIdx.x, c_lo = tid % T, tl = tid / T, u = blockIdx.y, tile = blockIdx.x;
+    const int b = u / a.nsh, s = u - b * a.nsh;
+    const int pcol = 2 * (tile * T + c_lo);   // columns pcol, pcol + 1
+    const bool valid = pcol + 1 < a.n2;
+    if (a.done && a.done[b] != 0) return;
+    c64d* const base = a.U + (size_t)u * N * a.n2 + (valid ? pcol : 0);
+    const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
+    __shared__ unsigned char supl[N];
+    if (a.sup != nullptr) {
+        const unsigned char* const sg = a.sup + (size_t)s * a.sup_groups;
+        for (int r = tid; r < N; r += T * PL::TMAX) supl[r] = sg[r / a.sup_rows];
+        __syncthreads();
+    }
+    c64d v[VMAX];
+#pragma unroll
+    for (int q = 0; q < VMAX; ++q) v[q] = c64d{0.0, 0.0};
+    {
+        const int r0 = tl < TPL_B ? tl : 0;
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) {
+            const int r = r0 + TPL_B * q, rr = r <= H ? r : N - r;
+            if (a.sup == nullptr || supl[rr] != 0) {
+                const c64d va = base[(size_t)rr * a.n2], vb = base[(size_t)rr * a.n2 + 1];
+                // Z = Ua + i Ub; beyond N / 2: Ua = conj(mirror), Ub = conj(mirror)
+                v[q] = r <= H ? c64d{va.x - vb.y, va.y + vb.x} : c64d{va.x + vb.y, vb.x - va.y};
+            }
+        }
+        if (!live_b) {
+#pragma unroll
+            for (int q = 0; q < PPT_B; ++q) v[q] = c64d{0.0, 0.0};
+        }
+    }
+    mix::line_fft<PL, INV, T>(v, data + c_lo, twl, tl);   // layout B -> layout A: Re = the samples of column pcol, Im = those of column pcol + 1
+#pragma unroll
+    for (int q = 0; q < PPT_A; ++q) v[q] = v[q] * a.scale;
+    if (a.mode == 1) {
+        if (live_a) {
+#pragma unroll
+            for (int q = 0; q < PPT_A; ++q) {
+                c64d* const o = base + (size_t)(tl + TPL_A * q) * a.n2;
+                o[0] = c64d{v[q].x, 0.0};
+                o[1] = c64d{v[q].y, 0.0};
+            }
+        }
+        return;
+    }
+    const c64d t = a.tau[((size_t)b * a.niter + a.iter) * a.nsh + s];
+#pragma unroll
+    for (int q = 0; q < PPT_A; ++q)
+        v[q] = live_a ? c64d{shrink(c64d{v[q].x, 0.0}, t, a.op).x, shrink(c64d{v[q].y, 0.0}, t, a.op).x} : c64d{0.0, 0.0};
+    mix::line_fft<PL, FWD, T>(v, data + c_lo, twl, tl);   // layout A -> layout B: Z'
+    // Z'[N - k] of the rows this thread stores: once round through LDS in natural order (own addressing: [row][pair of the tile])
+    __syncthreads();
+    if (live_b) {
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) data[(size_t)(tl + TPL_B * q) * T + c_lo] = v[q];
+    }
+    __syncthreads();
+    if (live_b) {
+#pragma unroll
+        for (int q = 0; q < PPT_B; ++q) {
+            const int r = tl + TPL_B * q;
+            if (r <= H && (a.sup == nullptr || supl[r] != 0)) {
+                const c64d z = v[q], p = data[(size_t)(r == 0 ? 0 : N - r) * T + c_lo];
+                base[(size_t)r * a.n2] = c64d{0.5 * (z.x + p.x), 0.5 * (z.y - p.y)};
+                base[(size_t)r * a.n2 + 1] = c64d{0.5 * (z.y + p.y), 0.5 * (p.x - z.x)};
+            }
+        }
+    }
+}
+
 template <class PL>
 __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void spread_row_kernel(const SpreadRow64 a)
 {
@@ -341,8 +425,8 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void spread_row_kernel(const S
     const int tid = threadIdx.x, line = tid / TMAX, tl = tid % TMAX, u = blockIdx.y, row = blockIdx.x * LB + line;
     const int b = u / a.nsh, s = u - b * a.nsh;
     if (a.done && a.done[b] != 0) return;
-    if (a.sup != nullptr && a.sup[(size_t)s * gridDim.x + blockIdx.x] == 0) return;   // the spectrum vanishes on this workgroup's rows: they are never read
-    const bool valid = row < a.n1;
+    if (a.sup != nullptr && a.sup[(size_t)s * a.sup_groups + blockIdx.x] == 0) return;   // the spectrum vanishes on this workgroup's rows: they are never read
+    const bool valid = row < a.rows;
     const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
     const size_t per = (size_t)a.n1 * N, rbase = (size_t)(valid ? row : 0) * N;
     const c64d* const frow = a.F + (size_t)b * per + rbase;
@@ -378,7 +462,7 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void gather_row_kernel(const G
     const c64d* const twl = a.tab;
     const int tid = threadIdx.x, line = tid / TMAX, tl = tid % TMAX, b = blockIdx.y, row = blockIdx.x * LB + line;
     if (a.done && a.done[b] != 0) return;
-    const bool valid = row < a.n1;
+    const bool valid = row < a.rows;
     const bool live_a = valid && tl < TPL_A, live_b = valid && tl < TPL_B;
     const size_t per = (size_t)a.n1 * N, rbase = (size_t)(valid ? row : 0) * N;
     c64d* const image = data + (size_t)line * PL::LINE;
@@ -387,7 +471,7 @@ __global__ __launch_bounds__(PL::ROWLB* PL::TMAX) void gather_row_kernel(const G
 #pragma unroll
     for (int q = 0; q < PPT_B; ++q) acc[q] = c64d{0.0, 0.0};
     for (int s = 0; s < a.nsh; ++s) {
-        if (a.sup != nullptr && a.sup[(size_t)s * gridDim.x + blockIdx.x] == 0) continue;   // (uniform over the workgroup)
+        if (a.sup != nullptr && a.sup[(size_t)s * a.sup_groups + blockIdx.x] == 0) continue;   // (uniform over the workgroup)
         const c64d* const urow = a.U + ((size_t)b * a.nsh + s) * per + rbase;
         const double* const prow = a.psi + (size_t)s * per + rbase;
         c64d v[VMAX];
@@ -432,6 +516,17 @@ hipError_t launch_shear_col(const ShearCol64& a, hipStream_t st)
     static bool attr = false;
     const hipError_t e = raise_lds<PL>(shear_col_kernel<PL>, lds, &attr);
     if (e != hipSuccess) return e;
+    if (a.pair) {
+        if constexpr (PL::N % 2 == 0) {
+            static bool attr2 = false;
+            const hipError_t e2 = raise_lds<PL>(shear_col_pair_kernel<PL>, lds, &attr2);
+            if (e2 != hipSuccess) return e2;
+            shear_col_pair_kernel<PL><<<dim3((a.n2 / 2 + PL::COLT - 1) / PL::COLT, a.nslices), PL::COLT * PL::TMAX, lds, st>>>(a);
+            return hipGetLastError();
+        } else {
+            return hipErrorNotSupported;
+        }
+    }
     shear_col_kernel<PL><<<dim3((a.n2 + PL::COLT - 1) / PL::COLT, a.nslices), PL::COLT * PL::TMAX, lds, st>>>(a);
     return hipGetLastError();
 }
@@ -443,7 +538,7 @@ hipError_t launch_spread_row(const SpreadRow64& a, hipStream_t st)
     static bool attr = false;
     const hipError_t e = raise_lds<PL>(spread_row_kernel<PL>, lds, &attr);
     if (e != hipSuccess) return e;
-    spread_row_kernel<PL><<<dim3((a.n1 + PL::ROWLB - 1) / PL::ROWLB, a.nb * a.nsh), PL::ROWLB * PL::TMAX, lds, st>>>(a);
+    spread_row_kernel<PL><<<dim3((a.rows + PL::ROWLB - 1) / PL::ROWLB, a.nb * a.nsh), PL::ROWLB * PL::TMAX, lds, st>>>(a);
     return hipGetLastError();
 }
 
@@ -454,7 +549,7 @@ hipError_t launch_gather_row(const GatherRow64& a, hipStream_t st)
     static bool attr = false;
     const hipError_t e = raise_lds<PL>(gather_row_kernel<PL>, lds, &attr);
     if (e != hipSuccess) return e;
-    gather_row_kernel<PL><<<dim3((a.n1 + PL::ROWLB - 1) / PL::ROWLB, a.nb), PL::ROWLB * PL::TMAX, lds, st>>>(a);
+    gather_row_kernel<PL><<<dim3((a.rows + PL::ROWLB - 1) / PL::ROWLB, a.nb), PL::ROWLB * PL::TMAX, lds, st>>>(a);
     return hipGetLastError();
 }
 

@@ -53,6 +53,8 @@ struct ShearCol64 {
     const int* done;           // [nb]
     const unsigned char* sup;  // [nsh][sup_groups] or NULL: 0 = the spectrum of shearlet s vanishes on rows g * sup_rows ... (+ sup_rows - 1): those rows of U are
     int sup_groups, sup_rows;  //   never written by the spread pass, read as zeros here and not stored (the gather pass skips them)
+    int pair;                  // 1: REAL cubes on symmetric spectra -- the coefficients are real, so U is Hermitian along its columns: only rows 0 ... N/2 exist,
+                               //   and two adjacent columns go through one complex transform (Z = Va + i Vb; n2 even, N even)
 };
 // rows of U[b * nsh + s] = inverse row transform (unscaled) of psi_s x F[b]
 struct SpreadRow64 {
@@ -62,7 +64,9 @@ struct SpreadRow64 {
     const mix::c64d* tab;
     int n1, nb, nsh;
     const int* done;
-    const unsigned char* sup;  // [nsh][row groups of the launch] or NULL (a group = the rows of one workgroup, Entry::row_lines)
+    const unsigned char* sup;  // [nsh][sup_groups] or NULL (a group = the rows of one workgroup, Entry::row_lines)
+    int sup_groups;
+    int rows;                  // rows 0 ... rows - 1 are worked on (n1, or n1 / 2 + 1 for Hermitian coefficient slices: ShearCol64::pair)
 };
 // rows of F[b] = sum_s psi_s x forward row transform of U[b * nsh + s]
 struct GatherRow64 {
@@ -73,6 +77,8 @@ struct GatherRow64 {
     int n1, nb, nsh;
     const int* done;
     const unsigned char* sup;
+    int sup_groups;
+    int rows;                  // as SpreadRow64::rows; the rows beyond are not written (the caller mirrors them)
 };
 
 struct Entry {
@@ -80,7 +86,7 @@ struct Entry {
     void (*build_tw)(mix::c64d* out);
     hipError_t (*col)(int mode, const ColArgs64& a, hipStream_t st);
     hipError_t (*row)(int mode, const RowArgs64& a, hipStream_t st);
-    hipError_t (*shear_col)(const ShearCol64& a, hipStream_t st);
+    hipError_t (*shear_col)(const ShearCol64& a, hipStream_t st);   // (ShearCol64::pair selects the two-columns-per-transform kernel)
     hipError_t (*spread_row)(const SpreadRow64& a, hipStream_t st);
     hipError_t (*gather_row)(const GatherRow64& a, hipStream_t st);
 };

@@ -12,7 +12,9 @@
 //   fused form (both extents have a plan on the double-precision register engine, p3d_mix64.hip): three passes over the coefficients --
 //     x Psi_s folded into the inverse row pass, the threshold into the column pass between its two transforms, x Psi_s and the sum over s into
 //     the forward row pass (80 B per coefficient instead of ~210), row groups on which a shearlet's spectrum vanishes skipped by all three
-//     (p3d_splan64::sup; P3D_SHEARLET64_NO_SUPPORT=1 moves every row) -- and the slice-sized passes of p3d_f64.hip's own loop around them;
+//     (p3d_splan64::sup; P3D_SHEARLET64_NO_SUPPORT=1 moves every row); REAL cubes on symmetric spectra have real coefficients, so the coefficient
+//     slices are Hermitian along their columns: rows 0 ... nil/2 only, two columns per transform (p3d_splan64::pair; P3D_SHEARLET64_NO_PAIR=1) --
+//     and the slice-sized passes of p3d_f64.hip's own loop around them;
 //   unfused form (any other shape; P3D_SHEARLET64_UNFUSED=1): separate kernels around p3d_f64.hip's line transforms (plan64_fft2), the
 //     coefficient buffer being that plan's work buffer.
 // Costs are sums of partial sums added in a fixed order (reproducible).
@@ -259,6 +261,34 @@ __global__ void sconv64_kernel(const double* sums, int* done, int nslices, int i
     if (iter > 2 && (d * d) / (cur * cur) < eps) done[s] = iter + 1;   // POCS.py:622, 631
 }
 
+// *asym is raised when some Psi_s(-k) differs from Psi_s(k) by more than 1e-11 (the spectra are at most 1; a frame generator evaluates mirrored samples along
+// different floating-point routes, the last bits may differ): real slices then have complex coefficients and the Hermitian form of the passes stays off
+__global__ void psisym64_kernel(const double* psi, int* asym, int nil, int nxl, int nsh)
+{
+    const size_t per = (size_t)nil * nxl, total = per * nsh;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = i / per, r = i - s * per;
+        const int k1 = (int)(r / nxl), k2 = (int)(r - (size_t)k1 * nxl);
+        const int m1 = k1 ? nil - k1 : 0, m2 = k2 ? nxl - k2 : 0;
+        bad = bad || (fabs(psi[i] - psi[s * per + (size_t)m1 * nxl + m2]) > 1e-11);
+    }
+    if (bad) atomicOr(asym, 1);
+}
+
+// F[b][k1][k2] = conj F[b][n1 - k1][(n2 - k2) mod n2] for k1 = n1/2 + 1 ... n1 - 1: the spectrum of a real slice, completed from the rows the gather pass computed
+__global__ void mirror_rows64_kernel(c64* F, int n1, int n2, const int* done)
+{
+    if (done && done[blockIdx.y] != 0) return;
+    c64* f = F + (size_t)blockIdx.y * n1 * n2;
+    const size_t total = (size_t)(n1 - n1 / 2 - 1) * n2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k1 = n1 / 2 + 1 + (int)(i / n2), k2 = (int)(i % n2);
+        const c64 m = f[(size_t)(n1 - k1) * n2 + (k2 ? n2 - k2 : 0)];
+        f[(size_t)k1 * n2 + k2] = c64{m.x, -m.y};
+    }
+}
+
 // sup[s][g] = 1 where rows g * G ... of Psi_s hold a non-zero sample (one wavefront per (g, s); sup zeroed before)
 __global__ void rowsup64_kernel(const double* psi, unsigned char* sup, int nil, int nxl, int G, int ng)
 {
@@ -282,6 +312,8 @@ struct p3d_splan64 {
     unsigned char* sup = nullptr;   // fused form: [nsh][sup_groups] row groups (of sup_rows rows: one workgroup of the row passes) on which Psi_s does not vanish
     int sup_groups = 0, sup_rows = 0;
     double sup_fraction = 1.0;
+    bool pair = false;           // fused form, REAL cubes: Hermitian coefficient slices (rows 0 ... nil/2 only), two columns per transform (symmetric spectra, nil and nxl even;
+                                 // P3D_SHEARLET64_NO_PAIR=1 switches it off)
     c64 *U = nullptr, *F = nullptr, *tau = nullptr;
     size_t tau_cap = 0, sums_cap = 0;
     double *sums = nullptr, *rowsum = nullptr, *stats = nullptr, *mask = nullptr;
@@ -453,6 +485,20 @@ int p3d_shearlet64_plan_create(p3d_splan64** out, int device, int nil, int nxl, 
         for (unsigned char f : host) on += f;
         p->sup_fraction = (double)on / (double)nflag;
     }
+    if (p->pf && nil % 2 == 0 && nxl % 2 == 0 && !getenv("P3D_SHEARLET64_NO_PAIR")) {
+        int* flag = nullptr;
+        int asym = 1;
+        if ((e = hipMalloc((void**)&flag, sizeof(int))) != hipSuccess) return bail("flag", e);
+        e = hipMemsetAsync(flag, 0, sizeof(int), p->stream);
+        if (e == hipSuccess) {
+            psisym64_kernel<<<1024, 256, 0, p->stream>>>(p->psi, flag, nil, nxl, nsh);
+            e = hipMemcpyAsync(&asym, flag, sizeof(int), hipMemcpyDeviceToHost, p->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+        hipFree(flag);
+        if (e != hipSuccess) return bail("symmetry check of Psi", e);
+        p->pair = asym == 0;
+    }
     *out = p;
     return P3D_OK;
 }
@@ -469,7 +515,7 @@ int p3d_shearlet64_fused_shape(int nil, int nxl)
 int p3d_shearlet64_info(p3d_splan64* p, int* fused, double* row_group_fraction)
 {
     if (!p || !fused) return s64fail(P3D_ERR_INVALID, "NULL argument");
-    *fused = p->pf ? 1 : 0;
+    *fused = p->pf ? (p->pair ? 3 : 1) : 0;   // bit 1: real cubes take the Hermitian form (two columns per transform)
     if (row_group_fraction) *row_group_fraction = p->sup ? p->sup_fraction : 1.0;
     return P3D_OK;
 }
@@ -486,8 +532,9 @@ int p3d_shearlet64_stats(p3d_splan64* p, const void* x, int dtype, int nslices, 
         S_RC(ensure_sums(p, (size_t)nslices));
         p3d::plan64_bind(p->pf, p->cur_x, nullptr);
         S_RC(p3d::plan64_shear_first(p->pf, dtype, p->sums, 0, 1.0, nslices, nullptr));
-        S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, p->nsh, nullptr, p->sup));
-        S_RC(p3d::plan64_shear_cols(p->pf, p->U, nullptr, nslices, p->nsh, 0, 0, 0, 0, 1, 1.0 / ((double)p->nil * p->nxl), nullptr, p->sup));
+        const int pair = (p->pair && real_dtype(dtype)) ? 1 : 0;
+        S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, p->nsh, nullptr, p->sup, pair ? p->nil / 2 + 1 : 0));
+        S_RC(p3d::plan64_shear_cols(p->pf, p->U, nullptr, nslices, p->nsh, 0, 0, 0, 0, 1, 1.0 / ((double)p->nil * p->nxl), nullptr, p->sup, pair));
     } else {
         supdate64_kernel<<<dim3(p->nil, nslices), 256, 0, p->stream>>>(p->F, p->cur_x, dtype, nullptr, nullptr, p->rowsum, 0, 0, 0, 1.0, p->nil, p->nxl, nullptr, 0, 0);
         S_RC(s_forward(p, nslices, nullptr));
@@ -535,13 +582,16 @@ int p3d_shearlet64_run(p3d_splan64* p, const void* x, int dtype, const double* m
     S_TRY(hipEventRecord(p->ev0, p->stream));
     if (p->pf) {
         const double scale = 1.0 / ((double)p->nil * p->nxl);
+        const int pair = (p->pair && real_only) ? 1 : 0, rows = pair ? p->nil / 2 + 1 : 0;
         p3d::plan64_bind(p->pf, p->cur_x, p->cur_out);
         S_RC(p3d::plan64_shear_first(p->pf, dtype, p->sums, adaptive ? 1 : 0, prm->alpha, nslices, p->done));
         for (int k = 0; k < niter; ++k) {
             const bool last = k + 1 == niter;
-            S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, nsh, p->done, p->sup));
-            S_RC(p3d::plan64_shear_cols(p->pf, p->U, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, 0, scale, p->done, p->sup));
-            S_RC(p3d::plan64_shear_gather(p->pf, p->U, p->psi, nslices, nsh, p->done, p->sup));
+            S_RC(p3d::plan64_shear_spread(p->pf, p->psi, p->U, nslices, nsh, p->done, p->sup, rows));
+            S_RC(p3d::plan64_shear_cols(p->pf, p->U, p->tau, nslices, nsh, niter, k, prm->thresh_op, real_only ? 1 : 0, 0, scale, p->done, p->sup, pair));
+            S_RC(p3d::plan64_shear_gather(p->pf, p->U, p->psi, nslices, nsh, p->done, p->sup, rows));
+            if (pair) mirror_rows64_kernel<<<dim3(blocks_for((size_t)(p->nil / 2) * p->nxl, 1024), nslices), 256, 0, p->stream>>>(
+                reinterpret_cast<c64*>(p3d::plan64_work(p->pf)), p->nil, p->nxl, p->done);
             S_RC(p3d::plan64_shear_back(p->pf, dtype, p->sums + (size_t)(k + 1) * nslices, last, adaptive ? 1 : 0, early ? 1 : 0, prm->alpha, nslices, p->done,
                                         last ? 1 : 0));
             if (early) sconv64_kernel<<<(nslices + 255) / 256, 256, 0, p->stream>>>(p->sums, p->done, nslices, k, prm->eps);

@@ -583,3 +583,42 @@ def test_single_precision_cubes_take_the_double_loop_where_it_is_the_fused_one(s
         calls.clear()
         fast = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, precision="float32", **kw)
         assert not calls and rel_l2(fast, want) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(64, 128), (600, 500), (1024, 256), (96, 1000)])
+@pytest.mark.parametrize("op", ["hard", "soft"])
+def test_two_columns_per_transform_in_double_precision(ffi, so, shape, op, monkeypatch):
+    """Real cubes on symmetric spectra (what scalesShearsAndSpectra builds) have real coefficients: the fused double-precision passes then work on Hermitian
+    coefficient slices -- rows 0 ... nil/2 only, two columns through one complex transform (mix64::shear_col_pair_kernel).  Against the general passes
+    (P3D_SHEARLET64_NO_PAIR=1) to rounding, statistics alike, and against the oracle; complex cubes are not affected."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    from oracle import pocs_oracle as po
+    from pseudo_3d_interpolation_amd.functions import shearlets
+    kw = dict(niter=5, thresh_op=op, thresh_model="exponential", eps=0.0, p_max=0.99, p_min=1e-2)
+    psi = shearlets.scalesShearsAndSpectra(shape)
+    mask = po.synthetic_mask(shape[0], shape[1], 0.6)
+    cube = (np.stack([po.synthetic_slice(shape[0], shape[1], 80 + s, real=True) for s in range(2)]) * mask).astype(np.float64)
+    P.release_plans()
+    with ffi.ShearletPlan64(psi, max_slices=2) as plan:
+        assert plan.fused and plan.paired
+        st_p = plan.stats(cube)
+    res_p = []
+    paired = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, results=res_p, **kw)
+    cplx = P.pocs_cube(cube[:1].astype(np.complex128), mask, transform_kind="SHEARLET", auxiliary_data=psi, **kw)
+    P.release_plans()
+    monkeypatch.setenv("P3D_SHEARLET64_NO_PAIR", "1")
+    with ffi.ShearletPlan64(psi, max_slices=2) as plan:
+        assert plan.fused and not plan.paired
+        st_g = plan.stats(cube)
+    res_g = []
+    general = P.pocs_cube(cube, mask, transform_kind="SHEARLET", auxiliary_data=psi, results=res_g, **kw)
+    P.release_plans()
+    monkeypatch.delenv("P3D_SHEARLET64_NO_PAIR")
+    np.testing.assert_allclose(st_p[..., [0, 2, 4]], st_g[..., [0, 2, 4]], rtol=1e-11)
+    assert rel_l2(paired, general) <= 1e-11, rel_l2(paired, general)   # (mirrored samples of a generated spectrum differ by up to 2e-13: the frame itself is symmetric to that)
+    assert rel_l2(np.real(cplx[0]), general[0]) <= 1e-11           # (the same slice as a complex cube: the general passes by construction)
+    for s in range(2):
+        np.testing.assert_allclose(res_p[s]["costs"], res_g[s]["costs"], rtol=1e-9, atol=1e-26)
+    if max(shape) <= 600:
+        want = so.pocs_cube_shearlet(cube, mask, psi, **kw)
+        assert rel_l2(paired, want) <= (1e-8 if op == "hard" else 1e-10)

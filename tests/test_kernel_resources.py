@@ -27,7 +27,7 @@ KNOWN_SCRATCH = {
     r"col_pipe_kernel<256, 32, \d, false>": "persistent column pass at 256 points (an experiment behind P3D_FORCE_COLPIPE)",
     r"flex_col_kernel<false, false>": "SGPR spills of the run-time radix dispatch (one tile per workgroup form)",
     r"chirp_col_kernel<2048, 0>": "chirp-z column iteration at 2048 points: 3 registers over the 128 of a 512-thread workgroup pair",
-    r"mix64::(col|shear_col)_kernel<mix::MixPlan<\d+, (8|4|2), .*> >": "double-precision column tiles on the register engine (p3d_mix64.hip; shear_col: the SHEARLET "
+    r"mix64::(col|shear_col|shear_col_pair)_kernel<mix::MixPlan<\d+, (8|4|2), .*> >": "double-precision column tiles on the register engine (p3d_mix64.hip; shear_col: the SHEARLET "
     "loop's column pass, same tile): whole 64-byte-per-row tiles (or the widest that fits) need 600-1024 threads, i.e. 128 VGPRs, and the last pass of complex128 "
     "butterflies spills 4-86 of them; the narrower tile that does not spill measured SLOWER (1024-point columns: 0.74 vs 0.71 ms per iteration of 32 slices, "
     "tools/mix64_try_plans.sh), and every length is 1.8-4 x faster than on the LDS-image passes (tools/f64_sweep.sh), so the spill is the accepted price",
