@@ -200,3 +200,29 @@ def test_fft_engine_host_emulation(tmp_path):
     res = subprocess.run([str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-2000:]
     assert "ALL OK" in res.stdout
+
+
+def test_which_calls_take_a_double_precision_loop(monkeypatch):
+    """functions.POCS._double_loop_wanted: the one routing rule of pocs_cube and sharding.pocs_block_on_device (no GPU needed: the library only looks up
+    its plan tables).  Double precision when asked for, for double-precision cubes, for WAVELET banks the float32 tiles do not hold, and for SHEARLET on
+    7-smooth extents that are not powers of two (the fused double-precision passes beat the unfused float32 ones there)."""
+    import pseudo_3d_interpolation_amd.functions.POCS as P
+    monkeypatch.delenv("P3D_PRECISION", raising=False)
+    psi = object()   # (only its presence matters here)
+    w = P._double_loop_wanted
+    assert w(np.complex64, 1024, 1024, "FFT", "hard", None) == (None, False)
+    assert w(np.complex64, 1024, 1024, "FFT", "soft", "reference") == ("reference", True)
+    assert w(np.complex128, 64, 64, "FFT", "soft", None) == (None, True)
+    assert w(np.float64, 64, 64, "WAVELET", "soft", "float32") == ("float32", False)
+    assert w(np.float32, 256, 256, "WAVELET", "soft", None, "db4")[1] is False
+    assert w(np.float32, 256, 256, "WAVELET", "soft", None, "db38")[1] is True          # 76 taps
+    assert w(np.float32, 256, 256, "WAVELET", "soft", "float32", "db38")[1] is False    # (the float32 kernels then refuse the bank)
+    assert w(np.float32, 1000, 1000, "SHEARLET", "hard", None, auxiliary_data=psi)[1] is True
+    assert w(np.float32, 1024, 2048, "SHEARLET", "hard", None, auxiliary_data=psi)[1] is False   # powers of two: the fused float32 passes
+    assert w(np.float32, 1009, 1000, "SHEARLET", "hard", None, auxiliary_data=psi)[1] is False   # a prime extent: no fused double-precision passes
+    assert w(np.float32, 1000, 1000, "SHEARLET", "hard", "float32", auxiliary_data=psi)[1] is False
+    assert w(np.float32, 1000, 1000, "SHEARLET", "hard-percentile", None, auxiliary_data=psi)[1] is False
+    monkeypatch.setenv("P3D_PRECISION", "reference")
+    assert w(np.complex64, 1024, 1024, "FFT", "hard", None) == ("reference", True)
+    with pytest.raises(ValueError):
+        w(np.complex64, 8, 8, "FFT", "hard", "double")
